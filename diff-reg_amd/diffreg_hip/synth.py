@@ -1,0 +1,135 @@
+"""Deterministic synthetic scene pairs and weights for the reverse-diffusion matching path.
+
+Everything here is derived from an integer hash (splitmix64 finaliser) of (seed, stream, index),
+so the same bits are produced on every box and with every numpy/torch version -- weights and
+inputs never have to be committed, only reference OUTPUTS are stored under tests/golden/.
+
+Shapes follow the reference's coarse level:
+  s_pcd [N,3], t_pcd [M,3]   superpoints inside vol_bnds (3D/configs/test/3dmatch.yaml:46)
+  src_feats [N,C], tgt_feats [M,C]  backbone features (matched points share a base vector)
+  x_T [N,M]  initial noise of the reverse process (3D/models/pipeline.py:224)
+"""
+import math
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_u01(seed, stream, n):
+    """n doubles in (0,1), a pure function of (seed, stream, index)."""
+    with np.errstate(over="ignore"):
+        base = _mix(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
+        idx = np.arange(n, dtype=np.uint64)
+        z = _mix(idx ^ base)
+        z = _mix(z + base)
+    return ((z >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / (1 << 53))
+
+
+def hash_uniform(seed, stream, shape, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * hash_u01(seed, stream, n)).reshape(shape)
+
+
+def hash_normal(seed, stream, shape):
+    n = int(np.prod(shape))
+    u1 = hash_u01(seed, 2 * stream + 1000003, n)
+    u2 = hash_u01(seed, 2 * stream + 1000004, n)
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------------
+# model dimensions of the three trees
+# --------------------------------------------------------------------------------------------
+VARIANTS = {
+    # 3D/configs/test/3dmatch.yaml:23,35-36,42-51
+    "3dmatch": dict(C=432, H=4, voxel=0.08, origin=(-3.6, -2.4, 1.14), skh_iters=3, bin_score=1.0,
+                    sample_rate=1.0, n_layers=6),
+    # 4D/configs/test/4dmatch.yaml:24,44,50,53
+    "4dmatch": dict(C=528, H=4, voxel=0.04, origin=(-3.6, -2.4, 1.14), skh_iters=3, bin_score=1.0,
+                    sample_rate=1.0, n_layers=6),
+}
+
+LAYER_TYPES = ("self", "cross", "self", "cross", "self", "cross")  # 3D/models/pipeline.py:142
+
+
+def make_weights(C, seed=7, n_layers=6, head_gain=1.0, dtype=np.float32):
+    """Weights of the denoising transformer + matching head in the reference's state-dict layout
+    (SURVEY.md section 8b): hash-uniform * 1/sqrt(fan_in), LayerNorm gamma=1, beta=0."""
+    w = {}
+    st = 0
+
+    def lin(out_f, in_f, gain=1.0):
+        nonlocal st
+        st += 1
+        a = gain * math.sqrt(3.0 / in_f)
+        return hash_uniform(seed, st, (out_f, in_f), -a, a).astype(dtype)
+
+    for l in range(n_layers):
+        p = "denoising_transformer.layers.%d." % l
+        w[p + "q_proj.weight"] = lin(C, C)
+        w[p + "k_proj.weight"] = lin(C, C)
+        w[p + "v_proj.weight"] = lin(C, C)
+        w[p + "merge.weight"] = lin(C, C)
+        w[p + "mlp.0.weight"] = lin(2 * C, 2 * C)
+        w[p + "mlp.2.weight"] = lin(C, 2 * C)
+        st += 1
+        w[p + "norm1.weight"] = (1.0 + 0.1 * hash_uniform(seed, st, (C,))).astype(dtype)
+        st += 1
+        w[p + "norm1.bias"] = (0.05 * hash_uniform(seed, st, (C,))).astype(dtype)
+        st += 1
+        w[p + "norm2.weight"] = (1.0 + 0.1 * hash_uniform(seed, st, (C,))).astype(dtype)
+        st += 1
+        w[p + "norm2.bias"] = (0.05 * hash_uniform(seed, st, (C,))).astype(dtype)
+    w["denoising_coarse_matching.src_proj.weight"] = lin(C, C, head_gain)
+    w["denoising_coarse_matching.tgt_proj.weight"] = lin(C, C)  # allocated, never used (Q1)
+    w["denoising_coarse_matching.bin_score"] = np.asarray(1.0, dtype=dtype)
+    return w
+
+
+def _rodrigues(axis, theta):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + math.sin(theta) * K + (1 - math.cos(theta)) * (K @ K)
+
+
+def make_pair(N, M, C, seed, overlap=0.6, feat_noise=0.3, pos_noise=0.01, max_angle_deg=45.0,
+              dtype=np.float32):
+    """One synthetic scene pair."""
+    lo = np.array([-3.6, -2.4, 1.14]) + 0.05
+    hi = np.array([1.093, 0.78, 2.92]) - 0.05
+    s_pcd = lo + (hi - lo) * hash_u01(seed, 11, N * 3).reshape(N, 3)
+    axis = hash_normal(seed, 12, (3,))
+    theta = math.radians(max_angle_deg) * float(hash_u01(seed, 13, 1)[0])
+    R = _rodrigues(axis, theta)
+    t = hash_uniform(seed, 14, (3,), -0.5, 0.5)
+    # rotate about the scene centre so the target stays inside the volume
+    ctr = 0.5 * (lo + hi)
+    n_ov = int(round(overlap * min(N, M)))
+    perm_src = np.argsort(hash_u01(seed, 15, N))       # which src points have a partner
+    perm_tgt = np.argsort(hash_u01(seed, 16, M))       # where the partner sits in tgt
+    t_pcd = lo + (hi - lo) * hash_u01(seed, 17, M * 3).reshape(M, 3)
+    moved = (s_pcd[perm_src[:n_ov]] - ctr) @ R.T + ctr + 0.1 * t
+    t_pcd[perm_tgt[:n_ov]] = moved + pos_noise * hash_normal(seed, 18, (n_ov, 3))
+    t_eff = ctr - R @ ctr + 0.1 * t          # t_pcd = R s_pcd + t_eff on the overlap
+    base_s = hash_normal(seed, 19, (N, C))
+    base_t = hash_normal(seed, 20, (M, C))
+    base_t[perm_tgt[:n_ov]] = base_s[perm_src[:n_ov]]
+    src_feats = base_s + feat_noise * hash_normal(seed, 21, (N, C))
+    tgt_feats = base_t + feat_noise * hash_normal(seed, 22, (M, C))
+    x_T = hash_normal(seed, 23, (N, M))
+    gt = np.stack([perm_src[:n_ov], perm_tgt[:n_ov]], 1).astype(np.int64)
+    return dict(s_pcd=s_pcd.astype(dtype), t_pcd=t_pcd.astype(dtype),
+                src_feats=src_feats.astype(dtype), tgt_feats=tgt_feats.astype(dtype),
+                x_T=x_T.astype(dtype), R_gt=R, t_gt=t_eff, gt_matches=gt)
+
+
+def step_noise(N, M, seed, n_steps, dtype=np.float32):
+    """Per-step noise xi_k (only the 4D variant adds sigma*xi, 4D/models/pipeline.py:188-190)."""
+    return np.stack([hash_normal(seed, 100 + k, (N, M)) for k in range(n_steps)]).astype(dtype)

@@ -1,0 +1,139 @@
+"""Pin the oracle (oracle/diffreg_oracle.py) against vectors produced by the reference itself
+(tests/golden/*.npz, minted by oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import diffreg_oracle as orc
+from tests.helpers import T, weights, pair, masks, sinkhorn_case
+
+SK_CASES = [(128, 128, 128, 128, 1.0, "f32"), (128, 128, 128, 128, 1.0, "f64"), (200, 256, 200, 256, 0.37, "f32"),
+            (96, 80, 70, 61, 1.0, "f32"), (96, 80, 70, 61, 0.37, "f64"), (256, 256, 256, 256, 1.0, "f32"),
+            (5, 7, 5, 7, 1.0, "f32"), (1, 1, 1, 1, 1.0, "f32")]
+
+
+@pytest.mark.parametrize("N,M,nv,mv,alpha,dt", SK_CASES)
+def test_sinkhorn_matches_reference(golden, N, M, nv, mv, alpha, dt):
+    g = golden("3dmatch_sinkhorn")
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    sc, sm, tm = sinkhorn_case(N, M, nv, mv, tdt)
+    Z = orc.sinkhorn_log(sc, torch.tensor(alpha, dtype=torch.float32), 3, sm, tm)
+    ref = g["logZ_%d_%d_%d_%d_%s_%s" % (N, M, nv, mv, str(alpha).replace(".", "p"), dt)]
+    assert Z.dtype == tdt
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(Z.numpy()))
+    tol = 2e-6 if dt == "f32" else 1e-12
+    assert np.abs(Z.numpy()[fin] - ref[fin]).max() < tol * max(1.0, np.abs(ref[fin]).max())
+
+
+@pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
+def test_position_code(golden, variant):
+    g = golden(variant + "_pe")
+    v = synth.VARIANTS[variant]
+    _, p = pair(variant, 64, 48, 3)
+    cos, sin = orc.vol_pe(p["p_s"], v["C"], v["origin"], v["voxel"])
+    np.testing.assert_allclose(cos[0, :16].numpy(), g["cos"], atol=1e-6)
+    np.testing.assert_allclose(sin[0, :16].numpy(), g["sin"], atol=1e-6)
+    rot = orc.rotary(p["f_s"], cos, sin)
+    np.testing.assert_allclose(rot[0, :16].numpy(), g["rot"], atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
+def test_attention_layer_and_denoiser(golden, variant):
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    _, p = pair(variant, 64, 48, 3)
+    C, H = v["C"], v["H"]
+    pes = orc.vol_pe(p["p_s"], C, v["origin"], v["voxel"])
+    pet = orc.vol_pe(p["p_t"], C, v["origin"], v["voxel"])
+    full = masks(64, 48)
+    part = masks(64, 48, 50, 41)
+    g = golden(variant + "_attn_layer")
+    pre = "denoising_transformer.layers.1."
+    fs, ft = p["f_s"], p["f_t"]
+    outs = dict(self_full=orc.attention_layer(W, pre, fs, fs, pes, pes, full[0], full[0], H),
+                cross_full=orc.attention_layer(W, pre, fs, ft, pes, pet, full[0], full[1], H),
+                self_mask=orc.attention_layer(W, pre, fs, fs, pes, pes, part[0], part[0], H),
+                cross_mask=orc.attention_layer(W, pre, fs, ft, pes, pet, part[0], part[1], H))
+    for k, o in outs.items():
+        np.testing.assert_allclose(o[0].numpy(), g[k], atol=2e-5, err_msg=k)
+    g = golden(variant + "_denoiser")
+    for tag, (ms, mt) in (("", full), ("_mask", part)):
+        hs, ht, pe_s, pe_t = orc.denoiser(W, v, fs, ft, p["p_s"], p["p_t"], ms, mt)
+        np.testing.assert_allclose(hs[0].numpy(), g["f_s" + tag], atol=1e-4)
+        np.testing.assert_allclose(ht[0].numpy(), g["f_t" + tag], atol=1e-4)
+        conf = orc.match_head(W, v, hs, ht, pe_s, pe_t, ms, mt)
+        np.testing.assert_allclose(conf[0].numpy(), g["conf" + tag], atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
+def test_procrustes(golden, variant):
+    g = golden(variant + "_procrustes")
+    C = synth.VARIANTS[variant]["C"]
+    pr = synth.make_pair(128, 128, C, seed=5)
+    gtm = np.zeros((128, 128))
+    gtm[pr["gt_matches"][:, 0], pr["gt_matches"][:, 1]] = 6.0
+    sc = T(gtm + synth.hash_normal(5, 77, (128, 128)))[None].float()
+    sm, tm = masks(128, 128, 120, 111)
+    conf = orc.sinkhorn_conf(sc, torch.tensor(1.0), 3, sm, tm)
+    for mc in (0, 40, 200):
+        R, t, Rf, tf, cond, ok = orc.procrustes(conf, T(pr["s_pcd"])[None], T(pr["t_pcd"])[None], sm, tm,
+                                                1.0, mc, variant)
+        np.testing.assert_allclose(R.numpy(), g["R_%d" % mc], atol=1e-5)
+        np.testing.assert_allclose(t.numpy(), g["t_%d" % mc], atol=1e-5)
+        np.testing.assert_allclose(Rf.numpy(), g["Rf_%d" % mc], atol=1e-5)
+        np.testing.assert_allclose(tf.numpy(), g["tf_%d" % mc], atol=1e-5)
+        np.testing.assert_allclose(cond.numpy(), g["cond_%d" % mc], rtol=1e-4)
+        assert np.array_equal(ok.numpy(), g["ok_%d" % mc])
+
+
+LOOPS = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
+         ("3dmatch", 128, 128, 128, 128, 20, 0, 11, "n128_s20_mc0"),
+         ("3dmatch", 96, 80, 96, 80, 5, 200, 12, "n96x80_s5_mc200"),
+         ("3dmatch", 256, 256, 256, 256, 20, 200, 13, "n256_s20_mc200"),
+         ("4dmatch", 128, 128, 112, 100, 5, 40, 21, "n128_s5_mc40_masked"),
+         ("4dmatch", 64, 96, 64, 96, 20, 40, 22, "n64x96_s20_mc40")]
+
+
+@pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", LOOPS)
+def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag):
+    g = golden("%s_loop_%s" % (variant, tag))
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    _, p = pair(variant, N, M, seed)
+    ms, mt = masks(N, M, nv, mv)
+    noise = T(synth.step_noise(N, M, seed, steps))[:, None]
+    trace = []
+    out = orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc,
+                           variant=variant, noise=noise, trace=trace)
+    conf = out["conf_matrix_pred"]
+    assert str(conf.dtype) == str(g["conf_dtype"])          # float64 (quirk Q2)
+    x0 = torch.stack([r["x0"][0] for r in trace])
+    np.testing.assert_allclose(x0[:, :16, :16].numpy(), g["x0_corner"], atol=2e-5)
+    np.testing.assert_allclose(x0[-1].numpy(), g["x0_last"], atol=2e-5)
+    np.testing.assert_allclose(x0.double().sum((1, 2)).numpy(), g["x0_sum"], rtol=1e-5)
+    np.testing.assert_allclose(torch.stack([r["R_forwd"][0] for r in trace]).numpy(), g["R_forwd"], atol=1e-4)
+    np.testing.assert_allclose(torch.stack([r["t_forwd"][0] for r in trace]).numpy(), g["t_forwd"], atol=1e-4)
+    c = conf[0].numpy()
+    np.testing.assert_allclose(c, g["conf"], atol=1e-6, rtol=1e-4)
+    if "match_pred" in g.files:
+        # exact on well-margined rows/columns; the rest only through conf
+        ref = set(map(tuple, g["match_pred"].tolist()))
+        got = set(map(tuple, out["match_pred"].tolist()))
+        srt = np.sort(g["conf"], 1)
+        solid_rows = np.nonzero(srt[:, -1] - srt[:, -2] > 1e-3 * srt[:, -1])[0]
+        am = g["conf"].argmax(1)
+        for i in solid_rows:
+            assert (0, int(i), int(am[i])) in got
+        assert len(ref ^ got) <= 0.02 * len(ref)
+
+
+def test_schedule_and_time_pairs():
+    ac, _, _ = orc.diffusion_schedule()
+    assert ac.dtype == torch.float64 and ac.shape == (1000,)
+    np.testing.assert_allclose(ac[[999, 949, 49, 0]].numpy(), [2.43e-9, 6.06e-3, 0.99201, 0.99996], rtol=2e-3)
+    tp = orc.time_pairs(20)
+    assert tp[0] == (999, 949) and tp[-1] == (49, 0) and len(tp) == 20
+    assert orc.time_pairs(1) == [(999, 0)]
+    assert orc.time_pairs(10)[0] == (999, 899) and orc.time_pairs(50)[0] == (999, 979)
