@@ -1,0 +1,559 @@
+// sinkhorn.hip -- batched Sinkhorn normalisation with dustbins for gfx950.
+//
+// Replaces log_optimal_transport + exp + slice of the reference (3D/models/matching.py:61-93 and
+// its three call sites, see include/diffreg_hip.h).  Two kernels:
+//
+//  sk_reg_kernel     one workgroup per tile, the whole tile (<= 256 x 256) lives in VGPRs as
+//                    row-max-shifted exponentials E_ij = exp(Z_ij - rho_i) in [0,1].  The log-domain
+//                    iteration  u_i = log mu_i - LSE_j(Z_ij + v_j),  v_j = log nu_j - LSE_i(Z_ij + u_i)
+//                    is run in its algebraically identical scaling form
+//                        a_i = mu_i / sum_j E_ij b_j ,   b_j = nu_j / sum_i E_ij a_i
+//                    (a_i = exp(u_i + rho_i), b_j = exp(v_j)), so each pass is one FMA per element
+//                    instead of one exp.  The dustbin row/column (score alpha everywhere) keep every
+//                    sum strictly positive, so the form is overflow/underflow safe for any finite
+//                    or -inf scores.  HBM traffic = read the tile once, write it once.
+//                    Row sums: 16 rows per wave, 4 columns per lane -> one butterfly reduce-scatter
+//                    (17 shuffles for 16 rows).  Column sums: per-wave partials through LDS.
+//
+//  sk_stream_kernel  any size / strict input dtype / log output: E is kept in a global workspace
+//                    (L2/MALL resident), one workgroup per tile, same scaling iteration.
+#include "common.h"
+
+namespace dr {
+
+struct SkArgs {
+    const void* scores;
+    const uint8_t* src_mask;
+    const uint8_t* tgt_mask;
+    const float* bin_score;
+    void* out;
+    void* ws;
+    int B, N, M, iters, flags, vec_in, vec_out;
+};
+
+// ---------------------------------------------------------------------------------------------
+// reduce-scatter of 16 per-lane values over the 64 lanes of a wave: on return lane l holds the
+// reduction of p[(l >> 2) & 15] over all lanes.
+// ---------------------------------------------------------------------------------------------
+template <typename Op>
+__device__ __forceinline__ float reduce16(const float (&p)[16], Op op) {
+    const int l = lane_id();
+    const bool b5 = l & 32, b4 = l & 16, b3 = l & 8, b2 = l & 4;
+    float q8[8], q4[4], q2[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float send = b5 ? p[k] : p[k + 8];
+        float keep = b5 ? p[k + 8] : p[k];
+        q8[k] = op(keep, __shfl_xor(send, 32));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float send = b4 ? q8[k] : q8[k + 4];
+        float keep = b4 ? q8[k + 4] : q8[k];
+        q4[k] = op(keep, __shfl_xor(send, 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float send = b3 ? q4[k] : q4[k + 2];
+        float keep = b3 ? q4[k + 2] : q4[k];
+        q2[k] = op(keep, __shfl_xor(send, 8));
+    }
+    float send = b2 ? q2[0] : q2[1];
+    float keep = b2 ? q2[1] : q2[0];
+    float r = op(keep, __shfl_xor(send, 4));
+    r = op(r, __shfl_xor(r, 2));
+    r = op(r, __shfl_xor(r, 1));
+    return r;
+}
+
+struct OpAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+__device__ __forceinline__ float bcast_lane(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+template <typename T, int CPL>
+struct VecIO;
+template <>
+struct VecIO<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct VecIO<double, 4> {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[4]) {
+        double2 t0 = *reinterpret_cast<const double2*>(p);
+        double2 t1 = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = (float)t0.x; v[1] = (float)t0.y; v[2] = (float)t1.x; v[3] = (float)t1.y;
+    }
+    static __device__ __forceinline__ void store(double* p, const float (&v)[4]) {
+        *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]);
+        *reinterpret_cast<double2*>(p + 2) = make_double2((double)v[2], (double)v[3]);
+    }
+};
+template <>
+struct VecIO<float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    }
+};
+template <>
+struct VecIO<double, 2> {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[2]) {
+        double2 t = *reinterpret_cast<const double2*>(p);
+        v[0] = (float)t.x; v[1] = (float)t.y;
+    }
+    static __device__ __forceinline__ void store(double* p, const float (&v)[2]) {
+        *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// register-resident kernel: NW waves x 16 rows, 64 lanes x CPL columns
+// ---------------------------------------------------------------------------------------------
+template <typename TIn, typename TOut, int NW, int CPL, bool VEC>
+__global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
+    constexpr int RPW = 16;
+    constexpr int MAXC = 64 * CPL;
+    __shared__ __attribute__((aligned(16))) float s_colpart[NW][MAXC];
+    __shared__ __attribute__((aligned(16))) float s_b[MAXC + 4];
+    __shared__ float s_dust[NW];
+    __shared__ float s_red[NW];
+
+    const int N = A.N, M = A.M;
+    const int tile = blockIdx.x;
+    const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M;
+    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M;
+    const float alpha = *A.bin_score;
+    const int row0 = w * RPW, col0 = lane * CPL;
+
+    // ---- issue all tile loads first ----------------------------------------------------------
+    float E[RPW][CPL];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) E[r][c] = -INFINITY;
+        if (row < N) {
+            if (VEC) {
+                if (col0 < M) VecIO<TIn, CPL>::load(src + (unsigned)(row * M + col0), E[r]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c)
+                    if (col0 + c < M) E[r][c] = (float)src[(unsigned)(row * M + col0 + c)];
+            }
+        }
+    }
+
+    // ---- mask sums (ms, ns) and per-thread validity -------------------------------------------
+    int ms = N, ns = M;
+    if (A.src_mask) ms = __syncthreads_count(t < N && A.src_mask[(size_t)tile * N + t]);
+    if (A.tgt_mask) ns = __syncthreads_count(t < M && A.tgt_mask[(size_t)tile * M + t]);
+    bool cvalid[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int col = col0 + c;
+        cvalid[c] = col < M && (!(A.flags & DR_SK_APPLY_MASK) || !A.tgt_mask || A.tgt_mask[(size_t)tile * M + col]);
+    }
+    unsigned rvalid = 0;   // bit r: row in range and not masked
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        const bool ok = row < N && (!(A.flags & DR_SK_APPLY_MASK) || !A.src_mask || A.src_mask[(size_t)tile * N + row]);
+        rvalid |= (ok ? 1u : 0u) << r;
+    }
+
+    // ---- x - min(x) over the raw tile (3D/models/pipeline.py:239,264) --------------------------
+    if (A.flags & DR_SK_MINSHIFT) {
+        float mn = INFINITY;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (row0 + r < N && col0 + c < M) mn = fminf(mn, E[r][c]);
+        mn = wave_min(mn);
+        if (lane == 0) s_red[w] = mn;
+        __syncthreads();
+        mn = s_red[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) mn = fminf(mn, s_red[k]);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) E[r][c] -= mn;
+    }
+
+    // ---- mask, row maxima, exponentials --------------------------------------------------------
+    float pm[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (!(((rvalid >> r) & 1u) && cvalid[c])) E[r][c] = -INFINITY;
+            m = fmaxf(m, E[r][c]);
+        }
+        pm[r] = m;
+    }
+    // lane-distributed per-row scalars: lane l holds the value of row row0 + ((l >> 2) & 15);
+    // readlane(x, 4r) broadcasts row r into an SGPR when a whole-wave multiplier is needed.
+    const bool my_row_in = row0 + ((lane >> 2) & 15) < N;
+    const float rho_l = fmaxf(alpha, reduce16(pm, OpMax()));
+    constexpr float LOG2E = 1.4426950408889634f;
+    // exp(alpha - rho_r): the dustbin-column entry of each row
+    const float ed_l = my_row_in ? exp2f((alpha - rho_l) * LOG2E) : 0.f;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float nrho = -bcast_lane(rho_l, 4 * r) * LOG2E;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) E[r][c] = exp2f(fmaf(E[r][c], LOG2E, nrho));   // exp(-inf) = 0
+    }
+
+    // ---- marginals (3D/models/matching.py:79-82; padded rows/cols keep mass, quirk Q19) ---------
+    const float tot = (float)(ms + ns);
+    const float mu = 1.f / tot, muN = (float)ns / tot, nu = mu, nuM = (float)ms / tot;
+
+    float bj[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) bj[c] = (col0 + c < M) ? 1.f : 0.f;
+    float bM = 1.f;
+    float a_l = 0.f;
+    float aN = 0.f;
+
+    for (int it = 0; it < A.iters; ++it) {
+        // row pass: a_i = mu / (sum_j E_ij b_j + ed_i b_M)
+        float p[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) s = fmaf(E[r][c], bj[c], s);
+            p[r] = s;
+        }
+        const float rs_l = reduce16(p, OpAdd());
+        a_l = my_row_in ? mu / fmaf(ed_l, bM, rs_l) : 0.f;
+        float bs = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) bs += bj[c];
+        bs = wave_sum(bs);
+        aN = muN / (bs + bM);
+        // column pass: b_j = nu / (sum_i E_ij a_i + a_N)
+        float cp[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) cp[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float ar = bcast_lane(a_l, 4 * r);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cp[c] = fmaf(E[r][c], ar, cp[c]);
+        }
+        const float dp = wave_sum((lane & 3) == 0 ? ed_l * a_l : 0.f);
+        VecIO<float, CPL>::store(&s_colpart[w][col0], cp);
+        if (lane == 0) s_dust[w] = dp;
+        __syncthreads();
+        if (t < MAXC) {
+            float c = aN;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) c += s_colpart[k][t];
+            s_b[t] = (t < M) ? nu / c : 0.f;
+        } else if (t == MAXC) {
+            float c = aN;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) c += s_dust[k];
+            s_b[MAXC] = nuM / c;
+        }
+        __syncthreads();
+        VecIO<float, CPL>::load(&s_b[col0], bj);
+        bM = s_b[MAXC];
+    }
+
+    // ---- conf_ij = E_ij a_i b_j exp(-norm)  (exp + [:-1,:-1] slice of matching.py:215-216) -----
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= N) continue;
+        float o[CPL];
+        const float ar = bcast_lane(a_l, 4 * r) * tot;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] = E[r][c] * ar * bj[c];
+        if (VEC) {
+            if (col0 < M) VecIO<TOut, CPL>::store(dst + (unsigned)(row * M + col0), o);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (col0 + c < M) dst[(unsigned)(row * M + col0 + c)] = (TOut)o[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming kernel: E in a global workspace, arbitrary N, M; compute type T
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ float t_log<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* s_scr, int nw) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) s_scr[wave_id()] = v;
+    __syncthreads();
+    T r = 0;
+    for (int k = 0; k < nw; ++k) r += s_scr[k];
+    return r;
+}
+
+template <typename TIn, typename T, typename TOut>
+__global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = A.N, M = A.M;
+    T* s_a = reinterpret_cast<T*>(smem);   // [N+1]
+    T* s_b = s_a + (N + 1);                // [M+1]
+    T* s_ed = s_b + (M + 1);               // [N]
+    T* s_rho = s_ed + N;                   // [N]
+    T* s_part = s_rho + N;                 // [4*256]
+    T* s_scr = s_part + 1024;              // [32]
+    __shared__ int s_cnt[2];
+
+    const int tile = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M;
+    T* Ew = reinterpret_cast<T*>(A.ws) + (size_t)tile * N * M;
+    const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
+    const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
+    const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0;
+    const T alpha = (T)(*A.bin_score);
+
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        for (int i = t; i < N; i += nthr) c0 += sm ? (sm[i] != 0) : 1;
+        for (int j = t; j < M; j += nthr) c1 += tm ? (tm[j] != 0) : 1;
+        if (c0) atomicAdd(&s_cnt[0], c0);
+        if (c1) atomicAdd(&s_cnt[1], c1);
+    }
+    __syncthreads();
+    const int ms = s_cnt[0], ns = s_cnt[1];
+    // marginals are float32 numbers in the reference even for a float64 state (quirk Q22)
+    const float normf = -logf((float)(ms + ns));
+    const float lmuN = logf((float)ns) + normf, lnuM = logf((float)ms) + normf;
+    const T mu = t_exp<T>((T)normf), muN = t_exp<T>((T)lmuN), nu = mu, nuM = t_exp<T>((T)lnuM);
+
+    T xmin = 0;
+    if (A.flags & DR_SK_MINSHIFT) {
+        T mn = (T)INFINITY;
+        for (size_t e = t; e < (size_t)N * M; e += nthr) {
+            T v = (T)src[e];
+            mn = v < mn ? v : mn;
+        }
+        mn = wave_min(mn);
+        if (lane == 0) s_scr[w] = mn;
+        __syncthreads();
+        mn = s_scr[0];
+        for (int k = 1; k < nw; ++k) mn = s_scr[k] < mn ? s_scr[k] : mn;
+        xmin = mn;
+        __syncthreads();
+    }
+    auto zval = [&](int i, int j) -> T {
+        T v = (T)src[(size_t)i * M + j] - xmin;
+        if (apply && ((sm && !sm[i]) || (tm && !tm[j]))) v = -(T)INFINITY;
+        return v;
+    };
+
+    // pass 0: rho_i, E_ij, first row scaling (b = 1)
+    for (int i = w; i < N; i += nw) {
+        T m = alpha;
+        for (int j = lane; j < M; j += WAVE) {
+            T v = zval(i, j);
+            m = v > m ? v : m;
+        }
+        m = wave_max(m);
+        T rs = 0;
+        for (int j = lane; j < M; j += WAVE) {
+            T e = t_exp<T>(zval(i, j) - m);
+            Ew[(size_t)i * M + j] = e;
+            rs += e;
+        }
+        rs = wave_sum(rs);
+        if (lane == 0) {
+            T ed = t_exp<T>(alpha - m);
+            s_rho[i] = m;
+            s_ed[i] = ed;
+            s_a[i] = mu / (rs + ed);
+        }
+    }
+    if (t == 0) s_a[N] = muN / ((T)M + (T)1);
+    for (int j = t; j <= M; j += nthr) s_b[j] = 1;
+    __syncthreads();
+
+    for (int it = 0; it < A.iters; ++it) {
+        if (it > 0) {
+            // row pass with the current b
+            T bs = 0;
+            for (int j = t; j < M; j += nthr) bs += s_b[j];
+            bs = block_sum(bs, s_scr, nw);
+            const T bM = s_b[M];
+            __syncthreads();
+            for (int i = w; i < N; i += nw) {
+                T rs = 0;
+                for (int j = lane; j < M; j += WAVE) rs += Ew[(size_t)i * M + j] * s_b[j];
+                rs = wave_sum(rs);
+                if (lane == 0) s_a[i] = mu / (rs + s_ed[i] * bM);
+            }
+            if (t == 0) s_a[N] = muN / (bs + bM);
+            __syncthreads();
+        }
+        // column pass with the new a
+        const T aN = s_a[N];
+        {
+            T dp = 0;
+            for (int i = t; i < N; i += nthr) dp += s_ed[i] * s_a[i];
+            dp = block_sum(dp, s_scr, nw);
+            if (t == 0) s_b[M] = nuM / (dp + aN);
+        }
+        const int g = t >> 8, jj = t & 255;     // 4 row groups x 256 columns (blockDim = 1024)
+        for (int base = 0; base < M; base += 256) {
+            const int j = base + jj;
+            T acc = 0;
+            if (j < M)
+                for (int i = g; i < N; i += 4) acc += Ew[(size_t)i * M + j] * s_a[i];
+            s_part[g * 256 + jj] = acc;
+            __syncthreads();
+            if (t < 256 && j < M) s_b[j] = nu / (s_part[jj] + s_part[256 + jj] + s_part[512 + jj] + s_part[768 + jj] + aN);
+            __syncthreads();
+        }
+    }
+
+    if (A.flags & DR_SK_OUT_LOG) {
+        // log Z = Z + u + v - norm with u_i = log a_i - rho_i, v_j = log b_j (matching.py:89-91)
+        TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * (N + 1) * (M + 1);
+        const T nrm = (T)normf;
+        for (size_t e = t; e < (size_t)(N + 1) * (M + 1); e += nthr) {
+            const int i = (int)(e / (M + 1)), j = (int)(e % (M + 1));
+            const T z = (i < N && j < M) ? zval(i, j) : alpha;
+            const T u = t_log<T>(s_a[i]) - (i < N ? s_rho[i] : alpha);
+            const T v = t_log<T>(s_b[j]);
+            dst[e] = (TOut)(z + u + v - nrm);
+        }
+    } else {
+        TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M;
+        const T S = t_exp<T>(-(T)normf);
+        for (size_t e = t; e < (size_t)N * M; e += nthr) {
+            const int i = (int)(e / M), j = (int)(e % M);
+            dst[e] = (TOut)(Ew[e] * (s_a[i] * S) * s_b[j]);
+        }
+    }
+}
+
+static size_t stream_lds_bytes(int N, int M, size_t esz) { return ((size_t)3 * N + M + 2 + 1024 + 32) * esz + 16; }
+
+template <typename TIn, typename T, typename TOut>
+static int launch_stream(const SkArgs& a, hipStream_t st) {
+    size_t lds = stream_lds_bytes(a.N, a.M, sizeof(T));
+    if (lds > 160 * 1024) return DR_ENOSUP;
+    if (lds > 64 * 1024)
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_stream_kernel<TIn, T, TOut>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((sk_stream_kernel<TIn, T, TOut>), dim3(a.B), dim3(1024), lds, st, a);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+template <typename TIn, typename TOut, bool VEC>
+static int launch_reg2(const SkArgs& a, hipStream_t st) {
+    if (a.N <= 128 && a.M <= 128) {
+        hipLaunchKernelGGL((sk_reg_kernel<TIn, TOut, 8, 2, VEC>), dim3(a.B), dim3(512), 0, st, a);
+    } else if (a.N <= 128) {
+        hipLaunchKernelGGL((sk_reg_kernel<TIn, TOut, 8, 4, VEC>), dim3(a.B), dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((sk_reg_kernel<TIn, TOut, 16, 4, VEC>), dim3(a.B), dim3(1024), 0, st, a);
+    }
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+template <typename TIn, typename TOut>
+static int launch_reg(const SkArgs& a, hipStream_t st) {
+    if (a.vec_in && a.vec_out) return launch_reg2<TIn, TOut, true>(a, st);
+    return launch_reg2<TIn, TOut, false>(a, st);
+}
+
+static bool reg_path(int N, int M, int flags) {
+    return !(flags & (DR_SK_STRICT | DR_SK_OUT_LOG)) && N <= 256 && M <= 256;
+}
+
+template <typename TIn>
+static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
+                             const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (B < 0 || N < 1 || M < 1 || iters < 1 || !scores || !bin_score || !out) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    constexpr bool in64 = sizeof(TIn) == 8;
+    const bool out32 = !in64 || (flags & DR_SK_OUT_F32);
+    SkArgs a;
+    a.scores = scores; a.src_mask = src_mask; a.tgt_mask = tgt_mask; a.bin_score = bin_score;
+    a.out = out; a.ws = ws; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
+    hipStream_t st = (hipStream_t)stream;
+    if (reg_path(N, M, flags)) {
+        const int cpl = (N <= 128 && M <= 128) ? 2 : 4;
+        const size_t in_al = cpl * sizeof(TIn) > 16 ? 16 : cpl * sizeof(TIn);
+        const size_t osz = out32 ? 4 : 8;
+        const size_t out_al = cpl * osz > 16 ? 16 : cpl * osz;
+        a.vec_in = (M % cpl == 0) && ((uintptr_t)scores % in_al == 0);
+        a.vec_out = (M % cpl == 0) && ((uintptr_t)out % out_al == 0);
+        if (out32) return launch_reg<TIn, float>(a, st);
+        return launch_reg<TIn, double>(a, st);
+    }
+    const bool strict64 = in64 && (flags & DR_SK_STRICT);
+    const size_t need = (size_t)B * N * M * (strict64 ? 8 : 4);
+    if (!ws || ws_bytes < need) return DR_EWORKSPACE;
+    a.vec_in = a.vec_out = 0;
+    if (strict64) {
+        if (out32) return launch_stream<TIn, double, float>(a, st);
+        return launch_stream<TIn, double, double>(a, st);
+    }
+    if (out32) return launch_stream<TIn, float, float>(a, st);
+    return launch_stream<TIn, float, double>(a, st);
+}
+
+}  // namespace dr
+
+extern "C" {
+
+size_t dr_sinkhorn_workspace_bytes(int B, int N, int M, int elem_bytes, int flags) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    if (dr::reg_path(N, M, flags)) return 0;
+    const bool strict64 = elem_bytes == 8 && (flags & DR_SK_STRICT);
+    return (size_t)B * N * M * (strict64 ? 8 : 4);
+}
+
+int dr_sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
+                    const float* bin_score, int iters, int flags, float* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    return dr::sinkhorn_dispatch<float>(B, N, M, scores, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
+                                        workspace_bytes, stream);
+}
+
+int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
+                    const float* bin_score, int iters, int flags, void* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    return dr::sinkhorn_dispatch<double>(B, N, M, scores, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
+                                         workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+"""Parity of dr_sinkhorn_* (HIP, through the C ABI) with the oracle.  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import diffreg_oracle as orc
+from tests.helpers import T, masks, sinkhorn_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [(128, 128, 128, 128, 1.0), (200, 256, 200, 256, 0.37), (96, 80, 70, 61, 1.0), (256, 256, 256, 256, 1.0),
+         (5, 7, 5, 7, 1.0), (1, 1, 1, 1, 1.0), (255, 253, 201, 77, 2.5), (130, 60, 130, 60, 1.0),
+         (64, 250, 64, 250, 1.0), (300, 200, 300, 180, 1.0), (512, 512, 512, 512, 1.0), (257, 33, 257, 33, 1.0)]
+
+
+def rel_err(got, ref):
+    """(max abs error, max relative error over entries that are not negligible)."""
+    got, ref = got.double().cpu(), ref.double()
+    ae = (got - ref).abs().max().item()
+    sel = ref.abs() > 1e-12 * ref.abs().max()
+    re_ = ((got - ref).abs() / ref.abs().clamp_min(1e-30))[sel].max().item()
+    return ae, re_
+
+
+@pytest.mark.parametrize("N,M,nv,mv,alpha", CASES)
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_conf_matches_oracle(N, M, nv, mv, alpha, dt):
+    from diffreg_hip import lib
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    sc, sm, tm = sinkhorn_case(N, M, nv, mv, tdt)
+    a = torch.tensor(alpha)
+    ref = orc.sinkhorn_log(sc, a, 3, sm, tm).exp()[:, :-1, :-1]
+    raw = T(3.0 * synth.hash_normal(1, N * 1000 + M, (1, N, M))).to(tdt)      # unmasked buffer
+    got = lib.sinkhorn(raw.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True)
+    assert got.dtype == tdt and got.shape == (1, N, M)
+    ae, re_ = rel_err(got, ref)
+    assert re_ < 2e-5 and ae < 1e-6, (ae, re_)
+    if dt == "f64":
+        g32 = lib.sinkhorn(raw.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True, out_f32=True)
+        assert g32.dtype == torch.float32
+        e32 = rel_err(g32, ref)
+        assert e32[1] < 2e-5, e32
+        gs = lib.sinkhorn(raw.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True, strict=True)
+        es = rel_err(gs, ref)
+        # float64 arithmetic end to end; the marginals are float32 logs in the reference (Q22), so the
+        # device logf vs host log ulp shows up at the 1e-7 level
+        assert es[1] < 2e-6, es
+
+
+@pytest.mark.parametrize("N,M,nv,mv", [(128, 128, 128, 128), (96, 80, 70, 61), (256, 256, 256, 256), (40, 300, 40, 300)])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_log_output_matches_oracle(N, M, nv, mv, dt):
+    from diffreg_hip import lib
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    sc, sm, tm = sinkhorn_case(N, M, nv, mv, tdt)
+    a = torch.tensor(1.0)
+    ref = orc.sinkhorn_log(sc, a, 3, sm, tm)
+    got = lib.sinkhorn(sc.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), log_output=True, strict=(dt == "f64")).cpu()
+    assert got.shape == (1, N + 1, M + 1)
+    fin = torch.isfinite(ref)
+    assert torch.equal(fin, torch.isfinite(got))
+    tol = 1e-4 if dt == "f32" else 5e-6         # 1e-4 abs on the log assignment
+    err = (got[fin] - ref[fin]).abs().max().item()
+    assert err < tol, err
+
+
+def test_minshift_and_batch_of_different_masks():
+    from diffreg_hip import lib
+    B, N, M = 5, 256, 256
+    x = T(synth.hash_normal(9, 1, (B, N, M))).float() * 2.0 + 3.0
+    a = torch.tensor(1.0)
+    nvs, mvs = [256, 200, 256, 17, 255], [256, 256, 131, 250, 1]
+    sm = torch.stack([torch.arange(N) < n for n in nvs])
+    tm = torch.stack([torch.arange(M) < m for m in mvs])
+    ref = []
+    for b in range(B):
+        s = x[b:b + 1] - x[b].min()
+        ref.append(orc.sinkhorn_conf(s, a, 3, sm[b:b + 1], tm[b:b + 1]))
+    ref = torch.cat(ref)
+    got = lib.sinkhorn(x.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), minshift=True, apply_mask=True)
+    assert rel_err(got, ref)[1] < 2e-5
+    xd = x.double()
+    got64 = lib.sinkhorn(xd.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), minshift=True, apply_mask=True)
+    assert got64.dtype == torch.float64 and rel_err(got64, ref)[1] < 2e-5
+
+
+def test_extreme_scores_do_not_overflow():
+    """the scaling form must survive what the log-domain reference survives (dustbins keep sums > 0)."""
+    from diffreg_hip import lib
+    N, M = 64, 96
+    x = T(synth.hash_normal(4, 2, (1, N, M))).float() * 60.0         # spread of ~ +-200
+    x[0, 3, :] = -300.0
+    x[0, :, 5] = 250.0
+    sm, tm = masks(N, M)
+    a = torch.tensor(1.0)
+    ref = orc.sinkhorn_conf(x, a, 3, sm, tm)
+    got = lib.sinkhorn(x.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV)).cpu()
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref.double()).abs().max().item() < 1e-6
+    big = ref > 1e-8
+    assert ((got.double() - ref.double()).abs() / ref.double().clamp_min(1e-30))[big].max().item() < 1e-4
+
+
+def test_full_size_batch_properties():
+    """BASELINE-size batch (1024 tiles of 256x256): size-independent properties of the output."""
+    from diffreg_hip import lib
+    B, N, M = 1024, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(B, N, M, generator=g) * 2).to(DEV)
+    a = torch.tensor(1.0, device=DEV)
+    conf = lib.sinkhorn(x, a, 3)
+    cs = conf.sum(1)
+    assert torch.isfinite(conf).all() and (conf >= 0).all()
+    assert (cs <= 1.0 + 1e-5).all()
+    again = lib.sinkhorn(x, a, 3)
+    assert torch.equal(conf, again)                       # deterministic
+    perm = torch.randperm(B, generator=g).to(DEV)
+    assert torch.equal(lib.sinkhorn(x[perm].contiguous(), a, 3), conf[perm])   # tiles are independent
+    for b in (0, 511, 1023):
+        sm, tm = masks(N, M)
+        ref = orc.sinkhorn_conf(x[b:b + 1].cpu(), torch.tensor(1.0), 3, sm, tm)
+        assert rel_err(conf[b:b + 1], ref)[1] < 2e-5
+
+
+def test_bad_arguments():
+    from diffreg_hip import lib
+    with pytest.raises(RuntimeError):
+        lib.sinkhorn(torch.zeros(1, 4, 4, device=DEV), torch.tensor(1.0), 0)
