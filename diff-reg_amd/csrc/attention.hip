@@ -1,0 +1,227 @@
+// attention.hip -- masked multi-head softmax attention on the f32-input MFMA (exact fp32 products).
+//
+// Replaces  a = einsum(q,k); masked_fill; a / sqrt(d); softmax; o = einsum(a, v)
+// (3D/models/transformero.py:79-85) without materialising the [L,S,H] score tensor.
+// One workgroup = one (segment, head, 32-query tile); its 4 waves split the 32-key tiles
+// (flash-style running max / sum per wave) and are merged through LDS at the end.
+//   S^T = K Q^T   (keys on the MFMA rows, queries on the lanes: a query's scores are lane-local,
+//                  16 in registers + 16 in lane^32, so the row max/sum need one cross-lane step)
+//   O^T = V^T P^T (d on the MFMA rows, queries on the lanes: the softmax rescale stays lane-local
+//                  and P^T is consumed straight from the score registers as the B operand)
+#include "kernels.h"
+
+namespace dr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int DG, int NDT>
+struct AttnGeom {
+    static constexpr int DP = DG * 8;            // padded head dim for the QK^T k-loop
+    static constexpr int QS = DP + 4;            // LDS row stride of the Q / K tiles
+    static constexpr int VS = NDT * 32;          // LDS row stride of the V tile
+    static constexpr int OS = NDT * 32 + 1;      // LDS row stride of the per-wave O tile
+    static constexpr int m1 = 32 * QS > 32 * VS ? 32 * QS : 32 * VS;
+    static constexpr int m2 = m1 > 32 * OS ? m1 : 32 * OS;
+    static constexpr int WBUF = (m2 + 15) / 16 * 16;      // floats per wave buffer
+    static constexpr int SMEM_FLOATS = 32 * QS + 4 * WBUF + 256;
+};
+
+template <int DG, int NDT>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
+    using G = AttnGeom<DG, NDT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* wbuf = smem + 32 * G::QS + (threadIdx.x >> 6) * G::WBUF;
+    float* s_ml = smem + 32 * G::QS + 4 * G::WBUF;      // [4][32] m, [4][32] l
+
+    // ---- which segment / head / query tile ---------------------------------------------------
+    int seg = blockIdx.z, qbase, kbase, Lq, Lk;
+    if (seg < A.nseg) {
+        qbase = A.q0 + seg * A.qstride; kbase = A.k0 + seg * A.kstride; Lq = A.Lq; Lk = A.Lk;
+    } else {
+        seg -= A.nseg;
+        qbase = A.q0b + seg * A.qstrideb; kbase = A.k0b + seg * A.kstrideb; Lq = A.Lqb; Lk = A.Lkb;
+    }
+    const int qt = blockIdx.x;
+    if (qt * 32 >= Lq) return;
+    const int head = blockIdx.y, d = A.d;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, l31 = lane & 31;
+    const int nv4 = d >> 2;                       // float4 per row (d % 4 == 0)
+
+    // ---- stage the Q tile (zero padded) ---------------------------------------------------------
+    for (int s = t; s < 32 * (G::DP / 4); s += 256) {
+        const int r = s / (G::DP / 4), c4 = s % (G::DP / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int qr = qt * 32 + r;
+        if (qr < Lq && c4 < nv4)
+            v = *reinterpret_cast<const float4*>(A.q + (size_t)(qbase + qr) * A.ldq + head * d + 4 * c4);
+        *reinterpret_cast<float4*>(Qs + r * G::QS + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    const int my_q = qt * 32 + l31;
+    const bool q_valid = my_q < Lq && (!A.qmask || A.qmask[qbase + my_q]);
+
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (Lk + 31) / 32;
+    for (int kt = w; kt < nkt; kt += 4) {
+        // ---- K tile -> LDS ------------------------------------------------------------------------
+        wave_lds_fence();
+        for (int s = lane; s < 32 * (G::DP / 4); s += 64) {
+            const int r = s / (G::DP / 4), c4 = s % (G::DP / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kr = kt * 32 + r;
+            if (kr < Lk && c4 < nv4)
+                v = *reinterpret_cast<const float4*>(A.k + (size_t)(kbase + kr) * A.ldk + head * d + 4 * c4);
+            *reinterpret_cast<float4*>(wbuf + r * G::QS + 4 * c4) = v;
+        }
+        wave_lds_fence();
+        // ---- S^T = K Q^T ----------------------------------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const float* kp = wbuf + l31 * G::QS + 4 * h;
+        const float* qp = Qs + l31 * G::QS + 4 * h;
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
+            const float4 b = *reinterpret_cast<const float4*>(qp + 8 * g);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, sc, 0, 0, 0);
+        }
+        // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float s = sc[r];
+            // transformero.py:82: fill where the query is valid and the key is not; keys beyond the
+            // segment exist only as tile padding
+            bool drop = kk >= Lk;
+            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            s = drop ? -INFINITY : s * A.scale;
+            sc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float alpha = 1.f, psum = 0.f;
+        if (m_new == -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        } else {
+            alpha = expf(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(sc[r] - m_new);
+                sc[r] = p;
+                psum += p;
+            }
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        // ---- V tile -> LDS (same buffer) ---------------------------------------------------------------
+        wave_lds_fence();
+        for (int s = lane; s < 32 * (G::VS / 4); s += 64) {
+            const int r = s / (G::VS / 4), c4 = s % (G::VS / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kr = kt * 32 + r;
+            if (kr < Lk && c4 < nv4)
+                v = *reinterpret_cast<const float4*>(A.v + (size_t)(kbase + kr) * A.ldv + head * d + 4 * c4);
+            *reinterpret_cast<float4*>(wbuf + r * G::VS + 4 * c4) = v;
+        }
+        wave_lds_fence();
+        // ---- O^T += V^T P^T : step r contracts keys (r&3)+8(r>>2) (h = 0 lanes) and +4 (h = 1 lanes) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::VS + l31;
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * i], sc[r], acc[i], 0, 0, 0);
+        }
+    }
+
+    // ---- merge the 4 waves: out = sum_w e^{m_w - m*} O_w / sum_w e^{m_w - m*} l_w ---------------------
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wbuf[l31 * G::OS + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][r];
+    if (h == 0) {
+        s_ml[w * 32 + l31] = m_run;
+        s_ml[128 + w * 32 + l31] = l_run;
+    }
+    __syncthreads();
+    const float* W0 = smem + 32 * G::QS;
+    for (int idx = t; idx < 32 * d; idx += 256) {
+        const int q = idx / d, c = idx % d;
+        if (qt * 32 + q >= Lq) continue;
+        float ms = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ms = fmaxf(ms, s_ml[k * 32 + q]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mk = s_ml[k * 32 + q];
+            const float e = (mk == -INFINITY) ? 0.f : expf(mk - ms);
+            num = fmaf(e, W0[k * G::WBUF + q * G::OS + c], num);
+            den = fmaf(e, s_ml[128 + k * 32 + q], den);
+        }
+        A.out[(size_t)(qbase + qt * 32 + q) * A.ldo + head * d + c] = num / den;
+    }
+}
+
+template <int DG, int NDT>
+static int configure_attn() {
+    using G = AttnGeom<DG, NDT>;
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(G::SMEM_FLOATS * sizeof(float))));
+    return DR_OK;
+}
+
+// > 64 KiB of dynamic LDS needs a function attribute; set it eagerly (never inside a stream capture)
+int attention_configure() {
+    int rc = configure_attn<8, 2>();
+    if (rc == DR_OK) rc = configure_attn<14, 4>();
+    if (rc == DR_OK) rc = configure_attn<17, 5>();
+    return rc;
+}
+
+template <int DG, int NDT>
+static int launch_attn(const AttnArgs& a, hipStream_t st) {
+    using G = AttnGeom<DG, NDT>;
+    const size_t lds = (size_t)G::SMEM_FLOATS * sizeof(float);
+    const int maxLq = a.nseg2 > 0 && a.Lqb > a.Lq ? a.Lqb : a.Lq;
+    dim3 grid((maxLq + 31) / 32, a.H, a.nseg + a.nseg2);
+    hipLaunchKernelGGL((attention_kernel<DG, NDT>), grid, dim3(256), lds, st, a);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t st) {
+    if (a.d % 4 || a.ldq % 4 || a.ldk % 4 || a.ldv % 4) return DR_ENOSUP;
+    if (a.nseg + a.nseg2 <= 0) return DR_OK;
+    if (a.d <= 64) return launch_attn<8, 2>(a, st);       // 2D-3D: d = 64
+    if (a.d <= 112) return launch_attn<14, 4>(a, st);     // 3DMatch: d = 108
+    if (a.d <= 136) return launch_attn<17, 5>(a, st);     // 4DMatch: d = 132
+    return DR_ENOSUP;
+}
+
+}  // namespace dr

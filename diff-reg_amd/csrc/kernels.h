@@ -1,0 +1,65 @@
+// kernels.h -- internal launch interface between the .hip translation units of libdiffreg_hip.
+#pragma once
+#include "common.h"
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------------
+// grouped "NT" GEMM:  out[r][c] = epi( sum_k A[r][k] * W[c][k] )   (nn.Linear without bias)
+// A may be the concatenation [A | A2] along k (torch.cat([x, msg], 2) of transformero.py:91).
+// ---------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_ROTARY = 2 };
+
+struct GemmProblem {
+    const float* A;     // [rows, K1] row-major, leading dimension lda
+    const float* A2;    // [rows, K - K1] or nullptr
+    const float* W;     // [ncols, K] row-major (the nn.Linear weight)
+    float* out;         // [rows, ldo]
+    const float* cosT;  // rotary tables [rows, C/2] (EPI_ROTARY)
+    const float* sinT;
+    int rows, ncols, K, K1, lda, lda2, ldo;
+    int epi;
+    int rot_C;          // rotary: column c uses table index (c % rot_C) / 2
+    float scale;        // applied last (1/sqrt(C) of matching.py:190)
+};
+
+struct GemmBatch {
+    GemmProblem p[4];
+    int n;
+};
+
+int launch_gemm(const GemmBatch& g, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// attention (transformero.py:79-85): segments of queries attending segments of keys
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q;       // [q_rows_total, ldq]   (rotary already applied)
+    const float* k;       // [k_rows_total, ldk]
+    const float* v;
+    float* out;           // [q_rows_total, ldo]
+    const uint8_t* qmask; // per q row (nullable = all valid)
+    const uint8_t* kmask; // per k row
+    int ldq, ldk, ldv, ldo;
+    int H, d;             // heads, head dim (C = H*d)
+    int nseg;             // number of segments
+    // segment g: queries rows [q0 + g*qstride, +Lq), keys rows [k0 + g*kstride, +Lk)
+    int q0, qstride, Lq, k0, kstride, Lk;
+    // second family of segments (self attention over src AND tgt in one launch); nseg2 may be 0
+    int nseg2, q0b, qstrideb, Lqb, k0b, kstrideb, Lkb;
+    float scale;          // 1/sqrt(d)
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+int attention_configure();
+
+// ---------------------------------------------------------------------------------------------
+// row-wise ops
+// ---------------------------------------------------------------------------------------------
+// out[r] = (res ? res[r] : 0) + LayerNorm(x[r]) * g + b      (eps = 1e-5)
+int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
+                     int ldo, int rows, int C, hipStream_t st);
+// rotary tables of warped points: p' = R p + t (R,t per pair, nullable), cos/sin [rows, C/2]
+int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
+                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st);
+
+}  // namespace dr

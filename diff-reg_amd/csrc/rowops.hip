@@ -1,0 +1,101 @@
+// rowops.hip -- HBM-bound row-wise kernels: LayerNorm(+residual), volumetric rotary tables.
+#include "kernels.h"
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------------
+// out[r] = res[r] + LN(x[r]) * g + b   -- one wave per row, row held in registers (C <= 1024)
+// nn.LayerNorm semantics (biased variance, eps inside the sqrt), transformero.py:40-41,88-94
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAX_PER_LANE = 16;   // C <= 64 * 16
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                        const float* __restrict__ b, const float* __restrict__ res,
+                                                        int ldres, float* __restrict__ out, int ldo, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * ldx;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < C ? v[i] - mean : 0.f;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            float y = (v[i] - mean) * rstd * g[c] + b[c];
+            if (res) y += res[(size_t)row * ldres + c];
+            out[(size_t)row * ldo + c] = y;
+        }
+    }
+}
+
+int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
+                     int ldo, int rows, int C, hipStream_t st) {
+    if (C > 64 * LN_MAX_PER_LANE) return DR_ENOSUP;
+    if (rows <= 0) return DR_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VolumetricPositionEncoding (position_encoding.py:16-23,49-87) of optionally warped points
+// (pipeline.py:306  R_forwd * s_pcd + t_forwd).  Tables are stored un-duplicated: [rows, C/2],
+// entry (axis a, frequency k) at a*(C/6) + k is the angle of channels 2*(a*C/6 + k), +1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vol_pe_kernel(const float* __restrict__ xyz, int rows, int rows_per_pair,
+                                                     const float* __restrict__ R, const float* __restrict__ tv, int C,
+                                                     float ox, float oy, float oz, float voxel,
+                                                     const float* __restrict__ freq, float* __restrict__ cosT,
+                                                     float* __restrict__ sinT, float* __restrict__ warped) {
+    const int nf = C / 6, half = C / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * half) return;
+    const int row = idx / half, e = idx % half;
+    const int a = e / nf, k = e % nf;
+    float px = xyz[row * 3 + 0], py = xyz[row * 3 + 1], pz = xyz[row * 3 + 2];
+    float p;
+    if (R) {
+        const float* Rp = R + (size_t)(row / rows_per_pair) * 9;
+        const float* tp = tv + (size_t)(row / rows_per_pair) * 3;
+        // matmul(R, p) + t in the operation order of a 3-term dot product followed by the add
+        p = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Rp[a * 3 + 0], px), __fmul_rn(Rp[a * 3 + 1], py)),
+                                __fmul_rn(Rp[a * 3 + 2], pz)), tp[a]);
+        if (warped && k == 0) warped[row * 3 + a] = p;
+    } else {
+        p = a == 0 ? px : (a == 1 ? py : pz);
+    }
+    const float o = a == 0 ? ox : (a == 1 ? oy : oz);
+    const float vox = __fdiv_rn(__fsub_rn(p, o), voxel);
+    const float ang = __fmul_rn(vox, freq[k]);
+    cosT[idx] = cosf(ang);
+    sinT[idx] = sinf(ang);
+}
+
+int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
+                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st) {
+    if (C % 6) return DR_ENOSUP;
+    const int total = rows * (C / 2);
+    if (total <= 0) return DR_OK;
+    hipLaunchKernelGGL(vol_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, st, xyz, rows, rows_per_pair, R, t, C, ox,
+                       oy, oz, voxel, freq, cosT, sinT, (float*)nullptr);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}  // namespace dr

@@ -1,0 +1,188 @@
+// stateops.hip -- element-wise / reduction kernels on the N x M diffusion state (HBM-bound).
+//   pair_min      x.min() per pair                          (3D/models/pipeline.py:239,264)
+//   ddim_update   predict_noise_from_start + DDIM step      (pipeline.py:246-256, 287-291; 4D/...:188-190)
+//   sigmoid       4D read-out                               (4D/models/pipeline.py:192)
+//   top1_union    mutual_topk_select(k=1, mutual=False)     (pipeline.py:12-65, 275-280)
+#include "kernels.h"
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict__ x, int NM, double* __restrict__ out) {
+    __shared__ double s[16];
+    const double* p = x + (size_t)blockIdx.x * NM;
+    double m = INFINITY;
+    for (int e = threadIdx.x; e < NM; e += 1024) m = fmin(m, p[e]);
+    m = wave_min(m);
+    if (lane_id() == 0) s[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = s[0];
+        for (int k = 1; k < 16; ++k) r = fmin(r, s[k]);
+        out[blockIdx.x] = r;
+    }
+}
+
+int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st) {
+    if (P <= 0) return DR_OK;
+    hipLaunchKernelGGL(pair_min_kernel, dim3(P), dim3(1024), 0, st, x, NM, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x <- x0 * sqrt(a_next) + c * ((sra * xs - x0) / srm1) [+ sigma * xi],  xs = x - shift (3D) or x (4D)
+// dtype bookkeeping of the reference (quirk Q2): the state is float32 on the first step, so
+// xs = float32(x) - float32(min) and sigma*xi are float32 operations there; x0*sqrt(a_next) is a
+// float32 product on every step (0-d float64 tensors do not promote); everything else is float64.
+// Masked entries (x was filled with -inf in place, pipeline.py:296) stay -inf.
+// ---------------------------------------------------------------------------------------------
+struct DdimArgs {
+    double* x;               // [P, N*M] state, updated in place
+    const float* x0;         // [P, N*M] x_start of this step
+    const double* shift;     // [P] per-pair minimum or nullptr
+    const float* noise;      // [P, N*M] xi of this step or nullptr
+    const uint8_t* src_mask; // nullable
+    const uint8_t* tgt_mask;
+    int N, M, first_step;
+    double sra, srm1, c, sigma;
+    float sqrt_an;
+};
+
+__global__ __launch_bounds__(256) void ddim_kernel(DdimArgs A) {
+    const int NM = A.N * A.M;
+    const int pair = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NM) return;
+    const size_t g = (size_t)pair * NM + e;
+    double xs = A.x[g];
+    if (A.shift) {
+        if (A.first_step) xs = (double)((float)xs - (float)A.shift[pair]);
+        else xs = xs - A.shift[pair];
+    }
+    bool masked = false;
+    if (A.src_mask) masked = !A.src_mask[(size_t)pair * A.N + e / A.M] || !A.tgt_mask[(size_t)pair * A.M + e % A.M];
+    const float x0 = A.x0[g];
+    const double eps = (A.sra * xs - (double)x0) / A.srm1;
+    double xn = (double)(x0 * A.sqrt_an) + A.c * eps;
+    if (A.noise) {
+        if (A.first_step) xn = xn + (double)((float)A.sigma * A.noise[g]);
+        else xn = xn + A.sigma * (double)A.noise[g];
+    }
+    A.x[g] = masked ? -INFINITY : xn;
+}
+
+int launch_ddim(const DdimArgs& a, int P, hipStream_t st) {
+    if (P <= 0) return DR_OK;
+    const int NM = a.N * a.M;
+    hipLaunchKernelGGL(ddim_kernel, dim3((NM + 255) / 256, P), dim3(256), 0, st, a);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_f64_kernel(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st) {
+    if (!n) return DR_OK;
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 1.0 / (1.0 + exp(-in[i]));
+}
+int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st) {
+    if (!n) return DR_OK;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-1 union: True at (i, argmax_j conf_ij) for every row and (argmax_i conf_ij, j) for every
+// column, listed row-major as [0, i, j] (int64).  One workgroup per pair; the <= N + M hits are
+// bitonic-sorted by flat index in LDS and de-duplicated.  First occurrence wins a tie.
+// ---------------------------------------------------------------------------------------------
+constexpr int T1_MAX = 4096;   // N + M <= T1_MAX
+
+template <typename T>
+__global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ conf, int N, int M, long long* __restrict__ out,
+                                                          int* __restrict__ count) {
+    __shared__ unsigned s_key[T1_MAX];
+    __shared__ int s_n;
+    const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const T* c = conf + (size_t)pair * N * M;
+    for (int i = t; i < T1_MAX; i += 1024) s_key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // row arg-max: one wave per row
+    for (int i = w; i < N; i += 16) {
+        T best = -INFINITY; int bj = 0x7fffffff;
+        for (int j = lane; j < M; j += 64) {
+            const T v = c[(size_t)i * M + j];
+            if (v > best || (v == best && j < bj) || bj == 0x7fffffff) { best = v; bj = j; }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const T ov = __shfl_xor(best, m); const int oj = __shfl_xor(bj, m);
+            if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+        }
+        if (lane == 0) s_key[i] = (unsigned)(i * M + bj);
+    }
+    // column arg-max: one thread per column (coalesced over j)
+    for (int j = t; j < M; j += 1024) {
+        T best = c[j]; int bi = 0;
+        for (int i = 1; i < N; ++i) {
+            const T v = c[(size_t)i * M + j];
+            if (v > best) { best = v; bi = i; }
+        }
+        s_key[N + j] = (unsigned)(bi * M + j);
+    }
+    __syncthreads();
+    int n2 = 1;
+    while (n2 < N + M) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (t == 0) {
+        int n = 0;
+        unsigned prev = 0xFFFFFFFFu;
+        long long* o = out + (size_t)pair * (N + M) * 3;
+        for (int i = 0; i < N + M; ++i) {
+            const unsigned k = s_key[i];
+            if (k == 0xFFFFFFFFu) break;
+            if (k != prev) {
+                o[n * 3] = 0; o[n * 3 + 1] = k / M; o[n * 3 + 2] = k % M;
+                ++n;
+                prev = k;
+            }
+        }
+        count[pair] = n;
+        s_n = n;
+    }
+}
+
+template <typename T>
+int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st) {
+    if (P <= 0) return DR_OK;
+    if (N + M > T1_MAX || (long)N * M >= 0xFFFFFFFFL) return DR_ENOSUP;
+    hipLaunchKernelGGL((top1_union_kernel<T>), dim3(P), dim3(1024), 0, st, conf, N, M, out, count);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t);
+template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t);
+
+}  // namespace dr
