@@ -62,4 +62,39 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* b, co
 int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
                   float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st);
 
+// ---------------------------------------------------------------------------------------------
+// top-K weighted Procrustes (procrustes.hip)
+// ---------------------------------------------------------------------------------------------
+int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_pcd, const uint8_t* src_mask,
+                      const uint8_t* tgt_mask, int P, int N, int M, int use_mask_len, float sample_rate, float max_cond,
+                      float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// diffusion-state kernels (stateops.hip)
+// ---------------------------------------------------------------------------------------------
+struct DdimArgs {
+    double* x;               // [P, N*M] state, updated in place
+    const float* x0;         // [P, N*M] x_start of this step
+    const double* shift;     // [P] per-pair minimum or nullptr
+    const float* noise;      // [P, N*M] xi of this step or nullptr
+    const uint8_t* src_mask; // nullable
+    const uint8_t* tgt_mask;
+    int N, M, first_step;
+    double sra, srm1, c, sigma;
+    float sqrt_an;
+};
+int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st);
+int launch_ddim(const DdimArgs& a, int P, hipStream_t st);
+int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st);
+int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t st);
+int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st);
+template <typename T>
+int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st);
+
+// sinkhorn.hip (internal form of dr_sinkhorn_*: `shift` = per-tile value subtracted first, nullable)
+int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,
+                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift, const uint8_t* sm, const uint8_t* tm,
+                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace dr

@@ -1,0 +1,482 @@
+// loop.hip -- host-side orchestration of the reverse-diffusion matching loop and the public
+// entry points of the individual ops.  Everything is enqueued on the caller's stream; there is no
+// host synchronisation anywhere, so the whole loop can be captured in a HIP graph.
+//
+// Token layout: all src superpoints of all P pairs, then all tgt superpoints:
+//   rows [0, P*N) = src (pair p at p*N), rows [P*N, P*(N+M)) = tgt (pair p at P*N + p*M).
+// Linear layers / LayerNorm / rotary are row-wise, so the P pairs simply widen the GEMMs; only the
+// attention, the N x M matrices and the Procrustes fit know about pair boundaries.
+#include "kernels.h"
+#include <string.h>
+
+namespace dr {
+
+struct Carver {
+    char* base;
+    size_t off, cap;
+    Carver(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+// buffers of one attention-layer evaluation over `T` token rows
+struct LayerWs {
+    float *qkv, *att, *mrg, *msg, *hid, *g2;
+    static size_t carve(Carver& c, LayerWs& w, size_t T, int C) {
+        w.qkv = c.take<float>(T * 3 * C);
+        w.att = c.take<float>(T * C);
+        w.mrg = c.take<float>(T * C);
+        w.msg = c.take<float>(T * C);
+        w.hid = c.take<float>(T * 2 * C);
+        w.g2 = c.take<float>(T * C);
+        return c.off;
+    }
+};
+
+struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k0 + p*Lk (+Lk)
+    int q0, Lq, k0, Lk;
+};
+
+// One GeometryAttentionLayer call (transformero.py:43-96) on token buffers.
+//   xin rows [xr0, xr0 + xrows) are the queries/residual stream, yin rows [yr0, yr0 + yrows) the
+//   source; out gets rows [xr0, xr0 + xrows).  fam2 may be null.
+static int layer_call(const dr_layer_weights& W, int C, int H, int P, const float* xin, int xr0, int xrows,
+                      const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
+                      const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
+                      hipStream_t st) {
+    const int halfC = C / 2, d = C / H;
+    const bool same = (xin == yin && xr0 == yr0 && xrows == yrows);
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot) {
+        p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
+        p.rows = rows; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.lda2 = 0; p.ldo = 3 * C;
+        p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
+        p.cosT = cosT + (size_t)r0 * halfC; p.sinT = sinT + (size_t)r0 * halfC;
+    };
+    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true);
+    proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
+    proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
+    g.n = 3;
+    (void)same;
+    int rc = launch_gemm(g, st);
+    if (rc) return rc;
+
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = ws.qkv; a.k = ws.qkv + C; a.v = ws.qkv + 2 * C; a.out = ws.att;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.H = H; a.d = d;
+    a.qmask = tokmask; a.kmask = tokmask;
+    a.nseg = P; a.q0 = f1.q0; a.qstride = f1.Lq; a.Lq = f1.Lq; a.k0 = f1.k0; a.kstride = f1.Lk; a.Lk = f1.Lk;
+    if (f2) {
+        a.nseg2 = P; a.q0b = f2->q0; a.qstrideb = f2->Lq; a.Lqb = f2->Lq; a.k0b = f2->k0; a.kstrideb = f2->Lk; a.Lkb = f2->Lk;
+    }
+    a.scale = 1.0f / sqrtf((float)d);
+    rc = launch_attention(a, st);
+    if (rc) return rc;
+
+    // message = norm1(merge(o))
+    memset(&g, 0, sizeof(g));
+    GemmProblem& m = g.p[0];
+    m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.out = ws.mrg + (size_t)xr0 * C;
+    m.rows = xrows; m.ncols = C; m.K = C; m.K1 = C; m.lda = C; m.ldo = C; m.epi = EPI_NONE; m.scale = 1.f;
+    g.n = 1;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st);
+    if (rc) return rc;
+    // message = norm2(mlp(cat[x, message]))
+    memset(&g, 0, sizeof(g));
+    GemmProblem& h = g.p[0];
+    h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.out = ws.hid + (size_t)xr0 * 2 * C;
+    h.rows = xrows; h.ncols = 2 * C; h.K = 2 * C; h.K1 = C; h.lda = C; h.lda2 = C; h.ldo = 2 * C; h.epi = EPI_RELU; h.scale = 1.f;
+    g.n = 1;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& o = g.p[0];
+    o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.out = ws.g2 + (size_t)xr0 * C;
+    o.rows = xrows; o.ncols = C; o.K = 2 * C; o.K1 = 2 * C; o.lda = 2 * C; o.ldo = C; o.epi = EPI_NONE; o.scale = 1.f;
+    g.n = 1;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    // e = x + message
+    return launch_layernorm(ws.g2 + (size_t)xr0 * C, C, W.norm2_w, W.norm2_b, xin + (size_t)xr0 * C, C, out + (size_t)xr0 * C, C,
+                            xrows, C, st);
+}
+
+// workspace of one denoiser + matching-head evaluation
+struct DenoiseWs {
+    LayerWs lw;
+    float *fa, *fb, *cosT, *sinT, *proj, *sim;
+    static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C) {
+        const size_t T = (size_t)P * (N + M);
+        LayerWs::carve(c, w.lw, T, C);
+        w.fa = c.take<float>(T * C);
+        w.fb = c.take<float>(T * C);
+        w.cosT = c.take<float>(T * (C / 2));
+        w.sinT = c.take<float>(T * (C / 2));
+        w.proj = c.take<float>(T * C);
+        w.sim = c.take<float>((size_t)P * N * M);
+    }
+};
+
+// six layers self, cross, ... (pipeline.py:142; transformero.py:170-186) starting from feat0,
+// then the matching head's projection + N x M similarity (matching.py:173-207).  PE tables must be
+// filled.  On return *final points at the buffer holding the refined features and ws.sim holds sim.
+static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
+                            const uint8_t* tokmask, DenoiseWs& ws, const float** final_feats, hipStream_t st) {
+    const int C = cfg.C, H = cfg.H, T = P * (N + M), PN = P * N, PM = P * M;
+    const float* cur = feat0;
+    float* bufs[2] = {ws.fa, ws.fb};
+    int which = 0;
+    const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        float* nxt = bufs[which];
+        int rc;
+        if (l % 2 == 0) {
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st);
+            if (rc) return rc;
+        } else {
+            // src attends tgt, then tgt attends the UPDATED src (quirk Q11)
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st);
+            if (rc) return rc;
+            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
+            if (rc) return rc;
+        }
+        cur = nxt;
+        which ^= 1;
+    }
+    *final_feats = cur;
+    // matching head: src_proj on BOTH sides (quirk Q1), rotary, / sqrt(C)
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& p = g.p[0];
+    p.A = cur; p.W = w.src_proj; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
+    p.epi = EPI_ROTARY; p.rot_C = C; p.cosT = ws.cosT; p.sinT = ws.sinT; p.scale = 1.0f / sqrtf((float)C);
+    g.n = 1;
+    int rc = launch_gemm(g, st);
+    if (rc) return rc;
+    // sim[p] = a_p b_p^T : one NT GEMM per pair, up to 4 per launch
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        memset(&g, 0, sizeof(g));
+        g.n = (P - p0) < 4 ? (P - p0) : 4;
+        for (int i = 0; i < g.n; ++i) {
+            GemmProblem& q = g.p[i];
+            const int pr = p0 + i;
+            q.A = ws.proj + (size_t)pr * N * C; q.W = ws.proj + ((size_t)PN + (size_t)pr * M) * C;
+            q.out = ws.sim + (size_t)pr * N * M; q.rows = N; q.ncols = M; q.K = C; q.K1 = C; q.lda = C; q.ldo = M;
+            q.epi = EPI_NONE; q.scale = 1.f;
+        }
+        rc = launch_gemm(g, st);
+        if (rc) return rc;
+    }
+    return DR_OK;
+}
+
+static int fill_pe(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* s_pcd,
+                   const float* Rf, const float* tf, const float* t_pcd, bool do_src, bool do_tgt, DenoiseWs& ws,
+                   hipStream_t st) {
+    const int halfC = cfg.C / 2;
+    int rc = DR_OK;
+    if (do_src)
+        rc = launch_vol_pe(s_pcd, P * N, N, Rf, tf, cfg.C, cfg.origin[0], cfg.origin[1], cfg.origin[2], cfg.voxel, w.pe_freq,
+                           ws.cosT, ws.sinT, st);
+    if (rc == DR_OK && do_tgt)
+        rc = launch_vol_pe(t_pcd, P * M, M, nullptr, nullptr, cfg.C, cfg.origin[0], cfg.origin[1], cfg.origin[2], cfg.voxel,
+                           w.pe_freq, ws.cosT + (size_t)P * N * halfC, ws.sinT + (size_t)P * N * halfC, st);
+    return rc;
+}
+
+struct LoopWs {
+    DenoiseWs dw;
+    float *feat0, *wconf, *x0, *R, *t, *Rf, *tf, *conf32;
+    double *x, *dmin, *cond;
+    int* ok;
+    uint8_t* tokmask;
+    void* skws;
+    size_t skws_bytes;
+    static size_t carve(Carver& c, LoopWs& w, const dr_loop_config& cfg, int P, int N, int M) {
+        const size_t T = (size_t)P * (N + M), NM = (size_t)P * N * M;
+        DenoiseWs::carve(c, w.dw, P, N, M, cfg.C);
+        w.feat0 = c.take<float>(T * cfg.C);
+        w.wconf = c.take<float>(NM);
+        w.x0 = c.take<float>(NM);
+        w.conf32 = c.take<float>(NM);
+        w.x = c.take<double>(NM);
+        w.dmin = c.take<double>(P);
+        w.cond = c.take<double>(P);
+        w.R = c.take<float>((size_t)P * 9);
+        w.t = c.take<float>((size_t)P * 3);
+        w.Rf = c.take<float>((size_t)P * 9);
+        w.tf = c.take<float>((size_t)P * 3);
+        w.ok = c.take<int>(P);
+        w.tokmask = c.take<uint8_t>(T);
+        const int strict = (cfg.flags & DR_LOOP_STRICT_F64) ? DR_SK_STRICT : 0;
+        size_t a = dr_sinkhorn_workspace_bytes(P, N, M, 8, strict);
+        size_t b = dr_sinkhorn_workspace_bytes(P, N, M, 4, 0);
+        w.skws_bytes = a > b ? a : b;
+        w.skws = w.skws_bytes ? (void*)c.take<char>(w.skws_bytes) : nullptr;
+        return c.off + 256;
+    }
+};
+
+}  // namespace dr
+
+using namespace dr;
+
+extern "C" {
+
+int dr_init(void) { return attention_configure(); }
+
+int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t, float origin_x,
+                  float origin_y, float origin_z, float voxel, const float* freq, float* cos_out, float* sin_out,
+                  void* stream) {
+    if (rows < 0 || C <= 0 || !xyz || !freq || !cos_out || !sin_out || rows_per_pair < 1) return DR_EINVAL;
+    if ((R == nullptr) != (t == nullptr)) return DR_EINVAL;
+    return launch_vol_pe(xyz, rows, rows_per_pair, R, t, C, origin_x, origin_y, origin_z, voxel, freq, cos_out, sin_out,
+                         (hipStream_t)stream);
+}
+
+int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, float* out, int epilogue, const float* cos_t,
+                  const float* sin_t, int rot_C, float scale, void* stream) {
+    if (rows < 0 || ncols <= 0 || K <= 0 || !x || !W || !out) return DR_EINVAL;
+    if ((epilogue & EPI_ROTARY) && (!cos_t || !sin_t || rot_C <= 0 || (rot_C & 1))) return DR_EINVAL;
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& p = g.p[0];
+    p.A = x; p.W = W; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = K; p.ldo = ncols;
+    p.epi = epilogue; p.cosT = cos_t; p.sinT = sin_t; p.rot_C = rot_C; p.scale = scale;
+    g.n = 1;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+size_t dr_attention_layer_workspace_bytes(int P, int Lx, int Ly, int C) {
+    Carver c(nullptr, 0);
+    LayerWs w;
+    const size_t T = (size_t)P * (Lx + Ly);
+    LayerWs::carve(c, w, T, C);
+    c.take<float>(T * C);          // x|y token buffer
+    c.take<float>(T * C);          // output token buffer
+    c.take<float>(T * (C / 2));    // cos
+    c.take<float>(T * (C / 2));    // sin
+    c.take<uint8_t>(T);
+    return c.off + 256;
+}
+
+int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int Lx, int Ly, const float* x, const float* y,
+                           const float* cos_x, const float* sin_x, const float* cos_y, const float* sin_y,
+                           const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!w || !x || !y || !out || P < 1 || Lx < 1 || Ly < 1 || C % H || (C / H) % 4 || C % 4) return DR_EINVAL;
+    if ((x_mask == nullptr) != (y_mask == nullptr)) return DR_EINVAL;
+    if (workspace_bytes < dr_attention_layer_workspace_bytes(P, Lx, Ly, C) || !workspace) return DR_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    LayerWs lw;
+    const size_t T = (size_t)P * (Lx + Ly), PX = (size_t)P * Lx, PY = (size_t)P * Ly;
+    const int halfC = C / 2;
+    LayerWs::carve(c, lw, T, C);
+    float* tok = c.take<float>(T * C);
+    float* otok = c.take<float>(T * C);
+    float* cosT = c.take<float>(T * halfC);
+    float* sinT = c.take<float>(T * halfC);
+    uint8_t* mask = c.take<uint8_t>(T);
+    DR_HIP_CHECK(hipMemcpyAsync(tok, x, PX * C * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(tok + PX * C, y, PY * C * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(cosT, cos_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(cosT + PX * halfC, cos_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(sinT, sin_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(sinT + PX * halfC, sin_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
+    if (x_mask) {
+        DR_HIP_CHECK(hipMemcpyAsync(mask, x_mask, PX, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(mask + PX, y_mask, PY, hipMemcpyDeviceToDevice, st));
+    }
+    const Family f{0, Lx, (int)PX, Ly};
+    int rc = layer_call(*w, C, H, P, tok, 0, (int)PX, tok, (int)PX, (int)PY, cosT, sinT, x_mask ? mask : nullptr, f, nullptr, lw,
+                        otok, st);
+    if (rc) return rc;
+    DR_HIP_CHECK(hipMemcpyAsync(out, otok, PX * C * 4, hipMemcpyDeviceToDevice, st));
+    return DR_OK;
+}
+
+int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_pcd, const float* tgt_pcd,
+                      const uint8_t* src_mask, const uint8_t* tgt_mask, int use_mask_len, float sample_rate,
+                      float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd, double* condition,
+                      int32_t* solution_mask, int32_t* topk_idx, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || !conf || !src_pcd || !tgt_pcd || !R || !t || !R_forwd || !t_forwd || !condition || !solution_mask)
+        return DR_EINVAL;
+    return launch_procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, P, N, M, use_mask_len, sample_rate, max_condition_num,
+                             R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream);
+}
+
+int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
+    return launch_top1_union<double>(conf, P, N, M, (long long*)matches, count, (hipStream_t)stream);
+}
+int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
+    return launch_top1_union<float>(conf, P, N, M, (long long*)matches, count, (hipStream_t)stream);
+}
+
+static int check_cfg(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M) {
+    if (!cfg || !w || P < 1 || N < 1 || M < 1) return DR_EINVAL;
+    if (cfg->C % cfg->H || (cfg->C / cfg->H) % 4 || cfg->C % 6 || cfg->n_layers < 1 || cfg->sk_iters < 1) return DR_EINVAL;
+    if (!w->layers || !w->src_proj || !w->bin_score || !w->pe_freq) return DR_EINVAL;
+    if (cfg->variant != DR_VARIANT_3DMATCH && cfg->variant != DR_VARIANT_4DMATCH) return DR_EINVAL;
+    return DR_OK;
+}
+
+size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, int M) {
+    if (!cfg || P < 1 || N < 1 || M < 1) return 0;
+    Carver c(nullptr, 0);
+    LoopWs w;
+    return LoopWs::carve(c, w, *cfg, P, N, M);
+}
+
+int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M, const float* src_feats,
+                          const float* tgt_feats, const float* s_pcd_warped, const float* t_pcd, const uint8_t* src_mask,
+                          const uint8_t* tgt_mask, float* src_out, float* tgt_out, float* conf, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    int rc = check_cfg(cfg, w, P, N, M);
+    if (rc) return rc;
+    if (!src_feats || !tgt_feats || !s_pcd_warped || !t_pcd || !conf) return DR_EINVAL;
+    if ((src_mask == nullptr) != (tgt_mask == nullptr)) return DR_EINVAL;
+    if (!workspace || workspace_bytes < dr_denoise_loop_workspace_bytes(cfg, P, N, M)) return DR_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    LoopWs L;
+    LoopWs::carve(c, L, *cfg, P, N, M);
+    const int C = cfg->C;
+    const size_t PN = (size_t)P * N, PM = (size_t)P * M;
+    DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
+    if (src_mask) {
+        DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
+    }
+    rc = fill_pe(*cfg, *w, P, N, M, s_pcd_warped, nullptr, nullptr, t_pcd, true, true, L.dw, st);
+    if (rc) return rc;
+    const float* fin = nullptr;
+    rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, src_mask ? L.tokmask : nullptr, L.dw, &fin, st);
+    if (rc) return rc;
+    if (src_out) DR_HIP_CHECK(hipMemcpyAsync(src_out, fin, PN * C * 4, hipMemcpyDeviceToDevice, st));
+    if (tgt_out) DR_HIP_CHECK(hipMemcpyAsync(tgt_out, fin + PN * C, PM * C * 4, hipMemcpyDeviceToDevice, st));
+    return sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters,
+                        DR_SK_OUT_CONF | (src_mask ? DR_SK_APPLY_MASK : 0), conf, L.skws, L.skws_bytes, st);
+}
+
+int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M, const float* src_feats,
+                    const float* tgt_feats, const float* s_pcd, const float* t_pcd, const uint8_t* src_mask,
+                    const uint8_t* tgt_mask, const float* x_T, const float* noise, double* conf, double* x_final,
+                    int64_t* matches, int32_t* match_count, float* R_final, float* t_final, const dr_loop_trace* trace,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_cfg(cfg, w, P, N, M);
+    if (rc) return rc;
+    if (!src_feats || !tgt_feats || !s_pcd || !t_pcd || !x_T || !conf || cfg->steps < 1 || !cfg->h_alphas_cumprod || !cfg->h_times)
+        return DR_EINVAL;
+    if ((src_mask == nullptr) != (tgt_mask == nullptr)) return DR_EINVAL;
+    const bool v4d = cfg->variant == DR_VARIANT_4DMATCH;
+    if (v4d && !noise) return DR_EINVAL;
+    if ((matches == nullptr) != (match_count == nullptr) || (R_final == nullptr) != (t_final == nullptr)) return DR_EINVAL;
+    if (!workspace || workspace_bytes < dr_denoise_loop_workspace_bytes(cfg, P, N, M)) return DR_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    LoopWs L;
+    LoopWs::carve(c, L, *cfg, P, N, M);
+    const int C = cfg->C;
+    const size_t PN = (size_t)P * N, PM = (size_t)P * M, NM = (size_t)P * N * M;
+    const uint8_t* tokmask = src_mask ? L.tokmask : nullptr;
+    const int strict = (cfg->flags & DR_LOOP_STRICT_F64) ? DR_SK_STRICT : 0;
+    const int mflag = src_mask ? DR_SK_APPLY_MASK : 0;
+
+    DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
+    DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
+    if (src_mask) {
+        DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
+    }
+    rc = launch_f32_to_f64(x_T, L.x, NM, st);     // exact widening; step 1 keeps float32 semantics
+    if (rc) return rc;
+    // the target cloud never moves: its position code is computed once (the reference recomputes it
+    // every step, transformero.py:166)
+    rc = fill_pe(*cfg, *w, P, N, M, s_pcd, nullptr, nullptr, t_pcd, false, true, L.dw, st);
+    if (rc) return rc;
+
+    const double* ac = cfg->h_alphas_cumprod;
+    for (int k = 0; k < cfg->steps; ++k) {
+        const int tcur = cfg->h_times[k], tnext = cfg->h_times[k + 1];
+        // -- x <- x - x.min() (3D only, pipeline.py:239); mask; Sinkhorn; exp; slice; float32 (pipeline.py:293-302)
+        const double* shift = nullptr;
+        if (!v4d) {
+            rc = launch_pair_min(L.x, P, N * M, L.dmin, st);
+            if (rc) return rc;
+            shift = L.dmin;
+        }
+        rc = sinkhorn_f64(P, N, M, L.x, shift, src_mask, tgt_mask, w->bin_score, cfg->sk_iters,
+                          DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
+        if (rc) return rc;
+        // -- denoising_soft_procrustes (pipeline.py:304)
+        rc = launch_procrustes(L.wconf, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
+                               cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st);
+        if (rc) return rc;
+        if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
+        if (trace && trace->t_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->t_forwd + (size_t)k * P * 3, L.tf, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
+        if (trace && trace->cond) DR_HIP_CHECK(hipMemcpyAsync(trace->cond + (size_t)k * P, L.cond, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+        // -- position code of the warped source (pipeline.py:306, transformero.py:165)
+        rc = fill_pe(*cfg, *w, P, N, M, s_pcd, L.Rf, L.tf, t_pcd, true, false, L.dw, st);
+        if (rc) return rc;
+        // -- denoising_transformer + denoising_coarse_matching (pipeline.py:243-244)
+        const float* fin = nullptr;
+        rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, &fin, st);
+        if (rc) return rc;
+        rc = sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0,
+                          L.skws, L.skws_bytes, st);
+        if (rc) return rc;
+        if (trace && trace->x0) DR_HIP_CHECK(hipMemcpyAsync(trace->x0 + (size_t)k * NM, L.x0, NM * 4, hipMemcpyDeviceToDevice, st));
+        // -- DDIM update (pipeline.py:246-256)
+        const double a = ac[tcur], an = ac[tnext];
+        DdimArgs d;
+        d.x = L.x; d.x0 = L.x0; d.shift = shift; d.noise = v4d ? noise + (size_t)k * NM : nullptr;
+        d.src_mask = src_mask; d.tgt_mask = tgt_mask; d.N = N; d.M = M; d.first_step = (k == 0);
+        d.sra = sqrt(1.0 / a); d.srm1 = sqrt(1.0 / a - 1.0);
+        d.sigma = 1.0 * sqrt((1.0 - a / an) * (1.0 - an) / (1.0 - a));
+        d.c = sqrt(1.0 - an - d.sigma * d.sigma);
+        d.sqrt_an = (float)sqrt(an);
+        rc = launch_ddim(d, P, st);
+        if (rc) return rc;
+    }
+    if (x_final) DR_HIP_CHECK(hipMemcpyAsync(x_final, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
+
+    // -- read-out
+    if (v4d) {
+        rc = launch_sigmoid(L.x, conf, NM, st);                       // 4D/models/pipeline.py:192
+        if (rc) return rc;
+    } else {
+        rc = launch_pair_min(L.x, P, N * M, L.dmin, st);              // pipeline.py:264-272
+        if (rc) return rc;
+        rc = sinkhorn_f64(P, N, M, L.x, L.dmin, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict,
+                          conf, L.skws, L.skws_bytes, st);
+        if (rc) return rc;
+        if (matches) {
+            rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st);
+            if (rc) return rc;
+        }
+    }
+    if (R_final) {
+        // soft_procrustes on float32(conf): the well-defined value of pipeline.py:282 (quirk Q3)
+        rc = launch_f64_to_f32(conf, L.conf32, NM, st);
+        if (rc) return rc;
+        rc = launch_procrustes(L.conf32, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
+                               cfg->max_condition_num, R_final, t_final, L.Rf, L.tf, L.cond, L.ok, nullptr, st);
+        if (rc) return rc;
+    }
+    return DR_OK;
+}
+
+}  // extern "C"

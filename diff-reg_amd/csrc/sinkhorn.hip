@@ -17,7 +17,7 @@
 //
 //  sk_stream_kernel  any size / strict input dtype / log output: E is kept in a global workspace
 //                    (L2/MALL resident), one workgroup per tile, same scaling iteration.
-#include "common.h"
+#include "kernels.h"
 
 namespace dr {
 
@@ -28,6 +28,7 @@ struct SkArgs {
     const float* bin_score;
     void* out;
     void* ws;
+    const double* shift;   // per-tile value subtracted from the scores on load (nullable)
     int B, N, M, iters, flags, vec_in, vec_out;
 };
 
@@ -77,9 +78,10 @@ template <typename T, int CPL>
 struct VecIO;
 template <>
 struct VecIO<float, 4> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4], double sh) {
         float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        const float s = (float)sh;
+        v[0] = t.x - s; v[1] = t.y - s; v[2] = t.z - s; v[3] = t.w - s;
     }
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -87,10 +89,10 @@ struct VecIO<float, 4> {
 };
 template <>
 struct VecIO<double, 4> {
-    static __device__ __forceinline__ void load(const double* p, float (&v)[4]) {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[4], double sh) {
         double2 t0 = *reinterpret_cast<const double2*>(p);
         double2 t1 = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = (float)t0.x; v[1] = (float)t0.y; v[2] = (float)t1.x; v[3] = (float)t1.y;
+        v[0] = (float)(t0.x - sh); v[1] = (float)(t0.y - sh); v[2] = (float)(t1.x - sh); v[3] = (float)(t1.y - sh);
     }
     static __device__ __forceinline__ void store(double* p, const float (&v)[4]) {
         *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]);
@@ -99,9 +101,10 @@ struct VecIO<double, 4> {
 };
 template <>
 struct VecIO<float, 2> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2], double sh) {
         float2 t = *reinterpret_cast<const float2*>(p);
-        v[0] = t.x; v[1] = t.y;
+        const float s = (float)sh;
+        v[0] = t.x - s; v[1] = t.y - s;
     }
     static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
         *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
@@ -109,9 +112,9 @@ struct VecIO<float, 2> {
 };
 template <>
 struct VecIO<double, 2> {
-    static __device__ __forceinline__ void load(const double* p, float (&v)[2]) {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[2], double sh) {
         double2 t = *reinterpret_cast<const double2*>(p);
-        v[0] = (float)t.x; v[1] = (float)t.y;
+        v[0] = (float)(t.x - sh); v[1] = (float)(t.y - sh);
     }
     static __device__ __forceinline__ void store(double* p, const float (&v)[2]) {
         *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]);
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
     TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M;
     const float alpha = *A.bin_score;
     const int row0 = w * RPW, col0 = lane * CPL;
+    const double sh = A.shift ? A.shift[tile] : 0.0;
 
     // ---- issue all tile loads first ----------------------------------------------------------
     float E[RPW][CPL];
@@ -147,11 +151,11 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
         for (int c = 0; c < CPL; ++c) E[r][c] = -INFINITY;
         if (row < N) {
             if (VEC) {
-                if (col0 < M) VecIO<TIn, CPL>::load(src + (unsigned)(row * M + col0), E[r]);
+                if (col0 < M) VecIO<TIn, CPL>::load(src + (unsigned)(row * M + col0), E[r], sh);
             } else {
 #pragma unroll
                 for (int c = 0; c < CPL; ++c)
-                    if (col0 + c < M) E[r][c] = (float)src[(unsigned)(row * M + col0 + c)];
+                    if (col0 + c < M) E[r][c] = (float)(src[(unsigned)(row * M + col0 + c)] - (TIn)sh);
             }
         }
     }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
             s_b[MAXC] = nuM / c;
         }
         __syncthreads();
-        VecIO<float, CPL>::load(&s_b[col0], bj);
+        VecIO<float, CPL>::load(&s_b[col0], bj, 0.0);
         bM = s_b[MAXC];
     }
 
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
     const float lmuN = logf((float)ns) + normf, lnuM = logf((float)ms) + normf;
     const T mu = t_exp<T>((T)normf), muN = t_exp<T>((T)lmuN), nu = mu, nuM = t_exp<T>((T)lnuM);
 
-    T xmin = 0;
+    T xmin = A.shift ? (T)A.shift[tile] : (T)0;
     if (A.flags & DR_SK_MINSHIFT) {
         T mn = (T)INFINITY;
         for (size_t e = t; e < (size_t)N * M; e += nthr) {
@@ -498,16 +502,16 @@ static bool reg_path(int N, int M, int flags) {
 }
 
 template <typename TIn>
-static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
-                             const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes,
-                             void* stream) {
+static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const double* shift, const uint8_t* src_mask,
+                             const uint8_t* tgt_mask, const float* bin_score, int iters, int flags, void* out, void* ws,
+                             size_t ws_bytes, void* stream) {
     if (B < 0 || N < 1 || M < 1 || iters < 1 || !scores || !bin_score || !out) return DR_EINVAL;
     if (B == 0) return DR_OK;
     constexpr bool in64 = sizeof(TIn) == 8;
     const bool out32 = !in64 || (flags & DR_SK_OUT_F32);
     SkArgs a;
     a.scores = scores; a.src_mask = src_mask; a.tgt_mask = tgt_mask; a.bin_score = bin_score;
-    a.out = out; a.ws = ws; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
+    a.out = out; a.ws = ws; a.shift = shift; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
     if (reg_path(N, M, flags)) {
         const int cpl = (N <= 128 && M <= 128) ? 2 : 4;
@@ -531,6 +535,15 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const uint8
     return launch_stream<TIn, float, double>(a, st);
 }
 
+int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,
+                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    return sinkhorn_dispatch<float>(B, N, M, scores, nullptr, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
+}
+int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift, const uint8_t* sm, const uint8_t* tm,
+                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    return sinkhorn_dispatch<double>(B, N, M, scores, shift, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
+}
+
 }  // namespace dr
 
 extern "C" {
@@ -545,14 +558,14 @@ size_t dr_sinkhorn_workspace_bytes(int B, int N, int M, int elem_bytes, int flag
 int dr_sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
                     const float* bin_score, int iters, int flags, float* out, void* workspace, size_t workspace_bytes,
                     void* stream) {
-    return dr::sinkhorn_dispatch<float>(B, N, M, scores, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
+    return dr::sinkhorn_dispatch<float>(B, N, M, scores, nullptr, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
                                         workspace_bytes, stream);
 }
 
 int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
                     const float* bin_score, int iters, int flags, void* out, void* workspace, size_t workspace_bytes,
                     void* stream) {
-    return dr::sinkhorn_dispatch<double>(B, N, M, scores, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
+    return dr::sinkhorn_dispatch<double>(B, N, M, scores, nullptr, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
                                          workspace_bytes, stream);
 }
 

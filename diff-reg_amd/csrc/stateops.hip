@@ -37,17 +37,6 @@ int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st)
 // float32 product on every step (0-d float64 tensors do not promote); everything else is float64.
 // Masked entries (x was filled with -inf in place, pipeline.py:296) stay -inf.
 // ---------------------------------------------------------------------------------------------
-struct DdimArgs {
-    double* x;               // [P, N*M] state, updated in place
-    const float* x0;         // [P, N*M] x_start of this step
-    const double* shift;     // [P] per-pair minimum or nullptr
-    const float* noise;      // [P, N*M] xi of this step or nullptr
-    const uint8_t* src_mask; // nullable
-    const uint8_t* tgt_mask;
-    int N, M, first_step;
-    double sra, srm1, c, sigma;
-    float sqrt_an;
-};
 
 __global__ __launch_bounds__(256) void ddim_kernel(DdimArgs A) {
     const int NM = A.N * A.M;
@@ -88,6 +77,17 @@ __global__ __launch_bounds__(256) void f32_to_f64_kernel(const float* __restrict
 int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st) {
     if (!n) return DR_OK;
     hipLaunchKernelGGL(f32_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t st) {
+    if (!n) return DR_OK;
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

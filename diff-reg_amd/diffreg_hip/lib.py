@@ -33,6 +33,48 @@ SIGNATURES = {
 }
 
 
+class LayerWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("q_proj", "k_proj", "v_proj", "merge", "mlp0", "mlp2", "norm1_w", "norm1_b",
+                                        "norm2_w", "norm2_b")]
+
+
+class LoopConfig(ctypes.Structure):
+    _fields_ = [("variant", c_int), ("C", c_int), ("H", c_int), ("n_layers", c_int), ("steps", c_int),
+                ("sk_iters", c_int), ("voxel", c_float), ("origin", c_float * 3), ("sample_rate", c_float),
+                ("max_condition_num", c_float), ("flags", c_int), ("h_alphas_cumprod", c_void_p),
+                ("h_times", c_void_p)]
+
+
+class LoopWeights(ctypes.Structure):
+    _fields_ = [("layers", ctypes.POINTER(LayerWeights)), ("src_proj", c_void_p), ("bin_score", c_void_p),
+                ("pe_freq", c_void_p)]
+
+
+class LoopTrace(ctypes.Structure):
+    _fields_ = [("x0", c_void_p), ("R_forwd", c_void_p), ("t_forwd", c_void_p), ("cond", c_void_p)]
+
+
+_P = ctypes.POINTER
+SIGNATURES.update({
+    "dr_init": (c_int, []),
+    "dr_vol_pe_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_linear_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                              c_float, c_void_p]),
+    "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
+                               [c_void_p, c_size_t, c_void_p]),
+    "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
+    "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),
+    "dr_denoise_loop": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 14 +
+                        [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
+    "dr_denoiser_match_f32": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 9 +
+                              [c_void_p, c_size_t, c_void_p]),
+})
+
+
 def _bind(table):
     for name, (res, args) in table.items():
         fn = getattr(_lib, name)
@@ -41,6 +83,16 @@ def _bind(table):
 
 
 _bind(SIGNATURES)
+_INIT_DONE = False
+
+
+def ensure_init():
+    """kernel attributes (dynamic LDS) -- needs a GPU, so it runs lazily before the first launch."""
+    global _INIT_DONE
+    if not _INIT_DONE:
+        check(_lib.dr_init())
+        _INIT_DONE = True
+
 
 SK_OUT_CONF, SK_OUT_LOG, SK_MINSHIFT, SK_APPLY_MASK, SK_OUT_F32, SK_STRICT = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10
 
@@ -108,3 +160,106 @@ def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift
     check(fn(B, N, M, ptr(scores), ptr(sm), ptr(tm), ptr(bs), int(iters), flags, ptr(out), ptr(ws), wsb,
              stream_of(scores)))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers of the remaining ops (all tensors on the ROCm device, float32 unless noted)
+# ------------------------------------------------------------------------------------------------
+def pe_freq(C, device):
+    """div_term of VolumetricPositionEncoding.forward (position_encoding.py:58), computed by torch so
+    that the table is the reference's own."""
+    import math
+    d = C // 3
+    # evaluated on the host like the oracle/reference CPU run, then moved (a device exp may differ by an ulp)
+    return torch.exp(torch.arange(0, d, 2, dtype=torch.float) * (-math.log(10000.0) / d)).to(device).contiguous()
+
+
+def vol_pe(xyz, C, origin, voxel, R=None, t=None, rows_per_pair=None):
+    """xyz [rows,3] -> (cos, sin) tables [rows, C/2] of the (optionally warped) points."""
+    ensure_init()
+    xyz = xyz.contiguous().float()
+    rows = xyz.shape[0]
+    cos = torch.empty(rows, C // 2, device=xyz.device)
+    sin = torch.empty_like(cos)
+    fr = pe_freq(C, xyz.device)
+    if R is not None:
+        R = R.contiguous().float()
+        t = t.contiguous().float()
+    check(_lib.dr_vol_pe_f32(rows, rows_per_pair or max(rows, 1), C, ptr(xyz), ptr(R), ptr(t), float(origin[0]),
+                             float(origin[1]), float(origin[2]), float(voxel), ptr(fr), ptr(cos), ptr(sin), stream_of(xyz)))
+    return cos, sin
+
+
+def linear(x, W, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
+    ensure_init()
+    x = x.contiguous()
+    W = W.contiguous()
+    out = torch.empty(x.shape[0], W.shape[0], device=x.device)
+    check(_lib.dr_linear_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(out), epilogue, ptr(cos), ptr(sin),
+                             rot_C, float(scale), stream_of(x)))
+    return out
+
+
+_LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
+               "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def layer_weights(tensors):
+    """tensors: the 10 tensors of one GeometryAttentionLayer in _LAYER_KEYS order (kept alive by the caller)."""
+    lw = LayerWeights()
+    for (name, _), tns in zip(LayerWeights._fields_, tensors):
+        assert tns.is_cuda and tns.is_contiguous() and tns.dtype == torch.float32
+        setattr(lw, name, tns.data_ptr())
+    return lw
+
+
+def attention_layer(tensors, C, H, x, y, cos_x, sin_x, cos_y, sin_y, x_mask=None, y_mask=None):
+    """x [P,Lx,C] attends y [P,Ly,C] (GeometryAttentionLayer.forward)."""
+    ensure_init()
+    P, Lx, _ = x.shape
+    Ly = y.shape[1]
+    lw = layer_weights(tensors)
+    out = torch.empty_like(x)
+    wsb = _lib.dr_attention_layer_workspace_bytes(P, Lx, Ly, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    xm, ym = mask_u8(x_mask), mask_u8(y_mask)
+    check(_lib.dr_attention_layer_f32(ctypes.byref(lw), C, H, P, Lx, Ly, ptr(x.contiguous()), ptr(y.contiguous()),
+                                      ptr(cos_x.contiguous()), ptr(sin_x.contiguous()), ptr(cos_y.contiguous()),
+                                      ptr(sin_y.contiguous()), ptr(xm), ptr(ym), ptr(out), ptr(ws), wsb, stream_of(x)))
+    return out
+
+
+def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_condition_num, use_mask_len=False,
+               want_topk=False):
+    """SoftProcrustesLayer.forward on device.  conf [P,N,M] float32 -> R,t,R_forwd,t_forwd,cond(f64),ok(bool)[,idx]."""
+    ensure_init()
+    if conf.dtype != torch.float32:
+        raise RuntimeError("procrustes: float32 conf expected (the reference raises on float64, quirk Q3)")
+    conf = conf.contiguous()
+    P, N, M = conf.shape
+    dev = conf.device
+    R = torch.empty(P, 3, 3, device=dev); t = torch.empty(P, 3, 1, device=dev)
+    Rf = torch.empty(P, 3, 3, device=dev); tf = torch.empty(P, 3, 1, device=dev)
+    cond = torch.empty(P, dtype=torch.float64, device=dev)
+    ok = torch.empty(P, dtype=torch.int32, device=dev)
+    K = int(float(torch.tensor(float(max(N, M)), dtype=torch.float32) * sample_rate))
+    idx = torch.empty(P, K, dtype=torch.int32, device=dev) if want_topk else None
+    sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    check(_lib.dr_procrustes_f32(P, N, M, ptr(conf), ptr(src_pcd.contiguous().float()), ptr(tgt_pcd.contiguous().float()),
+                                 ptr(sm), ptr(tm), 1 if use_mask_len else 0, float(sample_rate), float(max_condition_num),
+                                 ptr(R), ptr(t), ptr(Rf), ptr(tf), ptr(cond), ptr(ok), ptr(idx), stream_of(conf)))
+    res = (R, t, Rf, tf, cond, ok.bool())
+    return res + (idx,) if want_topk else res
+
+
+def top1_union(conf):
+    """conf [P,N,M] (f32/f64) -> list of int64 [K_p,3] match tensors (one host sync for the counts)."""
+    ensure_init()
+    conf = conf.contiguous()
+    P, N, M = conf.shape
+    out = torch.empty(P, N + M, 3, dtype=torch.int64, device=conf.device)
+    cnt = torch.empty(P, dtype=torch.int32, device=conf.device)
+    fn = _lib.dr_top1_union_f64 if conf.dtype == torch.float64 else _lib.dr_top1_union_f32
+    check(fn(P, N, M, ptr(conf), ptr(out), ptr(cnt), stream_of(conf)))
+    counts = cnt.cpu().tolist()
+    return [out[p, :counts[p]] for p in range(P)]

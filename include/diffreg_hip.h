@@ -73,6 +73,131 @@ int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* sr
                     void* out /* double*, or float* with DR_SK_OUT_F32 */, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * dr_init: sets kernel attributes (dynamic LDS sizes).  Call once per process before the first
+ * launch and before any stream capture (the Python loader does).
+ */
+int dr_init(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * VolumetricPositionEncoding.forward (3D/models/position_encoding.py:49-87) of `rows` points,
+ * optionally warped first by a per-pair rigid motion  p' = R p + t  (3D/models/pipeline.py:306).
+ *   xyz [rows,3]; R [rows/rows_per_pair, 9] row-major and t [.., 3], both NULL for no warp
+ *   freq [C/6] = exp(arange(0, C/3, 2) * (-ln 1e4 / (C/3)))  (device; the caller computes it so the
+ *               table is bit-identical to torch's)
+ *   cos_out, sin_out [rows, C/2]: entry a*(C/6)+k is the angle of channels 2(a*C/6+k) and +1
+ *               (the reference stores each angle twice: position_encoding.py:74-79)
+ */
+int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t,
+                  float origin_x, float origin_y, float origin_z, float voxel, const float* freq,
+                  float* cos_out, float* sin_out, void* stream);
+
+/* nn.Linear without bias (+ optional rotary / ReLU / scale epilogue): out[rows,ncols] = x W^T.
+ * epilogue bits: 1 = ReLU, 2 = rotary with cos/sin [rows, rot_C/2] (embed_rotary,
+ * position_encoding.py:25-35).  Used by the parity tests of the GEMM kernel. */
+int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, float* out, int epilogue,
+                  const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
+
+/* weights of one GeometryAttentionLayer in the reference state-dict layout ([out,in] row-major;
+ * 3D/models/transformero.py:26-41): host struct of device pointers */
+typedef struct {
+    const float *q_proj, *k_proj, *v_proj, *merge; /* [C,C]          */
+    const float *mlp0;                             /* [2C,2C]        */
+    const float *mlp2;                             /* [C,2C]         */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [C]       */
+} dr_layer_weights;
+
+/* GeometryAttentionLayer.forward(x, source, x_pe, source_pe, x_mask, source_mask)
+ * (3D/models/transformero.py:43-96) for P independent pairs:
+ *   x [P*Lx, C], y [P*Ly, C]; cos/sin tables [P*Lx, C/2] and [P*Ly, C/2]; masks uint8 or NULL
+ *   out [P*Lx, C] = x + LN2(mlp([x, LN1(merge(attn))]))
+ *   workspace: dr_attention_layer_workspace_bytes(P, Lx, Ly, C)
+ */
+size_t dr_attention_layer_workspace_bytes(int P, int Lx, int Ly, int C);
+int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int Lx, int Ly, const float* x,
+                           const float* y, const float* cos_x, const float* sin_x, const float* cos_y,
+                           const float* sin_y, const uint8_t* x_mask, const uint8_t* y_mask, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* SoftProcrustesLayer.forward (3D/models/procrustes.py:48-93): top-K of conf, weighted Kabsch,
+ * fp64 3x3 SVD ON DEVICE (replaces the .cpu().double().svd() of procrustes.py:35-36), gate.
+ *   conf [P,N,M] float32; src_pcd [P,N,3]; tgt_pcd [P,M,3]
+ *   use_mask_len: 0 = K from the padded sizes (3D, 2D3D), 1 = K from the mask sums (4D variant,
+ *                 4D/models/procrustes.py:61-62)
+ *   R,t = solution; R_forwd,t_forwd = solution or identity when cond >= max_condition_num;
+ *   topk_idx (optional, [P,K]) flat indices i*M+j of the selected entries in index order
+ */
+int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_pcd, const float* tgt_pcd,
+                      const uint8_t* src_mask, const uint8_t* tgt_mask, int use_mask_len, float sample_rate,
+                      float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
+                      double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
+
+/* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
+ * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */
+int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream);
+int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole reverse-diffusion loop of Pipeline.forward's eval branch
+ * (3D/models/pipeline.py:221-283; 4D/models/pipeline.py:156-197) for P independent pairs, enqueued
+ * on `stream` with no host synchronisation (so it can be captured in a HIP graph).
+ */
+#define DR_VARIANT_3DMATCH 0
+#define DR_VARIANT_4DMATCH 1
+#define DR_LOOP_STRICT_F64 0x1 /* run the fp64-state Sinkhorn calls in fp64 (streaming kernel) */
+
+typedef struct {
+    int variant;               /* DR_VARIANT_*                                              */
+    int C, H, n_layers;        /* feature dim, heads, layers (self, cross, self, ... )       */
+    int steps;                 /* SAMPLE_STEP                                                */
+    int sk_iters;              /* skh_iters                                                  */
+    float voxel, origin[3];    /* voxel_size, vol_bnds[0]                                    */
+    float sample_rate, max_condition_num; /* procrustes config                              */
+    int flags;                 /* DR_LOOP_*                                                  */
+    const double* h_alphas_cumprod; /* HOST [1000] float64 (pipeline.py:151-156)             */
+    const int32_t* h_times;    /* HOST [steps+1] reversed int(linspace(0,999,steps+1)), Q20  */
+} dr_loop_config;
+
+typedef struct {
+    const dr_layer_weights* layers; /* HOST array [n_layers] of device-pointer structs       */
+    const float* src_proj;     /* denoising_coarse_matching.src_proj.weight [C,C] (Q1)       */
+    const float* bin_score;    /* device pointer to one float                                */
+    const float* pe_freq;      /* device [C/6], see dr_vol_pe_f32                            */
+} dr_loop_weights;
+
+typedef struct {                /* all optional (NULL to skip); per-step records for parity tests */
+    float* x0;                 /* [steps,P,N,M]  x_start of every step                       */
+    float* R_forwd;            /* [steps,P,9]                                                */
+    float* t_forwd;            /* [steps,P,3]                                                */
+    double* cond;              /* [steps,P]                                                  */
+} dr_loop_trace;
+
+size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, int M);
+
+/* inputs : src_feats [P,N,C], tgt_feats [P,M,C], s_pcd [P,N,3], t_pcd [P,M,3] float32;
+ *          src_mask [P,N], tgt_mask [P,M] uint8 or NULL; x_T [P,N,M] float32 (the randn of
+ *          pipeline.py:224); noise [steps,P,N,M] float32 or NULL (xi, used by the 4D variant only)
+ * outputs: conf [P,N,M] float64 (conf_matrix_pred); x_final [P,N,M] float64 (optional);
+ *          matches [P,N+M,3] int64 + match_count [P] (3D variant; optional);
+ *          R_final [P,9], t_final [P,3] float32: soft_procrustes of float32(conf) (optional; the
+ *          reference's own call returns identity through a swallowed dtype error, quirk Q3)
+ */
+int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M,
+                    const float* src_feats, const float* tgt_feats, const float* s_pcd, const float* t_pcd,
+                    const uint8_t* src_mask, const uint8_t* tgt_mask, const float* x_T, const float* noise,
+                    double* conf, double* x_final, int64_t* matches, int32_t* match_count, float* R_final,
+                    float* t_final, const dr_loop_trace* trace, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* RepositioningTransformer.forward for layer types self/cross (3D/models/transformero.py:151-233)
+ * + Matching.forward (3D/models/matching.py:164-219) on already-warped points, for P pairs:
+ * one denoiser evaluation.  Outputs: src_out [P,N,C], tgt_out [P,M,C] (optional), conf [P,N,M]. */
+int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M,
+                          const float* src_feats, const float* tgt_feats, const float* s_pcd_warped,
+                          const float* t_pcd, const uint8_t* src_mask, const uint8_t* tgt_mask, float* src_out,
+                          float* tgt_out, float* conf, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

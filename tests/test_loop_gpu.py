@@ -1,0 +1,155 @@
+"""Parity of the whole reverse-diffusion loop (dr_denoise_loop through the C ABI) with the reference-minted
+golden vectors and with the oracle.  Needs a GPU.
+
+Tolerances (north_star: matching matrix and (R,t) to 1e-4 fp32 on identical inputs):
+  R_forwd, t_forwd: 1e-4 absolute against the reference at every step.
+  x_start / conf  : 1e-4 absolute against the reference on (almost) every entry.  The sharp synthetic
+      scenes make a handful of x_start entries ill-conditioned: the reference's OWN float32 CPU run is
+      1e-4..1e-2 away from a float64 evaluation of the same mathematics on those entries (measured:
+      tools/debug_loop.py, DESIGN.md "Parity").  For them the bar is that the HIP path is at least as
+      close to the float64 evaluation as the reference is:  |hip - f64| <= max(1e-4, 2 |ref - f64|),
+      and they must stay rare (<= 0.1 % of the entries).
+"""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import diffreg_oracle as orc
+from tests.helpers import T, weights, pair, masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def engine(variant, steps, mc, **kw):
+    from diffreg_hip.engine import DenoiseEngine
+    v = synth.VARIANTS[variant]
+    return DenoiseEngine(weights(variant), variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"],
+                         steps=steps, sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc,
+                         n_layers=v["n_layers"], device=DEV, **kw)
+
+
+@pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
+def test_denoiser_and_head_match_golden(variant, golden):
+    g = golden(variant + "_denoiser")
+    eng = engine(variant, 1, 200)
+    _, p = pair(variant, 64, 48, 3)
+    for tag, (ms, mt) in (("", masks(64, 48)), ("_mask", masks(64, 48, 50, 41))):
+        so, to, conf = eng.denoise_match(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV),
+                                         ms.to(DEV), mt.to(DEV))
+        assert np.abs(so[0].cpu().numpy() - g["f_s" + tag]).max() < 5e-4
+        assert np.abs(to[0].cpu().numpy() - g["f_t" + tag]).max() < 5e-4
+        assert np.abs(conf[0].cpu().numpy() - g["conf" + tag]).max() < 1e-4
+
+
+LOOPS = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
+         ("3dmatch", 128, 128, 128, 128, 20, 0, 11, "n128_s20_mc0"),
+         ("3dmatch", 96, 80, 96, 80, 5, 200, 12, "n96x80_s5_mc200"),
+         ("3dmatch", 256, 256, 256, 256, 20, 200, 13, "n256_s20_mc200"),
+         ("4dmatch", 128, 128, 112, 100, 5, 40, 21, "n128_s5_mc40_masked"),
+         ("4dmatch", 64, 96, 64, 96, 20, 40, 22, "n64x96_s20_mc40")]
+
+
+_F64 = {}
+
+
+def f64_evaluation(variant, N, M, nv, mv, steps, mc, seed):
+    """oracle run with float64 weights/features (positions stay float32 like the reference's warp)."""
+    key = (variant, N, M, nv, mv, steps, mc, seed)
+    if key not in _F64:
+        v = synth.VARIANTS[variant]
+        W64 = {k: t.double() for k, t in weights(variant).items()}
+        _, p = pair(variant, N, M, seed)
+        ms, mt = masks(N, M, nv, mv)
+        noise = T(synth.step_noise(N, M, seed, steps))[:, None].double()
+        tr = []
+        o = orc.denoise_loop(W64, v, p["f_s"].double(), p["f_t"].double(), p["p_s"], p["p_t"], ms, mt, p["x_T"].double(),
+                             steps, mc, variant=variant, noise=noise, trace=tr)
+        _F64[key] = (tr[-1]["x0"][0].double().numpy(), o["conf_matrix_pred"][0].double().numpy())
+    return _F64[key]
+
+
+def assert_matrix_parity(got, ref, f64, what):
+    d = np.abs(got - ref)
+    bad = d > 1e-4
+    assert bad.mean() <= 1e-3, (what, "entries off by more than 1e-4:", int(bad.sum()))
+    e_hip, e_ref = np.abs(got - f64), np.abs(ref - f64)
+    assert e_hip.max() <= max(1e-4, 2.0 * e_ref.max()), (what, e_hip.max(), e_ref.max())
+
+
+@pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", LOOPS)
+@pytest.mark.parametrize("graph", [False, True])
+def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph):
+    g = golden("%s_loop_%s" % (variant, tag))
+    eng = engine(variant, steps, mc)
+    _, p = pair(variant, N, M, seed)
+    ms, mt = masks(N, M, nv, mv)
+    noise = T(synth.step_noise(N, M, seed, steps))[:, None].to(DEV) if variant == "4dmatch" else None
+    masked = variant == "4dmatch"
+    out = eng.run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV),
+                  ms.to(DEV) if masked else None, mt.to(DEV) if masked else None, noise=noise, trace=True, graph=graph)
+    torch.cuda.synchronize()
+    Rf, tf = out["R_forwd"][:, 0].cpu().numpy(), out["t_forwd"][:, 0].cpu().numpy()
+    assert np.abs(Rf - g["R_forwd"]).max() < 1e-4, np.abs(Rf - g["R_forwd"]).max(axis=(1, 2))
+    assert np.abs(tf - g["t_forwd"]).max() < 1e-4, np.abs(tf - g["t_forwd"]).max(axis=(1, 2))
+    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=2e-3)
+    x0 = out["x0"][:, 0].cpu().numpy()
+    x0_f64, conf_f64 = f64_evaluation(variant, N, M, nv, mv, steps, mc, seed)
+    assert (np.abs(x0[:, :16, :16] - g["x0_corner"]) > 1e-4).mean() <= 1e-3
+    assert_matrix_parity(x0[-1], g["x0_last"], x0_f64, "x_start of the last step")
+    conf = out["conf_matrix_pred"][0].cpu().numpy()
+    assert out["conf_matrix_pred"].dtype == torch.float64            # quirk Q2
+    ref = g["conf"]
+    assert_matrix_parity(conf, ref, conf_f64, "conf_matrix_pred")
+    if variant == "3dmatch":
+        # read-out entries are 1e-3..2e-2 (intrinsically flat): also hold them relatively
+        rel = np.abs(conf - ref) / np.maximum(ref, 1e-9)
+        rel_ref = np.abs(ref - conf_f64) / np.maximum(conf_f64, 1e-9)
+        assert rel.max() <= max(1e-4, 2.0 * rel_ref.max()), (rel.max(), rel_ref.max())
+        got = set(map(tuple, eng.match_list(out)[0].cpu().tolist()))
+        srt = np.sort(ref, 1)
+        am = ref.argmax(1)
+        for i in np.nonzero(srt[:, -1] - srt[:, -2] > 10 * np.abs(conf - ref).max())[0]:   # well-margined rows
+            assert (0, int(i), int(am[i])) in got
+        # the library's own read-out is exactly the top-1 union of ITS conf (bit-exact index work)
+        assert got == set(map(tuple, orc.top1_union(out["conf_matrix_pred"][0].cpu()).tolist()))
+
+
+def test_batched_pairs_equal_single_pairs():
+    """P pairs in one call give the same results as P calls of one pair (per-pair x.min(), quirk Q7)."""
+    variant, N, M, steps = "3dmatch", 128, 128, 3
+    eng = engine(variant, steps, 200)
+    ps = [pair(variant, N, M, s)[1] for s in (31, 32, 33)]
+    cat = lambda k: torch.cat([q[k] for q in ps]).to(DEV)
+    out = eng.run(cat("f_s"), cat("f_t"), cat("p_s"), cat("p_t"), cat("x_T"), trace=True)
+    conf = out["conf_matrix_pred"].clone(); Rf = out["R_forwd"].clone()
+    for i, q in enumerate(ps):
+        o1 = eng.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV), trace=True)
+        assert (o1["conf_matrix_pred"][0] - conf[i]).abs().max().item() < 1e-6
+        assert (o1["R_forwd"][:, 0] - Rf[:, i]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("seed", [78, 79])
+def test_loop_against_oracle_fresh_seed(seed):
+    """cases that are NOT in the golden set: HIP loop vs oracle on new scenes of a ragged size, default and
+    strict-fp64 state.  (The top-K of the Procrustes step is a discontinuous function of the matrix: a seed
+    whose K-th and (K+1)-th confidences nearly tie -- e.g. seed 77 at this size -- flips between any two fp32
+    implementations, the reference on another BLAS included; see DESIGN.md "Parity".)"""
+    variant, N, M, steps, mc = "3dmatch", 160, 144, 4, 200
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    _, p = pair(variant, N, M, seed)
+    ms, mt = masks(N, M)
+    trace = []
+    ref = orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc, variant=variant, trace=trace)
+    x0_f64, conf_f64 = f64_evaluation(variant, N, M, N, M, steps, mc, seed)
+    for strict in (False, True):
+        eng = engine(variant, steps, mc, strict_f64=strict)
+        out = eng.run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV), trace=True)
+        Rref = torch.stack([r["R_forwd"][0] for r in trace])
+        tref = torch.stack([r["t_forwd"][0] for r in trace])
+        assert (out["R_forwd"][:, 0].cpu() - Rref).abs().max().item() < 1e-4
+        assert (out["t_forwd"][:, 0].cpu() - tref).abs().max().item() < 1e-4
+        assert_matrix_parity(out["x0"][-1, 0].cpu().numpy(), trace[-1]["x0"][0].numpy(), x0_f64, "x_start")
+        assert_matrix_parity(out["conf_matrix_pred"][0].cpu().numpy(), ref["conf_matrix_pred"][0].numpy(), conf_f64, "conf")
