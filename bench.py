@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- scene-pairs/s of the reverse-diffusion matching loop on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: the whole 20-denoise-step
+loop (3D/models/pipeline.py:221-283) for `--pairs` independent scene pairs (each a B = 1 problem of
+the reference), N = M = 256 superpoints, C = 432, warp active (max_condition_num = 200),
+inputs resident in HBM, launched as one HIP-graph replay.  Pairs shard across ranks with no
+data-path collective (weak scaling); RCCL is used only for the barrier / max-time / checksum gather.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel family (by GPU time, HIP events on the launch stream) vs its peak,
+                and the batched Sinkhorn micro-benchmark vs the 8 TB/s HBM peak (north_star)
+  cpu_baseline  the oracle (PyTorch CPU restatement, "port") timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "diff-reg_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HEAD_GAIN = 24.0
+PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
+
+
+def make_inputs(variant, P, N, M, seed0, device):
+    from diffreg_hip import synth
+    C = synth.VARIANTS[variant]["C"]
+    prs = [synth.make_pair(N, M, C, seed=seed0 + i) for i in range(P)]
+    st = lambda k: torch.from_numpy(np.stack([p[k] for p in prs])).to(device)
+    return prs, dict(f_s=st("src_feats"), f_t=st("tgt_feats"), p_s=st("s_pcd"), p_t=st("t_pcd"), x_T=st("x_T"))
+
+
+def make_engine(variant, steps, mc, device):
+    from diffreg_hip import synth
+    from diffreg_hip.engine import DenoiseEngine
+    v = synth.VARIANTS[variant]
+    W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
+    return W, DenoiseEngine(W, variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps,
+                            sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc,
+                            n_layers=v["n_layers"], device=device)
+
+
+def sinkhorn_microbench(device, B=4096, N=256, M=256, reps=10):
+    from diffreg_hip import lib
+    x = torch.randn(B, N, M, device=device) * 2
+    a = torch.tensor(1.0, device=device)
+    out = lib.sinkhorn(x, a, 3)
+    for _ in range(2):
+        lib.sinkhorn(x, a, 3, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.sinkhorn(x, a, 3, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    byts = B * N * M * 8
+    # latency of one tile
+    x1 = x[:1].contiguous()
+    o1 = lib.sinkhorn(x1, a, 3)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        lib.sinkhorn(x1, a, 3, out=o1)
+    e1.record()
+    torch.cuda.synchronize()
+    return dict(kernel="sk_reg_kernel<float,float,16,4>", bound="hbm", tiles_per_launch=B, bytes_per_tile=N * M * 8,
+                us_per_launch=ms * 1e3, achieved=byts / ms / 1e6, peak=PEAK_HBM_GBPS, unit="GB/s",
+                frac=byts / ms / 1e6 / PEAK_HBM_GBPS, traffic=None, single_tile_latency_us=e0.elapsed_time(e1) / 50 * 1e3)
+
+
+def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):
+    """oracle loop on the host cores: 1 warm-up pair + as many timed pairs as fit the budget (>= 1)."""
+    from diffreg_hip import synth
+    from oracle import diffreg_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    v = synth.VARIANTS[variant]
+    W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
+    ms = torch.ones(1, N, dtype=torch.bool)
+    mt = torch.ones(1, M, dtype=torch.bool)
+
+    def one(seed):
+        p = synth.make_pair(N, M, v["C"], seed=seed)
+        T = lambda a: torch.from_numpy(a)[None]
+        t0 = time.perf_counter()
+        orc.denoise_loop(W, v, T(p["src_feats"]), T(p["tgt_feats"]), T(p["s_pcd"]), T(p["t_pcd"]), ms, mt, T(p["x_T"]),
+                         steps, mc, variant=variant)
+        return time.perf_counter() - t0
+    one(1000)
+    times, t_start = [], time.perf_counter()
+    while not times or (time.perf_counter() - t_start < budget_s and len(times) < 10):
+        times.append(one(1001 + len(times)))
+    med = float(np.median(times))
+    return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d pairs of N=M=%d, %d denoise steps after 1 warm-up pair (median %.3f s/pair); "
+                       "oracle/diffreg_oracle.py on torch %s CPU" % (len(times), N, steps, med, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed passes of the hot path (K)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "16")),
+                    help="independent scene pairs per pass and per GPU")
+    ap.add_argument("--denoise-steps", type=int, default=20)
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--max-condition-num", type=float, default=200.0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diffreg_hip import lib
+    variant, N, M, P, S = "3dmatch", args.n, args.n, args.pairs, args.denoise_steps
+    W, eng = make_engine(variant, S, args.max_condition_num, dev)
+    prs, inp = make_inputs(variant, P, N, M, seed0=5000 + 1000 * rank, device=dev)
+    run = lambda graph: eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=graph)
+    use_graph = not args.no_graph
+
+    for _ in range(max(args.warmup, 1)):
+        out = run(use_graph)
+    torch.cuda.synchronize()
+    # timed region: exactly K passes, bracketed by barrier + synchronize
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run(use_graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    checksum = out["conf_matrix_pred"].sum().reshape(1).double()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # max over ranks
+        elapsed = float(tt.item())
+        dist.all_reduce(checksum, op=dist.ReduceOp.SUM)    # metric gather over xGMI (RCCL)
+    total_pairs = world * P * args.steps
+    value = total_pairs / elapsed
+
+    result = {
+        "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
+                               "%d independent B=1 pairs per pass per GPU, one HIP-graph replay per pass" % (N, S, args.max_condition_num, P),
+                   "pairs_per_pass_per_gpu": P, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
+                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32", "parallelism": "pairs sharded over %d GPU(s)" % world},
+        "conf_checksum": float(checksum.item()),
+    }
+
+    if rank == 0 and world == 1:
+        # ---- single-pair latency (the literal "batch=1" of configs[1]) -------------------------------
+        prs1, inp1 = make_inputs(variant, 1, N, M, seed0=7000, device=dev)
+        run1 = lambda: eng.run(inp1["f_s"], inp1["f_t"], inp1["p_s"], inp1["p_t"], inp1["x_T"], graph=use_graph)
+        for _ in range(3):
+            run1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            run1()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 10
+        result["single_pair"] = {"ms_per_pair": lat * 1e3, "pairs_per_s": 1.0 / lat}
+
+        if not args.no_breakdown:
+            # ---- per-kernel-family GPU time of the same pass (eager launches, HIP events on the stream) ---
+            run(False)
+            torch.cuda.synchronize()
+            lib.prof_enable(True)
+            reps = 2
+            for _ in range(reps):
+                run(False)
+            prof = lib.prof_collect()
+            lib.prof_enable(False)
+            tot = sum(v[1] for v in prof.values())
+            fam = {k: {"launches_per_pass": v[0] // reps, "ms_per_pass": v[1] / reps, "share": v[1] / tot,
+                       "avg_us_per_launch": (v[1] / v[0] * 1e3) if v[0] else 0.0} for k, v in prof.items()}
+            dom = max(prof, key=lambda k: prof[k][1])
+            c, ms_, work = prof[dom]
+            if dom in ("gemm", "attention"):
+                roof = dict(kernel=dom, bound="mfma", achieved=work / (ms_ * 1e-3) / 1e12, peak=PEAK_MFMA_F32_TFLOPS,
+                            unit="TFLOP/s", traffic=None)
+            else:
+                roof = dict(kernel=dom, bound="hbm", achieved=work / (ms_ * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
+                            traffic=None)
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["avg_us_per_launch"] = ms_ / c * 1e3
+            roof["work_per_launch"] = work / c
+            roof["note"] = "dominant family by GPU time; work = algorithmic FLOPs (2*rows*cols*K per GEMM) or bytes"
+            result["roofline"] = roof
+            result["kernel_families"] = fam
+        result["sinkhorn_roofline"] = sinkhorn_microbench(dev)
+        if "roofline" not in result:
+            result["roofline"] = result["sinkhorn_roofline"]
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(variant, N, M, S, args.max_condition_num)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,6 @@
 // api.hip -- version / error reporting of the C ABI.
-#include "common.h"
+#include "kernels.h"
+#include <vector>
 #include <stdio.h>
 #include <string.h>
 
@@ -8,9 +9,47 @@ static thread_local char g_hip_err[512] = "";
 void set_hip_error(hipError_t e, const char* where) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }
+
+bool g_prof_on = false;
+struct ProfRec { int kind; double work; hipEvent_t a, b; };
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+void prof_begin(int kind, double work, hipStream_t st) {
+    ProfRec r; r.kind = kind; r.work = work; r.a = get_event(); r.b = nullptr;
+    hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+}
+void prof_end(int kind, hipStream_t st) {
+    for (size_t i = g_prof.size(); i-- > 0;)
+        if (g_prof[i].kind == kind && !g_prof[i].b) { g_prof[i].b = get_event(); hipEventRecord(g_prof[i].b, st); return; }
+}
 }  // namespace dr
 
 extern "C" {
+void dr_prof_enable(int on) { dr::g_prof_on = on != 0; }
+
+/* synchronises the device, then fills calls[k], ms[k], work[k] (k < DR_PROF_KINDS) and clears the log */
+int dr_prof_collect(int* calls, double* ms, double* work) {
+    using namespace dr;
+    DR_HIP_CHECK(hipDeviceSynchronize());
+    for (int k = 0; k < PK_COUNT; ++k) { calls[k] = 0; ms[k] = 0; work[k] = 0; }
+    for (auto& r : g_prof) {
+        if (r.b) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, r.a, r.b);
+            calls[r.kind] += 1; ms[r.kind] += t; work[r.kind] += r.work;
+            g_pool.push_back(r.b);
+        }
+        g_pool.push_back(r.a);
+    }
+    g_prof.clear();
+    return DR_OK;
+}
+
 int dr_version(void) { return 100; /* 0.1.0 */ }
 
 const char* dr_strerror(int code) {

@@ -210,6 +210,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     const size_t lds = (size_t)G::SMEM_FLOATS * sizeof(float);
     const int maxLq = a.nseg2 > 0 && a.Lqb > a.Lq ? a.Lqb : a.Lq;
     dim3 grid((maxLq + 31) / 32, a.H, a.nseg + a.nseg2);
+    // 4 L S C per (segment): QK^T and PV
+    const double flops = 4.0 * a.H * a.d * ((double)a.nseg * a.Lq * a.Lk + (double)a.nseg2 * a.Lqb * a.Lkb);
+    ProfScope ps(PK_ATTN, flops, st);
     hipLaunchKernelGGL((attention_kernel<DG, NDT>), grid, dim3(256), lds, st, a);
     DR_LAUNCH_CHECK();
     return DR_OK;

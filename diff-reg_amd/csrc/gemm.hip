@@ -150,6 +150,9 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
         maxt = tl > maxt ? tl : maxt;
     }
     if (maxt == 0) return DR_OK;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    ProfScope ps(PK_GEMM, flops, st);
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, WK>), dim3(maxt, g.n), dim3(256), 0, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;

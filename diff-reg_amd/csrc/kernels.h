@@ -5,6 +5,20 @@
 namespace dr {
 
 // ---------------------------------------------------------------------------------------------
+// optional per-kernel-family timing with HIP events on the launch stream (dr_prof_* in the C ABI);
+// costs one branch per launch when disabled.  Never enable inside a stream capture.
+// ---------------------------------------------------------------------------------------------
+enum ProfKind { PK_GEMM = 0, PK_ATTN, PK_LN, PK_PE, PK_SINKHORN, PK_PROCRUSTES, PK_STATE, PK_COUNT };
+extern bool g_prof_on;
+void prof_begin(int kind, double work, hipStream_t st);
+void prof_end(int kind, hipStream_t st);
+struct ProfScope {
+    int kind; hipStream_t st; bool on;
+    ProfScope(int k, double work, hipStream_t s) : kind(k), st(s), on(g_prof_on) { if (on) prof_begin(k, work, s); }
+    ~ProfScope() { if (on) prof_end(kind, st); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // grouped "NT" GEMM:  out[r][c] = epi( sum_k A[r][k] * W[c][k] )   (nn.Linear without bias)
 // A may be the concatenation [A | A2] along k (torch.cat([x, msg], 2) of transformero.py:91).
 // ---------------------------------------------------------------------------------------------

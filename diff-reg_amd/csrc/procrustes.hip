@@ -274,6 +274,7 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
     // K = int(int(max(len_s, len_t) * rate))  with float32 arithmetic (procrustes.py:63-65)
     a.K_fixed = (int)((float)(N > M ? N : M) * sample_rate);
     if (a.K_fixed > PK_MAX) return DR_ENOSUP;
+    ProfScope ps(PK_PROCRUSTES, (double)P * N * M * 4.0, st);
     hipLaunchKernelGGL(procrustes_kernel, dim3(P), dim3(1024), 0, st, a);
     DR_LAUNCH_CHECK();
     return DR_OK;

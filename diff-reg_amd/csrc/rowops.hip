@@ -48,6 +48,7 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* b, co
                      int ldo, int rows, int C, hipStream_t st) {
     if (C > 64 * LN_MAX_PER_LANE) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
+    ProfScope ps(PK_LN, (double)rows * C * (res ? 12.0 : 8.0), st);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -92,6 +93,7 @@ int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R,
     if (C % 6) return DR_ENOSUP;
     const int total = rows * (C / 2);
     if (total <= 0) return DR_OK;
+    ProfScope ps(PK_PE, (double)total * 8.0, st);
     hipLaunchKernelGGL(vol_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, st, xyz, rows, rows_per_pair, R, t, C, ox,
                        oy, oz, voxel, freq, cosT, sinT, (float*)nullptr);
     DR_LAUNCH_CHECK();

@@ -513,6 +513,8 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
     a.scores = scores; a.src_mask = src_mask; a.tgt_mask = tgt_mask; a.bin_score = bin_score;
     a.out = out; a.ws = ws; a.shift = shift; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes: read the score tile once, write the conf tile once
+    ProfScope ps(PK_SINKHORN, (double)B * N * M * (sizeof(TIn) + (out32 ? 4.0 : 8.0)), st);
     if (reg_path(N, M, flags)) {
         const int cpl = (N <= 128 && M <= 128) ? 2 : 4;
         const size_t in_al = cpl * sizeof(TIn) > 16 ? 16 : cpl * sizeof(TIn);

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict
 
 int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st) {
     if (P <= 0) return DR_OK;
+    ProfScope ps(PK_STATE, (double)P * NM * 8.0, st);
     hipLaunchKernelGGL(pair_min_kernel, dim3(P), dim3(1024), 0, st, x, NM, out);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void ddim_kernel(DdimArgs A) {
 int launch_ddim(const DdimArgs& a, int P, hipStream_t st) {
     if (P <= 0) return DR_OK;
     const int NM = a.N * a.M;
+    ProfScope ps(PK_STATE, (double)P * NM * 20.0, st);
     hipLaunchKernelGGL(ddim_kernel, dim3((NM + 255) / 256, P), dim3(256), 0, st, a);
     DR_LAUNCH_CHECK();
     return DR_OK;

@@ -132,8 +132,8 @@ class DenoiseEngine:
         P, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         masked = src_mask is not None
-        key = (P, N, M, masked, trace)
-        ent = self._graphs.get(key) if graph else None
+        key = (P, N, M, masked, trace, bool(graph))
+        ent = self._graphs.get(key)
         if ent is None:
             b = self.make_buffers(P, N, M, masked=masked, trace=trace)
             g = None
@@ -148,8 +148,8 @@ class DenoiseEngine:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._enqueue(b)
-                self._graphs[key] = (b, g)
             ent = (b, g)
+            self._graphs[key] = ent
         b, g = ent
         self._fill(b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise)
         if g is not None:

@@ -57,6 +57,8 @@ class LoopTrace(ctypes.Structure):
 _P = ctypes.POINTER
 SIGNATURES.update({
     "dr_init": (c_int, []),
+    "dr_prof_enable": (None, [c_int]),
+    "dr_prof_collect": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dr_vol_pe_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
@@ -263,3 +265,18 @@ def top1_union(conf):
     check(fn(P, N, M, ptr(conf), ptr(out), ptr(cnt), stream_of(conf)))
     counts = cnt.cpu().tolist()
     return [out[p, :counts[p]] for p in range(P)]
+
+
+PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state")
+
+
+def prof_enable(on=True):
+    _lib.dr_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    """-> {family: (calls, total_ms, work)}; synchronises the device."""
+    n = len(PROF_KINDS)
+    calls = (ctypes.c_int * n)(); ms = (ctypes.c_double * n)(); work = (ctypes.c_double * n)()
+    check(_lib.dr_prof_collect(calls, ms, work))
+    return {k: (calls[i], ms[i], work[i]) for i, k in enumerate(PROF_KINDS)}
