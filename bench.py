@@ -162,11 +162,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     checksum = out["conf_matrix_pred"].sum().reshape(1).double()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # max over ranks
-        elapsed = float(tt.item())
-        dist.all_reduce(checksum, op=dist.ReduceOp.SUM)    # metric gather over xGMI (RCCL)
+    from diffreg_hip import shard
+    elapsed = shard.max_over_ranks(elapsed, dev)                       # max over ranks
+    checksum = shard.gather_metrics(checksum, dev)                     # metric gather (RCCL over xGMI when N > 1)
     total_pairs = world * P * args.steps
     value = total_pairs / elapsed
 

@@ -1,0 +1,177 @@
+"""models.pipeline.Pipeline with the reference's interface (3D/models/pipeline.py:130-379,
+4D/models/pipeline.py:80-292): backbone -> split_feats -> reverse-diffusion loop over the N x M
+matching matrix -> conf_matrix_pred / match_pred / (R, t).
+
+The evaluation branch (`not self.training and not eval_flag`) runs entirely in libdiffreg_hip through
+diffreg_hip.engine.DenoiseEngine (one HIP-graph replay per forward).  The KPFCN backbone is out of
+scope: it is taken from the reference tree when that is importable
+(`models.backbone.KPFCN`), or injected with `backbone=`.  The training branch (row f3) is not built.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from diffreg_hip.engine import DenoiseEngine
+from models.matching import Matching, log_optimal_transport, mutual_topk_select  # noqa: F401
+from models.procrustes import SoftProcrustesLayer
+from models.transformero import RepositioningTransformer
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def extract(a, t, x_shape):
+    out = a.gather(-1, t)
+    return out.reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
+@torch.no_grad()
+def cosine_beta_schedule(timesteps, s=0.008):
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+
+
+@torch.no_grad()
+def q_sample(x_start, t, noise=None, timesteps=1000):
+    if noise is None:
+        noise = torch.randn_like(x_start)
+    ac = torch.cumprod(1.0 - cosine_beta_schedule(timesteps).to(x_start.device), dim=0)
+    return extract(torch.sqrt(ac), t, x_start.shape) * x_start + extract(torch.sqrt(1.0 - ac), t, x_start.shape) * noise
+
+
+def _load_reference_backbone(kpfcn_config):
+    try:
+        from models.backbone import KPFCN          # resolves in the reference tree (models/__init__ extends __path__)
+    except Exception:                               # noqa: BLE001 - any import problem means "not available"
+        return None
+    return KPFCN(kpfcn_config)
+
+
+class Pipeline(nn.Module):
+    def __init__(self, config, backbone=None, variant=None, strict_reference=False):
+        super().__init__()
+        self.config = config
+        self.variant = variant or {"3dmatch": "3dmatch", "4dmatch": "4dmatch"}.get(
+            str(config.get("dataset", "3dmatch")) if hasattr(config, "get") else "3dmatch", "3dmatch")
+        #: True reproduces the reference's final (R,t) = identity (swallowed dtype error, quirk Q3)
+        self.strict_reference = strict_reference
+        self.backbone = backbone if backbone is not None else _load_reference_backbone(config["kpfcn_config"])
+        ct = config["coarse_transformer"]
+        self.pe_type = ct["pe_type"]
+        self.coarse_transformer = RepositioningTransformer(ct)
+        self.coarse_matching = Matching(config["coarse_matching"])
+        self.soft_procrustes = SoftProcrustesLayer(ct["procrustes"])
+        ct["layer_types"] = ["self", "cross", "self", "cross", "self", "cross"]      # the reference mutates config (Q12)
+        self.denoising_transformer = RepositioningTransformer(ct)
+        self.denoising_coarse_matching = Matching(config["coarse_matching"])
+        self.denoising_soft_procrustes = SoftProcrustesLayer(ct["procrustes"])
+        if self.variant == "4dmatch":
+            self.soft_procrustes.use_mask_len = self.denoising_soft_procrustes.use_mask_len = True
+        self.num_timesteps = 1000
+        self.sampling_timesteps = default(config["SAMPLE_STEP"], self.num_timesteps)
+        assert self.sampling_timesteps <= self.num_timesteps
+        self.ddim_sampling_eta = 1.0
+        ac = torch.cumprod(1.0 - cosine_beta_schedule(self.num_timesteps), dim=0)
+        self.register_buffer("alphas_cumprod", ac)
+        self.register_buffer("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1))
+        self._engine = None
+        self.use_graph = True
+
+    # -- engine lifetime: rebuilt whenever the weights may have moved / changed ----------------------
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _get_engine(self, device):
+        if self._engine is None or self._engine.device != torch.device(device):
+            ct = self.config["coarse_transformer"]
+            pc = ct["procrustes"]
+            pget = (lambda k: pc[k]) if isinstance(pc, dict) else (lambda k: getattr(pc, k))
+            sd = {k: v for k, v in self.state_dict().items()
+                  if k.startswith("denoising_transformer.") or k.startswith("denoising_coarse_matching.")}
+            self._engine = DenoiseEngine(sd, variant=self.variant, C=ct["feature_dim"], H=ct["n_head"],
+                                         voxel=ct["voxel_size"], origin=tuple(ct["vol_bnds"][0]),
+                                         steps=self.sampling_timesteps, sk_iters=self.config["coarse_matching"]["skh_iters"],
+                                         sample_rate=pget("sample_rate"), max_condition_num=pget("max_condition_num"),
+                                         n_layers=len(ct["layer_types"]), device=device)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, data, timers=None, eval_flag=False):
+        self.timers = timers
+        if self.backbone is None:
+            raise RuntimeError("Pipeline has no backbone: put a Diff-Reg checkout on sys.path (models.backbone.KPFCN) "
+                               "or pass backbone=... (see INTEGRATION.md)")
+        if self.timers: self.timers.tic("kpfcn backbone encode")
+        coarse_feats = self.backbone(data, phase="coarse")
+        if self.timers: self.timers.toc("kpfcn backbone encode")
+        if self.timers: self.timers.tic("coarse_preprocess")
+        src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask = self.split_feats(coarse_feats, data)
+        data.update({"s_pcd": s_pcd, "t_pcd": t_pcd})
+        if self.timers: self.timers.toc("coarse_preprocess")
+        if self.training:
+            raise NotImplementedError("the training branch (pipeline.py:182-216) is outside the accelerated path")
+        if eval_flag:
+            return data
+        P, N, _ = src_feats.shape
+        M = tgt_feats.shape[1]
+        dev = src_feats.device
+        eng = self._get_engine(dev)
+        S = self.sampling_timesteps
+        x_T = data["x_T"] if "x_T" in data else torch.randn(P, N, M, device=dev)          # pipeline.py:224
+        noise = None
+        if self.variant == "4dmatch":
+            noise = data["noise"] if "noise" in data else torch.randn(S, P, N, M, device=dev)
+        all_valid = bool(src_mask.all()) and bool(tgt_mask.all())
+        out = eng.run(src_feats.float(), tgt_feats.float(), s_pcd.float(), t_pcd.float(), x_T.float(),
+                      None if all_valid else src_mask, None if all_valid else tgt_mask, noise=noise, graph=self.use_graph)
+        conf = out["conf_matrix_pred"].clone()
+        data.update({"conf_matrix_pred": conf})
+        if self.variant == "3dmatch":
+            ml = eng.match_list(out)
+            match_pred = torch.cat([torch.cat([torch.full_like(m[:, :1], b), m[:, 1:]], 1) for b, m in enumerate(ml)]) \
+                if P > 1 else ml[0].clone()
+            data.update({"match_pred": match_pred})
+        if self.strict_reference:
+            R = torch.eye(3, dtype=torch.float64, device=dev)[None].repeat(P, 1, 1)
+            t = torch.zeros(P, 3, 1, dtype=torch.float64, device=dev)
+        else:
+            R, t = out["R_final"].clone(), out["t_final"].clone()
+        data.update({"R_s2t_pred": R, "t_s2t_pred": t})
+        return data
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
+            extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def split_feats(self, geo_feats, data):
+        """scatter the stacked coarse features / points into padded [B, N, .] tensors (pipeline.py:350-379)."""
+        pcd = data["points"][self.config["kpfcn_config"]["coarse_level"]]
+        src_mask, tgt_mask = data["src_mask"], data["tgt_mask"]
+        b_size, src_max = src_mask.shape
+        tgt_max = tgt_mask.shape[1]
+        src_feats = torch.zeros([b_size * src_max, geo_feats.shape[-1]]).type_as(geo_feats)
+        tgt_feats = torch.zeros([b_size * tgt_max, geo_feats.shape[-1]]).type_as(geo_feats)
+        src_pcd = torch.zeros([b_size * src_max, 3]).type_as(pcd)
+        tgt_pcd = torch.zeros([b_size * tgt_max, 3]).type_as(pcd)
+        src_feats[data["src_ind_coarse_split"]] = geo_feats[data["src_ind_coarse"]]
+        tgt_feats[data["tgt_ind_coarse_split"]] = geo_feats[data["tgt_ind_coarse"]]
+        src_pcd[data["src_ind_coarse_split"]] = pcd[data["src_ind_coarse"]]
+        tgt_pcd[data["tgt_ind_coarse_split"]] = pcd[data["tgt_ind_coarse"]]
+        return (src_feats.view(b_size, src_max, -1), tgt_feats.view(b_size, tgt_max, -1), src_pcd.view(b_size, src_max, -1),
+                tgt_pcd.view(b_size, tgt_max, -1), src_mask, tgt_mask)

@@ -1,0 +1,132 @@
+"""The drop-in `models` package: same names/signatures as the reference, HIP underneath.  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import diffreg_oracle as orc
+from tests.helpers import T, weights, pair, masks, sinkhorn_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def to_attr(d):
+    return AttrDict({k: to_attr(v) for k, v in d.items()}) if isinstance(d, dict) else d
+
+
+def ref_like_config(variant, steps, mc):
+    v = synth.VARIANTS[variant]
+    matching = dict(feature_dim=v["C"], confidence_threshold=0.2, entangled=False, dsmax_temperature=0.1,
+                    match_type="sinkhorn", skh_init_bin_score=1.0, skh_iters=3, skh_prefilter=False)
+    return to_attr(dict(dataset=variant, kpfcn_config=dict(coarse_level=-2, coarse_feature_dim=v["C"]), coarse_matching=matching,
+                        coarse_transformer=dict(feature_dim=v["C"], n_head=v["H"],
+                                                layer_types=["self", "cross", "positioning", "self", "cross"],
+                                                positioning_type="procrustes", pe_type="rotary",
+                                                vol_bnds=[list(v["origin"]), [1.093, 0.78, 2.92]], voxel_size=v["voxel"],
+                                                feature_matching=dict(matching), entangled=False,
+                                                procrustes=dict(max_condition_num=mc, sample_rate=1.0)),
+                        SAMPLE_STEP=steps))
+
+
+class StubBackbone(torch.nn.Module):
+    def forward(self, data, phase="coarse"):
+        return data["_feats"]
+
+
+def test_log_optimal_transport_and_modules():
+    from models.matching import log_optimal_transport, Matching
+    from models.position_encoding import VolumetricPositionEncoding
+    from models.procrustes import SoftProcrustesLayer
+    from models.transformero import GeometryAttentionLayer
+    sc, sm, tm = sinkhorn_case(96, 80, 70, 61, torch.float32)
+    Z = log_optimal_transport(sc.to(DEV), torch.tensor(1.0, device=DEV), 3, sm.to(DEV), tm.to(DEV)).cpu()
+    ref = orc.sinkhorn_log(sc, torch.tensor(1.0), 3, sm, tm)
+    fin = torch.isfinite(ref)
+    assert (Z[fin] - ref[fin]).abs().max().item() < 1e-4
+    variant = "3dmatch"
+    v = synth.VARIANTS[variant]
+    cfg = ref_like_config(variant, 1, 200)
+    _, p = pair(variant, 64, 48, 3)
+    pe_mod = VolumetricPositionEncoding(cfg.coarse_transformer)
+    code = pe_mod(p["p_s"].to(DEV))
+    cos, sin = orc.vol_pe(p["p_s"], v["C"], v["origin"], v["voxel"])
+    assert code.shape == (1, 64, v["C"], 2)
+    assert (code[..., 0].cpu() - cos).abs().max().item() < 2e-6 and (code[..., 1].cpu() - sin).abs().max().item() < 2e-6
+    W = weights(variant)
+    layer = GeometryAttentionLayer(cfg.coarse_transformer)
+    pre = "denoising_transformer.layers.1."
+    layer.load_state_dict({k[len(pre):]: t for k, t in W.items() if k.startswith(pre)})
+    layer = layer.to(DEV).eval()
+    code_t = pe_mod(p["p_t"].to(DEV))
+    out = layer(p["f_s"].to(DEV), p["f_t"].to(DEV), code, code_t, None, None).cpu()
+    ref_l = orc.attention_layer(W, pre, p["f_s"], p["f_t"], (cos, sin), orc.vol_pe(p["p_t"], v["C"], v["origin"], v["voxel"]),
+                                None, None, v["H"])
+    assert (out - ref_l).abs().max().item() < 1e-4
+    head = Matching(cfg.coarse_matching)
+    head.load_state_dict({k[len("denoising_coarse_matching."):]: t for k, t in W.items() if k.startswith("denoising_coarse_matching.")})
+    head = head.to(DEV).eval()
+    ms, mt = masks(64, 48)
+    data = {}
+    conf, cm = head(p["f_s"].to(DEV), p["f_t"].to(DEV), code, code_t, ms.to(DEV), mt.to(DEV), data, pe_type="rotary")
+    ref_c = orc.match_head(W, v, p["f_s"], p["f_t"], (cos, sin), orc.vol_pe(p["p_t"], v["C"], v["origin"], v["voxel"]), ms, mt)
+    assert (conf.cpu() - ref_c).abs().max().item() < 1e-4 and "src_feats_nopos" in data and cm.shape[1] == 3
+    proc = SoftProcrustesLayer(cfg.coarse_transformer.procrustes)
+    r = proc(ref_c.to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), ms.to(DEV), mt.to(DEV))
+    r_ref = orc.procrustes(ref_c, p["p_s"], p["p_t"], ms, mt, 1.0, 200)
+    assert (r[0].cpu() - r_ref[0]).abs().max().item() < 1e-4 and (r[1].cpu() - r_ref[1]).abs().max().item() < 1e-4
+    # float64 conf: default = well-defined (R,t); strict_reference = the reference's identity fallback (Q3)
+    r64 = proc(ref_c.double().to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), ms.to(DEV), mt.to(DEV), strict_reference=True)
+    assert torch.equal(r64[0].cpu(), torch.eye(3, dtype=torch.float64)[None])
+
+
+@pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", [
+    ("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
+    ("4dmatch", 128, 128, 112, 100, 5, 40, 21, "n128_s5_mc40_masked")])
+def test_pipeline_forward_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag):
+    """Pipeline(config).forward(data) with the reference's input dict and state-dict layout."""
+    from models.pipeline import Pipeline
+    g = golden("%s_loop_%s" % (variant, tag))
+    cfg = ref_like_config(variant, steps, mc)
+    model = Pipeline(cfg, backbone=StubBackbone())
+    assert cfg.coarse_transformer.layer_types == ["self", "cross"] * 3            # config mutation (Q12)
+    sd = model.state_dict()
+    assert sd["alphas_cumprod"].dtype == torch.float64 and "denoising_coarse_matching.tgt_proj.weight" in sd
+    W = weights(variant)
+    missing = [k for k in W if k not in sd]
+    assert not missing
+    sd.update({("module." + k)[7:]: t for k, t in W.items()})
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pr, p = pair(variant, N, M, seed)
+    feats = torch.cat([p["f_s"][0], p["f_t"][0]]).to(DEV)
+    pts = torch.cat([p["p_s"][0], p["p_t"][0]]).to(DEV)
+    ms, mt = masks(N, M, nv, mv)
+    data = {"points": [None, None, pts, None], "src_mask": ms.to(DEV), "tgt_mask": mt.to(DEV), "_feats": feats,
+            "src_ind_coarse_split": torch.arange(N, device=DEV), "tgt_ind_coarse_split": torch.arange(M, device=DEV),
+            "src_ind_coarse": torch.arange(N, device=DEV), "tgt_ind_coarse": torch.arange(N, N + M, device=DEV),
+            "x_T": p["x_T"].to(DEV), "noise": T(synth.step_noise(N, M, seed, steps))[:, None].to(DEV)}
+    out = model(data)
+    conf = out["conf_matrix_pred"]
+    assert conf.dtype == torch.float64 and conf.shape == (1, N, M)
+    d = np.abs(conf[0].cpu().numpy() - g["conf"])
+    assert (d > 1e-4).mean() <= 1e-3
+    assert out["R_s2t_pred"].shape == (1, 3, 3) and out["t_s2t_pred"].shape == (1, 3, 1)
+    assert torch.equal(out["s_pcd"].cpu(), p["p_s"])
+    if variant == "3dmatch":
+        mp = out["match_pred"]
+        assert mp.dtype == torch.int64 and mp.shape[1] == 3 and N <= mp.shape[0] <= N + M
+        # the final (R,t): the reference returns identity (Q3); ours is the fit on float32(conf)
+        r = orc.procrustes(conf.cpu().float(), p["p_s"], p["p_t"], ms, mt, 1.0, mc)
+        assert (out["R_s2t_pred"].cpu() - r[0]).abs().max().item() < 1e-4
+        model.strict_reference = True
+        out2 = model(dict(data))
+        assert torch.equal(out2["R_s2t_pred"].cpu().float(), torch.from_numpy(g["R_s2t_pred"]).float())
+    # eval_flag=True (validation) skips the loop (pipeline.py:221)
+    d2 = dict(data); d2.pop("conf_matrix_pred", None)
+    assert "conf_matrix_pred" not in model(d2, eval_flag=True)
