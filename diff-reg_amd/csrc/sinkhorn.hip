@@ -302,6 +302,153 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fast register-resident kernel: FULL tiles (N = 16 NW, M = 64 CPL), no masks, shift by pointer --
+// the shape of every Sinkhorn call of the 3D loop at N = M = 256 / 128.  Same mathematics as
+// sk_reg_kernel with every predicate removed, raw v_exp_f32, and cross-lane reductions on
+// v_permlane32_swap / v_permlane16_swap / DPP row rotations instead of ds_bpermute.
+// Per-row scalars are held 4 per lane: lane l owns rows 4 (l >> 4) + k, k = 0..3 of its wave.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap32(float& a, float& b) {   // lanes 32-63 of a <-> lanes 0-31 of b
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {   // odd 16-lane rows of a <-> even rows of b
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+template <int ROR>
+__device__ __forceinline__ float row_ror(float v) {            // rotate right inside each 16-lane row
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xF, 0xF, false));
+}
+template <typename Op>
+__device__ __forceinline__ float row_allreduce(float v, Op op) {
+    v = op(v, row_ror<8>(v));
+    v = op(v, row_ror<4>(v));
+    v = op(v, row_ror<2>(v));
+    v = op(v, row_ror<1>(v));
+    return v;
+}
+// 16 per-lane values -> q[k] = reduction over the wave of p[4 (lane >> 4) + k]
+template <typename Op>
+__device__ __forceinline__ void reduce16x4(float (&p)[16], float (&q)[4], Op op) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { swap32(p[k], p[k + 8]); p[k] = op(p[k], p[k + 8]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { swap16(p[k], p[k + 4]); p[k] = op(p[k], p[k + 4]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = row_allreduce(p[k], op);
+}
+__device__ __forceinline__ float wave_allsum_dpp(float v) {
+    v = row_allreduce(v, OpAdd());
+    return bcast_lane(v, 0) + bcast_lane(v, 16) + bcast_lane(v, 32) + bcast_lane(v, 48);
+}
+
+template <typename TIn, typename TOut, int NW, int CPL>
+__global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
+    constexpr int RPW = 16, N = NW * RPW, M = 64 * CPL;
+    __shared__ __attribute__((aligned(16))) float s_colpart[NW][M];
+    __shared__ __attribute__((aligned(16))) float s_b[M + 4];
+    __shared__ float s_dust[NW];
+
+    const int tile = blockIdx.x, lane = lane_id(), w = wave_id(), t = threadIdx.x;
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
+    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
+    const float alpha = *A.bin_score;
+    const double sh = A.shift ? A.shift[tile] : 0.0;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    float E[RPW][CPL];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) VecIO<TIn, CPL>::load(src + r * M, E[r], sh);
+
+    // row maxima -> rho (4 rows per lane), exponentials
+    float p[RPW], rho4[4], ed4[4], a4[4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float m = E[r][0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = fmaxf(m, E[r][c]);
+        p[r] = m;
+    }
+    reduce16x4(p, rho4, OpMax());
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rho4[k] = fmaxf(alpha, rho4[k]);
+        ed4[k] = __builtin_amdgcn_exp2f((alpha - rho4[k]) * LOG2E);     // dustbin-column entry of the row
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float nrho = -bcast_lane(rho4[r & 3], 16 * (r >> 2)) * LOG2E;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) E[r][c] = __builtin_amdgcn_exp2f(fmaf(E[r][c], LOG2E, nrho));
+    }
+
+    const float tot = (float)(N + M);
+    const float mu = 1.f / tot, muN = (float)M / tot, nu = mu, nuM = (float)N / tot;
+    float bj[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) bj[c] = 1.f;
+    float bM = 1.f, aN = 0.f;
+
+    for (int it = 0; it < A.iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            float s = E[r][0] * bj[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) s = fmaf(E[r][c], bj[c], s);
+            p[r] = s;
+        }
+        float rs4[4];
+        reduce16x4(p, rs4, OpAdd());
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = mu / fmaf(ed4[k], bM, rs4[k]);
+        float bs = bj[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) bs += bj[c];
+        aN = muN / (wave_allsum_dpp(bs) + bM);
+        float cp[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) cp[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float ar = bcast_lane(a4[r & 3], 16 * (r >> 2));
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cp[c] = fmaf(E[r][c], ar, cp[c]);
+        }
+        float dpl = ed4[0] * a4[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) dpl = fmaf(ed4[k], a4[k], dpl);
+        const float dp = bcast_lane(dpl, 0) + bcast_lane(dpl, 16) + bcast_lane(dpl, 32) + bcast_lane(dpl, 48);
+        VecIO<float, CPL>::store(&s_colpart[w][lane * CPL], cp);
+        if (lane == 0) s_dust[w] = dp;
+        __syncthreads();
+        if (t < M) {
+            float c = aN;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) c += s_colpart[k][t];
+            s_b[t] = nu / c;
+        } else if (t == M) {
+            float c = aN;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) c += s_dust[k];
+            s_b[M] = nuM / c;
+        }
+        __syncthreads();
+        VecIO<float, CPL>::load(&s_b[lane * CPL], bj, 0.0);
+        bM = s_b[M];
+    }
+
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float ar = bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot;
+        float o[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] = E[r][c] * ar * bj[c];
+        VecIO<TOut, CPL>::store(dst + r * M, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // streaming kernel: E in a global workspace, arbitrary N, M; compute type T
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T t_exp(T x);
@@ -493,6 +640,17 @@ static int launch_reg2(const SkArgs& a, hipStream_t st) {
 }
 template <typename TIn, typename TOut>
 static int launch_reg(const SkArgs& a, hipStream_t st) {
+    const bool plain = a.vec_in && a.vec_out && !a.src_mask && !a.tgt_mask && !(a.flags & DR_SK_MINSHIFT);
+    if (plain && a.N == 256 && a.M == 256) {
+        hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 16, 4>), dim3(a.B), dim3(1024), 0, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
+    if (plain && a.N == 128 && a.M == 128) {
+        hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 8, 2>), dim3(a.B), dim3(512), 0, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     if (a.vec_in && a.vec_out) return launch_reg2<TIn, TOut, true>(a, st);
     return launch_reg2<TIn, TOut, false>(a, st);
 }
