@@ -83,6 +83,8 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
                       const uint8_t* tgt_mask, int P, int N, int M, int use_mask_len, float sample_rate, float max_cond,
                       float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st);
 
+int read_proc_stamps(long long* h_out);
+
 // ---------------------------------------------------------------------------------------------
 // diffusion-state kernels (stateops.hip)
 // ---------------------------------------------------------------------------------------------

@@ -315,6 +315,9 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                              R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream);
 }
 
+/* diagnostics: wall-clock phase stamps (100 MHz ticks) of the last dr_procrustes launch, pair 0 */
+int dr_debug_procrustes_stamps(long long* h_out8) { return read_proc_stamps(h_out8); }
+
 int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream) {
     if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
     return launch_top1_union<double>(conf, P, N, M, (long long*)matches, count, (hipStream_t)stream);

@@ -3,9 +3,10 @@
 // per-step `.cpu().double().svd()` round trip (procrustes.py:35-36, quirk Q13): no host sync.
 //
 // One workgroup per pair:
-//   1. radix select (4 x 8-bit histogram passes over the tile, L2 resident) -> key of the K-th largest
-//   2. deterministic compaction in index order (ballot ranks) of the entries > tau plus the first
-//      entries == tau  (torch.sort is unstable, ties are unspecified upstream: lowest index first)
+//   1. the tile (<= 256 x 256) is read once into registers as ordered keys; radix select (4 x 8-bit
+//      digits, run-length aggregated LDS atomics, parallel bin search) -> key of the K-th largest
+//   2. entries > tau, plus the first entries == tau in a fixed (thread, element) order (torch.sort is
+//      unstable, ties are unspecified upstream), feed the moment sums directly -- deterministic
 //   3. fp64 sums  W1 = sum|w|, sum w X, sum w Y, sum w Y X^T  ->  Sxy = sum w^ Y X^T - (2 - s) Ybar Xbar^T
 //      with w^ = w / (W1 + eps), s = sum w^  (identical to (Y - Ybar)^T (w^ (X - Xbar)), procrustes.py:27-33)
 //   4. one-sided Jacobi SVD, R = U diag(1,1,det U det V) V^T, t = Ybar - R Xbar, cond = Dmax / Dmin
@@ -20,50 +21,83 @@ __device__ __forceinline__ unsigned order_key(float v) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // larger float <=> larger key
 }
 
-__device__ void svd3_jacobi(double A[3][3], double U[3][3], double S[3], double V[3][3]) {
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < 3; ++i) {
-                    al += A[i][p] * A[i][p];
-                    be += A[i][q] * A[i][q];
-                    ga += A[i][p] * A[i][q];
-                }
-                if (ga == 0.0 || fabs(ga) <= 1e-300) continue;
-                off = fmax(off, fabs(ga) / sqrt(al * be + 1e-300));
-                const double zeta = (be - al) / (2.0 * ga);
-                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
-                for (int i = 0; i < 3; ++i) {
-                    const double ap = A[i][p], aq = A[i][q];
-                    A[i][p] = c * ap - s * aq;
-                    A[i][q] = s * ap + c * aq;
-                    const double vp = V[i][p], vq = V[i][q];
-                    V[i][p] = c * vp - s * vq;
-                    V[i][q] = s * vp + c * vq;
-                }
-            }
-        if (off < 1e-15) break;
+// One-sided Jacobi SVD of a 3x3 matrix, A = U diag(S) V^T, S descending.  Every index is static so the
+// matrices stay in registers (a dynamically indexed local array would live in scratch).
+// v_rcp_f64 / v_rsq_f64 seeds (~2^-26 accurate... at least 20 bits) + two Newton steps: ~1e-16 relative, a
+// fraction of the instruction count of the IEEE-exact division / sqrt expansions (this code runs on ONE lane)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
+__device__ __forceinline__ void jacobi_rotate(double (&A)[3][3], double (&V)[3][3], const int p, const int q, double& off) {
+    double al = 0, be = 0, ga = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        al += A[i][p] * A[i][p];
+        be += A[i][q] * A[i][q];
+        ga += A[i][p] * A[i][q];
     }
+    if (fabs(ga) <= 1e-300) return;
+    off = fmax(off, fabs(ga) * fast_rsqrt(al * be + 1e-300));
+    const double zeta = (be - al) * 0.5 * fast_rcp(ga);
+    const double z2 = 1.0 + zeta * zeta;
+    const double tt = (zeta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + z2 * fast_rsqrt(z2));
+    const double c = fast_rsqrt(1.0 + tt * tt), s = c * tt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double ap = A[i][p], aq = A[i][q];
+        A[i][p] = c * ap - s * aq;
+        A[i][q] = s * ap + c * aq;
+        const double vp = V[i][p], vq = V[i][q];
+        V[i][p] = c * vp - s * vq;
+        V[i][q] = s * vp + c * vq;
+    }
+}
+
+__device__ __forceinline__ void swap_cols(double (&A)[3][3], double (&V)[3][3], double (&S)[3], const int a, const int b) {
+    if (S[b] > S[a]) {
+        const double ts = S[a]; S[a] = S[b]; S[b] = ts;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double ta = A[i][a]; A[i][a] = A[i][b]; A[i][b] = ta;
+            const double tv = V[i][a]; V[i][a] = V[i][b]; V[i][b] = tv;
+        }
+    }
+}
+
+__device__ __forceinline__ void svd3_jacobi(double (&A)[3][3], double (&U)[3][3], double (&S)[3], double (&V)[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        jacobi_rotate(A, V, 0, 1, off);
+        jacobi_rotate(A, V, 0, 2, off);
+        jacobi_rotate(A, V, 1, 2, off);
+        if (off < 1e-12) break;        // quadratic convergence: the next sweep would be ~1e-24
+    }
+#pragma unroll
     for (int j = 0; j < 3; ++j) S[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
-    // sort descending (columns of A and V move together)
-    for (int a = 0; a < 2; ++a)
-        for (int b = a + 1; b < 3; ++b)
-            if (S[b] > S[a]) {
-                double ts = S[a]; S[a] = S[b]; S[b] = ts;
-                for (int i = 0; i < 3; ++i) {
-                    double ta = A[i][a]; A[i][a] = A[i][b]; A[i][b] = ta;
-                    double tv = V[i][a]; V[i][a] = V[i][b]; V[i][b] = tv;
-                }
-            }
+    swap_cols(A, V, S, 0, 1);
+    swap_cols(A, V, S, 0, 2);
+    swap_cols(A, V, S, 1, 2);
     const double tiny = 1e-200;
+#pragma unroll
     for (int j = 0; j < 2; ++j)
+#pragma unroll
         for (int i = 0; i < 3; ++i) U[i][j] = S[j] > tiny ? A[i][j] / S[j] : (i == j ? 1.0 : 0.0);
     if (S[2] > 1e-14 * S[0] && S[2] > tiny) {
+#pragma unroll
         for (int i = 0; i < 3; ++i) U[i][2] = A[i][2] / S[2];
     } else {   // rank deficient: complete the basis (cond = inf/huge rejects it unless the gate is open)
         U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
@@ -72,7 +106,7 @@ __device__ void svd3_jacobi(double A[3][3], double U[3][3], double S[3], double 
     }
 }
 
-__device__ __forceinline__ double det3(const double m[3][3]) {
+__device__ __forceinline__ double det3(const double (&m)[3][3]) {
     return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
@@ -91,20 +125,153 @@ struct ProcArgs {
     float sample_rate, max_cond;
 };
 
+__device__ __forceinline__ float key_value(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+constexpr int CAND_MAX = 4096;   // candidate list held in LDS
+
+// phase stamps of pair 0 (wall clock, 100 MHz ticks) for tools/: written by one lane, never read by kernels
+__device__ long long g_proc_stamps[8];
+#define PROC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_proc_stamps[i] = wall_clock64(); } while (0)
+
+// radix select over the keys enumerated by `for_each` (4 x 8-bit digits, run-length aggregated LDS
+// atomics, parallel bin search by wave 0): on return tau = key of the K-th largest, remaining = how
+// many keys == tau belong to the top K.  Block-wide; K >= 1 and K <= number of enumerated keys.
+template <int PASSES = 4, typename ForEach>
+__device__ __forceinline__ void radix_select(ForEach&& for_each, unsigned K, unsigned* s_hist, unsigned* s_pr, unsigned& tau,
+                                             unsigned& remaining) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    unsigned prefix = 0, mask = 0;
+    remaining = K;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) s_hist[t] = 0;
+        __syncthreads();
+        int cur = -1;
+        unsigned cnt = 0;
+        for_each([&](unsigned k, int) {
+            if (k != 0u && (k & mask) == prefix) {
+                const int b = (int)((k >> shift) & 255u);
+                if (b == cur) {
+                    ++cnt;
+                } else {
+                    if (cnt) atomicAdd(&s_hist[cur], cnt);
+                    cur = b;
+                    cnt = 1;
+                }
+            }
+        });
+        if (cnt) atomicAdd(&s_hist[cur], cnt);
+        __syncthreads();
+        if (w == 0) {
+            // lane l owns bins 255-4l .. 252-4l (descending); find the bin holding the `remaining`-th key
+            unsigned h[4], c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h[q] = s_hist[255 - 4 * lane - q]; c += h[q]; }
+            unsigned incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const unsigned long long hit = __ballot(incl >= remaining);
+            const int first = __ffsll((long long)hit) - 1;
+            if (lane == first) {
+                unsigned cum = incl - c;
+                int q = 0;
+                for (; q < 3; ++q) {
+                    if (cum + h[q] >= remaining) break;
+                    cum += h[q];
+                }
+                s_pr[0] = prefix | ((unsigned)(255 - 4 * lane - q) << shift);
+                s_pr[1] = remaining - cum;
+            }
+        }
+        __syncthreads();
+        prefix = s_pr[0];
+        remaining = s_pr[1];
+        mask |= 0xFFu << shift;
+    }
+    tau = prefix;
+}
+
+// exclusive prefix (over the 1024 threads, thread order) of a per-thread count; also the block total
+__device__ __forceinline__ int block_excl_scan(int v, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = s_w[k];
+        if (k < w) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + incl - v;
+}
+
+// REG: the tile (N*M <= 65536) is read ONCE and kept as 64 ordered keys per thread.  !REG: every pass
+// streams the tile (L2).  Selection in two levels: the K-th largest of the 1024 per-thread maxima, L,
+// is a lower bound of the K-th largest entry (there are >= K entries >= L), so only entries >= L --
+// typically K..1.2 K of them -- are compacted into LDS and selected exactly; if they do not fit
+// (flat or massively tied tiles) the full-tile radix select runs instead.
+template <bool REG>
 __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_prefix, s_remaining;
-    __shared__ int s_wcnt[2][16];
-    __shared__ int s_sel[PK_MAX];
+    __shared__ unsigned s_pr[2];
+    __shared__ int s_w[16];
+    __shared__ unsigned s_ckey[CAND_MAX];
+    __shared__ int s_cidx[CAND_MAX];
     __shared__ double s_red[16][16];
     __shared__ int s_len[2];
+    __shared__ int s_nsel;
 
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int N = A.N, M = A.M, NM = N * M;
     const float* conf = A.conf + (size_t)pair * NM;
 
+    PROC_STAMP(0);
+    unsigned key[REG ? 64 : 1];
+    // register image: key[4 q + c] is element e = 4 (1024 q + t) + c  (16 coalesced 16-byte loads per thread)
+    const bool vec4 = REG && (NM % 4 == 0) && (((uintptr_t)conf & 15) == 0);
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = 4 * (q * 1024 + t);
+            if (vec4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NM) v = *reinterpret_cast<const float4*>(conf + e);
+                key[4 * q + 0] = e < NM ? order_key(v.x) : 0u;      // 0 = "no element" (only one NaN pattern maps to key 0)
+                key[4 * q + 1] = e < NM ? order_key(v.y) : 0u;
+                key[4 * q + 2] = e < NM ? order_key(v.z) : 0u;
+                key[4 * q + 3] = e < NM ? order_key(v.w) : 0u;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) key[4 * q + c] = e + c < NM ? order_key(conf[e + c]) : 0u;
+            }
+        }
+    }
+    auto for_each = [&](auto&& f) {
+        if (REG) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) f(key[i], 4 * ((i >> 2) * 1024 + t) + (i & 3));
+        } else {
+            for (int e = t; e < NM; e += 1024) f(order_key(conf[e]), e);
+        }
+    };
+
     // ---- K (procrustes.py:61-65; 4D/models/procrustes.py:61-62 uses the mask sums, quirk Q17) -------
     int K = A.K_fixed;
+    if (t == 0) s_nsel = 0;
     if (A.use_mask_len) {
         if (t < 2) s_len[t] = 0;
         __syncthreads();
@@ -119,80 +286,17 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     }
     if (K > NM) K = NM;
     if (K > PK_MAX) K = PK_MAX;
-
-    // ---- radix select of the K-th largest key ----------------------------------------------------------
-    unsigned prefix = 0, mask = 0, remaining = (unsigned)K;
-    if (K > 0) {
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (t < 256) s_hist[t] = 0;
-            __syncthreads();
-            for (int e = t; e < NM; e += 1024) {
-                const unsigned key = order_key(conf[e]);
-                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (t == 0) {
-                unsigned cum = 0;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (cum + s_hist[b] >= remaining) break;
-                    cum += s_hist[b];
-                }
-                s_prefix = prefix | ((unsigned)b << shift);
-                s_remaining = remaining - cum;
-            }
-            __syncthreads();
-            prefix = s_prefix;
-            remaining = s_remaining;
-            mask |= 0xFFu << shift;
-            __syncthreads();
-        }
-    }
-    const unsigned tau = prefix;            // key of the K-th largest entry; take `remaining` entries == tau
-    const int n_gt_total = K - (int)remaining;
-
-    // ---- compaction in index order ------------------------------------------------------------------------
-    const int per_wave = ((NM + 15) / 16 + 63) / 64 * 64;
-    const int beg = w * per_wave, end = (beg + per_wave < NM) ? beg + per_wave : NM;
-    int cg = 0, ce = 0;
-    for (int base = beg; base < end; base += 64) {
-        const int e = base + lane;
-        const unsigned key = e < end ? order_key(conf[e]) : 0u;
-        const bool gt = e < end && key > tau, eq = e < end && key == tau;
-        cg += __popcll(__ballot(gt));
-        ce += __popcll(__ballot(eq));
-    }
-    if (lane == 0) { s_wcnt[0][w] = cg; s_wcnt[1][w] = ce; }
-    __syncthreads();
-    int off_g = 0, off_e = 0;
-    for (int k = 0; k < w; ++k) { off_g += s_wcnt[0][k]; off_e += s_wcnt[1][k]; }
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int base = beg; base < end && K > 0; base += 64) {
-        const int e = base + lane;
-        const unsigned key = e < end ? order_key(conf[e]) : 0u;
-        const bool gt = e < end && key > tau, eq = e < end && key == tau;
-        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-        if (gt) s_sel[off_g + __popcll(bg & lt_mask)] = e;
-        if (eq) {
-            const int rank = off_e + __popcll(be & lt_mask);
-            if (rank < (int)remaining) s_sel[n_gt_total + rank] = e;
-        }
-        off_g += __popcll(bg);
-        off_e += __popcll(be);
-    }
     __syncthreads();
 
-    // ---- weighted sums in fp64 ---------------------------------------------------------------------------
     double acc[16];
+    int n_listed = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0;
     const float* Xs = A.src_pcd + (size_t)pair * N * 3;
     const float* Ys = A.tgt_pcd + (size_t)pair * M * 3;
-    for (int s = t; s < K; s += 1024) {
-        const int e = s_sel[s];
-        const double wv = (double)conf[e];
-        const int i = e / M, j = e % M;
+    auto take = [&](unsigned k, int e) {
+        const double wv = (double)key_value(k);
+        const int i = e / M, j = e - i * M;
         const double x0 = Xs[i * 3], x1 = Xs[i * 3 + 1], x2 = Xs[i * 3 + 2];
         const double y0 = Ys[j * 3], y1 = Ys[j * 3 + 1], y2 = Ys[j * 3 + 2];
         acc[0] += fabs(wv);
@@ -201,18 +305,99 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         acc[7] += wv * y0 * x0; acc[8] += wv * y0 * x1; acc[9] += wv * y0 * x2;
         acc[10] += wv * y1 * x0; acc[11] += wv * y1 * x1; acc[12] += wv * y1 * x2;
         acc[13] += wv * y2 * x0; acc[14] += wv * y2 * x1; acc[15] += wv * y2 * x2;
-        if (A.topk_idx) A.topk_idx[(size_t)pair * K + s] = e;
+        if (A.topk_idx) A.topk_idx[(size_t)pair * K + atomicAdd(&s_nsel, 1)] = e;
+    };
+
+    PROC_STAMP(1);
+    if (K > 0) {
+        // ---- level 1: lower bound L from the per-thread maxima ---------------------------------------------
+        unsigned tmax = 0;
+        for_each([&](unsigned k, int) { tmax = k > tmax ? k : tmax; });
+        unsigned L = 0, dummy;
+        int ncand = NM;
+        if (K <= 1024) {
+            // (threads whose slice is empty have tmax = 0 and are not enumerated; K <= #non-empty is
+            //  guaranteed when K <= min(NM, 1024) because slices are filled round-robin)
+            // two 8-bit digits suffice for a bound: L = the 16-bit bucket of the K-th largest thread maximum
+            radix_select<2>([&](auto&& f) { f(tmax, 0); }, (unsigned)K, s_hist, s_pr, L, dummy);
+            int c = 0;
+            for_each([&](unsigned k, int) { c += (k >= L && k != 0u) ? 1 : 0; });
+            int off = block_excl_scan(c, s_w, ncand);
+            if (ncand <= CAND_MAX) {
+                for_each([&](unsigned k, int e) {
+                    if (k >= L && k != 0u) { s_ckey[off] = k; s_cidx[off] = e; ++off; }
+                });
+            }
+            __syncthreads();
+        }
+        PROC_STAMP(2);
+        unsigned tau = 0, remaining = 0;
+        if (ncand > CAND_MAX) {
+            // ---- fallback: radix select over the whole tile, then compact the K selected entries ------------
+            // (rare path: streams the tile from memory so that its branchy code is not unrolled 64x)
+            auto for_mem = [&](auto&& f) {
+                for (int e = t; e < NM; e += 1024) f(order_key(conf[e]), e);
+            };
+            unsigned ftau, frem;
+            radix_select(for_mem, (unsigned)K, s_hist, s_pr, ftau, frem);
+            int cg = 0, ce = 0;
+            for_mem([&](unsigned k, int) {
+                cg += k > ftau ? 1 : 0;
+                ce += (k == ftau && k != 0u) ? 1 : 0;
+            });
+            int tg, te;
+            int off_g = block_excl_scan(cg, s_w, tg);
+            int rank_e = block_excl_scan(ce, s_w, te);
+            for_mem([&](unsigned k, int e) {
+                if (k > ftau) {
+                    s_ckey[off_g] = k; s_cidx[off_g] = e; ++off_g;
+                } else if (k == ftau && k != 0u) {
+                    if (rank_e < (int)frem) { s_ckey[tg + rank_e] = k; s_cidx[tg + rank_e] = e; }
+                    ++rank_e;
+                }
+            });
+            ncand = K;                      // the list now holds exactly the top K: select all of it below
+            __syncthreads();
+        }
+        // ---- exact selection among the listed candidates (thread t owns entries t, t+1024, ..) ----------------
+        auto for_cand = [&](auto&& f) {
+            for (int c = t; c < ncand; c += 1024) f(s_ckey[c], s_cidx[c]);
+        };
+        n_listed = ncand;
+        if (ncand > K) radix_select(for_cand, (unsigned)K, s_hist, s_pr, tau, remaining);
+        PROC_STAMP(3);
+        int ties = 0;
+        for_cand([&](unsigned k, int e) {
+            if (k > tau) take(k, e);
+            else if (k == tau) ++ties;
+        });
+        int tot_ties;
+        int rank = block_excl_scan(ties, s_w, tot_ties);
+        for_cand([&](unsigned k, int e) {
+            if (k == tau) {
+                if (rank < (int)remaining) take(k, e);
+                ++rank;
+            }
+        });
     }
+    PROC_STAMP(4);
+    // only the waves that own list entries (entry c belongs to thread c % 1024) hold non-zero sums
+    if (w * 64 < n_listed) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const double v = wave_sum(acc[i]);
-        if (lane == 0) s_red[w][i] = v;
+        for (int i = 0; i < 16; ++i) {
+            const double v = wave_sum(acc[i]);
+            if (lane == 0) s_red[w][i] = v;
+        }
+    } else if (lane < 16) {
+        s_red[w][lane] = 0.0;
     }
     __syncthreads();
     if (t != 0) return;
     double sum[16];
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         double v = 0;
+#pragma unroll
         for (int k = 0; k < 16; ++k) v += s_red[k][i];
         sum[i] = v;
     }
@@ -221,23 +406,36 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     double mx[3] = {sum[1] * inv, sum[2] * inv, sum[3] * inv};
     double my[3] = {sum[4] * inv, sum[5] * inv, sum[6] * inv};
     double Sxy[3][3], U[3][3], V[3][3], D[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
         for (int b = 0; b < 3; ++b) Sxy[a][b] = sum[7 + 3 * a + b] * inv - (2.0 - sw) * my[a] * mx[b];
     // the reference forms Sxy in fp32 before `.double()` (procrustes.py:33-34)
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
         for (int b = 0; b < 3; ++b) Sxy[a][b] = (double)(float)Sxy[a][b];
     double Aw[3][3];
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
         for (int b = 0; b < 3; ++b) Aw[a][b] = Sxy[a][b];
+    PROC_STAMP(5);
     svd3_jacobi(Aw, U, D, V);
+    PROC_STAMP(6);
     const double cond = D[0] / D[2];
     const double dd = det3(U) * det3(V);
     double Rm[3][3];
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
         for (int b = 0; b < 3; ++b) Rm[a][b] = U[a][0] * V[b][0] + U[a][1] * V[b][1] + dd * U[a][2] * V[b][2];
     float Rf32[9], tf32[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
         for (int b = 0; b < 3; ++b) Rf32[a * 3 + b] = (float)Rm[a][b];
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         // t = mean_Y - R mean_X in fp32 like the reference (procrustes.py:43)
         const float mxf[3] = {(float)mx[0], (float)mx[1], (float)mx[2]};
@@ -249,16 +447,24 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     const bool good = cond < (double)A.max_cond;     // NaN or inf -> false (procrustes.py:87)
     float* R = A.R + (size_t)pair * 9; float* tt = A.t + (size_t)pair * 3;
     float* Rf = A.Rf + (size_t)pair * 9; float* tf = A.tf + (size_t)pair * 3;
+#pragma unroll
     for (int i = 0; i < 9; ++i) {
         R[i] = Rf32[i];
         Rf[i] = good ? Rf32[i] : ((i % 4 == 0) ? 1.f : 0.f);
     }
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         tt[i] = tf32[i];
         tf[i] = good ? tf32[i] : 0.f;
     }
     A.cond[pair] = cond;
     A.ok[pair] = good ? 1 : 0;
+    PROC_STAMP(7);
+}
+
+int read_proc_stamps(long long* h_out) {
+    DR_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_proc_stamps), sizeof(long long) * 8));
+    return DR_OK;
 }
 
 int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_pcd, const uint8_t* src_mask,
@@ -275,7 +481,10 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
     a.K_fixed = (int)((float)(N > M ? N : M) * sample_rate);
     if (a.K_fixed > PK_MAX) return DR_ENOSUP;
     ProfScope ps(PK_PROCRUSTES, (double)P * N * M * 4.0, st);
-    hipLaunchKernelGGL(procrustes_kernel, dim3(P), dim3(1024), 0, st, a);
+    if ((long)N * M <= 65536)
+        hipLaunchKernelGGL(procrustes_kernel<true>, dim3(P), dim3(1024), 0, st, a);
+    else
+        hipLaunchKernelGGL(procrustes_kernel<false>, dim3(P), dim3(1024), 0, st, a);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

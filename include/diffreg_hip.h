@@ -141,6 +141,10 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
                       double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
 
+/* diagnostics for tools/: 8 wall-clock stamps (100 MHz ticks) of the phases of the last
+ * dr_procrustes_f32 launch (pair 0); synchronises the device. */
+int dr_debug_procrustes_stamps(long long* h_out8);
+
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
  * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */
 int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream);
