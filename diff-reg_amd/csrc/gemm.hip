@@ -15,90 +15,141 @@ namespace dr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // k per staged chunk
-constexpr int LDT = BK + 4;   // padded LDS row stride (floats)
+// Geometry: a wave owns TM x TN MFMA tiles (32x32 each); a workgroup is WM x WN x WK waves (4 in all);
+// K is staged in chunks of BKC floats (double-buffered LDS, one barrier per chunk), of which each of
+// the WK k-groups of waves consumes BKC / WK.
+template <int TM, int TN, int WM, int WN, int WK, int BKC>
+struct GemmGeom {
+    static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr int LDT = BKC + 4;                         // padded LDS row stride (floats)
+    static constexpr int C4 = BKC / 4;                          // float4 per staged row
+    static constexpr int A_SLOTS = (BM * C4 + 255) / 256, B_SLOTS = (BN * C4 + 255) / 256;
+    static constexpr int STAGE = (BM + BN) * LDT;               // floats per buffer
+    static constexpr int RED = (WK > 1) ? 4 * TM * TN * 16 * 64 : 0;
+    static constexpr int SMEM_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
+    static constexpr int GROUPS = BKC / WK / 8;                 // 8-wide k groups per wave per chunk
+};
 
-template <int WM, int WN, int WK>
+template <int TM, int TN, int WM, int WN, int WK, int BKC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
     static_assert(WM * WN * WK == 4, "4 waves");
-    constexpr int BM = 32 * WM, BN = 32 * WN;
-    constexpr int A_SLOTS = BM * 8 / 256 > 0 ? BM * 8 / 256 : 1;   // float4 slots per thread
-    constexpr int B_SLOTS = BN * 8 / 256 > 0 ? BN * 8 / 256 : 1;
-    constexpr int STAGE = (BM + BN) * LDT;                          // floats per buffer
-    constexpr int RED = (WK > 1) ? 4 * 16 * 64 : 0;
-    constexpr int SMEM = 2 * STAGE > RED ? 2 * STAGE : RED;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
+    constexpr int BM = GG::BM, BN = GG::BN, LDT = GG::LDT, C4 = GG::C4, STAGE = GG::STAGE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const GemmProblem& P = G.p[blockIdx.y];
-    const int tiles_n = (P.ncols + BN - 1) / BN, tiles_m = (P.rows + BM - 1) / BM;
+    // problem fields once into registers (re-reading the kernarg segment inside the k-loop costs a scalar-load
+    // round trip per use)
+    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA2 = P.A2;
+    const float* __restrict__ pW = P.W;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
+    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
     if ((int)blockIdx.x >= tiles_n * tiles_m) return;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
-    const int K = P.K, K1 = P.A2 ? P.K1 : P.K;
-    const int nchunks = (K + BK - 1) / BK;
+    const int nchunks = (K + BKC - 1) / BKC;
 
-    float4 ra[A_SLOTS], rb[B_SLOTS];
-    auto load_chunk = [&](int ch) {
-        const int k0 = ch * BK;
+    // per-thread staging slots: (row, k-offset) are loop invariant; out-of-range rows are clamped to a valid
+    // row and zeroed by a select, so the loads carry no branches
+    float4 ra[GG::A_SLOTS], rb[GG::B_SLOTS];
+    const float* a1p[GG::A_SLOTS];
+    const float* a2p[GG::A_SLOTS];
+    const float* bp[GG::B_SLOTS];
+    int akc[GG::A_SLOTS], bkc[GG::B_SLOTS];
+    bool aok[GG::A_SLOTS], bok[GG::B_SLOTS];
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) {
-            const int slot = t + s * 256;
-            const int r = slot >> 3, k = k0 + 4 * (slot & 7);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (slot < BM * 8 && row0 + r < P.rows && k < K) {
-                if (k < K1) v = *reinterpret_cast<const float4*>(P.A + (size_t)(row0 + r) * P.lda + k);
-                else v = *reinterpret_cast<const float4*>(P.A2 + (size_t)(row0 + r) * P.lda2 + (k - K1));
-            }
-            ra[s] = v;
+    for (int s = 0; s < GG::A_SLOTS; ++s) {
+        const int slot = t + s * 256, r = slot / C4;
+        akc[s] = 4 * (slot % C4);
+        aok[s] = slot < BM * C4 && row0 + r < rows;
+        const int rc = min(row0 + r, rows - 1);
+        a1p[s] = pA + (size_t)rc * lda;
+        a2p[s] = pA2 ? pA2 + (size_t)rc * lda2 - K1 : a1p[s];
+    }
+#pragma unroll
+    for (int s = 0; s < GG::B_SLOTS; ++s) {
+        const int slot = t + s * 256, r = slot / C4;
+        bkc[s] = 4 * (slot % C4);
+        bok[s] = slot < BN * C4 && col0 + r < ncols;
+        bp[s] = pW + (size_t)min(col0 + r, ncols - 1) * K;
+    }
+    auto load_chunk = [&](int ch) {
+        const int k0 = ch * BKC;
+#pragma unroll
+        for (int s = 0; s < GG::A_SLOTS; ++s) {
+            const int k = k0 + akc[s];
+            const int kc = min(k, K - 4);
+            const float* src = (kc < K1 ? a1p[s] : a2p[s]) + kc;
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            const bool ok = aok[s] && k < K;
+            ra[s] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) {
-            const int slot = t + s * 256;
-            const int r = slot >> 3, k = k0 + 4 * (slot & 7);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (slot < BN * 8 && col0 + r < P.ncols && k < K)
-                v = *reinterpret_cast<const float4*>(P.W + (size_t)(col0 + r) * K + k);
-            rb[s] = v;
+        for (int s = 0; s < GG::B_SLOTS; ++s) {
+            const int k = k0 + bkc[s];
+            const float4 v = *reinterpret_cast<const float4*>(bp[s] + min(k, K - 4));
+            const bool ok = bok[s] && k < K;
+            rb[s] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
     auto store_chunk = [&](int buf) {
         float* As = smem + buf * STAGE;
         float* Bs = As + BM * LDT;
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) {
+        for (int s = 0; s < GG::A_SLOTS; ++s) {
             const int slot = t + s * 256;
-            if (slot < BM * 8) *reinterpret_cast<float4*>(As + (slot >> 3) * LDT + 4 * (slot & 7)) = ra[s];
+            if (slot < BM * C4) *reinterpret_cast<float4*>(As + (slot / C4) * LDT + akc[s]) = ra[s];
         }
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) {
+        for (int s = 0; s < GG::B_SLOTS; ++s) {
             const int slot = t + s * 256;
-            if (slot < BN * 8) *reinterpret_cast<float4*>(Bs + (slot >> 3) * LDT + 4 * (slot & 7)) = rb[s];
+            if (slot < BN * C4) *reinterpret_cast<float4*>(Bs + (slot / C4) * LDT + bkc[s]) = rb[s];
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
-    constexpr int GROUPS = BK / 8 / WK;          // 8-wide k groups per wave per chunk
     const int h = lane >> 5, l31 = lane & 31;
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) load_chunk(ch + 1);
-        const float* As = smem + (ch & 1) * STAGE + (wm * 32 + l31) * LDT + wk * GROUPS * 8 + 4 * h;
-        const float* Bs = smem + (ch & 1) * STAGE + BM * LDT + (wn * 32 + l31) * LDT + wk * GROUPS * 8 + 4 * h;
+        const float* As = smem + (ch & 1) * STAGE + (wm * TM * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
+        const float* Bs = smem + (ch & 1) * STAGE + BM * LDT + (wn * TN * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
+        // fragments of group g+1 are fetched while the MFMAs of group g issue
+        float4 a[2][TM], b[2][TN];
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            const float4 a = *reinterpret_cast<const float4*>(As + 8 * g);
-            const float4 b = *reinterpret_cast<const float4*>(Bs + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDT);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDT);
+#pragma unroll
+        for (int g = 0; g < GG::GROUPS; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < GG::GROUPS) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDT + 8 * (g + 1));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDT + 8 * (g + 1));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].x, b[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].y, b[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].z, b[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].w, b[cur][j].w, acc[i][j], 0, 0, 0);
+                }
         }
         if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
         __syncthreads();
@@ -108,69 +159,107 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
         // reduce the WK partial accumulators of each (wm, wn) through LDS
         float* red = smem;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[(w * 16 + i) * 64 + lane] = acc[i];
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((w * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
         __syncthreads();
         if (wk != 0) return;
 #pragma unroll
         for (int o = 1; o < WK; ++o)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += red[((w + o) * 16 + i) * 64 + lane];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((((w + o) * TM + i) * TN + j) * 16 + r) * 64 + lane];
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-    const int col = col0 + wn * 32 + l31;
-    const bool col_ok = col < P.ncols;
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int halfC = P.rot_C >> 1;
-    const int ridx = (P.epi & EPI_ROTARY) ? (col % P.rot_C) >> 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        float v = acc[i];
-        if (P.epi & EPI_ROTARY) {
-            // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
-            const float other = __shfl_xor(v, 1);
-            if (row < P.rows && col_ok) {
-                const float c = P.cosT[(size_t)row * halfC + ridx], s = P.sinT[(size_t)row * halfC + ridx];
-                const float sw = (col & 1) ? other : -other;
-                v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, s));
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + (wn * TN + j) * 32 + l31;
+        const bool col_ok = col < ncols;
+        const int ridx = (P.epi & EPI_ROTARY) ? (col % P.rot_C) >> 1 : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[i][j][r];
+                if (P.epi & EPI_ROTARY) {
+                    // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
+                    const float other = __shfl_xor(v, 1);
+                    if (row < rows && col_ok) {
+                        const float c = P.cosT[(size_t)row * halfC + ridx], s = P.sinT[(size_t)row * halfC + ridx];
+                        const float sw = (col & 1) ? other : -other;
+                        v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, s));
+                    }
+                }
+                if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
+                v *= P.scale;
+                if (row < rows && col_ok) P.out[(size_t)row * P.ldo + col] = v;
             }
-        }
-        if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
-        v *= P.scale;
-        if (row < P.rows && col_ok) P.out[(size_t)row * P.ldo + col] = v;
     }
 }
 
-template <int WM, int WN, int WK>
+template <int TM, int TN, int WM, int WN, int WK, int BKC>
+static int configure_cfg() {
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GG::SMEM_FLOATS * sizeof(float))));
+    return DR_OK;
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int BKC>
 static int launch_cfg(const GemmBatch& g, hipStream_t st) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
     int maxt = 0;
     for (int i = 0; i < g.n; ++i) {
-        const int tl = ((g.p[i].rows + BM - 1) / BM) * ((g.p[i].ncols + BN - 1) / BN);
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
         maxt = tl > maxt ? tl : maxt;
     }
     if (maxt == 0) return DR_OK;
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM, flops, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, WK>), dim3(maxt, g.n), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>), dim3(maxt, g.n), dim3(256), GG::SMEM_FLOATS * sizeof(float), st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
 
+//                 TM TN WM WN WK BKC
+#define CFG_SMALL  1, 1, 1, 1, 4, 128    /*  32 x  32 tile, k split over the 4 waves, deep chunks (latency-bound sizes) */
+#define CFG_MEDIUM 1, 1, 2, 2, 1, 64     /*  64 x  64 tile                                                            */
+#define CFG_LARGE  2, 1, 2, 2, 1, 32     /* 128 x  64 tile, 64 x 32 per wave                                          */
+
+int gemm_configure() {
+    int rc = configure_cfg<CFG_SMALL>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_MEDIUM>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_LARGE>();
+    return rc;
+}
+
+static int g_force_cfg = -1;   // tools/: force a configuration (0 small, 1 medium, 2 large)
+void gemm_force_config(int c) { g_force_cfg = c; }
+
 int launch_gemm(const GemmBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 4) return DR_EINVAL;
-    long tiles64 = 0;
+    long nL = 0, nM = 0;
     for (int i = 0; i < g.n; ++i) {
         const GemmProblem& p = g.p[i];
         if (p.K % 4 || p.lda % 4 || (p.A2 && (p.K1 % 4 || p.lda2 % 4))) return DR_ENOSUP;
         if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2) & 15) return DR_ENOSUP;
-        tiles64 += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64);
+        nL += (long)((p.rows + 127) / 128) * ((p.ncols + 63) / 64);
+        nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64);
     }
-    // fill the 256 CUs: wide tiles when there is enough work, otherwise split k inside the workgroup
-    if (tiles64 >= 512) return launch_cfg<2, 2, 1>(g, st);
-    if (tiles64 >= 128) return launch_cfg<2, 1, 2>(g, st);
-    return launch_cfg<1, 1, 4>(g, st);
+    int cfg = nL >= 256 ? 2 : (nM >= 128 ? 1 : 0);     // fill the 256 CUs before growing the tile
+    if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
+    if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
+    return launch_cfg<CFG_SMALL>(g, st);
 }
 
 }  // namespace dr

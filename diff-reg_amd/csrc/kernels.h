@@ -43,6 +43,8 @@ struct GemmBatch {
 };
 
 int launch_gemm(const GemmBatch& g, hipStream_t st);
+int gemm_configure();
+void gemm_force_config(int c);
 
 // ---------------------------------------------------------------------------------------------
 // attention (transformero.py:79-85): segments of queries attending segments of keys

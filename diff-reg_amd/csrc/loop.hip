@@ -232,7 +232,14 @@ using namespace dr;
 
 extern "C" {
 
-int dr_init(void) { return attention_configure(); }
+int dr_init(void) {
+    int rc = attention_configure();
+    if (rc == DR_OK) rc = gemm_configure();
+    return rc;
+}
+
+/* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
+void dr_debug_gemm_config(int c) { gemm_force_config(c); }
 
 int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t, float origin_x,
                   float origin_y, float origin_z, float voxel, const float* freq, float* cos_out, float* sin_out,

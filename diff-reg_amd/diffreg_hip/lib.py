@@ -67,6 +67,7 @@ SIGNATURES.update({
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
+    "dr_debug_gemm_config": (None, [c_int]),
     "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -141,6 +141,9 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
                       double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
 
+/* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
+void dr_debug_gemm_config(int c);
+
 /* diagnostics for tools/: 8 wall-clock stamps (100 MHz ticks) of the phases of the last
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
