@@ -23,10 +23,11 @@ template <int DG, int NDT>
 struct AttnGeom {
     static constexpr int DP = DG * 8;            // padded head dim for the QK^T k-loop
     static constexpr int QS = DP + 4;            // LDS row stride of the Q / K tiles
-    static constexpr int VS = NDT * 32;          // LDS row stride of the V tile
-    static constexpr int OS = NDT * 32 + 1;      // LDS row stride of the per-wave O tile
-    static constexpr int m1 = 32 * QS > 32 * VS ? 32 * QS : 32 * VS;
-    static constexpr int m2 = m1 > 32 * OS ? m1 : 32 * OS;
+    // the V tile uses the SAME image as the K tile (row stride QS); PV reads columns up to NDT*32-1 of a
+    // row, i.e. past d into the next row: those products only land in output rows (dcol >= d) that are
+    // never stored.  The per-wave O tile for the merge is [dcol][32 queries], XOR-swizzled.
+    static constexpr int m1 = 32 * QS + NDT * 32;         // last row may be read NDT*32 wide
+    static constexpr int m2 = m1 > NDT * 32 * 32 ? m1 : NDT * 32 * 32;
     static constexpr int WBUF = (m2 + 15) / 16 * 16;      // floats per wave buffer
     static constexpr int SMEM_FLOATS = 32 * QS + 4 * WBUF + 256;
 };
@@ -75,17 +76,32 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (Lk + 31) / 32;
-    for (int kt = w; kt < nkt; kt += 4) {
-        // ---- K tile -> LDS ------------------------------------------------------------------------
-        wave_lds_fence();
-        for (int s = lane; s < 32 * (G::DP / 4); s += 64) {
-            const int r = s / (G::DP / 4), c4 = s % (G::DP / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // tile staging: lane owns DG float4 slots of the [32][DP/4] image; slot s = lane + 64 j -> row s / (DP/4)
+    float4 kreg[DG], vreg[DG];
+    auto load_tile = [&](const float* base, int ld, int kt, float4 (&reg)[DG]) {
+#pragma unroll
+        for (int j = 0; j < DG; ++j) {
+            const int sl = lane + 64 * j;
+            const int r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
             const int kr = kt * 32 + r;
-            if (kr < Lk && c4 < nv4)
-                v = *reinterpret_cast<const float4*>(A.k + (size_t)(kbase + kr) * A.ldk + head * d + 4 * c4);
-            *reinterpret_cast<float4*>(wbuf + r * G::QS + 4 * c4) = v;
+            const bool ok = kr < Lk && c4 < nv4;
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(kbase + min(kr, Lk - 1)) * ld + head * d + 4 * min(c4, nv4 - 1));
+            reg[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
+    };
+    auto store_tile = [&](const float4 (&reg)[DG]) {
+#pragma unroll
+        for (int j = 0; j < DG; ++j) {
+            const int sl = lane + 64 * j;
+            *reinterpret_cast<float4*>(wbuf + (sl / (G::DP / 4)) * G::QS + 4 * (sl % (G::DP / 4))) = reg[j];
+        }
+    };
+    if (w < nkt) load_tile(A.k, A.ldk, w, kreg);
+    for (int kt = w; kt < nkt; kt += 4) {
+        // ---- K tile -> LDS; V tile of the same keys starts loading -------------------------------------
+        wave_lds_fence();
+        store_tile(kreg);
+        load_tile(A.v, A.ldv, kt, vreg);
         wave_lds_fence();
         // ---- S^T = K Q^T ----------------------------------------------------------------------------
         f32x16 sc;
@@ -138,32 +154,30 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
         for (int i = 0; i < NDT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
-        // ---- V tile -> LDS (same buffer) ---------------------------------------------------------------
+        // ---- V tile -> LDS (same buffer); the K tile of this wave's next keys starts loading -------------
         wave_lds_fence();
-        for (int s = lane; s < 32 * (G::VS / 4); s += 64) {
-            const int r = s / (G::VS / 4), c4 = s % (G::VS / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int kr = kt * 32 + r;
-            if (kr < Lk && c4 < nv4)
-                v = *reinterpret_cast<const float4*>(A.v + (size_t)(kbase + kr) * A.ldv + head * d + 4 * c4);
-            *reinterpret_cast<float4*>(wbuf + r * G::VS + 4 * c4) = v;
-        }
+        store_tile(vreg);
+        if (kt + 4 < nkt) load_tile(A.k, A.ldk, kt + 4, kreg);
         wave_lds_fence();
         // ---- O^T += V^T P^T : step r contracts keys (r&3)+8(r>>2) (h = 0 lanes) and +4 (h = 1 lanes) ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::VS + l31;
+            const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::QS + l31;
 #pragma unroll
             for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * i], sc[r], acc[i], 0, 0, 0);
         }
     }
 
     // ---- merge the 4 waves: out = sum_w e^{m_w - m*} O_w / sum_w e^{m_w - m*} l_w ---------------------
+    // per-wave O tile image: [dcol][q ^ (dcol & 31)] (conflict-free for the lane = q writes and the lane = dcol reads)
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wbuf[l31 * G::OS + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][r];
+        for (int r = 0; r < 16; ++r) {
+            const int dc = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            wbuf[dc * 32 + (l31 ^ (dc & 31))] = acc[i][r];
+        }
     if (h == 0) {
         s_ml[w * 32 + l31] = m_run;
         s_ml[128 + w * 32 + l31] = l_run;
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
         for (int k = 0; k < 4; ++k) {
             const float mk = s_ml[k * 32 + q];
             const float e = (mk == -INFINITY) ? 0.f : expf(mk - ms);
-            num = fmaf(e, W0[k * G::WBUF + q * G::OS + c], num);
+            num = fmaf(e, W0[k * G::WBUF + c * 32 + (q ^ (c & 31))], num);
             den = fmaf(e, s_ml[128 + k * 32 + q], den);
         }
         A.out[(size_t)(qbase + qt * 32 + q) * A.ldo + head * d + c] = num / den;

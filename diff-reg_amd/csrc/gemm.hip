@@ -20,20 +20,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the WK k-groups of waves consumes BKC / WK.
 template <int TM, int TN, int WM, int WN, int WK, int BKC>
 struct GemmGeom {
+    static constexpr int NW = WM * WN * WK, NT = 64 * NW;       // waves / threads per workgroup
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static constexpr int LDT = BKC + 4;                         // padded LDS row stride (floats)
     static constexpr int C4 = BKC / 4;                          // float4 per staged row
-    static constexpr int A_SLOTS = (BM * C4 + 255) / 256, B_SLOTS = (BN * C4 + 255) / 256;
+    static constexpr int A_SLOTS = (BM * C4 + NT - 1) / NT, B_SLOTS = (BN * C4 + NT - 1) / NT;
     static constexpr int STAGE = (BM + BN) * LDT;               // floats per buffer
-    static constexpr int RED = (WK > 1) ? 4 * TM * TN * 16 * 64 : 0;
+    static constexpr int RED = (WK > 1) ? NW * TM * TN * 16 * 64 : 0;
     static constexpr int SMEM_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
     static constexpr int GROUPS = BKC / WK / 8;                 // 8-wide k groups per wave per chunk
+    static constexpr int NACC = (TM * TN == 1) ? 2 : 1;         // independent accumulators per tile
 };
 
 template <int TM, int TN, int WM, int WN, int WK, int BKC>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
-    static_assert(WM * WN * WK == 4, "4 waves");
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G) {
     using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
+    constexpr int NT = GG::NT;
     constexpr int BM = GG::BM, BN = GG::BN, LDT = GG::LDT, C4 = GG::C4, STAGE = GG::STAGE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
     bool aok[GG::A_SLOTS], bok[GG::B_SLOTS];
 #pragma unroll
     for (int s = 0; s < GG::A_SLOTS; ++s) {
-        const int slot = t + s * 256, r = slot / C4;
+        const int slot = t + s * NT, r = slot / C4;
         akc[s] = 4 * (slot % C4);
         aok[s] = slot < BM * C4 && row0 + r < rows;
         const int rc = min(row0 + r, rows - 1);
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
     }
 #pragma unroll
     for (int s = 0; s < GG::B_SLOTS; ++s) {
-        const int slot = t + s * 256, r = slot / C4;
+        const int slot = t + s * NT, r = slot / C4;
         bkc[s] = 4 * (slot % C4);
         bok[s] = slot < BN * C4 && col0 + r < ncols;
         bp[s] = pW + (size_t)min(col0 + r, ncols - 1) * K;
@@ -83,40 +85,47 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
             const int k = k0 + akc[s];
             const int kc = min(k, K - 4);
             const float* src = (kc < K1 ? a1p[s] : a2p[s]) + kc;
-            const float4 v = *reinterpret_cast<const float4*>(src);
-            const bool ok = aok[s] && k < K;
-            ra[s] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-        }
+            ra[s] = *reinterpret_cast<const float4*>(src);      // zeroing of invalid slots happens at store time:
+        }                                                       // touching the data here would wait for the load
 #pragma unroll
         for (int s = 0; s < GG::B_SLOTS; ++s) {
             const int k = k0 + bkc[s];
-            const float4 v = *reinterpret_cast<const float4*>(bp[s] + min(k, K - 4));
-            const bool ok = bok[s] && k < K;
-            rb[s] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            rb[s] = *reinterpret_cast<const float4*>(bp[s] + min(k, K - 4));
         }
     };
-    auto store_chunk = [&](int buf) {
-        float* As = smem + buf * STAGE;
+    auto store_chunk = [&](int ch) {
+        float* As = smem + (ch & 1) * STAGE;
         float* Bs = As + BM * LDT;
+        const int k0 = ch * BKC;
 #pragma unroll
         for (int s = 0; s < GG::A_SLOTS; ++s) {
-            const int slot = t + s * 256;
-            if (slot < BM * C4) *reinterpret_cast<float4*>(As + (slot / C4) * LDT + akc[s]) = ra[s];
+            const int slot = t + s * NT;
+            const bool ok = aok[s] && k0 + akc[s] < K;
+            const float4 v = ra[s];
+            if (slot < BM * C4)
+                *reinterpret_cast<float4*>(As + (slot / C4) * LDT + akc[s]) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
         for (int s = 0; s < GG::B_SLOTS; ++s) {
-            const int slot = t + s * 256;
-            if (slot < BN * C4) *reinterpret_cast<float4*>(Bs + (slot / C4) * LDT + bkc[s]) = rb[s];
+            const int slot = t + s * NT;
+            const bool ok = bok[s] && k0 + bkc[s] < K;
+            const float4 v = rb[s];
+            if (slot < BN * C4)
+                *reinterpret_cast<float4*>(Bs + (slot / C4) * LDT + bkc[s]) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN][GG::NACC];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int n = 0; n < GG::NACC; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][n][r] = 0.f;
 
     load_chunk(0);
     store_chunk(0);
@@ -141,20 +150,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDT + 8 * (g + 1));
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].x, b[cur][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].y, b[cur][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].z, b[cur][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].w, b[cur][j].w, acc[i][j], 0, 0, 0);
-                }
+            // consecutive MFMAs go to DIFFERENT accumulators (tiles, or the even/odd-group pair of a single
+            // tile): a dependent accumulate chain alone does not keep the 64-cycle pipe full
+            constexpr int NA = GG::NACC;
+            const int q = (NA == 2) ? (g & 1) : 0;
+#define DR_MFMA_STEP(E)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
+        acc[i][j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].E, b[cur][j].E, acc[i][j][q], 0, 0, 0);
+            DR_MFMA_STEP(x)
+            DR_MFMA_STEP(y)
+            DR_MFMA_STEP(z)
+            DR_MFMA_STEP(w)
+#undef DR_MFMA_STEP
         }
-        if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+        if (ch + 1 < nchunks) store_chunk(ch + 1);
         __syncthreads();
     }
 
+    if (GG::NACC == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][0][r] += acc[i][j][GG::NACC - 1][r];
+    }
     if (WK > 1) {
         // reduce the WK partial accumulators of each (wm, wn) through LDS
         float* red = smem;
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(((w * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) red[(((w * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][0][r];
         __syncthreads();
         if (wk != 0) return;
 #pragma unroll
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((((w + o) * TM + i) * TN + j) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) acc[i][j][0][r] += red[((((w + o) * TM + i) * TN + j) * 16 + r) * 64 + lane];
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmBatch G) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[i][j][r];
+                float v = acc[i][j][0][r];
                 if (P.epi & EPI_ROTARY) {
                     // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
                     const float other = __shfl_xor(v, 1);
@@ -225,7 +245,7 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM, flops, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>), dim3(maxt, g.n), dim3(256), GG::SMEM_FLOATS * sizeof(float), st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -234,11 +254,15 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
 #define CFG_SMALL  1, 1, 1, 1, 4, 128    /*  32 x  32 tile, k split over the 4 waves, deep chunks (latency-bound sizes) */
 #define CFG_MEDIUM 1, 1, 2, 2, 1, 64     /*  64 x  64 tile                                                            */
 #define CFG_LARGE  2, 1, 2, 2, 1, 32     /* 128 x  64 tile, 64 x 32 per wave                                          */
+#define CFG_XL     2, 2, 2, 2, 1, 32     /* 128 x 128 tile, 64 x 64 per wave (4 accumulator tiles)                    */
+#define CFG_LARGE8 1, 1, 4, 2, 1, 32     /* 128 x  64 tile, 8 waves of 32 x 32 (two per SIMD share the staged tiles)  */
 
 int gemm_configure() {
     int rc = configure_cfg<CFG_SMALL>();
     if (rc == DR_OK) rc = configure_cfg<CFG_MEDIUM>();
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_LARGE8>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_XL>();
     return rc;
 }
 
@@ -247,16 +271,24 @@ void gemm_force_config(int c) { g_force_cfg = c; }
 
 int launch_gemm(const GemmBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 4) return DR_EINVAL;
-    long nL = 0, nM = 0;
+    long nL = 0, nM = 0, nX = 0;
+    double useful = 0, padded = 0;
     for (int i = 0; i < g.n; ++i) {
         const GemmProblem& p = g.p[i];
         if (p.K % 4 || p.lda % 4 || (p.A2 && (p.K1 % 4 || p.lda2 % 4))) return DR_ENOSUP;
         if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2) & 15) return DR_ENOSUP;
         nL += (long)((p.rows + 127) / 128) * ((p.ncols + 63) / 64);
         nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64);
+        const long tx = (long)((p.rows + 127) / 128) * ((p.ncols + 127) / 128);
+        nX += tx;
+        useful += (double)p.rows * p.ncols;
+        padded += (double)tx * 128 * 128;
     }
     int cfg = nL >= 256 ? 2 : (nM >= 128 ? 1 : 0);     // fill the 256 CUs before growing the tile
+    (void)nX; (void)useful; (void)padded;              // 128 x 128 tiles (cfg 4) measured within noise of cfg 2: not auto-selected
     if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg == 4) return launch_cfg<CFG_XL>(g, st);
+    if (cfg == 3) return launch_cfg<CFG_LARGE8>(g, st);
     if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
     if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
     return launch_cfg<CFG_SMALL>(g, st);

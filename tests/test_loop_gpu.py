@@ -34,13 +34,19 @@ def engine(variant, steps, mc, **kw):
 def test_denoiser_and_head_match_golden(variant, golden):
     g = golden(variant + "_denoiser")
     eng = engine(variant, 1, 200)
+    v = synth.VARIANTS[variant]
+    W64 = {k: t.double() for k, t in weights(variant).items()}
     _, p = pair(variant, 64, 48, 3)
     for tag, (ms, mt) in (("", masks(64, 48)), ("_mask", masks(64, 48, 50, 41))):
         so, to, conf = eng.denoise_match(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV),
                                          ms.to(DEV), mt.to(DEV))
         assert np.abs(so[0].cpu().numpy() - g["f_s" + tag]).max() < 5e-4
         assert np.abs(to[0].cpu().numpy() - g["f_t" + tag]).max() < 5e-4
-        assert np.abs(conf[0].cpu().numpy() - g["conf" + tag]).max() < 1e-4
+        # conf: 1e-4 against the reference, or -- on the few sharp, ill-conditioned entries -- at least as close to a
+        # float64 evaluation as the reference's own float32 run is (see the module docstring)
+        hs, ht, pe_s, pe_t = orc.denoiser(W64, v, p["f_s"].double(), p["f_t"].double(), p["p_s"], p["p_t"], ms, mt)
+        c64 = orc.match_head(W64, v, hs, ht, pe_s, pe_t, ms, mt)[0].numpy()
+        assert_matrix_parity(conf[0].cpu().numpy(), g["conf" + tag], c64, "matching head conf")
 
 
 LOOPS = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
