@@ -76,31 +76,45 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (Lk + 31) / 32;
+    const float sc2 = A.scale * 1.4426950408889634f;
     // tile staging: lane owns DG float4 slots of the [32][DP/4] image; slot s = lane + 64 j -> row s / (DP/4)
     float4 kreg[DG], vreg[DG];
+    // per-slot descriptor, computed once: row r (bits 0-7), LDS float offset (bits 8-23), column-valid (bit 31);
+    // global column offset = head*d + 4*min(c4, nv4-1)
+    unsigned sdesc[DG];
+    int scol[DG];
+#pragma unroll
+    for (int j = 0; j < DG; ++j) {
+        const int sl = lane + 64 * j;
+        const int r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
+        sdesc[j] = (unsigned)r | ((unsigned)(r * G::QS + 4 * c4) << 8) | (c4 < nv4 ? 0x80000000u : 0u);
+        scol[j] = head * d + 4 * min(c4, nv4 - 1);
+    }
     auto load_tile = [&](const float* base, int ld, int kt, float4 (&reg)[DG]) {
+        const int lim = Lk - 1 - kt * 32;                         // last valid row of this tile
+        const float* tb = base + (size_t)(kbase + kt * 32) * ld;
 #pragma unroll
         for (int j = 0; j < DG; ++j) {
-            const int sl = lane + 64 * j;
-            const int r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
-            const int kr = kt * 32 + r;
-            const bool ok = kr < Lk && c4 < nv4;
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(kbase + min(kr, Lk - 1)) * ld + head * d + 4 * min(c4, nv4 - 1));
-            reg[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            const int r = (int)(sdesc[j] & 0xFFu);
+            reg[j] = *reinterpret_cast<const float4*>(tb + min(r, lim) * ld + scol[j]);
         }
     };
-    auto store_tile = [&](const float4 (&reg)[DG]) {
+    // zeroing of padding rows / columns happens at store time (touching the data earlier would wait for the load)
+    auto store_tile_k = [&](const float4 (&reg)[DG], int kt) {
+        const int lim = Lk - 1 - kt * 32;
 #pragma unroll
         for (int j = 0; j < DG; ++j) {
-            const int sl = lane + 64 * j;
-            *reinterpret_cast<float4*>(wbuf + (sl / (G::DP / 4)) * G::QS + 4 * (sl % (G::DP / 4))) = reg[j];
+            const bool ok = (int)(sdesc[j] & 0xFFu) <= lim && (sdesc[j] >> 31);
+            const float4 v = reg[j];
+            *reinterpret_cast<float4*>(wbuf + ((sdesc[j] >> 8) & 0xFFFFu)) =
+                make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
     if (w < nkt) load_tile(A.k, A.ldk, w, kreg);
     for (int kt = w; kt < nkt; kt += 4) {
         // ---- K tile -> LDS; V tile of the same keys starts loading -------------------------------------
         wave_lds_fence();
-        store_tile(kreg);
+        store_tile_k(kreg, kt);
         load_tile(A.v, A.ldv, kt, vreg);
         wave_lds_fence();
         // ---- S^T = K Q^T ----------------------------------------------------------------------------
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
             // segment exist only as tile padding
             bool drop = kk >= Lk;
             if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
-            s = drop ? -INFINITY : s * A.scale;
+            s = drop ? -INFINITY : s * sc2;                     // log2-domain logits: 2^(s*scale*log2 e)
             sc[r] = s;
             mx = fmaxf(mx, s);
         }
@@ -139,10 +153,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         } else {
-            alpha = expf(m_run - m_new);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = expf(sc[r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
                 sc[r] = p;
                 psum += p;
             }
@@ -156,15 +170,28 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
             for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
         // ---- V tile -> LDS (same buffer); the K tile of this wave's next keys starts loading -------------
         wave_lds_fence();
-        store_tile(vreg);
+        store_tile_k(vreg, kt);
         if (kt + 4 < nkt) load_tile(A.k, A.ldk, kt + 4, kreg);
         wave_lds_fence();
         // ---- O^T += V^T P^T : step r contracts keys (r&3)+8(r>>2) (h = 0 lanes) and +4 (h = 1 lanes) ----
+        // MFMA row l31 of tile i is feature NDT*l31 + i (any bijection works: output rows are only labels), so the
+        // NDT operands of a step are NDT consecutive floats of one V row: one vector LDS read per step
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::QS + l31;
+            const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::QS + NDT * l31;
+            float vv[NDT];
+            if (NDT == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(vp);
+                vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;
+            } else if (NDT == 2) {
+                const float2 t2 = *reinterpret_cast<const float2*>(vp);
+                vv[0] = t2.x; vv[1] = t2.y;
+            } else {
 #pragma unroll
-            for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * i], sc[r], acc[i], 0, 0, 0);
+                for (int i = 0; i < NDT; ++i) vv[i] = vp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i], sc[r], acc[i], 0, 0, 0);
         }
     }
 
@@ -175,7 +202,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     for (int i = 0; i < NDT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int dc = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int dc = NDT * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
             wbuf[dc * 32 + (l31 ^ (dc & 31))] = acc[i][r];
         }
     if (h == 0) {
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float mk = s_ml[k * 32 + q];
-            const float e = (mk == -INFINITY) ? 0.f : expf(mk - ms);
+            const float e = (mk == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mk - ms);
             num = fmaf(e, W0[k * G::WBUF + c * 32 + (q ^ (c & 31))], num);
             den = fmaf(e, s_ml[128 + k * 32 + q], den);
         }
