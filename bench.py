@@ -80,7 +80,7 @@ def sinkhorn_microbench(device, B=4096, N=256, M=256, reps=10):
         lib.sinkhorn(x1, a, 3, out=o1)
     e1.record()
     torch.cuda.synchronize()
-    return dict(kernel="sk_reg_kernel<float,float,16,4>", bound="hbm", tiles_per_launch=B, bytes_per_tile=N * M * 8,
+    return dict(kernel="sk_fast_kernel<float,float,16,4>", bound="hbm", tiles_per_launch=B, bytes_per_tile=N * M * 8,
                 us_per_launch=ms * 1e3, achieved=byts / ms / 1e6, peak=PEAK_HBM_GBPS, unit="GB/s",
                 frac=byts / ms / 1e6 / PEAK_HBM_GBPS, traffic=None, single_tile_latency_us=e0.elapsed_time(e1) / 50 * 1e3)
 
@@ -89,7 +89,9 @@ def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):
     """oracle loop on the host cores: 1 warm-up pair + as many timed pairs as fit the budget (>= 1)."""
     from diffreg_hip import synth
     from oracle import diffreg_oracle as orc
-    cores = os.cpu_count() or 1
+    # the loop is ~1 500 small torch ops per pair: more threads than ~16 only add synchronisation cost (measured on the GPU box: 8 -> 1.26, 16 -> 1.46, 32 -> 0.77, 64 -> 0.33 pairs/s)
+    # (256 threads on the 256-CPU GPU box are > 100x slower than 32)
+    cores = int(os.environ.get("DIFFREG_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     v = synth.VARIANTS[variant]
     W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
@@ -103,10 +105,12 @@ def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):
         orc.denoise_loop(W, v, T(p["src_feats"]), T(p["tgt_feats"]), T(p["s_pcd"]), T(p["t_pcd"]), ms, mt, T(p["x_T"]),
                          steps, mc, variant=variant)
         return time.perf_counter() - t0
-    one(1000)
-    times, t_start = [], time.perf_counter()
-    while not times or (time.perf_counter() - t_start < budget_s and len(times) < 10):
-        times.append(one(1001 + len(times)))
+    t_start = time.perf_counter()
+    times = [one(1000)]                               # warm-up pair (kept only if the budget is already spent)
+    if time.perf_counter() - t_start < budget_s:
+        times = []
+        while not times or (time.perf_counter() - t_start < budget_s and len(times) < 10):
+            times.append(one(1001 + len(times)))
     med = float(np.median(times))
     return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d pairs of N=M=%d, %d denoise steps after 1 warm-up pair (median %.3f s/pair); "
@@ -118,8 +122,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed passes of the hot path (K)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "16")),
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "64")),
                     help="independent scene pairs per pass and per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFREG_BENCH_STREAMS", "2")),
+                    help="the pairs of a pass are split into this many batches, one captured graph each, replayed "
+                         "concurrently on separate HIP streams")
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--max-condition-num", type=float, default=200.0)
@@ -142,9 +149,19 @@ def main():
     from diffreg_hip import lib
     variant, N, M, P, S = "3dmatch", args.n, args.n, args.pairs, args.denoise_steps
     W, eng = make_engine(variant, S, args.max_condition_num, dev)
-    prs, inp = make_inputs(variant, P, N, M, seed0=5000 + 1000 * rank, device=dev)
-    run = lambda graph: eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=graph)
     use_graph = not args.no_graph
+    nstreams = max(1, min(args.streams, P)) if use_graph else 1
+    per = [P // nstreams + (1 if i < P % nstreams else 0) for i in range(nstreams)]
+    groups, inp = [], None
+    for gi, pg in enumerate(per):
+        _, ig = make_inputs(variant, pg, N, M, seed0=5000 + 1000 * rank + 100 * gi, device=dev)
+        inp = inp or ig
+        groups.append(dict(src_feats=ig["f_s"], tgt_feats=ig["f_t"], s_pcd=ig["p_s"], t_pcd=ig["p_t"], x_T=ig["x_T"]))
+
+    def run(graph):
+        if graph:
+            return eng.run_streams(groups, nstreams)[0]
+        return eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)
 
     for _ in range(max(args.warmup, 1)):
         out = run(use_graph)
@@ -173,8 +190,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
-                               "%d independent B=1 pairs per pass per GPU, one HIP-graph replay per pass" % (N, S, args.max_condition_num, P),
-                   "pairs_per_pass_per_gpu": P, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
+                               "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, P, nstreams),
+                   "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
                    "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32", "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
     }
@@ -204,6 +221,7 @@ def main():
             prof = lib.prof_collect()
             lib.prof_enable(False)
             tot = sum(v[1] for v in prof.values())
+            # (eager launches of ONE of the concurrent batches)
             fam = {k: {"launches_per_pass": v[0] // reps, "ms_per_pass": v[1] / reps, "share": v[1] / tot,
                        "avg_us_per_launch": (v[1] / v[0] * 1e3) if v[0] else 0.0} for k, v in prof.items()}
             dom = max(prof, key=lambda k: prof[k][1])
@@ -218,6 +236,7 @@ def main():
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
             roof["note"] = "dominant family by GPU time; work = algorithmic FLOPs (2*rows*cols*K per GEMM) or bytes"
+            roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof
             result["kernel_families"] = fam
         result["sinkhorn_roofline"] = sinkhorn_microbench(dev)

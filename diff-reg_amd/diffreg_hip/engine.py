@@ -105,9 +105,11 @@ class DenoiseEngine:
             lib.ptr(b["R_final"]), lib.ptr(b["t_final"]), ctypes.byref(tr) if tr is not None else None, lib.ptr(b["ws"]),
             b["ws_bytes"], lib.stream_of(b["conf"])))
 
-    def make_buffers(self, P, N, M, masked=False, trace=False):
+    def make_buffers(self, P, N, M, masked=False, trace=False, private_ws=False):
         dev, C, S = self.device, self.C, self.steps
         ws, need = self._workspace(P, N, M)
+        if private_ws:          # concurrent batches must not share scratch memory
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
         b = dict(P=P, N=N, M=M, ws=ws, ws_bytes=need, trace=trace,
                  src_feats=torch.zeros(P, N, C, device=dev), tgt_feats=torch.zeros(P, M, C, device=dev),
                  s_pcd=torch.zeros(P, N, 3, device=dev), t_pcd=torch.zeros(P, M, 3, device=dev),
@@ -126,16 +128,16 @@ class DenoiseEngine:
         return b
 
     def run(self, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask=None, tgt_mask=None, noise=None, trace=False,
-            graph=False):
+            graph=False, _slot=0):
         """Run the loop for P pairs.  Returns a dict of device tensors (conf float64, x_final, matches list (3D),
         R_final, t_final, and the per-step trace when asked)."""
         P, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         masked = src_mask is not None
-        key = (P, N, M, masked, trace, bool(graph))
+        key = (P, N, M, masked, trace, bool(graph), _slot)
         ent = self._graphs.get(key)
         if ent is None:
-            b = self.make_buffers(P, N, M, masked=masked, trace=trace)
+            b = self.make_buffers(P, N, M, masked=masked, trace=trace, private_ws=_slot > 0)
             g = None
             if graph:
                 self._fill(b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise)
@@ -175,6 +177,25 @@ class DenoiseEngine:
         if b["trace"]:
             out.update(x0=b["tr_x0"], R_forwd=b["tr_R"], t_forwd=b["tr_t"], cond=b["tr_cond"])
         return out
+
+    # ------------------------------------------------------------------------------------------
+    def run_streams(self, groups, n_streams=2):
+        """Run several independent batches of pairs concurrently, one captured graph per batch, replayed on
+        `n_streams` HIP streams so that the tails / small launches of one batch overlap the big launches of another.
+        groups: list of dicts with the keyword arguments of run() (src_feats, tgt_feats, s_pcd, t_pcd, x_T, ...).
+        Returns the list of result dicts (buffers are per group and stay valid until the group is run again)."""
+        cur = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_streams") or len(self._streams) < n_streams:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        outs = []
+        for gi, kw in enumerate(groups):
+            st = self._streams[gi % n_streams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.run(graph=True, _slot=gi, **kw))
+        for st in self._streams[:n_streams]:
+            cur.wait_stream(st)
+        return outs
 
     @staticmethod
     def match_list(out):

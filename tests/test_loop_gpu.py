@@ -159,3 +159,31 @@ def test_loop_against_oracle_fresh_seed(seed):
         assert (out["t_forwd"][:, 0].cpu() - tref).abs().max().item() < 1e-4
         assert_matrix_parity(out["x0"][-1, 0].cpu().numpy(), trace[-1]["x0"][0].numpy(), x0_f64, "x_start")
         assert_matrix_parity(out["conf_matrix_pred"][0].cpu().numpy(), ref["conf_matrix_pred"][0].numpy(), conf_f64, "conf")
+
+
+def test_cfg3_shape_4dmatch_512():
+    """BASELINE configs[2] shape (4DMatch, N = M = 512, C = 528, d_head = 132): tiles larger than the register-resident
+    Sinkhorn / Procrustes paths, two pairs with different padding masks, 2 denoise steps, against the oracle."""
+    variant, N, M, steps, mc = "4dmatch", 512, 512, 2, 40
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    eng = engine(variant, steps, mc)
+    prs, cases = [], [(512, 512, 61), (470, 391, 62)]
+    for nv, mv, seed in cases:
+        prs.append(pair(variant, N, M, seed)[1])
+    cat = lambda k: torch.cat([q[k] for q in prs]).to(DEV)
+    ms = torch.stack([torch.arange(N) < c[0] for c in cases])
+    mt = torch.stack([torch.arange(M) < c[1] for c in cases])
+    noise = torch.stack([T(synth.step_noise(N, M, c[2], steps)) for c in cases], 1)          # [steps, P, N, M]
+    out = eng.run(cat("f_s"), cat("f_t"), cat("p_s"), cat("p_t"), cat("x_T"), ms.to(DEV), mt.to(DEV), noise=noise.to(DEV), trace=True)
+    for i, (nv, mv, seed) in enumerate(cases):
+        q = prs[i]
+        tr = []
+        ref = orc.denoise_loop(W, v, q["f_s"], q["f_t"], q["p_s"], q["p_t"], ms[i:i + 1], mt[i:i + 1], q["x_T"], steps, mc,
+                               variant=variant, noise=noise[:, i:i + 1], trace=tr)
+        Rref = torch.stack([r["R_forwd"][0] for r in tr])
+        assert (out["R_forwd"][:, i].cpu() - Rref).abs().max().item() < 1e-4
+        d = (out["x0"][-1, i].cpu() - tr[-1]["x0"][0]).abs()
+        assert (d > 1e-4).float().mean().item() <= 1e-3, d.max().item()
+        dc = (out["conf_matrix_pred"][i].cpu() - ref["conf_matrix_pred"][0]).abs()
+        assert (dc > 1e-4).double().mean().item() <= 1e-3, dc.max().item()
