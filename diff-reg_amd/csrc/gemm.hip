@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Geometry: a wave owns TM x TN MFMA tiles (32x32 each); a workgroup is WM x WN x WK waves (4 in all);
 // K is staged in chunks of BKC floats (double-buffered LDS, one barrier per chunk), of which each of
 // the WK k-groups of waves consumes BKC / WK.
-template <int TM, int TN, int WM, int WN, int WK, int BKC>
+template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
 struct GemmGeom {
     static constexpr int NW = WM * WN * WK, NT = 64 * NW;       // waves / threads per workgroup
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -27,14 +27,14 @@ struct GemmGeom {
     static constexpr int A_SLOTS = (BM * C4 + NT - 1) / NT, B_SLOTS = (BN * C4 + NT - 1) / NT;
     static constexpr int STAGE = (BM + BN) * LDT;               // floats per buffer
     static constexpr int RED = (WK > 1) ? NW * TM * TN * 16 * 64 : 0;
-    static constexpr int SMEM_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
+    static constexpr int SMEM_FLOATS = NBUF * STAGE > RED ? NBUF * STAGE : RED;
     static constexpr int GROUPS = BKC / WK / 8;                 // 8-wide k groups per wave per chunk
     static constexpr int NACC = (TM * TN == 1) ? 2 : 1;         // independent accumulators per tile
 };
 
-template <int TM, int TN, int WM, int WN, int WK, int BKC>
+template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G) {
-    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC, NBUF>;
     constexpr int NT = GG::NT;
     constexpr int BM = GG::BM, BN = GG::BN, LDT = GG::LDT, C4 = GG::C4, STAGE = GG::STAGE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
         }
     };
     auto store_chunk = [&](int ch) {
-        float* As = smem + (ch & 1) * STAGE;
+        float* As = smem + (NBUF == 2 ? (ch & 1) : 0) * STAGE;
         float* Bs = As + BM * LDT;
         const int k0 = ch * BKC;
 #pragma unroll
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
     const int h = lane >> 5, l31 = lane & 31;
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) load_chunk(ch + 1);
-        const float* As = smem + (ch & 1) * STAGE + (wm * TM * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
-        const float* Bs = smem + (ch & 1) * STAGE + BM * LDT + (wn * TN * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
+        const float* As = smem + (NBUF == 2 ? (ch & 1) : 0) * STAGE + (wm * TM * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
+        const float* Bs = smem + (NBUF == 2 ? (ch & 1) : 0) * STAGE + BM * LDT + (wn * TN * 32 + l31) * LDT + wk * GG::GROUPS * 8 + 4 * h;
         // fragments of group g+1 are fetched while the MFMAs of group g issue
         float4 a[2][TM], b[2][TN];
 #pragma unroll
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
             DR_MFMA_STEP(w)
 #undef DR_MFMA_STEP
         }
+        if (NBUF == 1) __syncthreads();          // single buffer: everyone is done reading before it is overwritten
         if (ch + 1 < nchunks) store_chunk(ch + 1);
         __syncthreads();
     }
@@ -225,17 +226,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
     }
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int BKC>
+template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
 static int configure_cfg() {
-    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>,
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC, NBUF>;
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, WK, BKC, NBUF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GG::SMEM_FLOATS * sizeof(float))));
     return DR_OK;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int BKC>
+template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
 static int launch_cfg(const GemmBatch& g, hipStream_t st) {
-    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC>;
+    using GG = GemmGeom<TM, TN, WM, WN, WK, BKC, NBUF>;
     int maxt = 0;
     for (int i = 0; i < g.n; ++i) {
         const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
@@ -245,7 +246,7 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM, flops, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC, NBUF>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -255,6 +256,10 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
 #define CFG_MEDIUM 1, 1, 2, 2, 1, 64     /*  64 x  64 tile                                                            */
 #define CFG_LARGE  2, 1, 2, 2, 1, 32     /* 128 x  64 tile, 64 x 32 per wave                                          */
 #define CFG_XL     2, 2, 2, 2, 1, 32     /* 128 x 128 tile, 64 x 64 per wave (4 accumulator tiles)                    */
+#define CFG_L64    2, 1, 2, 2, 1, 64     /* experiment: 128 x 64 tile, 64-deep chunks (1 workgroup per CU)             */
+#define CFG_XL64   2, 2, 2, 2, 1, 64     /* experiment: 128 x 128 tile, 64-deep chunks                                 */
+#define CFG_L1B    2, 1, 2, 2, 1, 32, 1  /* 128 x  64 tile, single LDS buffer: 27 KB -> 5 workgroups per CU            */
+#define CFG_XL1B   2, 2, 2, 2, 1, 32, 1  /* 128 x 128 tile, single LDS buffer: 36 KB -> 4 workgroups per CU            */
 #define CFG_LARGE8 1, 1, 4, 2, 1, 32     /* 128 x  64 tile, 8 waves of 32 x 32 (two per SIMD share the staged tiles)  */
 
 int gemm_configure() {
@@ -263,6 +268,10 @@ int gemm_configure() {
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE>();
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE8>();
     if (rc == DR_OK) rc = configure_cfg<CFG_XL>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_L1B>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_XL1B>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_L64>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_XL64>();
     return rc;
 }
 
@@ -284,9 +293,13 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         useful += (double)p.rows * p.ncols;
         padded += (double)tx * 128 * 128;
     }
-    int cfg = nL >= 256 ? 2 : (nM >= 128 ? 1 : 0);     // fill the 256 CUs before growing the tile
+    int cfg = nL >= 256 ? 7 : (nM >= 128 ? 1 : 0);     // fill the 256 CUs before growing the tile (7 = single-buffer large)
     (void)nX; (void)useful; (void)padded;              // 128 x 128 tiles (cfg 4) measured within noise of cfg 2: not auto-selected
     if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg == 8) return launch_cfg<CFG_XL1B>(g, st);
+    if (cfg == 7) return launch_cfg<CFG_L1B>(g, st);
+    if (cfg == 6) return launch_cfg<CFG_XL64>(g, st);
+    if (cfg == 5) return launch_cfg<CFG_L64>(g, st);
     if (cfg == 4) return launch_cfg<CFG_XL>(g, st);
     if (cfg == 3) return launch_cfg<CFG_LARGE8>(g, st);
     if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
