@@ -56,6 +56,9 @@ VARIANTS = {
                     sample_rate=1.0, n_layers=6),
 }
 
+VARIANTS["2d3d"] = dict(C=256, H=4, skh_iters=3, bin_score=1.0, sample_rate=1.0, n_layers=6, img_dim=512, dino_dim=1024,
+                        pcd_dim=512)     # EXP/config.py:116-139
+
 LAYER_TYPES = ("self", "cross", "self", "cross", "self", "cross")  # 3D/models/pipeline.py:142
 
 
@@ -133,3 +136,69 @@ def make_pair(N, M, C, seed, overlap=0.6, feat_noise=0.3, pos_noise=0.01, max_an
 def step_noise(N, M, seed, n_steps, dtype=np.float32):
     """Per-step noise xi_k (only the 4D variant adds sigma*xi, 4D/models/pipeline.py:188-190)."""
     return np.stack([hash_normal(seed, 100 + k, (N, M)) for k in range(n_steps)]).astype(dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# 2D-3D variant (Diff-Reg-2d3d): CrossModalFusionModule + Matching weights, image/point-cloud pairs
+# --------------------------------------------------------------------------------------------
+def make_weights_2d3d(seed=9, head_gain=1.0, emb_gain=0.1, dtype=np.float32):
+    v = VARIANTS["2d3d"]
+    C = v["C"]
+    w = {}
+    st = [0]
+
+    def lin(name, out_f, in_f, gain=1.0, bias=True):
+        st[0] += 1
+        a = gain * math.sqrt(3.0 / in_f)
+        w[name + ".weight"] = hash_uniform(seed, st[0], (out_f, in_f), -a, a).astype(dtype)
+        if bias:
+            st[0] += 1
+            w[name + ".bias"] = (0.1 * gain * hash_uniform(seed, st[0], (out_f,))).astype(dtype)
+
+    def norm(name):
+        st[0] += 1
+        w[name + ".weight"] = (1.0 + 0.1 * hash_uniform(seed, st[0], (C,))).astype(dtype)
+        st[0] += 1
+        w[name + ".bias"] = (0.05 * hash_uniform(seed, st[0], (C,))).astype(dtype)
+
+    p = "denoising_transformer."
+    lin(p + "img_emb_proj", C, 42, emb_gain); lin(p + "pcd_emb_proj", C, 63, emb_gain)
+    lin(p + "img_in_proj", C, v["img_dim"]); lin(p + "img_in_proj_dino", C, v["dino_dim"]); lin(p + "img_in_proj_all", C, 2 * C)
+    lin(p + "pcd_in_proj", C, v["pcd_dim"]); lin(p + "out_proj", C, C)
+    for l in range(v["n_layers"]):
+        q = p + "transformer.%d." % l
+        for nm in ("q_token_layer", "k_token_layer", "v_token_layer"):
+            lin(q + "attention.attention." + nm, C, C)
+        lin(q + "attention.linear", C, C); norm(q + "attention.norm")
+        lin(q + "output.expand", 2 * C, C); lin(q + "output.squeeze", C, 2 * C); norm(q + "output.norm")
+    lin("denoising_coarse_matching.src_proj", C, C, head_gain, bias=False)
+    lin("denoising_coarse_matching.tgt_proj", C, C, bias=False)
+    w["denoising_coarse_matching.bin_score"] = np.asarray(1.0, dtype=dtype)
+    return w
+
+
+def make_pair_2d3d(N, M, seed, weights=None, overlap=0.6, tok_noise=0.05, dtype=np.float32):
+    """N point-cloud nodes (src) and M image patches (tgt): patch pixel coordinates [M,2] (normalised), the
+    depth-back-projected patch centres t_pcd_da [M,3] and backbone features.  With `weights` (make_weights_2d3d)
+    the point features of matched nodes are solved (least squares through pcd_in_proj) so that their input TOKEN
+    equals the matched patch's token: the random-weight fusion module then yields correlated features and a
+    structured matching matrix, like a trained model would."""
+    v = VARIANTS["2d3d"]
+    base = make_pair(N, M, 64, seed, overlap=overlap)
+    rngs = lambda s, shape: hash_normal(seed, s, shape)
+    gi, gj = base["gt_matches"][:, 0], base["gt_matches"][:, 1]
+    img_feats = rngs(47, (M, v["img_dim"]))
+    img_dino = rngs(48, (M, v["dino_dim"]))
+    pcd_feats = rngs(49, (N, v["pcd_dim"]))
+    if weights is not None:
+        W = {k: a.astype(np.float64) for k, a in weights.items() if k.startswith("denoising_transformer.") and "_in_proj" in k}
+        p = "denoising_transformer."
+        u = np.concatenate([img_feats @ W[p + "img_in_proj.weight"].T + W[p + "img_in_proj.bias"],
+                            img_dino @ W[p + "img_in_proj_dino.weight"].T + W[p + "img_in_proj_dino.bias"]], 1)
+        tok_img = np.maximum(u, 0) @ W[p + "img_in_proj_all.weight"].T + W[p + "img_in_proj_all.bias"]     # [M, C]
+        target = tok_img[gj] + tok_noise * rngs(50, (len(gj), v["C"])) - W[p + "pcd_in_proj.bias"]
+        pcd_feats[gi] = target @ np.linalg.pinv(W[p + "pcd_in_proj.weight"]).T
+    pix = hash_uniform(seed, 46, (M, 2), 0.0, 1.0)
+    return dict(s_pcd=base["s_pcd"], t_pcd_da=base["t_pcd"], img_pixels=pix.astype(dtype), img_feats=img_feats.astype(dtype),
+                img_dino=img_dino.astype(dtype), pcd_feats=pcd_feats.astype(dtype), x_T=base["x_T"],
+                gt_matches=base["gt_matches"], R_gt=base["R_gt"], t_gt=base["t_gt"])

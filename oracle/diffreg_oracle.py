@@ -302,3 +302,92 @@ def inlier_ratio(match_pred, p_s, p_t, R_gt, t_gt, thr=0.1):
     moved = p_s[0, i].double() @ torch.as_tensor(R_gt, dtype=F64).T + torch.as_tensor(t_gt, dtype=F64)
     d = (moved - p_t[0, j].double()).norm(dim=1)
     return float((d < thr).double().mean())
+
+
+# ==========================================================================================
+# 2D-3D variant (row a10).  2D3D/ = Diff-Reg-2d3d/, EXP/ = its experiments/2d3dmatr.rgbdv2.stage4.level3.stage1/
+# ==========================================================================================
+def fourier_embedding(p, L=10):
+    """[..., D] -> [..., (2L+1) D]: [p | per level l: sin(2^l p) (D values), cos(2^l p) (D values)]
+    (2D3D/vision3d/layers/embedding.py:75-100 with use_pi=False, use_input=True)."""
+    shape = p.shape[:-1]
+    D = p.shape[-1]
+    x = p.reshape(-1, 1, D)
+    fac = (2.0 ** torch.arange(0, L).float()).view(1, -1, 1)
+    th = fac * x
+    emb = torch.cat([torch.sin(th), torch.cos(th)], dim=-1).reshape(*shape, 2 * L * D)
+    return torch.cat([p, emb], dim=-1)
+
+
+def linear(x, W, pre):
+    return x @ W[pre + ".weight"].T + W[pre + ".bias"]
+
+
+def transformer_layer_2d3d(W, pre, x, y, H):
+    """post-LN layer of 2D3D/vision3d/layers/transformer.py:58-158 (MultiHeadAttention), :161-220 (AttentionLayer),
+    :223-238 (AttentionOutput), :241-301 (TransformerLayer); no masks are passed on the path (EXP/model.py:658-664)."""
+    B, Lq, C = x.shape
+    S = y.shape[1]
+    d = C // H
+    q = linear(x, W, pre + "attention.attention.q_token_layer").view(B, Lq, H, d).transpose(1, 2)
+    k = linear(y, W, pre + "attention.attention.k_token_layer").view(B, S, H, d).transpose(1, 2)
+    v = linear(y, W, pre + "attention.attention.v_token_layer").view(B, S, H, d).transpose(1, 2)
+    a = torch.softmax(torch.einsum("bhnc,bhmc->bhnm", q, k) / d ** 0.5, dim=-1)
+    h = torch.matmul(a, v).transpose(1, 2).reshape(B, Lq, C)
+    z = layer_norm(linear(h, W, pre + "attention.linear") + x, W[pre + "attention.norm.weight"], W[pre + "attention.norm.bias"])
+    f = linear(torch.relu(linear(z, W, pre + "output.expand")), W, pre + "output.squeeze")
+    return layer_norm(z + f, W[pre + "output.norm.weight"], W[pre + "output.norm.bias"])
+
+
+def fusion_module(W, cfg, img_feats, img_dino, img_pixels, pcd_feats, pcd_points, prefix="denoising_transformer."):
+    """CrossModalFusionModule.forward (EXP/fusion_module.py:61-107): same weights for the image and the point call;
+    in a cross block the points attend to the UPDATED image tokens."""
+    H = cfg["H"]
+    img = torch.relu(torch.cat([linear(img_feats, W, prefix + "img_in_proj"), linear(img_dino, W, prefix + "img_in_proj_dino")], -1))
+    img = linear(img, W, prefix + "img_in_proj_all") + linear(fourier_embedding(img_pixels), W, prefix + "img_emb_proj")
+    pts = pcd_points - pcd_points.mean(dim=1)                       # fusion_module.py:56 (mean over the nodes, B = 1)
+    pcd = linear(pcd_feats, W, prefix + "pcd_in_proj") + linear(fourier_embedding(pts), W, prefix + "pcd_emb_proj")
+    for l in range(cfg["n_layers"]):
+        pre = prefix + "transformer.%d." % l
+        if l % 2 == 0:
+            img = transformer_layer_2d3d(W, pre, img, img, H)
+            pcd = transformer_layer_2d3d(W, pre, pcd, pcd, H)
+        else:
+            img = transformer_layer_2d3d(W, pre, img, pcd, H)
+            pcd = transformer_layer_2d3d(W, pre, pcd, img, H)
+    return linear(img, W, prefix + "out_proj"), linear(pcd, W, prefix + "out_proj")
+
+
+def match_head_2d3d(W, cfg, f_src, f_tgt, mask_s, mask_t, prefix="denoising_coarse_matching."):
+    """EXP/matching.py:91-147: src_proj on both sides (Q1), no position code, / sqrt(C), Sinkhorn."""
+    C = f_src.shape[-1]
+    Wp = W[prefix + "src_proj.weight"]
+    a = (f_src @ Wp.T) / C ** 0.5
+    b = (f_tgt @ Wp.T) / C ** 0.5
+    return sinkhorn_conf(torch.einsum("bsc,btc->bst", a, b), W[prefix + "bin_score"], cfg["skh_iters"], mask_s, mask_t)
+
+
+def denoise_loop_2d3d(W, cfg, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, mask_s, mask_t, mask_t_da, x_T,
+                      steps, max_cond, trace=None):
+    """EXP/model.py:637-694 + get_warped_from_noising_matching3D3D (:830-846).  src = point nodes [1,N,.], tgt = image
+    patches [1,M,.]; the warp uses the depth-back-projected patch centres t_pcd_da and their mask; no min-shift;
+    deterministic update; Procrustes K from the mask sums (EXP/procrustes.py:61-62)."""
+    ac, sra, srm1 = diffusion_schedule()
+    x = x_T.clone()
+    bin_score = W["denoising_coarse_matching.bin_score"]
+    for k, (t, tn) in enumerate(time_pairs(steps)):
+        x.masked_fill_(~pair_mask(mask_s, mask_t_da), float("-inf"))
+        Z = sinkhorn_log(x, bin_score, cfg["skh_iters"], mask_s, mask_t_da)
+        conf = Z.exp()[:, :-1, :-1].contiguous().float()
+        R, tt, Rf, tf, cond, ok = procrustes(conf, s_pcd, t_pcd_da, mask_s, mask_t_da, cfg["sample_rate"], max_cond, "4dmatch")
+        warped = (Rf.float() @ s_pcd.transpose(1, 2) + tf.float()).transpose(1, 2)
+        f_img, f_pcd = fusion_module(W, cfg, img_feats, img_dino, img_pixels, pcd_feats, warped)
+        x0 = match_head_2d3d(W, cfg, f_pcd, f_img, mask_s, mask_t)
+        eps = (sra[t].view(1, 1, 1) * x - x0) / srm1[t].view(1, 1, 1)
+        sigma, c, sqrt_an = ddim_coefficients(ac, t, tn)
+        x = x0 * sqrt_an + c * eps
+        if trace is not None:
+            trace.append(dict(x0=x0, R_forwd=Rf, t_forwd=tf, cond=cond, x=x.clone()))
+    s = x.masked_fill(~pair_mask(mask_s, mask_t), float("-inf"))
+    conf = sinkhorn_log(s, bin_score, cfg["skh_iters"], mask_s, mask_t).exp()[:, :-1, :-1].contiguous()
+    return dict(conf_matrix_pred=conf, match_pred=top1_union(conf[0]), x_final=x)

@@ -267,11 +267,92 @@ def run_tree(variant):
         run_loop(64, 96, 64, 96, 20, 40, seed=22, tag="n64x96_s20_mc40")
 
 
+def run_2d3d():
+    """row a10: the reference's CrossModalFusionModule / Matching / SoftProcrustesLayer / log_optimal_transport /
+    mutual_topk_select composed in the order of MATR2D3D.forward's reverse sampling (EXP/model.py:637-694, 830-846);
+    MATR2D3D itself cannot be built offline (DINOv2 / Depth-Anything downloads)."""
+    import torch
+    for m in ("vision3d.ext", "ipdb", "open3d", "cv2", "easydict", "pykeops", "pykeops.torch", "pytorch3d", "pytorch3d.ops"):
+        sys.modules[m] = MagicMock()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    tree = os.path.join(REF, "Diff-Reg-2d3d")
+    exp = os.path.join(tree, "experiments", "2d3dmatr.rgbdv2.stage4.level3.stage1")
+    sys.path.insert(0, tree)
+    sys.path.insert(0, exp)
+    os.chdir(exp)
+    torch.set_num_threads(8)
+    from diffreg_hip import synth
+    from fusion_module import CrossModalFusionModule
+    from matching import Matching, log_optimal_transport
+    from procrustes import SoftProcrustesLayer
+    from vision3d.ops import mutual_topk_select
+    sys.path.insert(0, ROOT)
+    from oracle.diffreg_oracle import diffusion_schedule, time_pairs
+
+    v = synth.VARIANTS["2d3d"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Wnp = synth.make_weights_2d3d(seed=9, head_gain=HEAD_GAIN_2D3D)
+    fus = CrossModalFusionModule(v["img_dim"], v["pcd_dim"], v["C"], v["C"], v["H"], ["self", "cross"] * 3, use_embedding=True)
+    fus.load_state_dict({k[len("denoising_transformer."):]: T(a) for k, a in Wnp.items() if k.startswith("denoising_transformer.")})
+    mcfg = to_attr(dict(feature_dim=v["C"], confidence_threshold=0.2, entangled=False, dsmax_temperature=0.1,
+                        match_type="sinkhorn", skh_init_bin_score=1.0, skh_iters=3, skh_prefilter=False))
+    head = Matching(mcfg)
+    head.load_state_dict({k[len("denoising_coarse_matching."):]: T(a) for k, a in Wnp.items() if k.startswith("denoising_coarse_matching.")})
+    fus.eval(); head.eval()
+    ac, sra, srm1 = diffusion_schedule()
+    save = lambda name, **kw: np.savez_compressed(os.path.join(OUT, "2d3d_%s.npz" % name), **kw)
+
+    def run(N, M, nv, mv, mv_da, steps, mc, seed, tag):
+        proc = SoftProcrustesLayer(to_attr(dict(sample_rate=1.0, max_condition_num=mc)))
+        pr = synth.make_pair_2d3d(N, M, seed, weights=Wnp)
+        g = lambda k: T(pr[k])[None]
+        src_mask = torch.arange(N)[None] < nv
+        tgt_mask = torch.arange(M)[None] < mv
+        tgt_mask_da = torch.arange(M)[None] < mv_da
+        x = g("x_T").clone()
+        rec = dict(x0=[], Rf=[], tf=[], cond=[])
+        with torch.no_grad():
+            f_img0, f_pcd0 = fus(g("img_feats"), g("img_dino"), g("img_pixels"), g("pcd_feats"), g("s_pcd"))
+            c0, _, _, _ = head(f_pcd0, f_img0, src_mask, tgt_mask, True)
+            for (t, tn) in time_pairs(steps):
+                x.masked_fill_(~(src_mask[..., None] * tgt_mask_da[:, None]).bool(), float("-inf"))
+                Z = log_optimal_transport(x, head.bin_score, head.skh_iters, src_mask, tgt_mask_da)
+                cd = Z.exp()[:, :-1, :-1].contiguous().type(torch.float32)
+                R, tt, Rf, tf, cond, ok = proc(cd, g("s_pcd"), g("t_pcd_da"), src_mask, tgt_mask_da)
+                warped = (torch.matmul(Rf.type(torch.float32), g("s_pcd").transpose(1, 2)) + tf.type(torch.float32)).transpose(1, 2)
+                f_img, f_pcd = fus(g("img_feats"), g("img_dino"), g("img_pixels"), g("pcd_feats"), warped)
+                x0, _, _, _ = head(f_pcd, f_img, src_mask, tgt_mask, True)
+                tc = torch.full((1,), t, dtype=torch.long)
+                pred = (sra.gather(-1, tc).reshape(1, 1, 1) * x - x0) / srm1.gather(-1, tc).reshape(1, 1, 1)
+                a, an = ac[t], ac[tn]
+                sigma = 1.0 * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                c = (1 - an - sigma ** 2).sqrt()
+                x = x0 * an.sqrt() + c * pred
+                rec["x0"].append(x0[0].clone()); rec["Rf"].append(Rf[0].clone()); rec["tf"].append(tf[0].clone()); rec["cond"].append(cond[0].clone())
+            sim = x
+            sim.masked_fill_(~(src_mask[..., None] * tgt_mask[:, None]).bool(), float("-inf"))
+            Z = log_optimal_transport(sim, head.bin_score, head.skh_iters, src_mask, tgt_mask)
+            conf = Z.exp()[:, :-1, :-1].contiguous()
+            i, j, sc = mutual_topk_select(conf.squeeze(0), 1, largest=True, threshold=None, mutual=False)
+        x0s = torch.stack(rec["x0"])
+        save("loop_" + tag, f_img0=f_img0[0].numpy(), f_pcd0=f_pcd0[0].numpy(), conf0=c0[0].numpy(), conf=conf[0].numpy(),
+             conf_dtype=str(conf.dtype), x0_corner=x0s[:, :16, :16].numpy(), x0_last=x0s[-1].numpy(),
+             x0_sum=x0s.double().sum((1, 2)).numpy(), R_forwd=torch.stack(rec["Rf"]).numpy(), t_forwd=torch.stack(rec["tf"]).numpy(),
+             cond=torch.stack(rec["cond"]).numpy(), match_i=i.numpy(), match_j=j.numpy())
+        print(tag, "conf", conf.dtype, "x0 rowmax mean %.3f" % float(x0s[-1].max(1)[0].mean()), "cond", rec["cond"][:3])
+
+    run(96, 160, 90, 150, 141, 3, 200, 31, "n96x160_s3_masked")
+    # (the random-weight fusion module gives fairly flat matrices, whose top-K is unstable over many steps with the
+    #  warp active; the long run therefore uses the identity warp, the short masked run exercises the Procrustes feedback)
+    run(128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")
+
+
+HEAD_GAIN_2D3D = 16.0
 HEAD_GAIN = 24.0   # sharpens x_start so the synthetic scenes give near-permutation matrices (section 8c F7)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run_tree(sys.argv[1])
+        run_2d3d() if sys.argv[1] == "2d3d" else run_tree(sys.argv[1])
     else:
-        for v in TREES:
+        for v in list(TREES) + ["2d3d"]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), v])

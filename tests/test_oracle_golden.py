@@ -137,3 +137,34 @@ def test_schedule_and_time_pairs():
     assert tp[0] == (999, 949) and tp[-1] == (49, 0) and len(tp) == 20
     assert orc.time_pairs(1) == [(999, 0)]
     assert orc.time_pairs(10)[0] == (999, 899) and orc.time_pairs(50)[0] == (999, 979)
+
+
+@pytest.mark.parametrize("N,M,nv,mv,mv_da,steps,mc,seed,tag", [(96, 160, 90, 150, 141, 3, 200, 31, "n96x160_s3_masked"),
+                                                                 (128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")])
+def test_2d3d_loop_matches_reference(golden, N, M, nv, mv, mv_da, steps, mc, seed, tag):
+    """row a10: fusion module, matching head and the reverse-sampling loop of the 2D-3D variant."""
+    g = golden("2d3d_loop_" + tag)
+    v = synth.VARIANTS["2d3d"]
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W = {k: T(a) for k, a in Wn.items()}
+    pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
+    q = lambda k: T(pr[k])[None]
+    ms, mt = masks(N, M, nv, mv)
+    mt_da = torch.arange(M)[None] < mv_da
+    f_img, f_pcd = orc.fusion_module(W, v, q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"))
+    np.testing.assert_allclose(f_img[0].numpy(), g["f_img0"], atol=2e-5)
+    np.testing.assert_allclose(f_pcd[0].numpy(), g["f_pcd0"], atol=2e-5)
+    # (the restatement composes the same maths from different torch primitives -- x @ W.T + b vs addmm, einsum vs
+    #  matmul -- so float32 features agree to ~1e-5 and the confidences to ~1e-5 absolute)
+    np.testing.assert_allclose(orc.match_head_2d3d(W, v, f_pcd, f_img, ms, mt)[0].numpy(), g["conf0"], atol=3e-5)
+    trace = []
+    out = orc.denoise_loop_2d3d(W, v, q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"),
+                                ms, mt, mt_da, q("x_T"), steps, mc, trace=trace)
+    assert str(out["conf_matrix_pred"].dtype) == str(g["conf_dtype"])
+    np.testing.assert_allclose(torch.stack([r["R_forwd"][0] for r in trace]).numpy(), g["R_forwd"], atol=1e-4)
+    np.testing.assert_allclose(torch.stack([r["t_forwd"][0] for r in trace]).numpy(), g["t_forwd"], atol=1e-4)
+    np.testing.assert_allclose(trace[-1]["x0"][0].numpy(), g["x0_last"], atol=1e-4)
+    np.testing.assert_allclose(out["conf_matrix_pred"][0].numpy(), g["conf"], atol=1e-5, rtol=1e-3)
+    got = set(map(tuple, out["match_pred"][:, 1:].tolist()))
+    want = set(zip(g["match_i"].tolist(), g["match_j"].tolist()))
+    assert len(got ^ want) <= 0.05 * len(want)
