@@ -219,9 +219,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
                         v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, s));
                     }
                 }
+                if (P.bias && col_ok) v += P.bias[col];
                 if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
                 v *= P.scale;
-                if (row < rows && col_ok) P.out[(size_t)row * P.ldo + col] = v;
+                if (row < rows && col_ok) {
+                    if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
+                    P.out[(size_t)row * P.ldo + col] = v;
+                }
             }
     }
 }

@@ -31,6 +31,8 @@ struct GemmProblem {
     float* out;         // [rows, ldo]
     const float* cosT;  // rotary tables [rows, C/2] (EPI_ROTARY)
     const float* sinT;
+    const float* bias;  // [ncols] added before the activation (nn.Linear with bias) or nullptr
+    const float* addend; // [rows, ldo] added last (e.g. tokens + embedding projection) or nullptr
     int rows, ncols, K, K1, lda, lda2, ldo;
     int epi;
     int rot_C;          // rotary: column c uses table index (c % rot_C) / 2
@@ -74,6 +76,15 @@ int attention_configure();
 // out[r] = (res ? res[r] : 0) + LayerNorm(x[r]) * g + b      (eps = 1e-5)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                      int ldo, int rows, int C, hipStream_t st);
+// post-LN form: out[r] = LayerNorm(x[r] + res[r]) * g + b   (vision3d AttentionLayer / AttentionOutput)
+int launch_layernorm_postadd(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
+                             int ldo, int rows, int C, hipStream_t st);
+// warped = R p + t per pair (R, t nullable), mean over the rows of each pair, Fourier embedding
+// [p - mean | sin(2^l .), cos(2^l .)] of width (2L+1)*3 zero-padded to ldo (EXP/fusion_module.py:55-59)
+int launch_fourier3d(const float* xyz, int P, int rows_per_pair, const float* R, const float* t, int L, float* emb, int ldo,
+                     float* warped_ws, hipStream_t st);
+// Fourier embedding of 2-D pixel coordinates, no centring (EXP/fusion_module.py:50-53)
+int launch_fourier2d(const float* pix, int rows, int L, float* emb, int ldo, hipStream_t st);
 // rotary tables of warped points: p' = R p + t (R,t per pair, nullable), cos/sin [rows, C/2]
 int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
                   float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st);

@@ -9,6 +9,7 @@ namespace dr {
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAX_PER_LANE = 16;   // C <= 64 * 16
 
+template <bool POSTADD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                         const float* __restrict__ b, const float* __restrict__ res,
                                                         int ldres, float* __restrict__ out, int ldo, int rows, int C) {
@@ -22,6 +23,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < C ? xr[c] : 0.f;
+        if (POSTADD && c < C) v[i] += res[(size_t)row * ldres + c];
         s += v[i];
     }
     const float mean = wave_sum(s) / (float)C;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < C) {
             float y = (v[i] - mean) * rstd * g[c] + b[c];
-            if (res) y += res[(size_t)row * ldres + c];
+            if (!POSTADD && res) y += res[(size_t)row * ldres + c];
             out[(size_t)row * ldo + c] = y;
         }
     }
@@ -49,7 +51,96 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* b, co
     if (C > 64 * LN_MAX_PER_LANE) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
     ProfScope ps(PK_LN, (double)rows * C * (res ? 12.0 : 8.0), st);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int launch_layernorm_postadd(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
+                             int ldo, int rows, int C, hipStream_t st) {
+    if (C > 64 * LN_MAX_PER_LANE || !res) return DR_ENOSUP;
+    if (rows <= 0) return DR_OK;
+    ProfScope ps(PK_LN, (double)rows * C * 12.0, st);
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FourierEmbedding(length L, use_pi=False, use_input=True) (2D3D/vision3d/layers/embedding.py:75-100):
+// [p (D) | level 0: sin (D), cos (D) | level 1: ... ], factors 2^l exact in float32
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_mean_kernel(const float* __restrict__ xyz, int n, const float* __restrict__ R,
+                                                        const float* __restrict__ tv, float* __restrict__ warped) {
+    // one workgroup per pair: warped = R p + t, then subtract the mean over the n rows (points.mean(dim=1))
+    __shared__ double s[4][3];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const float* p = xyz + (size_t)pair * n * 3;
+    float* wp = warped + (size_t)pair * n * 3;
+    double acc[3] = {0, 0, 0};
+    for (int i = t; i < n; i += 256) {
+        float q[3] = {p[i * 3], p[i * 3 + 1], p[i * 3 + 2]};
+        if (R) {
+            const float* Rp = R + pair * 9;
+            const float* tp = tv + pair * 3;
+            float o[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                o[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Rp[a * 3], q[0]), __fmul_rn(Rp[a * 3 + 1], q[1])), __fmul_rn(Rp[a * 3 + 2], q[2])), tp[a]);
+            q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wp[i * 3 + a] = q[a]; acc[a] += (double)q[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v = wave_sum(acc[a]);
+        if ((t & 63) == 0) s[t >> 6][a] = v;
+    }
+    __syncthreads();
+    float mean[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = (float)((s[0][a] + s[1][a] + s[2][a] + s[3][a]) / (double)n);
+    __syncthreads();
+    for (int i = t; i < n; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) wp[i * 3 + a] = __fsub_rn(wp[i * 3 + a], mean[a]);
+}
+
+__global__ __launch_bounds__(256) void fourier_kernel(const float* __restrict__ p, int rows, int D, int L, float* __restrict__ emb,
+                                                      int ldo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * ldo) return;
+    const int row = idx / ldo, c = idx % ldo;
+    float v = 0.f;
+    if (c < D) {
+        v = p[row * D + c];
+    } else if (c < (2 * L + 1) * D) {
+        const int e = c - D, l = e / (2 * D), r = e % (2 * D);
+        const float th = __fmul_rn(ldexpf(1.0f, l), p[row * D + (r % D)]);
+        v = r < D ? sinf(th) : cosf(th);
+    }
+    emb[idx] = v;
+}
+
+int launch_fourier3d(const float* xyz, int P, int rows_per_pair, const float* R, const float* t, int L, float* emb, int ldo,
+                     float* warped_ws, hipStream_t st) {
+    if (P <= 0) return DR_OK;
+    if (ldo < (2 * L + 1) * 3) return DR_EINVAL;
+    ProfScope ps(PK_PE, (double)P * rows_per_pair * (ldo + 6) * 4.0, st);
+    hipLaunchKernelGGL(warp_mean_kernel, dim3(P), dim3(256), 0, st, xyz, rows_per_pair, R, t, warped_ws);
+    const int total = P * rows_per_pair * ldo;
+    hipLaunchKernelGGL(fourier_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)warped_ws, P * rows_per_pair, 3, L, emb, ldo);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int launch_fourier2d(const float* pix, int rows, int L, float* emb, int ldo, hipStream_t st) {
+    if (rows <= 0) return DR_OK;
+    if (ldo < (2 * L + 1) * 2) return DR_EINVAL;
+    const int total = rows * ldo;
+    ProfScope ps(PK_PE, (double)total * 4.0, st);
+    hipLaunchKernelGGL(fourier_kernel, dim3((total + 255) / 256), dim3(256), 0, st, pix, rows, 2, L, emb, ldo);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

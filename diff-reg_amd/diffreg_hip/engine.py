@@ -202,3 +202,106 @@ class DenoiseEngine:
         """[K_p,3] int64 tensors (one host sync)."""
         cnt = out["match_count"].cpu().tolist()
         return [out["matches_padded"][p, :cnt[p]] for p in range(len(cnt))]
+
+
+class DenoiseEngine2D3D:
+    """2D-3D variant: reverse sampling of MATR2D3D.forward (EXP/model.py:637-694) with the
+    CrossModalFusionModule denoiser, through dr_denoise_loop_2d3d.  `state` uses the reference's names
+    (`denoising_transformer.*` = CrossModalFusionModule, `denoising_coarse_matching.*` = Matching)."""
+    _LAYER = (("q_w", "attention.attention.q_token_layer.weight"), ("q_b", "attention.attention.q_token_layer.bias"),
+              ("k_w", "attention.attention.k_token_layer.weight"), ("k_b", "attention.attention.k_token_layer.bias"),
+              ("v_w", "attention.attention.v_token_layer.weight"), ("v_b", "attention.attention.v_token_layer.bias"),
+              ("lin_w", "attention.linear.weight"), ("lin_b", "attention.linear.bias"),
+              ("norm1_w", "attention.norm.weight"), ("norm1_b", "attention.norm.bias"),
+              ("expand_w", "output.expand.weight"), ("expand_b", "output.expand.bias"),
+              ("squeeze_w", "output.squeeze.weight"), ("squeeze_b", "output.squeeze.bias"),
+              ("norm2_w", "output.norm.weight"), ("norm2_b", "output.norm.bias"))
+    _TOP = (("img_emb_b", "img_emb_proj.bias"), ("pcd_emb_b", "pcd_emb_proj.bias"), ("img_in_w", "img_in_proj.weight"),
+            ("img_in_b", "img_in_proj.bias"), ("dino_w", "img_in_proj_dino.weight"), ("dino_b", "img_in_proj_dino.bias"),
+            ("all_w", "img_in_proj_all.weight"), ("all_b", "img_in_proj_all.bias"), ("pcd_in_w", "pcd_in_proj.weight"),
+            ("pcd_in_b", "pcd_in_proj.bias"), ("out_w", "out_proj.weight"), ("out_b", "out_proj.bias"))
+
+    def __init__(self, state, *, C=256, H=4, n_layers=6, img_dim=512, dino_dim=1024, pcd_dim=512, steps=10, sk_iters=3,
+                 sample_rate=1.0, max_condition_num=200.0, device="cuda:0", strict_f64=False,
+                 prefix_t="denoising_transformer.", prefix_m="denoising_coarse_matching."):
+        lib.ensure_init()
+        self.device = torch.device(device)
+        self.C, self.steps = C, steps
+        f = lambda k: state[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep = []
+        self._layers = (lib.FusionLayerWeights * n_layers)()
+        for l in range(n_layers):
+            for field, name in self._LAYER:
+                tns = f(prefix_t + "transformer.%d.%s" % (l, name))
+                self._keep.append(tns)
+                setattr(self._layers[l], field, tns.data_ptr())
+        w = lib.FusionWeights()
+        w.layers = ctypes.cast(self._layers, ctypes.POINTER(lib.FusionLayerWeights))
+        for field, name in self._TOP:
+            tns = f(prefix_t + name)
+            self._keep.append(tns)
+            setattr(w, field, tns.data_ptr())
+        # K = 42 / 63 are not multiples of 4: zero-pad the embedding projections to 44 / 64 input columns
+        ie = torch.nn.functional.pad(f(prefix_t + "img_emb_proj.weight"), (0, 2)).contiguous()
+        pe = torch.nn.functional.pad(f(prefix_t + "pcd_emb_proj.weight"), (0, 1)).contiguous()
+        sp = f(prefix_m + "src_proj.weight")
+        bs = f(prefix_m + "bin_score").reshape(1)
+        self._keep += [ie, pe, sp, bs]
+        w.img_emb_w, w.pcd_emb_w, w.src_proj, w.bin_score = ie.data_ptr(), pe.data_ptr(), sp.data_ptr(), bs.data_ptr()
+        self.w = w
+        self._ac = np.ascontiguousarray(cosine_alphas_cumprod().numpy())
+        self._cfgs = {}
+        self._base = dict(C=C, H=H, n_layers=n_layers, img_dim=img_dim, dino_dim=dino_dim, pcd_dim=pcd_dim, sk_iters=sk_iters,
+                          sample_rate=sample_rate, max_condition_num=max_condition_num, flags=1 if strict_f64 else 0)
+        self._ws = None
+
+    def _cfg(self, steps):
+        if steps not in self._cfgs:
+            cfg = lib.Loop2D3DConfig()
+            for k, v in self._base.items():
+                setattr(cfg, k, v)
+            cfg.steps = steps
+            times = np.ascontiguousarray(np.asarray(sampling_times(max(steps, 1)), dtype=np.int32))
+            cfg.h_alphas_cumprod = self._ac.ctypes.data
+            cfg.h_times = times.ctypes.data
+            self._cfgs[steps] = (cfg, times)
+        return self._cfgs[steps][0]
+
+    def _call(self, steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace):
+        P, M, _ = img_feats.shape
+        N = pcd_feats.shape[1]
+        cfg = self._cfg(steps)
+        need = lib.raw().dr_denoise_loop_2d3d_workspace_bytes(ctypes.byref(cfg), P, N, M)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        dev = self.device
+        c = lambda t_: None if t_ is None else t_.contiguous()
+        conf = torch.empty(P, N, M, dtype=torch.float64, device=dev)
+        xf = torch.empty(P, N, M, dtype=torch.float64, device=dev)
+        matches = torch.zeros(P, N + M, 3, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(P, dtype=torch.int32, device=dev)
+        img_out = torch.empty(P, M, self.C, device=dev)
+        pcd_out = torch.empty(P, N, self.C, device=dev)
+        sm, tm, tmd = (lib.mask_u8(m) for m in masks) if masks is not None else (None, None, None)
+        tr, trb = None, {}
+        if trace and steps > 0:
+            trb = dict(x0=torch.empty(steps, P, N, M, device=dev), R_forwd=torch.empty(steps, P, 3, 3, device=dev),
+                       t_forwd=torch.empty(steps, P, 3, 1, device=dev), cond=torch.empty(steps, P, dtype=torch.float64, device=dev))
+            tr = lib.LoopTrace()
+            tr.x0, tr.R_forwd, tr.t_forwd, tr.cond = (trb[k].data_ptr() for k in ("x0", "R_forwd", "t_forwd", "cond"))
+        lib.check(lib.raw().dr_denoise_loop_2d3d(
+            ctypes.byref(cfg), ctypes.byref(self.w), P, N, M, lib.ptr(c(img_feats)), lib.ptr(c(img_dino)), lib.ptr(c(img_pixels)),
+            lib.ptr(c(pcd_feats)), lib.ptr(c(s_pcd)), lib.ptr(c(t_pcd_da)), lib.ptr(sm), lib.ptr(tm), lib.ptr(tmd), lib.ptr(c(x_T)),
+            lib.ptr(conf), lib.ptr(xf), lib.ptr(matches), lib.ptr(cnt), lib.ptr(img_out), lib.ptr(pcd_out),
+            ctypes.byref(tr) if tr is not None else None, lib.ptr(self._ws), need, lib.stream_of(img_feats)))
+        out = dict(conf_matrix_pred=conf, x_final=xf, matches_padded=matches, match_count=cnt, img_feats=img_out, pcd_feats=pcd_out)
+        out.update(trb)
+        return out
+
+    def fuse_and_match(self, img_feats, img_dino, img_pixels, pcd_feats, pcd_points, masks=None):
+        """CrossModalFusionModule.forward + Matching.forward once: -> img feats, pcd feats, conf (x_start) float32."""
+        o = self._call(0, img_feats, img_dino, img_pixels, pcd_feats, pcd_points, None, masks, None, False)
+        return o["img_feats"], o["pcd_feats"], o["conf_matrix_pred"].float()
+
+    def run(self, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, x_T, masks=None, trace=False):
+        return self._call(self.steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace)

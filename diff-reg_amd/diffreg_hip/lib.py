@@ -50,6 +50,24 @@ class LoopWeights(ctypes.Structure):
                 ("pe_freq", c_void_p)]
 
 
+class FusionLayerWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "lin_w", "lin_b", "norm1_w", "norm1_b",
+                                        "expand_w", "expand_b", "squeeze_w", "squeeze_b", "norm2_w", "norm2_b")]
+
+
+class FusionWeights(ctypes.Structure):
+    _fields_ = [("layers", ctypes.POINTER(FusionLayerWeights))] + \
+               [(n, c_void_p) for n in ("img_emb_w", "img_emb_b", "pcd_emb_w", "pcd_emb_b", "img_in_w", "img_in_b", "dino_w",
+                                        "dino_b", "all_w", "all_b", "pcd_in_w", "pcd_in_b", "out_w", "out_b", "src_proj",
+                                        "bin_score")]
+
+
+class Loop2D3DConfig(ctypes.Structure):
+    _fields_ = [("C", c_int), ("H", c_int), ("n_layers", c_int), ("img_dim", c_int), ("dino_dim", c_int), ("pcd_dim", c_int),
+                ("steps", c_int), ("sk_iters", c_int), ("sample_rate", c_float), ("max_condition_num", c_float),
+                ("flags", c_int), ("h_alphas_cumprod", c_void_p), ("h_times", c_void_p)]
+
+
 class LoopTrace(ctypes.Structure):
     _fields_ = [("x0", c_void_p), ("R_forwd", c_void_p), ("t_forwd", c_void_p), ("cond", c_void_p)]
 
@@ -74,6 +92,9 @@ SIGNATURES.update({
     "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),
     "dr_denoise_loop": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 14 +
                         [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
+    "dr_denoise_loop_2d3d_workspace_bytes": (c_size_t, [_P(Loop2D3DConfig), c_int, c_int, c_int]),
+    "dr_denoise_loop_2d3d": (c_int, [_P(Loop2D3DConfig), _P(FusionWeights), c_int, c_int, c_int] + [c_void_p] * 16 +
+                             [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
     "dr_denoiser_match_f32": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 9 +
                               [c_void_p, c_size_t, c_void_p]),
 })

@@ -213,6 +213,57 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
                           const float* t_pcd, const uint8_t* src_mask, const uint8_t* tgt_mask, float* src_out,
                           float* tgt_out, float* conf, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
+ * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)
+ * with CrossModalFusionModule (EXP/fusion_module.py:61-107, vision3d/layers/transformer.py:58-301)
+ * as the denoiser and the position-free Matching head (EXP/matching.py:91-147).
+ * src = N point-cloud nodes, tgt = M image patches.
+ */
+typedef struct {        /* one vision3d TransformerLayer: weights [out,in] row-major, biases [out] */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;     /* attention.attention.{q,k,v}_token_layer   */
+    const float *lin_w, *lin_b, *norm1_w, *norm1_b;     /* attention.linear, attention.norm          */
+    const float *expand_w, *expand_b, *squeeze_w, *squeeze_b, *norm2_w, *norm2_b; /* output.*        */
+} dr_fusion_layer_weights;
+
+typedef struct {
+    const dr_fusion_layer_weights* layers;   /* HOST array [n_layers] */
+    const float *img_emb_w, *img_emb_b;      /* img_emb_proj: weight zero-padded to [C, 44] (K = 42 -> 44)  */
+    const float *pcd_emb_w, *pcd_emb_b;      /* pcd_emb_proj: weight zero-padded to [C, 64] (K = 63 -> 64)  */
+    const float *img_in_w, *img_in_b;        /* img_in_proj      [C, img_dim]                               */
+    const float *dino_w, *dino_b;            /* img_in_proj_dino [C, dino_dim]                              */
+    const float *all_w, *all_b;              /* img_in_proj_all  [C, 2C]                                    */
+    const float *pcd_in_w, *pcd_in_b;        /* pcd_in_proj      [C, pcd_dim]                               */
+    const float *out_w, *out_b;              /* out_proj         [C, C]                                     */
+    const float* src_proj;                   /* denoising_coarse_matching.src_proj.weight [C,C] (Q1)        */
+    const float* bin_score;
+} dr_fusion_weights;
+
+typedef struct {
+    int C, H, n_layers;          /* hidden/output dim (256), heads (4), blocks (self, cross, ...)   */
+    int img_dim, dino_dim, pcd_dim;
+    int steps, sk_iters;
+    float sample_rate, max_condition_num;
+    int flags;                   /* DR_LOOP_*                                                     */
+    const double* h_alphas_cumprod;
+    const int32_t* h_times;
+} dr_loop2d3d_config;
+
+size_t dr_denoise_loop_2d3d_workspace_bytes(const dr_loop2d3d_config* cfg, int P, int N, int M);
+
+/* inputs : img_feats [P,M,img_dim], img_dino [P,M,dino_dim], img_pixels [P,M,2], pcd_feats [P,N,pcd_dim],
+ *          s_pcd [P,N,3] (point nodes), t_pcd_da [P,M,3] (depth-back-projected patch centres),
+ *          src_mask [P,N], tgt_mask [P,M], tgt_mask_da [P,M] uint8 (all three or none), x_T [P,N,M]
+ * outputs: conf [P,N,M] float64; matches [P,N+M,3] int64 + match_count [P] (optional); x_final (optional);
+ *          trace as in dr_denoise_loop; steps == 0 runs ONE fusion + matching evaluation on s_pcd as given
+ *          and writes x_start into conf as float64 (used by the component tests) */
+int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights* w, int P, int N, int M,
+                         const float* img_feats, const float* img_dino, const float* img_pixels,
+                         const float* pcd_feats, const float* s_pcd, const float* t_pcd_da, const uint8_t* src_mask,
+                         const uint8_t* tgt_mask, const uint8_t* tgt_mask_da, const float* x_T, double* conf,
+                         double* x_final, int64_t* matches, int32_t* match_count, float* img_out, float* pcd_out,
+                         const dr_loop_trace* trace, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
