@@ -80,9 +80,15 @@ def sinkhorn_microbench(device, B=4096, N=256, M=256, reps=10):
         lib.sinkhorn(x1, a, 3, out=o1)
     e1.record()
     torch.cuda.synchronize()
+    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 correction + WRITE_SIZE)
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_sinkhorn_pmc_traffic.json")
+    if os.path.exists(pmc) and B == 4096 and N == 256 and M == 256:
+        traffic, src = json.load(open(pmc))["hbm_bytes_per_launch"], "profiles/r01_sinkhorn_pmc_traffic.json"
     return dict(kernel="sk_fast_kernel<float,float,16,4>", bound="hbm", tiles_per_launch=B, bytes_per_tile=N * M * 8,
                 us_per_launch=ms * 1e3, achieved=byts / ms / 1e6, peak=PEAK_HBM_GBPS, unit="GB/s",
-                frac=byts / ms / 1e6 / PEAK_HBM_GBPS, traffic=None, single_tile_latency_us=e0.elapsed_time(e1) / 50 * 1e3)
+                frac=byts / ms / 1e6 / PEAK_HBM_GBPS, traffic=traffic, traffic_source=src, algorithmic_bytes=byts,
+                single_tile_latency_us=e0.elapsed_time(e1) / 50 * 1e3)
 
 
 def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):

@@ -62,3 +62,23 @@ def test_2d3d_two_pairs_equal_single_pairs():
         d = lambda k: q(k).to(DEV)
         one = eng.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"))
         assert (one["conf_matrix_pred"][0] - c_both[i]).abs().max().item() < 1e-6
+
+
+def test_cfg5_shape_1024x2048():
+    """BASELINE configs[4] shape: N = 1024 point nodes x M = 2048 image patches (tiles beyond the register-resident
+    Sinkhorn / Procrustes paths), one denoise step against the oracle."""
+    N, M, steps, mc = 1024, 2048, 1, 200
+    W, eng, q = setup(N, M, 51, steps, mc)
+    ms, mt = masks(N, M, 1000, 2000)
+    mt_da = torch.arange(M)[None] < 1900
+    d = lambda k: q(k).to(DEV)
+    out = eng.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"),
+                  (ms.to(DEV), mt.to(DEV), mt_da.to(DEV)), trace=True)
+    tr = []
+    ref = orc.denoise_loop_2d3d(W, synth.VARIANTS["2d3d"], q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"),
+                                q("t_pcd_da"), ms, mt, mt_da, q("x_T"), steps, mc, trace=tr)
+    assert (out["R_forwd"][0, 0].cpu() - tr[0]["R_forwd"][0]).abs().max().item() < 1e-4
+    dx = (out["x0"][0, 0].cpu() - tr[0]["x0"][0]).abs()
+    assert (dx > 1e-4).float().mean().item() <= 1e-3, dx.max().item()
+    dc = (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs()
+    assert (dc > 1e-4).double().mean().item() <= 1e-3, dc.max().item()
