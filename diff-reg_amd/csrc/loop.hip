@@ -48,9 +48,10 @@ struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k
 static int layer_call(const dr_layer_weights& W, int C, int H, int P, const float* xin, int xr0, int xrows,
                       const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
                       const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
-                      hipStream_t st) {
+                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr) {
+    // kv_cached: K|V of the source rows were projected earlier ([tokens, 2C], rotary applied to K): skip them.
+    // kv_store : project ONLY K|V of the source rows into this buffer and return (used to fill the cache).
     const int halfC = C / 2, d = C / H;
-    const bool same = (xin == yin && xr0 == yr0 && xrows == yrows);
     GemmBatch g;
     memset(&g, 0, sizeof(g));
     auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot) {
@@ -59,18 +60,30 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
         p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
         p.cosT = cosT + (size_t)r0 * halfC; p.sinT = sinT + (size_t)r0 * halfC;
     };
+    int rc;
+    if (kv_store) {
+        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true);
+        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false);
+        g.p[0].out = kv_store + (size_t)yr0 * 2 * C; g.p[0].ldo = 2 * C;
+        g.p[1].out = kv_store + (size_t)yr0 * 2 * C + C; g.p[1].ldo = 2 * C;
+        g.n = 2;
+        return launch_gemm(g, st);
+    }
     proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true);
-    proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
-    proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
-    g.n = 3;
-    (void)same;
-    int rc = launch_gemm(g, st);
+    g.n = 1;
+    if (!kv_cached) {
+        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
+        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
+        g.n = 3;
+    }
+    rc = launch_gemm(g, st);
     if (rc) return rc;
 
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = ws.qkv; a.k = ws.qkv + C; a.v = ws.qkv + 2 * C; a.out = ws.att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.H = H; a.d = d;
+    if (kv_cached) { a.k = kv_cached; a.v = kv_cached + C; a.ldk = a.ldv = 2 * C; }
     a.qmask = tokmask; a.kmask = tokmask;
     a.nseg = P; a.q0 = f1.q0; a.qstride = f1.Lq; a.Lq = f1.Lq; a.k0 = f1.k0; a.kstride = f1.Lk; a.Lk = f1.Lk;
     if (f2) {
@@ -114,9 +127,12 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
 struct DenoiseWs {
     LayerWs lw;
     float *fa, *fb, *cosT, *sinT, *proj, *sim;
+    float *tgt_l0, *kv_l1;      // step-invariant: layer-0 output of the tgt rows, layer-1 K|V of those rows
     static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C) {
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
+        w.tgt_l0 = c.take<float>(T * C);
+        w.kv_l1 = c.take<float>(T * 2 * C);
         w.fa = c.take<float>(T * C);
         w.fb = c.take<float>(T * C);
         w.cosT = c.take<float>(T * (C / 2));
@@ -129,8 +145,23 @@ struct DenoiseWs {
 // six layers self, cross, ... (pipeline.py:142; transformero.py:170-186) starting from feat0,
 // then the matching head's projection + N x M similarity (matching.py:173-207).  PE tables must be
 // filled.  On return *final points at the buffer holding the refined features and ws.sim holds sim.
+// The tgt cloud never moves and layer 0 is a self layer, so the tgt half of layer 0 and the K|V projections of
+// layer 1's first cross call do not depend on the step (the reference recomputes them 20 times): fill_tgt_cache
+// evaluates them once per loop, denoiser_and_sim(use_cache) reuses them.  Results are bit-identical.
+static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
+                          const uint8_t* tokmask, DenoiseWs& ws, hipStream_t st) {
+    const int C = cfg.C, H = cfg.H, PN = P * N, PM = P * M;
+    const Family self_t{PN, M, PN, M};
+    int rc = layer_call(w.layers[0], C, H, P, feat0, PN, PM, feat0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
+                        ws.tgt_l0, st);
+    if (rc || cfg.n_layers < 2) return rc;
+    return layer_call(w.layers[1], C, H, P, nullptr, 0, 0, ws.tgt_l0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
+                      nullptr, st, nullptr, ws.kv_l1);
+}
+
 static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
-                            const uint8_t* tokmask, DenoiseWs& ws, const float** final_feats, hipStream_t st) {
+                            const uint8_t* tokmask, DenoiseWs& ws, const float** final_feats, hipStream_t st,
+                            bool use_cache = false) {
     const int C = cfg.C, H = cfg.H, T = P * (N + M), PN = P * N, PM = P * M;
     const float* cur = feat0;
     float* bufs[2] = {ws.fa, ws.fb};
@@ -139,7 +170,18 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     for (int l = 0; l < cfg.n_layers; ++l) {
         float* nxt = bufs[which];
         int rc;
-        if (l % 2 == 0) {
+        if (use_cache && l == 0) {
+            // src half only; the tgt half comes from the cache
+            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st);
+            if (rc) return rc;
+            DR_HIP_CHECK(hipMemcpyAsync(nxt + (size_t)PN * C, ws.tgt_l0 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
+        } else if (use_cache && l == 1) {
+            rc = layer_call(w.layers[1], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st,
+                            ws.kv_l1);
+            if (rc) return rc;
+            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
+            if (rc) return rc;
+        } else if (l % 2 == 0) {
             rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st);
             if (rc) return rc;
         } else {
@@ -417,6 +459,8 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     // every step, transformero.py:166)
     rc = fill_pe(*cfg, *w, P, N, M, s_pcd, nullptr, nullptr, t_pcd, false, true, L.dw, st);
     if (rc) return rc;
+    rc = fill_tgt_cache(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, st);
+    if (rc) return rc;
 
     const double* ac = cfg->h_alphas_cumprod;
     for (int k = 0; k < cfg->steps; ++k) {
@@ -443,7 +487,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         if (rc) return rc;
         // -- denoising_transformer + denoising_coarse_matching (pipeline.py:243-244)
         const float* fin = nullptr;
-        rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, &fin, st);
+        rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, &fin, st, true);
         if (rc) return rc;
         rc = sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0,
                           L.skws, L.skws_bytes, st);
