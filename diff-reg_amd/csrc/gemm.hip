@@ -264,6 +264,8 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
 #define CFG_XL64   2, 2, 2, 2, 1, 64     /* experiment: 128 x 128 tile, 64-deep chunks                                 */
 #define CFG_L1B    2, 1, 2, 2, 1, 32, 1  /* 128 x  64 tile, single LDS buffer: 27 KB -> 5 workgroups per CU            */
 #define CFG_XL1B   2, 2, 2, 2, 1, 32, 1  /* 128 x 128 tile, single LDS buffer: 36 KB -> 4 workgroups per CU            */
+#define CFG_M1B    1, 1, 2, 2, 1, 32, 1  /*  64 x  64 tile, single LDS buffer: 18 KB -> 8 workgroups per CU            */
+#define CFG_M1B64  1, 1, 2, 2, 1, 64, 1  /*  64 x  64 tile, 64-deep chunks, single buffer: 35 KB -> 4 per CU             */
 #define CFG_LARGE8 1, 1, 4, 2, 1, 32     /* 128 x  64 tile, 8 waves of 32 x 32 (two per SIMD share the staged tiles)  */
 
 int gemm_configure() {
@@ -272,6 +274,8 @@ int gemm_configure() {
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE>();
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE8>();
     if (rc == DR_OK) rc = configure_cfg<CFG_XL>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_M1B>();
+    if (rc == DR_OK) rc = configure_cfg<CFG_M1B64>();
     if (rc == DR_OK) rc = configure_cfg<CFG_L1B>();
     if (rc == DR_OK) rc = configure_cfg<CFG_XL1B>();
     if (rc == DR_OK) rc = configure_cfg<CFG_L64>();
@@ -297,9 +301,13 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         useful += (double)p.rows * p.ncols;
         padded += (double)tx * 128 * 128;
     }
-    int cfg = nL >= 256 ? 7 : (nM >= 128 ? 1 : 0);     // fill the 256 CUs before growing the tile (7 = single-buffer large)
+    int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
+                                     // every configuration measured on the loop's shapes (tools/gemm_bench.py)
+    (void)nL;
     (void)nX; (void)useful; (void)padded;              // 128 x 128 tiles (cfg 4) measured within noise of cfg 2: not auto-selected
     if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg == 10) return launch_cfg<CFG_M1B64>(g, st);
+    if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
     if (cfg == 8) return launch_cfg<CFG_XL1B>(g, st);
     if (cfg == 7) return launch_cfg<CFG_L1B>(g, st);
     if (cfg == 6) return launch_cfg<CFG_XL64>(g, st);
