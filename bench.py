@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--breakdown-only", action="store_true",
+                    help="run only the eager, event-timed passes of one batch (the command profiled with rocprofv3 for profiles/)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +172,9 @@ def main():
             return eng.run_streams(groups, nstreams)[0]
         return eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)
 
+    if args.breakdown_only:
+        use_graph = False
+        args.no_single_pair = args.no_cpu_baseline = True
     for _ in range(max(args.warmup, 1)):
         out = run(use_graph)
     torch.cuda.synchronize()
@@ -204,17 +210,18 @@ def main():
 
     if rank == 0 and world == 1:
         # ---- single-pair latency (the literal "batch=1" of configs[1]) -------------------------------
-        prs1, inp1 = make_inputs(variant, 1, N, M, seed0=7000, device=dev)
-        run1 = lambda: eng.run(inp1["f_s"], inp1["f_t"], inp1["p_s"], inp1["p_t"], inp1["x_T"], graph=use_graph)
-        for _ in range(3):
-            run1()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            run1()
-        torch.cuda.synchronize()
-        lat = (time.perf_counter() - t1) / 10
-        result["single_pair"] = {"ms_per_pair": lat * 1e3, "pairs_per_s": 1.0 / lat}
+        if not args.no_single_pair:
+            prs1, inp1 = make_inputs(variant, 1, N, M, seed0=7000, device=dev)
+            run1 = lambda: eng.run(inp1["f_s"], inp1["f_t"], inp1["p_s"], inp1["p_t"], inp1["x_T"], graph=use_graph)
+            for _ in range(3):
+                run1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                run1()
+            torch.cuda.synchronize()
+            lat = (time.perf_counter() - t1) / 10
+            result["single_pair"] = {"ms_per_pair": lat * 1e3, "pairs_per_s": 1.0 / lat}
 
         if not args.no_breakdown:
             # ---- per-kernel-family GPU time of the same pass (eager launches, HIP events on the stream) ---
@@ -245,8 +252,9 @@ def main():
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof
             result["kernel_families"] = fam
-        result["sinkhorn_roofline"] = sinkhorn_microbench(dev)
-        if "roofline" not in result:
+        if not args.breakdown_only:
+            result["sinkhorn_roofline"] = sinkhorn_microbench(dev)
+        if "roofline" not in result and "sinkhorn_roofline" in result:
             result["roofline"] = result["sinkhorn_roofline"]
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(variant, N, M, S, args.max_condition_num)
