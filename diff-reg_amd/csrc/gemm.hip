@@ -9,11 +9,51 @@
 // over k does not care about.  One ds_read_b128 per operand feeds 4 MFMAs.
 // 4 waves per workgroup arranged WM x WN x WK (WK = split of the k range inside the workgroup,
 // reduced through LDS) so that small problems (256..512 rows) still spread over the chip.
+#include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 namespace dr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Epilogue shared by both kernels.  C/D layout of the 32x32 MFMA (any input type): col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+template <int TM, int TN, class Acc>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, Acc acc, int rows, int ncols, int row0, int col0,
+                                              int wm, int wn, int lane) {
+    const int h = lane >> 5, l31 = lane & 31;
+    const int halfC = P.rot_C >> 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + (wn * TN + j) * 32 + l31;
+        const bool col_ok = col < ncols;
+        const int ridx = (P.epi & EPI_ROTARY) ? (col % P.rot_C) >> 1 : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc(i, j)[r];
+                if (P.epi & EPI_ROTARY) {
+                    // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
+                    const float other = __shfl_xor(v, 1);
+                    if (row < rows && col_ok) {
+                        const float c = P.cosT[(size_t)row * halfC + ridx], s = P.sinT[(size_t)row * halfC + ridx];
+                        const float sw = (col & 1) ? other : -other;
+                        v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, s));
+                    }
+                }
+                if (P.bias && col_ok) v += P.bias[col];
+                if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
+                v *= P.scale;
+                if (row < rows && col_ok) {
+                    if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
+                    P.out[(size_t)row * P.ldo + col] = v;
+                }
+            }
+    }
+}
 
 // Geometry: a wave owns TM x TN MFMA tiles (32x32 each); a workgroup is WM x WN x WK waves (4 in all);
 // K is staged in chunks of BKC floats (double-buffered LDS, one barrier per chunk), of which each of
@@ -197,37 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
                     for (int r = 0; r < 16; ++r) acc[i][j][0][r] += red[((((w + o) * TM + i) * TN + j) * 16 + r) * 64 + lane];
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int halfC = P.rot_C >> 1;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + (wn * TN + j) * 32 + l31;
-        const bool col_ok = col < ncols;
-        const int ridx = (P.epi & EPI_ROTARY) ? (col % P.rot_C) >> 1 : 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[i][j][0][r];
-                if (P.epi & EPI_ROTARY) {
-                    // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
-                    const float other = __shfl_xor(v, 1);
-                    if (row < rows && col_ok) {
-                        const float c = P.cosT[(size_t)row * halfC + ridx], s = P.sinT[(size_t)row * halfC + ridx];
-                        const float sw = (col & 1) ? other : -other;
-                        v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, s));
-                    }
-                }
-                if (P.bias && col_ok) v += P.bias[col];
-                if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
-                v *= P.scale;
-                if (row < rows && col_ok) {
-                    if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
-                    P.out[(size_t)row * P.ldo + col] = v;
-                }
-            }
-    }
+    gemm_epilogue<TM, TN>(P, [&](int i, int j) -> const f32x16& { return acc[i][j][0]; }, rows, ncols, row0, col0, wm, wn, lane);
 }
 
 template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
@@ -251,6 +261,579 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM, flops, st);
     hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC, NBUF>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-operand variant: fp32 result from bf16 MFMAs.  Every fp32 operand x is written (round-to-nearest at each
+// level) as hi + mid + lo, three bf16 numbers, exact to ~2^-27 |x|; the product keeps the six terms down to
+// 2^-18 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) and accumulates them in fp32 on v_mfma_f32_32x32x16_bf16.
+// bf16 x bf16 products are exact in fp32, so the dropped terms (<= 2^-26 relative) are below the rounding of the
+// fp32 accumulation itself: measured against an fp64 GEMM the result is as close as the f32-input MFMA kernel's
+// (tests/test_ops_gpu.py::test_gemm_split_accuracy).  Six bf16 MFMAs (32 cycles each, K = 16) replace eight
+// f32 MFMAs (64 cycles each, K = 2): 2.67x the f32-input MFMA rate.
+// The split happens once per staged element, on the way from the global-load registers into LDS, which holds the
+// three planes of a row side by side ([row][plane][BK] bf16, 16 B pad -> odd 16-B slot stride, conflict-free
+// ds_read_b128); a lane's fragment is 8 consecutive k of its row (operand map of the 32x32x16 MFMA).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int TM, int TN, int WM, int WN, int BK, int NBUF>
+struct SplitGeom {
+    static constexpr int NW = WM * WN, NT = 64 * NW;
+    static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr int PL = BK * 2;                           // bytes of one plane of one row
+    static constexpr int ROWB = 3 * PL + 16;                    // padded row stride (bytes)
+    static constexpr int S8 = BK / 8;                           // 8-float staging slots per row
+    static constexpr int A_SLOTS = (BM * S8 + NT - 1) / NT, B_SLOTS = (BN * S8 + NT - 1) / NT;
+    static constexpr int STAGE = (BM + BN) * ROWB;              // bytes per buffer
+    static constexpr int SMEM = NBUF * STAGE;
+    static constexpr int KSTEPS = BK / 16;
+};
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const f32x2 f = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+    const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 r2 = {r.x - __uint_as_float(mid << 16), r.y - __uint_as_float(mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+__device__ __forceinline__ void split8_store(char* dst, int plane_bytes, const float4& u, const float4& v, bool ok) {
+    uint4 hi, mid, lo;
+    split_pair(ok ? u.x : 0.f, ok ? u.y : 0.f, hi.x, mid.x, lo.x);
+    split_pair(ok ? u.z : 0.f, ok ? u.w : 0.f, hi.y, mid.y, lo.y);
+    split_pair(ok ? v.x : 0.f, ok ? v.y : 0.f, hi.z, mid.z, lo.z);
+    split_pair(ok ? v.z : 0.f, ok ? v.w : 0.f, hi.w, mid.w, lo.w);
+    *reinterpret_cast<uint4*>(dst) = hi;
+    *reinterpret_cast<uint4*>(dst + plane_bytes) = mid;
+    *reinterpret_cast<uint4*>(dst + 2 * plane_bytes) = lo;
+}
+
+template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split_kernel(GemmBatch G) {
+    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
+    constexpr int NT = GG::NT, BM = GG::BM, BN = GG::BN, ROWB = GG::ROWB, PL = GG::PL, S8 = GG::S8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const GemmProblem& P = G.p[blockIdx.y];
+    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA2 = P.A2;
+    const float* __restrict__ pW = P.W;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
+    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wn = w % WN, wm = w / WN;
+    const int nchunks = (K + BK - 1) / BK;
+
+    // staging slots of 8 consecutive k (K % 4 == 0: a slot is two float4, each all-valid or all-invalid)
+    float4 ra[GG::A_SLOTS][2], rb[GG::B_SLOTS][2];
+    const float* a1p[GG::A_SLOTS];
+    const float* a2p[GG::A_SLOTS];
+    const float* bp[GG::B_SLOTS];
+    int akc[GG::A_SLOTS], bkc[GG::B_SLOTS];
+    bool aok[GG::A_SLOTS], bok[GG::B_SLOTS];
+#pragma unroll
+    for (int s = 0; s < GG::A_SLOTS; ++s) {
+        const int slot = t + s * NT, r = slot / S8;
+        akc[s] = 8 * (slot % S8);
+        aok[s] = slot < BM * S8 && row0 + r < rows;
+        const int rc = min(row0 + r, rows - 1);
+        a1p[s] = pA + (size_t)rc * lda;
+        a2p[s] = pA2 ? pA2 + (size_t)rc * lda2 - K1 : a1p[s];
+    }
+#pragma unroll
+    for (int s = 0; s < GG::B_SLOTS; ++s) {
+        const int slot = t + s * NT, r = slot / S8;
+        bkc[s] = 8 * (slot % S8);
+        bok[s] = slot < BN * S8 && col0 + r < ncols;
+        bp[s] = pW + (size_t)min(col0 + r, ncols - 1) * K;
+    }
+    auto load_chunk = [&](int ch) {
+        const int k0 = ch * BK;
+#pragma unroll
+        for (int s = 0; s < GG::A_SLOTS; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int kc = min(k0 + akc[s] + 4 * q, K - 4);
+                ra[s][q] = *reinterpret_cast<const float4*>((kc < K1 ? a1p[s] : a2p[s]) + kc);
+            }
+#pragma unroll
+        for (int s = 0; s < GG::B_SLOTS; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                rb[s][q] = *reinterpret_cast<const float4*>(bp[s] + min(k0 + bkc[s] + 4 * q, K - 4));
+    };
+    auto store_chunk = [&](int ch) {
+        char* As = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE;
+        char* Bs = As + BM * ROWB;
+        const int k0 = ch * BK;
+#pragma unroll
+        for (int s = 0; s < GG::A_SLOTS; ++s) {
+            const int slot = t + s * NT;
+            if (slot < BM * S8) {
+                float4 u = ra[s][0], v = ra[s][1];
+                if (!(aok[s] && k0 + akc[s] < K)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(aok[s] && k0 + akc[s] + 4 < K)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ABL == 1) {
+                    char* d = As + (slot / S8) * ROWB + akc[s] * 2;
+                    *reinterpret_cast<float4*>(d) = u; *reinterpret_cast<float4*>(d + PL) = v; *reinterpret_cast<float4*>(d + 2 * PL) = u;
+                } else
+                split8_store(As + (slot / S8) * ROWB + akc[s] * 2, PL, u, v, true);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < GG::B_SLOTS; ++s) {
+            const int slot = t + s * NT;
+            if (slot < BN * S8) {
+                float4 u = rb[s][0], v = rb[s][1];
+                if (!(bok[s] && k0 + bkc[s] < K)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(bok[s] && k0 + bkc[s] + 4 < K)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ABL == 1) {
+                    char* d = Bs + (slot / S8) * ROWB + bkc[s] * 2;
+                    *reinterpret_cast<float4*>(d) = u; *reinterpret_cast<float4*>(d + PL) = v; *reinterpret_cast<float4*>(d + 2 * PL) = u;
+                } else
+                split8_store(Bs + (slot / S8) * ROWB + bkc[s] * 2, PL, u, v, true);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks && ABL != 2) load_chunk(ch + 1);
+        const char* As = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE + (wm * TM * 32 + l31) * ROWB + 16 * h;
+        const char* Bs = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE + BM * ROWB + (wn * TN * 32 + l31) * ROWB + 16 * h;
+#pragma unroll
+        for (int ks = 0; ks < GG::KSTEPS; ++ks) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + p * PL + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + p * PL + ks * 32);
+            // smallest terms first; consecutive MFMAs go to different accumulators
+#define DR_SPLIT_STEP(PA, PB)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
+            if (ABL == 3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(a[i][p]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(b[j][p]));
+                continue;
+            }
+            DR_SPLIT_STEP(2, 0)
+            DR_SPLIT_STEP(0, 2)
+            DR_SPLIT_STEP(1, 1)
+            DR_SPLIT_STEP(1, 0)
+            DR_SPLIT_STEP(0, 1)
+            DR_SPLIT_STEP(0, 0)
+#undef DR_SPLIT_STEP
+        }
+        if (NBUF == 1) __syncthreads();
+        if (ch + 1 < nchunks) store_chunk(ch + 1);
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(P, [&](int i, int j) -> const f32x16& { return acc[i][j]; }, rows, ncols, row0, col0, wm, wn, lane);
+}
+
+template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
+static int configure_split() {
+    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_split_kernel<TM, TN, WM, WN, BK, NBUF, ABL>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM));
+    return DR_OK;
+}
+
+template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
+static int launch_split(const GemmBatch& g, hipStream_t st) {
+    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
+    int maxt = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        maxt = tl > maxt ? tl : maxt;
+    }
+    if (maxt == 0) return DR_OK;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    ProfScope ps(PK_GEMM, flops, st);
+    hipLaunchKernelGGL((gemm_nt_split_kernel<TM, TN, WM, WN, BK, NBUF, ABL>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+//                  TM TN WM WN BK NBUF
+#define SPL_128x128_1 2, 2, 2, 2, 32, 1   /* 53 KB */
+#define SPL_128x128_h 2, 2, 2, 2, 16, 2   /* 57 KB */
+#define SPL_128x64_2  2, 1, 2, 2, 32, 2   /* 80 KB */
+#define SPL_128x64_1  2, 1, 2, 2, 32, 1   /* 40 KB */
+#define SPL_64x64_1   1, 1, 2, 2, 32, 1   /* 27 KB */
+#define SPL_64x64_2   1, 1, 2, 2, 32, 2   /* 53 KB */
+#define SPL_256x64_1  2, 2, 4, 1, 32, 1   /* 256 x 64 tile, 4 waves stacked on rows: 67 KB */
+#define SPL_128x64_h  2, 1, 2, 2, 16, 2   /* 43 KB */
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide split-operand kernel: the layer GEMMs (rows = thousands of tokens, ncols = K = C or 2C).
+// What bounds the 64..128-column tiles above is not the MFMA but the staging: every column tile re-fetches and
+// re-splits its A rows (7 times for C = 432) and splits the same weights again in every row tile.  Here
+//   * the weights are split ONCE per call into a packed image (pack_weights_kernel) that IS the LDS image of a
+//     224-column B tile, k-chunk by k-chunk: [K/16][ncols/224][224 rows][3 planes][16 k] bf16 with the 16-byte
+//     row pad included (112-byte rows = 7 16-B slots, odd -> conflict-free ds_read_b128) and zero-filled past
+//     ncols / K.  A B tile chunk is then 25 KB contiguous in global memory and is copied by LDS-DMA
+//     (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPRs, nothing for the compiler to re-schedule);
+//   * a workgroup spans 224 columns (two column tiles for C = 432), its 4 waves stacked on rows, each wave
+//     holding a 32 x 224 strip of accumulators and streaming the B fragments through registers, so an A element
+//     is fetched and split only ceil(ncols / 224) times.
+// Rows past the end are clamped (their results are never stored); k past the end multiplies packed zeros.
+// Per k-chunk: DMA of the next B chunk and the global loads of the A chunk after next are issued first; the
+// split of the next A chunk into LDS sits between the MFMA groups of the column tiles; one barrier.
+struct WideGeom {
+    static constexpr int TN = 7, NWV = 4, BK = 16;
+    static constexpr int NT = 64 * NWV, BM = 32 * NWV, BN = 32 * TN;
+    static constexpr int PL = BK * 2, ROWB = 3 * PL + 16;
+    static constexpr int A_BYTES = BM * ROWB;                    // 14,336
+    static constexpr int B_IMG = ((BN * ROWB + 1023) / 1024) * 1024;   // 25,600: whole 1 KB DMA instructions
+    static constexpr int B_DMAS = B_IMG / 1024;                  // 25 wave-instructions per chunk
+    static constexpr int STAGE = A_BYTES + B_IMG, SMEM = 2 * STAGE;    // 79,872 B -> two workgroups per CU
+};
+
+__device__ long long g_gemm_stamps[256];
+#define GEMM_STAMP(i) do { if (ABL == 9 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 256) g_gemm_stamps[i] = wall_clock64(); } while (0)
+int read_gemm_stamps(long long* h_out) {
+    DR_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gemm_stamps), sizeof(long long) * 256));
+    return DR_OK;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_wide_kernel(GemmBatch G) {
+    using GG = WideGeom;
+    constexpr int TN = GG::TN, BM = GG::BM, BN = GG::BN, ROWB = GG::ROWB, PL = GG::PL, BK = GG::BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const GemmProblem& P = G.p[blockIdx.y];
+    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA2 = P.A2;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
+    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nchunks = (K + BK - 1) / BK;
+
+    // A: thread t stages 8 consecutive k of row t / 2 (one float4 pair per chunk); two register sets alternate
+    const int ar = t >> 1, akc = 8 * (t & 1), alds = ar * ROWB + akc * 2;
+    const float* a1p = pA + (size_t)min(row0 + ar, rows - 1) * lda;
+    const float* a2p = pA2 ? pA2 + (size_t)min(row0 + ar, rows - 1) * lda2 - K1 : a1p;
+    float4 ra[2][2];
+    auto load_a = [&](int ch, float4 (&dst)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kc = min(ch * BK + akc + 4 * q, K - 4);
+            dst[q] = *reinterpret_cast<const float4*>((kc < K1 ? a1p : a2p) + kc);
+        }
+    };
+    // B: wave w issues the DMA instructions w, w + 4, ... of the 25 that copy one packed tile chunk
+    const char* bsrc = reinterpret_cast<const char*>(P.Wsplit) + (size_t)tn * GG::B_IMG + lane * 16;
+    const size_t bstep = (size_t)tiles_n * GG::B_IMG;
+    auto dma_b = [&](int ch) {
+        const char* src = bsrc + (size_t)ch * bstep;
+        char* dst = lds + (ch & 1) * GG::STAGE + GG::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < (GG::B_DMAS + 3) / 4; ++i) {
+            const int ins = w + 4 * i;
+            if (ins < GG::B_DMAS)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + ins * 1024), (lds_void*)(dst + ins * 1024), 16, 0, 0);
+        }
+    };
+    // The split planes are written with asm ds_write_b128: hipcc orders every LDS store it knows about behind the
+    // LDS-DMA in flight (s_waitcnt vmcnt(0)), which would also wait for the A loads just issued for chunk ch + 2.
+    // The DMA and these stores touch disjoint bytes of the stage; lgkmcnt(0) before the barrier retires them.
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+    auto store_a = [&](int ch, const float4 (&src)[2]) {
+        const unsigned d = lds_base + (ch & 1) * GG::STAGE + alds;
+        uint4 hi, mid, lo;
+        if (ABL == 1) {
+            hi = __builtin_bit_cast(uint4, src[0]); mid = __builtin_bit_cast(uint4, src[1]); lo = hi;
+        } else {
+            split_pair(src[0].x, src[0].y, hi.x, mid.x, lo.x);
+            split_pair(src[0].z, src[0].w, hi.y, mid.y, lo.y);
+            split_pair(src[1].x, src[1].y, hi.z, mid.z, lo.z);
+            split_pair(src[1].z, src[1].w, hi.w, mid.w, lo.w);
+        }
+        const u32x4 vh = {hi.x, hi.y, hi.z, hi.w}, vm = {mid.x, mid.y, mid.z, mid.w}, vl = {lo.x, lo.y, lo.z, lo.w};
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:32\n\tds_write_b128 %0, %3 offset:64"
+                     :: "v"(d), "v"(vh), "v"(vm), "v"(vl) : "memory");
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // One k-chunk; cur = register set holding A(ch + 1), nxt = the set A(ch + 2) is fetched into.
+    // A column tile is 6 dependent MFMAs (32 cycles each); the staging of the next chunk is cut into pieces that are
+    // issued in the gaps between them, pinned there by sched_barrier (left alone hipcc gathers them after the MFMAs,
+    // where nothing hides them):  gap G = 5 j + g  (tile j, after its MFMA g)
+    //   G 0..6   one B DMA instruction each (wave w: instructions w, w + 4, ..)      -> landed long before the barrier
+    //   G 7, 8   the two float4 of A(ch + 2)
+    //   G 15..18 split of A(ch + 1), one pair of planes' worth per gap;  G 19 its three ds_write_b128
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto chunk = [&](int ch, float4 (&cur)[2], float4 (&nxt)[2]) __attribute__((always_inline)) {
+        const bool has_next = ch + 1 < nchunks;
+        const bool do_load = has_next && ABL != 2;
+        GEMM_STAMP(8 + 8 * ch);
+        const unsigned sbase = lds_base + (ch & 1) * GG::STAGE;
+        const unsigned Ab = sbase + (w * 32 + l31) * ROWB + 16 * h;
+        const unsigned Bb = sbase + GG::A_BYTES + l31 * ROWB + 16 * h;
+        const char* dsrc = bsrc + (size_t)(ch + 1) * bstep;
+        char* ddst = lds + ((ch + 1) & 1) * GG::STAGE + GG::A_BYTES;
+        const unsigned adst = lds_base + ((ch + 1) & 1) * GG::STAGE + alds;
+        uint4 hi, mid, lo;
+        auto gap = [&](int G) __attribute__((always_inline)) {
+            if (G < 7) {
+                const int ins = wu + 4 * G;
+                if (do_load && ins < GG::B_DMAS)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(dsrc + ins * 1024), (lds_void*)(ddst + ins * 1024), 16, 0, 0);
+            } else if (G < 9) {
+                if (do_load) {
+                    const int kc = min((ch + 2) * BK + akc + 4 * (G - 7), K - 4);
+                    nxt[G - 7] = *reinterpret_cast<const float4*>((kc < K1 ? a1p : a2p) + kc);
+                }
+            } else if (G >= 15 && G < 19 && has_next) {
+                if (ABL == 1) {
+                    if (G == 15) { hi = __builtin_bit_cast(uint4, cur[0]); mid = __builtin_bit_cast(uint4, cur[1]); lo = hi; }
+                } else if (G == 15) split_pair(cur[0].x, cur[0].y, hi.x, mid.x, lo.x);
+                else if (G == 16) split_pair(cur[0].z, cur[0].w, hi.y, mid.y, lo.y);
+                else if (G == 17) split_pair(cur[1].x, cur[1].y, hi.z, mid.z, lo.z);
+                else split_pair(cur[1].z, cur[1].w, hi.w, mid.w, lo.w);
+            } else if (G == 19 && has_next) {
+                const u32x4 vh = {hi.x, hi.y, hi.z, hi.w}, vm = {mid.x, mid.y, mid.z, mid.w}, vl = {lo.x, lo.y, lo.z, lo.w};
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:32\n\tds_write_b128 %0, %3 offset:64"
+                             :: "v"(adst), "v"(vh), "v"(vm), "v"(vl) : "memory");
+            }
+        };
+        // Fragment reads are asm ds_read_b128 with hand-counted waits: hipcc's own bookkeeping answers the first use
+        // of tile j's fragments with lgkmcnt(0), which also waits for the prefetch of tile j + 1 just issued
+        // (LDS operations retire in order, so "all but the newest 3" is the wait that is needed).
+        u32x4 a[3], b[2][3];
+#define DR_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#pragma unroll
+        for (int p = 0; p < 3; ++p) DR_LDS_READ(a[p], Ab, p * PL);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) DR_LDS_READ(b[0][p], Bb, p * PL);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = j & 1;
+            if (j + 1 < TN) {                                   // fragments of tile j + 1 fly while tile j multiplies
+#pragma unroll
+                for (int p = 0; p < 3; ++p) DR_LDS_READ(b[cb ^ 1][p], Bb, (j + 1) * 32 * ROWB + p * PL);
+                // the ds_writes of gap 19 sit between the reads of tile 5 and those of tile 4 in the LDS queue
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // MFMAs must not be hoisted above the wait (guide rule 18)
+            if (j == 0) GEMM_STAMP(8 + 8 * ch + 2);
+            if (j == 4) GEMM_STAMP(8 + 8 * ch + 4);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[0]), a1 = __builtin_bit_cast(bf16x8, a[1]), a2 = __builtin_bit_cast(bf16x8, a[2]);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[cb][0]), b1 = __builtin_bit_cast(bf16x8, b[cb][1]), b2 = __builtin_bit_cast(bf16x8, b[cb][2]);
+#define DR_MFMA_GAP(X, Y, g)                                                              \
+    if (ABL != 3) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Y, acc[j], 0, 0, 0); \
+    else asm volatile("" ::"v"(X), "v"(Y));                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    if (g < 5) { gap(5 * j + g); __builtin_amdgcn_sched_barrier(0); }
+            // smallest terms first
+            DR_MFMA_GAP(a2, b0, 0)
+            DR_MFMA_GAP(a0, b2, 1)
+            DR_MFMA_GAP(a1, b1, 2)
+            DR_MFMA_GAP(a1, b0, 3)
+            DR_MFMA_GAP(a0, b1, 4)
+            DR_MFMA_GAP(a0, b0, 5)
+#undef DR_MFMA_GAP
+            if (j == 3) GEMM_STAMP(8 + 8 * ch + 3);
+        }
+#undef DR_LDS_READ
+        GEMM_STAMP(8 + 8 * ch + 5);
+    };
+
+    GEMM_STAMP(0);
+    dma_b(0);
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+    store_a(0, ra[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
+        chunk(c0, ra[1], ra[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        GEMM_STAMP(8 + 8 * c0 + 6);
+        if (c0 + 1 < nchunks) {
+            chunk(c0 + 1, ra[0], ra[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            GEMM_STAMP(8 + 8 * c0 + 14);
+        }
+    }
+    GEMM_STAMP(1);
+    // Epilogue through LDS (the stage buffers are free after the last barrier): the MFMA result layout has a lane's
+    // 16 values in 16 different rows, which stored directly is 112 dword stores per lane in 128-byte row pieces with
+    // per-element address arithmetic.  Each wave transposes its 32 x 224 strip in two passes (4 then 3 column tiles)
+    // through a private [32][136] float region, and every lane then owns float4s of whole rows: 512-byte row
+    // segments, the rotary pair (2k, 2k+1) inside one float4, cos/sin as one float2, addend as a float4.
+    {
+        constexpr int EST = 136;                                // row stride (floats): rows 4 apart land 32 banks apart
+        float* const ep = reinterpret_cast<float*>(lds) + w * 32 * EST;
+        const int epi = P.epi, halfC = P.rot_C >> 1, rotC = P.rot_C, ldo = P.ldo;
+        const float scale = P.scale;
+        const float* __restrict__ bias = P.bias;
+        const float* __restrict__ addend = P.addend;
+        const float* __restrict__ cosT = P.cosT;
+        const float* __restrict__ sinT = P.sinT;
+        float* __restrict__ outp = P.out;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int j0 = pass * 4, nt = pass ? TN - 4 : 4;    // column tiles of this pass
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj >= nt) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EST + jj * 32 + l31] = acc[j0 + jj][r];
+            }
+            // the wave re-reads only its own region: no workgroup barrier, the LDS queue is in order per wave
+            const int c4 = (lane & 31) * 4;                     // column offset inside the pass
+            const int col = col0 + j0 * 32 + c4;
+            const bool col_ok = c4 < nt * 32 && col < ncols;    // ncols % 4 == 0 (launch check)
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias && col_ok) bv = *reinterpret_cast<const float4*>(bias + col);
+            const int ridx = (epi & EPI_ROTARY) ? (col % rotC) >> 1 : 0;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 2 + (lane >> 5), row = row0 + w * 32 + rl;
+                float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4);
+                if (row < rows && col_ok) {
+                    if (epi & EPI_ROTARY) {
+                        // x*cos + swap(x)*sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
+                        const float2 c = *reinterpret_cast<const float2*>(cosT + (size_t)row * halfC + ridx);
+                        const float2 sn = *reinterpret_cast<const float2*>(sinT + (size_t)row * halfC + ridx);
+                        const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+                        v.x = __fadd_rn(__fmul_rn(x0, c.x), __fmul_rn(-x1, sn.x));
+                        v.y = __fadd_rn(__fmul_rn(x1, c.x), __fmul_rn(x0, sn.x));
+                        v.z = __fadd_rn(__fmul_rn(x2, c.y), __fmul_rn(-x3, sn.y));
+                        v.w = __fadd_rn(__fmul_rn(x3, c.y), __fmul_rn(x2, sn.y));
+                    }
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (epi & EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    float* o = outp + (size_t)row * ldo + col;
+                    if (addend) {
+                        const float4 ad = *reinterpret_cast<const float4*>(addend + (size_t)row * ldo + col);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    *reinterpret_cast<float4*>(o) = v;
+                }
+            }
+        }
+    }
+    GEMM_STAMP(2);
+}
+
+// W [ncols][K] fp32 -> the packed split image described above (one thread per 8 k of one row of one tile chunk)
+__global__ void pack_weights_kernel(const float* __restrict__ W, char* __restrict__ out, int ncols, int K) {
+    using GG = WideGeom;
+    const int nck = (K + 15) / 16, tiles_n = (ncols + GG::BN - 1) / GG::BN;
+    const size_t n = (size_t)nck * tiles_n * GG::BN * 2, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int half = (int)(i & 1);
+    size_t rest = i >> 1;
+    const int r = (int)(rest % GG::BN); rest /= GG::BN;
+    const int tn = (int)(rest % tiles_n), ch = (int)(rest / tiles_n);
+    const int col = tn * GG::BN + r, k = ch * 16 + half * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (col < ncols && k + e < K) ? W[(size_t)col * K + k + e] : 0.f;
+    uint4 hi, mid, lo;
+    split_pair(x[0], x[1], hi.x, mid.x, lo.x);
+    split_pair(x[2], x[3], hi.y, mid.y, lo.y);
+    split_pair(x[4], x[5], hi.z, mid.z, lo.z);
+    split_pair(x[6], x[7], hi.w, mid.w, lo.w);
+    char* d = out + ((size_t)ch * tiles_n + tn) * GG::B_IMG + (size_t)r * GG::ROWB + half * 16;
+    *reinterpret_cast<uint4*>(d) = hi;
+    *reinterpret_cast<uint4*>(d + GG::PL) = mid;
+    *reinterpret_cast<uint4*>(d + 2 * GG::PL) = lo;
+}
+
+size_t gemm_packed_weight_bytes(int ncols, int K) {
+    return (size_t)((K + 15) / 16) * ((ncols + WideGeom::BN - 1) / WideGeom::BN) * WideGeom::B_IMG;
+}
+
+int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t st) {
+    const size_t n = (size_t)((K + 15) / 16) * ((ncols + WideGeom::BN - 1) / WideGeom::BN) * WideGeom::BN * 2;
+    if (n == 0) return DR_OK;
+    // (the 16-byte row pads and the tail of each tile image are copied to LDS but never read as operands)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, (char*)out, ncols, K);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+template <int ABL = 0>
+static int configure_wide() {
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)WideGeom::SMEM));
+    return DR_OK;
+}
+
+template <int ABL = 0>
+static int launch_wide(const GemmBatch& g, hipStream_t st) {
+    using GG = WideGeom;
+    int maxt = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        maxt = tl > maxt ? tl : maxt;
+    }
+    if (maxt == 0) return DR_OK;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    ProfScope ps(PK_GEMM, flops, st);
+    hipLaunchKernelGGL((gemm_nt_wide_kernel<ABL>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -280,11 +863,38 @@ int gemm_configure() {
     if (rc == DR_OK) rc = configure_cfg<CFG_XL1B>();
     if (rc == DR_OK) rc = configure_cfg<CFG_L64>();
     if (rc == DR_OK) rc = configure_cfg<CFG_XL64>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x128_1>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x128_h>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_2>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_1>();
+    if (rc == DR_OK) rc = configure_split<SPL_64x64_1>();
+    if (rc == DR_OK) rc = configure_split<SPL_64x64_2>();
+    if (rc == DR_OK) rc = configure_split<SPL_256x64_1>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_h>();
+    if (rc == DR_OK) rc = configure_wide<0>();
+    if (rc == DR_OK) rc = configure_wide<1>();
+    if (rc == DR_OK) rc = configure_wide<2>();
+    if (rc == DR_OK) rc = configure_wide<3>();
+    if (rc == DR_OK) rc = configure_wide<9>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 1>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 2>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 3>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 1>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 2>();
+    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 3>();
     return rc;
 }
 
 static int g_force_cfg = -1;   // tools/: force a configuration (0 small, 1 medium, 2 large)
 void gemm_force_config(int c) { g_force_cfg = c; }
+
+// shapes / alignments the wide split kernel takes (everything else stays on the f32-MFMA kernels)
+static bool wide_ok(const GemmProblem& p) {
+    if (!p.Wsplit || p.K % 8 || (p.A2 && p.K1 % 8) || p.ncols % 4 || p.ldo % 4) return false;
+    if (((uintptr_t)p.out | (uintptr_t)p.addend | (uintptr_t)p.bias | (uintptr_t)p.Wsplit) & 15) return false;
+    if ((p.epi & EPI_ROTARY) && (p.rot_C % 4 || ((uintptr_t)p.cosT | (uintptr_t)p.sinT) & 7)) return false;
+    return true;
+}
 
 int launch_gemm(const GemmBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 4) return DR_EINVAL;
@@ -301,11 +911,45 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         useful += (double)p.rows * p.ncols;
         padded += (double)tx * 128 * 128;
     }
+    // wide split-operand kernel: packed weights given and enough 128 x 224 tiles to occupy the chip
+    long nW = 0;
+    bool wide = true;
+    for (int i = 0; i < g.n; ++i) {
+        wide = wide && wide_ok(g.p[i]);
+        nW += (long)((g.p[i].rows + 127) / 128) * ((g.p[i].ncols + 223) / 224);
+    }
+    static const int wide_min = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
+    if (wide && nW >= wide_min && g_force_cfg < 0) return launch_wide<0>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every configuration measured on the loop's shapes (tools/gemm_bench.py)
     (void)nL;
     (void)nX; (void)useful; (void)padded;              // 128 x 128 tiles (cfg 4) measured within noise of cfg 2: not auto-selected
+    static const int env_cfg = [] { const char* e = getenv("DR_GEMM_CFG"); return e ? atoi(e) : -1; }();   // tools/: tile experiments
+    if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
     if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg >= 50 && cfg < 60) {
+        for (int i = 0; i < g.n; ++i)
+            if (!wide_ok(g.p[i])) return DR_ENOSUP;
+        if (cfg == 50) return launch_wide<0>(g, st);
+        if (cfg == 51) return launch_wide<1>(g, st);
+        if (cfg == 52) return launch_wide<2>(g, st);
+        if (cfg == 53) return launch_wide<3>(g, st);
+        if (cfg == 59) return launch_wide<9>(g, st);
+    }
+    if (cfg == 31) return launch_split<SPL_128x64_1, 1>(g, st);
+    if (cfg == 32) return launch_split<SPL_128x64_1, 2>(g, st);
+    if (cfg == 33) return launch_split<SPL_128x64_1, 3>(g, st);
+    if (cfg == 41) return launch_split<SPL_128x128_1, 1>(g, st);
+    if (cfg == 42) return launch_split<SPL_128x128_1, 2>(g, st);
+    if (cfg == 43) return launch_split<SPL_128x128_1, 3>(g, st);
+    if (cfg == 20) return launch_split<SPL_128x128_1>(g, st);
+    if (cfg == 21) return launch_split<SPL_128x128_h>(g, st);
+    if (cfg == 22) return launch_split<SPL_128x64_2>(g, st);
+    if (cfg == 23) return launch_split<SPL_128x64_1>(g, st);
+    if (cfg == 24) return launch_split<SPL_64x64_1>(g, st);
+    if (cfg == 25) return launch_split<SPL_64x64_2>(g, st);
+    if (cfg == 26) return launch_split<SPL_256x64_1>(g, st);
+    if (cfg == 27) return launch_split<SPL_128x64_h>(g, st);
     if (cfg == 10) return launch_cfg<CFG_M1B64>(g, st);
     if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
     if (cfg == 8) return launch_cfg<CFG_XL1B>(g, st);

@@ -28,6 +28,7 @@ struct GemmProblem {
     const float* A;     // [rows, K1] row-major, leading dimension lda
     const float* A2;    // [rows, K - K1] or nullptr
     const float* W;     // [ncols, K] row-major (the nn.Linear weight)
+    const void* Wsplit; // the same weight packed by launch_pack_weights (bf16 x 3 split image) or nullptr
     float* out;         // [rows, ldo]
     const float* cosT;  // rotary tables [rows, C/2] (EPI_ROTARY)
     const float* sinT;
@@ -45,8 +46,11 @@ struct GemmBatch {
 };
 
 int launch_gemm(const GemmBatch& g, hipStream_t st);
+size_t gemm_packed_weight_bytes(int ncols, int K);
+int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t st);
 int gemm_configure();
 void gemm_force_config(int c);
+int read_gemm_stamps(long long* h_out256);
 
 // ---------------------------------------------------------------------------------------------
 // attention (transformero.py:79-85): segments of queries attending segments of keys

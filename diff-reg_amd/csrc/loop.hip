@@ -38,6 +38,46 @@ struct LayerWs {
     }
 };
 
+// split-operand images of one layer's weights (launch_pack_weights), filled once per loop call
+struct PackedLayer {
+    void *q, *k, *v, *merge, *mlp0, *mlp2;
+};
+struct PackedWeights {
+    static constexpr int MAXL = 16;
+    PackedLayer layer[MAXL];
+    void* src_proj;
+    bool on;
+    static void carve(Carver& c, PackedWeights& w, int n_layers, int C) {
+        w.on = n_layers <= MAXL && C % 8 == 0;
+        for (int l = 0; l < n_layers && w.on; ++l) {
+            PackedLayer& L = w.layer[l];
+            L.q = c.take<char>(gemm_packed_weight_bytes(C, C));
+            L.k = c.take<char>(gemm_packed_weight_bytes(C, C));
+            L.v = c.take<char>(gemm_packed_weight_bytes(C, C));
+            L.merge = c.take<char>(gemm_packed_weight_bytes(C, C));
+            L.mlp0 = c.take<char>(gemm_packed_weight_bytes(2 * C, 2 * C));
+            L.mlp2 = c.take<char>(gemm_packed_weight_bytes(C, 2 * C));
+        }
+        w.src_proj = w.on ? c.take<char>(gemm_packed_weight_bytes(C, C)) : nullptr;
+    }
+    int fill(const dr_loop_weights& W, int n_layers, int C, hipStream_t st) const {
+        if (!on) return DR_OK;
+        int rc = DR_OK;
+        for (int l = 0; l < n_layers && rc == DR_OK; ++l) {
+            const dr_layer_weights& w = W.layers[l];
+            const PackedLayer& L = layer[l];
+            rc = launch_pack_weights(w.q_proj, C, C, L.q, st);
+            if (rc == DR_OK) rc = launch_pack_weights(w.k_proj, C, C, L.k, st);
+            if (rc == DR_OK) rc = launch_pack_weights(w.v_proj, C, C, L.v, st);
+            if (rc == DR_OK) rc = launch_pack_weights(w.merge, C, C, L.merge, st);
+            if (rc == DR_OK) rc = launch_pack_weights(w.mlp0, 2 * C, 2 * C, L.mlp0, st);
+            if (rc == DR_OK) rc = launch_pack_weights(w.mlp2, C, 2 * C, L.mlp2, st);
+        }
+        if (rc == DR_OK) rc = launch_pack_weights(W.src_proj, C, C, src_proj, st);
+        return rc;
+    }
+};
+
 struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k0 + p*Lk (+Lk)
     int q0, Lq, k0, Lk;
 };
@@ -48,32 +88,33 @@ struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k
 static int layer_call(const dr_layer_weights& W, int C, int H, int P, const float* xin, int xr0, int xrows,
                       const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
                       const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
-                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr) {
+                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr,
+                      const PackedLayer* pk = nullptr) {
     // kv_cached: K|V of the source rows were projected earlier ([tokens, 2C], rotary applied to K): skip them.
     // kv_store : project ONLY K|V of the source rows into this buffer and return (used to fill the cache).
     const int halfC = C / 2, d = C / H;
     GemmBatch g;
     memset(&g, 0, sizeof(g));
-    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot) {
-        p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
+    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot, const void* Wpk) {
+        p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.Wsplit = Wpk; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
         p.rows = rows; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.lda2 = 0; p.ldo = 3 * C;
         p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
         p.cosT = cosT + (size_t)r0 * halfC; p.sinT = sinT + (size_t)r0 * halfC;
     };
     int rc;
     if (kv_store) {
-        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true);
-        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false);
+        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true, pk ? pk->k : nullptr);
+        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false, pk ? pk->v : nullptr);
         g.p[0].out = kv_store + (size_t)yr0 * 2 * C; g.p[0].ldo = 2 * C;
         g.p[1].out = kv_store + (size_t)yr0 * 2 * C + C; g.p[1].ldo = 2 * C;
         g.n = 2;
         return launch_gemm(g, st);
     }
-    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true);
+    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true, pk ? pk->q : nullptr);
     g.n = 1;
     if (!kv_cached) {
-        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
-        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
+        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true, pk ? pk->k : nullptr);
+        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false, pk ? pk->v : nullptr);
         g.n = 3;
     }
     rc = launch_gemm(g, st);
@@ -96,7 +137,7 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     // message = norm1(merge(o))
     memset(&g, 0, sizeof(g));
     GemmProblem& m = g.p[0];
-    m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.out = ws.mrg + (size_t)xr0 * C;
+    m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.Wsplit = pk ? pk->merge : nullptr; m.out = ws.mrg + (size_t)xr0 * C;
     m.rows = xrows; m.ncols = C; m.K = C; m.K1 = C; m.lda = C; m.ldo = C; m.epi = EPI_NONE; m.scale = 1.f;
     g.n = 1;
     rc = launch_gemm(g, st);
@@ -106,14 +147,14 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     // message = norm2(mlp(cat[x, message]))
     memset(&g, 0, sizeof(g));
     GemmProblem& h = g.p[0];
-    h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.out = ws.hid + (size_t)xr0 * 2 * C;
+    h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.Wsplit = pk ? pk->mlp0 : nullptr; h.out = ws.hid + (size_t)xr0 * 2 * C;
     h.rows = xrows; h.ncols = 2 * C; h.K = 2 * C; h.K1 = C; h.lda = C; h.lda2 = C; h.ldo = 2 * C; h.epi = EPI_RELU; h.scale = 1.f;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
     memset(&g, 0, sizeof(g));
     GemmProblem& o = g.p[0];
-    o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.out = ws.g2 + (size_t)xr0 * C;
+    o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.Wsplit = pk ? pk->mlp2 : nullptr; o.out = ws.g2 + (size_t)xr0 * C;
     o.rows = xrows; o.ncols = C; o.K = 2 * C; o.K1 = 2 * C; o.lda = 2 * C; o.ldo = C; o.epi = EPI_NONE; o.scale = 1.f;
     g.n = 1;
     rc = launch_gemm(g, st);
@@ -128,9 +169,11 @@ struct DenoiseWs {
     LayerWs lw;
     float *fa, *fb, *cosT, *sinT, *proj, *sim;
     float *tgt_l0, *kv_l1;      // step-invariant: layer-0 output of the tgt rows, layer-1 K|V of those rows
-    static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C) {
+    PackedWeights pw;
+    static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C, int n_layers) {
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
+        PackedWeights::carve(c, w.pw, n_layers, C);
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
         w.fa = c.take<float>(T * C);
@@ -152,11 +195,12 @@ static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, i
                           const uint8_t* tokmask, DenoiseWs& ws, hipStream_t st) {
     const int C = cfg.C, H = cfg.H, PN = P * N, PM = P * M;
     const Family self_t{PN, M, PN, M};
+    const PackedLayer* pk0 = ws.pw.on ? &ws.pw.layer[0] : nullptr;
     int rc = layer_call(w.layers[0], C, H, P, feat0, PN, PM, feat0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                        ws.tgt_l0, st);
+                        ws.tgt_l0, st, nullptr, nullptr, pk0);
     if (rc || cfg.n_layers < 2) return rc;
     return layer_call(w.layers[1], C, H, P, nullptr, 0, 0, ws.tgt_l0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                      nullptr, st, nullptr, ws.kv_l1);
+                      nullptr, st, nullptr, ws.kv_l1, ws.pw.on ? &ws.pw.layer[1] : nullptr);
 }
 
 static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
@@ -169,26 +213,27 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
     for (int l = 0; l < cfg.n_layers; ++l) {
         float* nxt = bufs[which];
+        const PackedLayer* pk = ws.pw.on ? &ws.pw.layer[l] : nullptr;
         int rc;
         if (use_cache && l == 0) {
             // src half only; the tgt half comes from the cache
-            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st);
+            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
             if (rc) return rc;
             DR_HIP_CHECK(hipMemcpyAsync(nxt + (size_t)PN * C, ws.tgt_l0 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
         } else if (use_cache && l == 1) {
             rc = layer_call(w.layers[1], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st,
-                            ws.kv_l1);
+                            ws.kv_l1, nullptr, pk);
             if (rc) return rc;
-            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
+            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
             if (rc) return rc;
         } else if (l % 2 == 0) {
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st, nullptr, nullptr, pk);
             if (rc) return rc;
         } else {
             // src attends tgt, then tgt attends the UPDATED src (quirk Q11)
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
             if (rc) return rc;
-            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
+            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
             if (rc) return rc;
         }
         cur = nxt;
@@ -199,7 +244,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     GemmBatch g;
     memset(&g, 0, sizeof(g));
     GemmProblem& p = g.p[0];
-    p.A = cur; p.W = w.src_proj; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
+    p.A = cur; p.W = w.src_proj; p.Wsplit = ws.pw.on ? ws.pw.src_proj : nullptr; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
     p.epi = EPI_ROTARY; p.rot_C = C; p.cosT = ws.cosT; p.sinT = ws.sinT; p.scale = 1.0f / sqrtf((float)C);
     g.n = 1;
     int rc = launch_gemm(g, st);
@@ -245,7 +290,7 @@ struct LoopWs {
     size_t skws_bytes;
     static size_t carve(Carver& c, LoopWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), NM = (size_t)P * N * M;
-        DenoiseWs::carve(c, w.dw, P, N, M, cfg.C);
+        DenoiseWs::carve(c, w.dw, P, N, M, cfg.C, cfg.n_layers);
         w.feat0 = c.take<float>(T * cfg.C);
         w.wconf = c.take<float>(NM);
         w.x0 = c.take<float>(NM);
@@ -282,6 +327,7 @@ int dr_init(void) {
 
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
+int dr_debug_gemm_stamps(long long* h_out256) { return read_gemm_stamps(h_out256); }
 
 int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t, float origin_x,
                   float origin_y, float origin_z, float voxel, const float* freq, float* cos_out, float* sin_out,
@@ -300,6 +346,26 @@ int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, fl
     memset(&g, 0, sizeof(g));
     GemmProblem& p = g.p[0];
     p.A = x; p.W = W; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = K; p.ldo = ncols;
+    p.epi = epilogue; p.cosT = cos_t; p.sinT = sin_t; p.rot_C = rot_C; p.scale = scale;
+    g.n = 1;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+size_t dr_packed_weight_bytes(int ncols, int K) { return (ncols > 0 && K > 0) ? gemm_packed_weight_bytes(ncols, K) : 0; }
+
+int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* stream) {
+    if (ncols <= 0 || K <= 0 || !W || !packed || ((uintptr_t)packed & 15)) return DR_EINVAL;
+    return launch_pack_weights(W, ncols, K, packed, (hipStream_t)stream);
+}
+
+int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
+                         int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream) {
+    if (rows < 0 || ncols <= 0 || K <= 0 || !x || !W || !packed || !out) return DR_EINVAL;
+    if ((epilogue & EPI_ROTARY) && (!cos_t || !sin_t || rot_C <= 0 || (rot_C & 1))) return DR_EINVAL;
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& p = g.p[0];
+    p.A = x; p.W = W; p.Wsplit = packed; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = K; p.ldo = ncols;
     p.epi = epilogue; p.cosT = cos_t; p.sinT = sin_t; p.rot_C = rot_C; p.scale = scale;
     g.n = 1;
     return launch_gemm(g, (hipStream_t)stream);
@@ -412,6 +478,8 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
     }
+    rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);
+    if (rc) return rc;
     rc = fill_pe(*cfg, *w, P, N, M, s_pcd_warped, nullptr, nullptr, t_pcd, true, true, L.dw, st);
     if (rc) return rc;
     const float* fin = nullptr;
@@ -454,6 +522,8 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
     }
     rc = launch_f32_to_f64(x_T, L.x, NM, st);     // exact widening; step 1 keeps float32 semantics
+    if (rc) return rc;
+    rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);  // split-operand images of the weights (the caller may have updated them)
     if (rc) return rc;
     // the target cloud never moves: its position code is computed once (the reference recomputes it
     // every step, transformero.py:166)

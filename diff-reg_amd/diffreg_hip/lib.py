@@ -81,12 +81,17 @@ SIGNATURES.update({
                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                               c_float, c_void_p]),
+    "dr_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "dr_pack_weight_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_linear_packed_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_int, c_float, c_void_p]),
     "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
     "dr_debug_gemm_config": (None, [c_int]),
     "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
+    "dr_debug_gemm_stamps": (c_int, [c_void_p]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),
@@ -222,6 +227,25 @@ def linear(x, W, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
     out = torch.empty(x.shape[0], W.shape[0], device=x.device)
     check(_lib.dr_linear_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(out), epilogue, ptr(cos), ptr(sin),
                              rot_C, float(scale), stream_of(x)))
+    return out
+
+
+def pack_weight(W):
+    """bf16 x 3 split image of an nn.Linear weight [ncols, K] for linear(..., packed=...)."""
+    ensure_init()
+    W = W.contiguous()
+    out = torch.empty(_lib.dr_packed_weight_bytes(W.shape[0], W.shape[1]), dtype=torch.uint8, device=W.device)
+    check(_lib.dr_pack_weight_f32(W.shape[0], W.shape[1], ptr(W), ptr(out), stream_of(W)))
+    return out
+
+
+def linear_packed(x, W, packed, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
+    ensure_init()
+    x = x.contiguous()
+    W = W.contiguous()
+    out = torch.empty(x.shape[0], W.shape[0], device=x.device)
+    check(_lib.dr_linear_packed_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(packed), ptr(out), epilogue,
+                                    ptr(cos), ptr(sin), rot_C, float(scale), stream_of(x)))
     return out
 
 

@@ -107,6 +107,16 @@ int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const fl
 int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, float* out, int epilogue,
                   const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
 
+/* The same nn.Linear with the weight pre-packed for the split-operand MFMA path: W (fp32) is written once as
+ * hi + mid + lo bf16 planes (dr_pack_weight_f32 into dr_packed_weight_bytes bytes, 16-byte aligned) and the
+ * GEMM accumulates the six significant bf16 x bf16 products in fp32 -- fp32-level accuracy (error vs an fp64
+ * product within that of the f32-input MFMA kernel, tests/test_ops_gpu.py) at 2.67x the f32 MFMA rate.
+ * Needs K % 8 == 0; W is still passed for shapes the packed kernel does not take. */
+size_t dr_packed_weight_bytes(int ncols, int K);
+int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* stream);
+int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
+                         int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
+
 /* weights of one GeometryAttentionLayer in the reference state-dict layout ([out,in] row-major;
  * 3D/models/transformero.py:26-41): host struct of device pointers */
 typedef struct {
@@ -147,6 +157,7 @@ void dr_debug_gemm_config(int c);
 /* diagnostics for tools/: 8 wall-clock stamps (100 MHz ticks) of the phases of the last
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
+int dr_debug_gemm_stamps(long long* h_out256);
 
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
  * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */
