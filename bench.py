@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed passes of the hot path (K)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "64")),
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "128")),
                     help="independent scene pairs per pass and per GPU")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFREG_BENCH_STREAMS", "2")),
                     help="the pairs of a pass are split into this many batches, one captured graph each, replayed "

@@ -776,6 +776,228 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     GEMM_STAMP(2);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 8-wave form of the wide kernel: same 128 x 224 workgroup tile, same LDS images and DMA, but the 7 column tiles
+// of a 32-row strip are shared by two waves (4 + 3 tiles; wave w: strip w & 3, half w >> 2, so the two halves of a
+// strip sit on the same SIMD and balance it).  A workgroup then has two waves per SIMD whose MFMA groups fill
+// each other's staging / wait / barrier gaps even when only one workgroup fits the launch on a CU (the layer
+// GEMMs of one batch are 128..512 tiles on 256 CUs), and with 64 accumulator registers per wave two workgroups
+// (four waves per SIMD) still fit.
+template <int SUB, int ABL = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_wide8_kernel(GemmBatch G) {
+    // SUB = 16-deep k-chunks per LDS stage (per barrier): 1 -> 80 KB, two workgroups per CU; 2 -> 160 KB, one
+    // workgroup per CU with twice the time for a stage's DMA to land and half the barriers.
+    using GG = WideGeom;
+    constexpr int BM = GG::BM, BN = GG::BN, ROWB = GG::ROWB, PL = GG::PL, BK = GG::BK;
+    constexpr int SSTAGE = SUB * GG::STAGE;                     // a stage = SUB x (A image | B image)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const GemmProblem& P = G.p[blockIdx.y];
+    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA2 = P.A2;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
+    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w), wm = wu & 3, wn = wu >> 2;
+    const int nchunks = (K + BK - 1) / BK, nstages = (nchunks + SUB - 1) / SUB;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // A: thread t stages 4 consecutive k of row t / 4 per 16-chunk (64 contiguous bytes per row per load)
+    const int ar = t >> 2, akc = 4 * (t & 3), alds = ar * ROWB + akc * 2;
+    const float* a1p = pA + (size_t)min(row0 + ar, rows - 1) * lda;
+    const float* a2p = pA2 ? pA2 + (size_t)min(row0 + ar, rows - 1) * lda2 - K1 : a1p;
+    float4 ra[2][SUB];
+    auto load_a = [&](int ch, float4& dst) {
+        const int kc = min(ch * BK + akc, K - 4);
+        dst = *reinterpret_cast<const float4*>((kc < K1 ? a1p : a2p) + kc);
+    };
+    const char* bsrc = reinterpret_cast<const char*>(P.Wsplit) + (size_t)tn * GG::B_IMG + lane * 16;
+    const size_t bstep = (size_t)tiles_n * GG::B_IMG;
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+    auto split4 = [&](const float4& v, uint2& hi, uint2& mid, uint2& lo) {
+        if (ABL == 1) { hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); mid = hi; lo = hi; return; }
+        split_pair(v.x, v.y, hi.x, mid.x, lo.x);
+        split_pair(v.z, v.w, hi.y, mid.y, lo.y);
+    };
+    auto write_a = [&](unsigned dst, const uint2& hi, const uint2& mid, const uint2& lo) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 vh = {hi.x, hi.y}, vm = {mid.x, mid.y}, vl = {lo.x, lo.y};
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:32\n\tds_write_b64 %0, %3 offset:64"
+                     :: "v"(dst), "v"(vh), "v"(vm), "v"(vl) : "memory");
+    };
+    // DMA instruction i (0 .. SUB * 25 - 1) of stage st: sub-chunk i / 25, KB i % 25 of its B image
+    auto dma = [&](int st, int i) __attribute__((always_inline)) {
+        const int sub = i / GG::B_DMAS, ins = i % GG::B_DMAS, ch = min(st * SUB + sub, nchunks - 1);
+        __builtin_amdgcn_global_load_lds((glb_void*)(bsrc + (size_t)ch * bstep + ins * 1024),
+                                         (lds_void*)(lds + (st & 1) * SSTAGE + sub * GG::STAGE + GG::A_BYTES + ins * 1024), 16, 0, 0);
+    };
+    constexpr int NDMA = (SUB * GG::B_DMAS + 7) / 8;             // DMA instructions per wave per stage (4 or 7)
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // One stage of one wave: SUB sub-chunks x NTL column tiles x 6 dependent MFMAs; the staging of the next stage goes
+    // into the gaps between them (gap G counts MFMAs of the stage, skipping the last of each tile):
+    //   G < NDMA: a B DMA instruction (wave w: w, w + 8, ..);  G NDMA ..: the float4s of A two stages ahead;
+    //   then the split of the next stage's A and its ds_write_b64s.
+    auto stage = [&](int st, auto ntl_t, float4 (&cur)[SUB], float4 (&nxt)[SUB]) __attribute__((always_inline)) {
+        constexpr int NTL = decltype(ntl_t)::value;
+        const bool has_next = st + 1 < nstages;
+        const bool do_load = has_next && ABL != 2;
+        const unsigned sb0 = lds_base + (st & 1) * SSTAGE;
+        const unsigned adst = lds_base + ((st + 1) & 1) * SSTAGE + alds;
+        uint2 hi[SUB], mid[SUB], lo[SUB];
+        auto gap = [&](int G) __attribute__((always_inline)) {
+            if (G < NDMA) {
+                const int i = wu + 8 * G;
+                if (do_load && i < SUB * GG::B_DMAS) dma(st + 1, i);
+            } else if (G < NDMA + SUB) {
+                if (do_load) load_a((st + 2) * SUB + (G - NDMA), nxt[G - NDMA]);
+            } else if (G >= NDMA + SUB + 2 && G < NDMA + 2 * SUB + 2) {
+                if (has_next) split4(cur[G - NDMA - SUB - 2], hi[G - NDMA - SUB - 2], mid[G - NDMA - SUB - 2], lo[G - NDMA - SUB - 2]);
+            } else if (G >= NDMA + 2 * SUB + 2 && G < NDMA + 3 * SUB + 2) {
+                const int q = G - NDMA - 2 * SUB - 2;
+                if (has_next) write_a(adst + q * GG::STAGE, hi[q], mid[q], lo[q]);
+            }
+        };
+#define DR_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            if (SUB > 1 && sub > 0 && st * SUB + sub >= nchunks) break;          // odd number of 16-chunks: uniform
+            const unsigned sbase = sb0 + sub * GG::STAGE;
+            const unsigned Ab = sbase + (wm * 32 + l31) * ROWB + 16 * h;
+            const unsigned Bb = sbase + GG::A_BYTES + ((NTL == 4 ? 0 : 4) * 32 + l31) * ROWB + 16 * h;
+            u32x4 a[3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) DR_LDS_READ(a[p], Ab, p * PL);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) DR_LDS_READ(b[0][p], Bb, p * PL);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int cb = j & 1;
+                if (j + 1 < NTL) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) DR_LDS_READ(b[cb ^ 1][p], Bb, (j + 1) * 32 * ROWB + p * PL);
+                    asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[0]), a1 = __builtin_bit_cast(bf16x8, a[1]), a2 = __builtin_bit_cast(bf16x8, a[2]);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[cb][0]), b1 = __builtin_bit_cast(bf16x8, b[cb][1]), b2 = __builtin_bit_cast(bf16x8, b[cb][2]);
+#define DR_MFMA_GAP(X, Y, g)                                                              \
+    if (ABL != 3) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Y, acc[j], 0, 0, 0); \
+    else asm volatile("" ::"v"(X), "v"(Y));                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    if (g < 5) { gap(5 * (sub * NTL + j) + g); __builtin_amdgcn_sched_barrier(0); }
+                DR_MFMA_GAP(a2, b0, 0)
+                DR_MFMA_GAP(a0, b2, 1)
+                DR_MFMA_GAP(a1, b1, 2)
+                DR_MFMA_GAP(a1, b0, 3)
+                DR_MFMA_GAP(a0, b1, 4)
+                DR_MFMA_GAP(a0, b0, 5)
+#undef DR_MFMA_GAP
+            }
+        }
+#undef DR_LDS_READ
+    };
+
+    // prologue: stage 0 staged, A of stage 1 in registers
+    {
+#pragma unroll
+        for (int g = 0; g < NDMA; ++g) {
+            const int i = wu + 8 * g;
+            if (i < SUB * GG::B_DMAS) dma(0, i);
+        }
+#pragma unroll
+        for (int q = 0; q < SUB; ++q) load_a(q, ra[0][q]);
+#pragma unroll
+        for (int q = 0; q < SUB; ++q) load_a(SUB + q, ra[1][q]);
+#pragma unroll
+        for (int q = 0; q < SUB; ++q) {
+            uint2 hi, mid, lo;
+            split4(ra[0][q], hi, mid, lo);
+            write_a(lds_base + q * GG::STAGE + alds, hi, mid, lo);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int s0 = 0; s0 < nstages; s0 += 2) {
+        if (wn == 0) stage(s0, std::integral_constant<int, 4>{}, ra[1], ra[0]);
+        else stage(s0, std::integral_constant<int, 3>{}, ra[1], ra[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s0 + 1 < nstages) {
+            if (wn == 0) stage(s0 + 1, std::integral_constant<int, 4>{}, ra[0], ra[1]);
+            else stage(s0 + 1, std::integral_constant<int, 3>{}, ra[0], ra[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // epilogue through LDS as in the 4-wave kernel; a wave owns a private [32][72] float region and moves two column
+    // tiles per pass (rows of 256 bytes: a lane stores float4 (lane & 15) of row 4 it + (lane >> 4))
+    {
+        constexpr int EST = 72;
+        float* const ep = reinterpret_cast<float*>(lds) + wu * 32 * EST;
+        const int epi = P.epi, halfC = P.rot_C >> 1, rotC = P.rot_C, ldo = P.ldo;
+        const float scale = P.scale;
+        const float* __restrict__ bias = P.bias;
+        const float* __restrict__ addend = P.addend;
+        const float* __restrict__ cosT = P.cosT;
+        const float* __restrict__ sinT = P.sinT;
+        float* __restrict__ outp = P.out;
+        const int ntl = wn ? 3 : 4;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                if (pass * 2 + jj >= ntl) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EST + jj * 32 + l31] = acc[pass * 2 + jj][r];
+            }
+            const int c4 = (lane & 15) * 4;
+            const int col = col0 + (wn * 4 + pass * 2) * 32 + c4;
+            const bool col_ok = c4 < (ntl - pass * 2) * 32 && col < ncols;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias && col_ok) bv = *reinterpret_cast<const float4*>(bias + col);
+            const int ridx = (epi & EPI_ROTARY) ? (col % rotC) >> 1 : 0;
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 4 + (lane >> 4), row = row0 + wm * 32 + rl;
+                float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4);
+                if (row < rows && col_ok) {
+                    if (epi & EPI_ROTARY) {
+                        const float2 c = *reinterpret_cast<const float2*>(cosT + (size_t)row * halfC + ridx);
+                        const float2 sn = *reinterpret_cast<const float2*>(sinT + (size_t)row * halfC + ridx);
+                        const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+                        v.x = __fadd_rn(__fmul_rn(x0, c.x), __fmul_rn(-x1, sn.x));
+                        v.y = __fadd_rn(__fmul_rn(x1, c.x), __fmul_rn(x0, sn.x));
+                        v.z = __fadd_rn(__fmul_rn(x2, c.y), __fmul_rn(-x3, sn.y));
+                        v.w = __fadd_rn(__fmul_rn(x3, c.y), __fmul_rn(x2, sn.y));
+                    }
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (epi & EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    if (addend) {
+                        const float4 ad = *reinterpret_cast<const float4*>(addend + (size_t)row * ldo + col);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    *reinterpret_cast<float4*>(outp + (size_t)row * ldo + col) = v;
+                }
+            }
+        }
+    }
+}
+
 // W [ncols][K] fp32 -> the packed split image described above (one thread per 8 k of one row of one tile chunk)
 __global__ void pack_weights_kernel(const float* __restrict__ W, char* __restrict__ out, int ncols, int K) {
     using GG = WideGeom;
@@ -818,6 +1040,30 @@ template <int ABL = 0>
 static int configure_wide() {
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)WideGeom::SMEM));
+    return DR_OK;
+}
+
+template <int SUB, int ABL = 0>
+static int configure_wide8() {
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_wide8_kernel<SUB, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(SUB * WideGeom::SMEM)));
+    return DR_OK;
+}
+
+template <int SUB, int ABL = 0>
+static int launch_wide8(const GemmBatch& g, hipStream_t st) {
+    using GG = WideGeom;
+    int maxt = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        maxt = tl > maxt ? tl : maxt;
+    }
+    if (maxt == 0) return DR_OK;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    ProfScope ps(PK_GEMM, flops, st);
+    hipLaunchKernelGGL((gemm_nt_wide8_kernel<SUB, ABL>), dim3(maxt, g.n), dim3(512), SUB * GG::SMEM, st, g);
+    DR_LAUNCH_CHECK();
     return DR_OK;
 }
 
@@ -876,6 +1122,10 @@ int gemm_configure() {
     if (rc == DR_OK) rc = configure_wide<2>();
     if (rc == DR_OK) rc = configure_wide<3>();
     if (rc == DR_OK) rc = configure_wide<9>();
+    if (rc == DR_OK) rc = configure_wide8<1>();
+    if (rc == DR_OK) rc = configure_wide8<2>();
+    if (rc == DR_OK) rc = configure_wide8<2, 2>();
+    if (rc == DR_OK) rc = configure_wide8<2, 3>();
     if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 1>();
     if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 2>();
     if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 3>();
@@ -919,7 +1169,12 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         nW += (long)((g.p[i].rows + 127) / 128) * ((g.p[i].ncols + 223) / 224);
     }
     static const int wide_min = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
-    if (wide && nW >= wide_min && g_force_cfg < 0) return launch_wide<0>(g, st);
+    // Launched alone, up to ~1.5 tiles per CU the 8-wave form (one workgroup per CU, two 16-chunks per barrier) is
+    // 8-13 % faster (tools/gemm_split.py); inside the loop, where the engine keeps two batches in flight on two
+    // streams, its 160 KB of LDS keeps the other stream's kernels off the CU and the 4-wave form wins by 2 %
+    // (bench.py, DR_GEMM_WIDE8_MAX sweep) -- so it is opt-in.
+    static const int wide8_max = [] { const char* e = getenv("DR_GEMM_WIDE8_MAX"); return e ? atoi(e) : 0; }();
+    if (wide && nW >= wide_min && g_force_cfg < 0) return nW <= wide8_max ? launch_wide8<2>(g, st) : launch_wide<0>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every configuration measured on the loop's shapes (tools/gemm_bench.py)
     (void)nL;
@@ -935,6 +1190,14 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         if (cfg == 52) return launch_wide<2>(g, st);
         if (cfg == 53) return launch_wide<3>(g, st);
         if (cfg == 59) return launch_wide<9>(g, st);
+    }
+    if (cfg >= 60 && cfg < 70) {
+        for (int i = 0; i < g.n; ++i)
+            if (!wide_ok(g.p[i])) return DR_ENOSUP;
+        if (cfg == 60) return launch_wide8<1>(g, st);
+        if (cfg == 61) return launch_wide8<2>(g, st);
+        if (cfg == 62) return launch_wide8<2, 2>(g, st);
+        if (cfg == 63) return launch_wide8<2, 3>(g, st);
     }
     if (cfg == 31) return launch_split<SPL_128x64_1, 1>(g, st);
     if (cfg == 32) return launch_split<SPL_128x64_1, 2>(g, st);

@@ -17,7 +17,7 @@ for rows, ncols, K in [(1000, 432, 432), (8192, 432, 432), (777, 864, 864), (130
             kw = dict(cos=ang.cos().contiguous(), sin=ang.sin().contiguous(), rot_C=ncols)
         lib.raw().dr_debug_gemm_config(-1)
         a = lib.linear(x, W, epilogue=epi, scale=0.37, **kw)
-        lib.raw().dr_debug_gemm_config(50)
+        lib.raw().dr_debug_gemm_config(int(os.environ.get("CFG", "50")))
         b = lib.linear_packed(x, W, Wp, epilogue=epi, scale=0.37, **kw)
         lib.raw().dr_debug_gemm_config(-1)
         d = (a - b).abs().max().item()
