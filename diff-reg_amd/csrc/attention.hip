@@ -8,6 +8,7 @@
 //                  16 in registers + 16 in lane^32, so the row max/sum need one cross-lane step)
 //   O^T = V^T P^T (d on the MFMA rows, queries on the lanes: the softmax rescale stays lane-local
 //                  and P^T is consumed straight from the score registers as the B operand)
+#include <cstdlib>
 #include "kernels.h"
 
 namespace dr {
@@ -229,11 +230,205 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Flash form: one workgroup = one (segment, head, 128-query block); wave w owns queries 32 w .. 32 w + 31 of the
+// block for the whole key range (no merge), its Q fragments live in registers, and the 4 waves share every K / V
+// tile, which all 256 threads stage together (global -> registers one tile ahead -> the other LDS buffer).
+// Against the kernel above (4 waves x their own K/V tiles of a 32-query block): a K/V tile is fetched and written
+// to LDS once per 128 queries instead of once per 32, there is no cross-wave merge, and a wave runs 8 key tiles
+// back to back instead of 2 between a prologue and an epilogue.  Same arithmetic per (query, key).
+template <int DG, int NDT>
+struct FlashGeom {
+    static constexpr int DP = DG * 8, QS = DP + 4;
+    static constexpr int TILE = 32 * QS;                         // floats per K or V tile image
+    static constexpr int SLOTS = (32 * (DP / 4) + 255) / 256;    // float4 staging slots per thread and tile
+    static constexpr int SMEM_FLOATS = 4 * TILE + NDT * 32 + 64; // 2 buffers x (K | V); PV over-reads past the last row
+};
+
+template <int DG, int NDT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_flash_kernel(AttnArgs A) {
+    using G = FlashGeom<DG, NDT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    int seg = blockIdx.z, qbase, kbase, Lq, Lk;
+    if (seg < A.nseg) {
+        qbase = A.q0 + seg * A.qstride; kbase = A.k0 + seg * A.kstride; Lq = A.Lq; Lk = A.Lk;
+    } else {
+        seg -= A.nseg;
+        qbase = A.q0b + seg * A.qstrideb; kbase = A.k0b + seg * A.kstrideb; Lq = A.Lqb; Lk = A.Lkb;
+    }
+    const int qb = blockIdx.x * 128;
+    if (qb >= Lq) return;
+    const int head = blockIdx.y, d = A.d;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, l31 = lane & 31;
+    const int nv4 = d >> 2;
+
+    // ---- Q fragments of this lane's query: group g holds k = 8 g + 4 h .. + 3 (zero past d / past Lq) ---------
+    const int my_q = qb + w * 32 + l31;
+    const bool q_in = my_q < Lq;
+    const bool q_valid = q_in && (!A.qmask || A.qmask[qbase + my_q]);
+    float4 qf[DG];
+    {
+        const float* qrow = A.q + (size_t)(qbase + min(my_q, Lq - 1)) * A.ldq + head * d;
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+            const int c4 = 2 * g + h;
+            float4 v = *reinterpret_cast<const float4*>(qrow + 4 * min(c4, nv4 - 1));
+            if (!(q_in && c4 < nv4)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[g] = v;
+        }
+    }
+
+    // ---- K / V staging slots --------------------------------------------------------------------------------
+    int srow[G::SLOTS], slds[G::SLOTS], scol[G::SLOTS];
+    bool scv[G::SLOTS], sact[G::SLOTS];
+#pragma unroll
+    for (int j = 0; j < G::SLOTS; ++j) {
+        const int sl = t + 256 * j, slc = min(sl, 32 * (G::DP / 4) - 1);
+        const int r = slc / (G::DP / 4), c4 = slc % (G::DP / 4);
+        sact[j] = sl < 32 * (G::DP / 4);
+        srow[j] = r; slds[j] = r * G::QS + 4 * c4; scv[j] = c4 < nv4;
+        scol[j] = head * d + 4 * min(c4, nv4 - 1);
+    }
+    float4 kreg[G::SLOTS], vreg[G::SLOTS];
+    auto load_tiles = [&](int kt) {
+        const int lim = Lk - 1 - kt * 32;
+        const float* kb = A.k + (size_t)(kbase + kt * 32) * A.ldk;
+        const float* vb = A.v + (size_t)(kbase + kt * 32) * A.ldv;
+#pragma unroll
+        for (int j = 0; j < G::SLOTS; ++j) {
+            const int r = min(srow[j], lim);
+            kreg[j] = *reinterpret_cast<const float4*>(kb + (size_t)r * A.ldk + scol[j]);
+            vreg[j] = *reinterpret_cast<const float4*>(vb + (size_t)r * A.ldv + scol[j]);
+        }
+    };
+    auto store_tiles = [&](int kt) {
+        const int lim = Lk - 1 - kt * 32;
+        float* Kt = smem + (kt & 1) * 2 * G::TILE;
+        float* Vt = Kt + G::TILE;
+#pragma unroll
+        for (int j = 0; j < G::SLOTS; ++j) {
+            if (!sact[j]) continue;
+            const bool ok = srow[j] <= lim && scv[j];
+            const float4 kv = kreg[j], vv = vreg[j];
+            *reinterpret_cast<float4*>(Kt + slds[j]) = make_float4(ok ? kv.x : 0.f, ok ? kv.y : 0.f, ok ? kv.z : 0.f, ok ? kv.w : 0.f);
+            *reinterpret_cast<float4*>(Vt + slds[j]) = make_float4(ok ? vv.x : 0.f, ok ? vv.y : 0.f, ok ? vv.z : 0.f, ok ? vv.w : 0.f);
+        }
+    };
+
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nkt = (Lk + 31) / 32;
+    const float sc2 = A.scale * 1.4426950408889634f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const float* Kt = smem + (kt & 1) * 2 * G::TILE;
+        const float* Vt = Kt + G::TILE;
+        // ---- S^T = K Q^T ----------------------------------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const float* kp = Kt + l31 * G::QS + 4 * h;
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
+            const float4 b = qf[g];
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, sc, 0, 0, 0);
+        }
+        // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float s = sc[r];
+            bool drop = kk >= Lk;                                // transformero.py:82
+            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            s = drop ? -INFINITY : s * sc2;
+            sc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float alpha = 1.f, psum = 0.f;
+        if (m_new == -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        } else {
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                sc[r] = p;
+                psum += p;
+            }
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        // ---- O^T += V^T P^T (MFMA row l31 of tile i is feature NDT * l31 + i) ---------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vp = Vt + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::QS + NDT * l31;
+            float vv[NDT];
+            if (NDT == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(vp);
+                vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;
+            } else if (NDT == 2) {
+                const float2 t2 = *reinterpret_cast<const float2*>(vp);
+                vv[0] = t2.x; vv[1] = t2.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NDT; ++i) vv[i] = vp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i], sc[r], acc[i], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tiles(kt + 1);                   // the other buffer: last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- out[q][f] = O^T[f][q] / l : through LDS (the tile buffers are free) so that rows are written contiguously
+    float* ob = smem + w * G::TILE;                              // [32 queries][QS]
+    const float inv = 1.0f / l_run;                              // a fully masked query gives 0/0 = NaN like the reference softmax
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = NDT * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+            if (f < G::QS) ob[l31 * G::QS + f] = acc[i][r] * inv;
+        }
+    wave_lds_fence();
+    for (int idx = lane; idx < 32 * nv4; idx += 64) {
+        const int q = idx / nv4, c4 = idx % nv4;
+        const int qq = qb + w * 32 + q;
+        if (qq < Lq)
+            *reinterpret_cast<float4*>(A.out + (size_t)(qbase + qq) * A.ldo + head * d + 4 * c4) =
+                *reinterpret_cast<const float4*>(ob + q * G::QS + 4 * c4);
+    }
+}
+
 template <int DG, int NDT>
 static int configure_attn() {
     using G = AttnGeom<DG, NDT>;
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(G::SMEM_FLOATS * sizeof(float))));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(FlashGeom<DG, NDT>::SMEM_FLOATS * sizeof(float))));
     return DR_OK;
 }
 
@@ -254,6 +449,15 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // 4 L S C per (segment): QK^T and PV
     const double flops = 4.0 * a.H * a.d * ((double)a.nseg * a.Lq * a.Lk + (double)a.nseg2 * a.Lqb * a.Lkb);
     ProfScope ps(PK_ATTN, flops, st);
+    static const int flash = [] { const char* e = getenv("DR_ATTN_FLASH"); return e ? atoi(e) : 1; }();
+    if (flash && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0) {
+        dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
+        using FG = FlashGeom<DG, NDT>;
+        const size_t flds = (size_t)FG::SMEM_FLOATS * sizeof(float);
+        hipLaunchKernelGGL((attention_flash_kernel<DG, NDT>), fgrid, dim3(256), flds, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     hipLaunchKernelGGL((attention_kernel<DG, NDT>), grid, dim3(256), lds, st, a);
     DR_LAUNCH_CHECK();
     return DR_OK;
