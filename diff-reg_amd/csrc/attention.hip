@@ -440,6 +440,9 @@ int attention_configure() {
     return rc;
 }
 
+static int g_flash_min = -1;    // tests / tools: force the flash form from this many workgroups (-1 = default rule)
+void attention_force_flash_min(int n) { g_flash_min = n; }
+
 template <int DG, int NDT>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
     using G = AttnGeom<DG, NDT>;
@@ -449,9 +452,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // 4 L S C per (segment): QK^T and PV
     const double flops = 4.0 * a.H * a.d * ((double)a.nseg * a.Lq * a.Lk + (double)a.nseg2 * a.Lqb * a.Lkb);
     ProfScope ps(PK_ATTN, flops, st);
-    static const int flash = [] { const char* e = getenv("DR_ATTN_FLASH"); return e ? atoi(e) : 1; }();
-    if (flash && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0) {
-        dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
+    // the flash form has a quarter of the workgroups: below ~one per CU the 32-query kernel fills the chip better
+    static const int flash_env = [] { const char* e = getenv("DR_ATTN_FLASH_MIN"); return e ? atoi(e) : 256; }();
+    const int flash_min = g_flash_min >= 0 ? g_flash_min : flash_env;
+    dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
+    if ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0) {
         using FG = FlashGeom<DG, NDT>;
         const size_t flds = (size_t)FG::SMEM_FLOATS * sizeof(float);
         hipLaunchKernelGGL((attention_flash_kernel<DG, NDT>), fgrid, dim3(256), flds, st, a);

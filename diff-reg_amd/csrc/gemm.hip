@@ -1138,6 +1138,11 @@ int gemm_configure() {
 static int g_force_cfg = -1;   // tools/: force a configuration (0 small, 1 medium, 2 large)
 void gemm_force_config(int c) { g_force_cfg = c; }
 
+int gemm_wide_min_tiles() {
+    static const int v = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
+    return v;
+}
+
 // shapes / alignments the wide split kernel takes (everything else stays on the f32-MFMA kernels)
 static bool wide_ok(const GemmProblem& p) {
     if (!p.Wsplit || p.K % 8 || (p.A2 && p.K1 % 8) || p.ncols % 4 || p.ldo % 4) return false;

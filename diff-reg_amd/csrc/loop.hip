@@ -47,8 +47,11 @@ struct PackedWeights {
     PackedLayer layer[MAXL];
     void* src_proj;
     bool on;
-    static void carve(Carver& c, PackedWeights& w, int n_layers, int C) {
-        w.on = n_layers <= MAXL && C % 8 == 0;
+    static void carve(Carver& c, PackedWeights& w, int n_layers, int C, size_t T) {
+        // the largest launch of the loop is the q|k|v projection of all T tokens (3 problems, ceil(C / 224) column tiles):
+        // if even that is below the wide kernel's threshold nothing would read the images
+        const long big = (long)((T + 127) / 128) * ((C + 223) / 224) * 3;
+        w.on = n_layers <= MAXL && C % 8 == 0 && big >= gemm_wide_min_tiles();
         for (int l = 0; l < n_layers && w.on; ++l) {
             PackedLayer& L = w.layer[l];
             L.q = c.take<char>(gemm_packed_weight_bytes(C, C));
@@ -173,7 +176,7 @@ struct DenoiseWs {
     static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C, int n_layers) {
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
-        PackedWeights::carve(c, w.pw, n_layers, C);
+        PackedWeights::carve(c, w.pw, n_layers, C, T);
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
         w.fa = c.take<float>(T * C);
@@ -327,6 +330,7 @@ int dr_init(void) {
 
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
+void dr_debug_attention_config(int flash_min_workgroups) { attention_force_flash_min(flash_min_workgroups); }
 int dr_debug_gemm_stamps(long long* h_out256) { return read_gemm_stamps(h_out256); }
 
 int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t, float origin_x,

@@ -30,6 +30,44 @@ def test_linear_matches_fp64(rows, ncols, K):
     assert (got_relu.double() - 0.5 * ref.clamp_min(0)).abs().max().item() < 2e-6 * scale * max(1.0, (K / 432) ** 0.5)
 
 
+@pytest.mark.parametrize("cfg", [50, 60, 61])        # 4-wave, 8-wave, 8-wave with two k-chunks per barrier
+@pytest.mark.parametrize("rows,ncols,K", [(1000, 432, 432), (4096, 432, 864), (777, 864, 864), (130, 224, 16), (129, 228, 440),
+                                           (5, 4, 8), (8192, 432, 432)])
+def test_gemm_split_accuracy(rows, ncols, K, cfg):
+    """The split-operand GEMM (packed bf16 x 3 weights, six bf16 MFMA products, fp32 accumulate) is an fp32 GEMM:
+    its error against an fp64 product stays within 1.25x that of the f32-input MFMA kernel accumulating in the same
+    order (one chain over k), below that of torch's own fp32 matmul, and within the absolute bound of
+    test_linear_matches_fp64 -- with every epilogue, on ragged shapes."""
+    from diffreg_hip import lib
+    raw = lib.raw()
+    x = (T(synth.hash_normal(5, rows + K, (rows, K))).float() * 3).to(DEV)
+    W = (T(synth.hash_uniform(6, ncols + K, (ncols, K))).float() / K ** 0.5).to(DEV)
+    Wp = lib.pack_weight(W)
+    ref = x.double() @ W.double().T
+    scale = ref.abs().max().item()
+    try:
+        raw.dr_debug_gemm_config(9)             # 64 x 64 tiles: one accumulation chain over k, like the split kernel
+        base = lib.linear(x, W)
+        raw.dr_debug_gemm_config(cfg)
+        got = lib.linear_packed(x, W, Wp)
+        e_base, e_got = (base.double() - ref).abs(), (got.double() - ref).abs()
+        assert e_got.max().item() < 2e-6 * scale * max(1.0, (K / 432) ** 0.5)
+        assert e_got.mean().item() <= 1.25 * e_base.mean().item() + 1e-9
+        assert e_got.mean().item() <= 1.05 * ((x @ W.T).double() - ref).abs().mean().item() + 1e-9
+        for epi in (1, 2, 3):
+            kw = {}
+            if epi & 2:
+                ang = T(synth.hash_uniform(7, rows, (rows, ncols // 2))).float().to(DEV) * 6.28
+                kw = dict(cos=ang.cos().contiguous(), sin=ang.sin().contiguous(), rot_C=ncols)
+            raw.dr_debug_gemm_config(-1)
+            a = lib.linear(x, W, epilogue=epi, scale=0.37, **kw)
+            raw.dr_debug_gemm_config(cfg)
+            b = lib.linear_packed(x, W, Wp, epilogue=epi, scale=0.37, **kw)
+            assert (a - b).abs().max().item() < 4e-6 * scale * max(1.0, (K / 432) ** 0.5), epi
+    finally:
+        raw.dr_debug_gemm_config(-1)
+
+
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
 def test_vol_pe_and_rotary_linear(variant, golden):
     from diffreg_hip import lib
@@ -75,10 +113,15 @@ def test_attention_layer(variant, golden):
     g = golden(variant + "_attn_layer")
     cases = dict(self_full=(fs, fs, cs, ss, cs, ss, full[0], full[0]), cross_full=(fs, ft, cs, ss, ct, st, full[0], full[1]),
                  self_mask=(fs, fs, cs, ss, cs, ss, part[0], part[0]), cross_mask=(fs, ft, cs, ss, ct, st, part[0], part[1]))
-    for name, (x, y, cx, sx, cy, sy, mx, my) in cases.items():
-        got = lib.attention_layer(tens, C, H, x.to(DEV), y.to(DEV), cx, sx, cy, sy, mx.to(DEV), my.to(DEV)).cpu()
-        err = np.abs(got[0].numpy() - g[name]).max()
-        assert err < 1e-4, (name, err)          # north_star tolerance: 1e-4 fp32
+    for flash_min in (100000, 1):               # the 32-query kernel, then the 128-query (flash) kernel forced
+        lib.raw().dr_debug_attention_config(flash_min)
+        try:
+            for name, (x, y, cx, sx, cy, sy, mx, my) in cases.items():
+                got = lib.attention_layer(tens, C, H, x.to(DEV), y.to(DEV), cx, sx, cy, sy, mx.to(DEV), my.to(DEV)).cpu()
+                err = np.abs(got[0].numpy() - g[name]).max()
+                assert err < 1e-4, (name, flash_min, err)          # north_star tolerance: 1e-4 fp32
+        finally:
+            lib.raw().dr_debug_attention_config(-1)
     # two pairs in one call == two single calls
     _, p2 = pair(variant, 64, 48, 4)
     x2 = torch.cat([fs, p2["f_s"]]).to(DEV)
@@ -90,6 +133,38 @@ def test_attention_layer(variant, golden):
     ref2 = orc.attention_layer(Wd, pre, p2["f_s"], p2["f_t"], pes2, pet2, None, None, H)
     assert np.abs(both[0].numpy() - g["cross_full"]).max() < 1e-4
     assert (both[1] - ref2[0]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("Lx,Ly", [(200, 130), (128, 129), (33, 300)])
+def test_attention_flash_ragged(Lx, Ly):
+    """128-query kernel on lengths that are no multiple of its blocks (partial waves, partial key tiles, masks),
+    two pairs per call, against the oracle layer."""
+    from diffreg_hip import lib
+    variant = "3dmatch"
+    v = synth.VARIANTS[variant]
+    C, H = v["C"], v["H"]
+    Wd = weights(variant)
+    pre = "denoising_transformer.layers.1."
+    tens = [Wd[pre + k].to(DEV) for k in lib._LAYER_KEYS]
+    xs, ys, pex, pey = [], [], [], []
+    for seed in (11, 12):
+        _, p = pair(variant, Lx, Ly, seed)
+        xs.append(p["f_s"]); ys.append(p["f_t"])
+        pex.append(orc.vol_pe(p["p_s"], C, v["origin"], v["voxel"])); pey.append(orc.vol_pe(p["p_t"], C, v["origin"], v["voxel"]))
+    mx, my = masks(Lx, Ly, Lx - 7, Ly - 5)
+    x2, y2 = torch.cat(xs).to(DEV), torch.cat(ys).to(DEV)
+    cx = torch.cat([half_tables(*q)[0] for q in pex]).to(DEV); sx = torch.cat([half_tables(*q)[1] for q in pex]).to(DEV)
+    cy = torch.cat([half_tables(*q)[0] for q in pey]).to(DEV); sy = torch.cat([half_tables(*q)[1] for q in pey]).to(DEV)
+    m2x, m2y = torch.cat([mx, mx]).to(DEV), torch.cat([my, my]).to(DEV)
+    lib.raw().dr_debug_attention_config(1)
+    try:
+        got = lib.attention_layer(tens, C, H, x2, y2, cx, sx, cy, sy, m2x, m2y).cpu()
+    finally:
+        lib.raw().dr_debug_attention_config(-1)
+    for i in range(2):
+        ref = orc.attention_layer(Wd, pre, xs[i], ys[i], pex[i], pey[i], mx, my, H)[0]
+        valid = mx[0].bool()
+        assert (got[i][valid] - ref[valid]).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
