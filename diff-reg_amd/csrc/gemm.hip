@@ -21,8 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 template <int TM, int TN, class Acc>
 __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, Acc acc, int rows, int ncols, int row0, int col0,
-                                              int wm, int wn, int lane) {
+                                              int wm, int wn, int lane, size_t out_off = 0) {
     const int h = lane >> 5, l31 = lane & 31;
+    float* __restrict__ outp = P.out + out_off;
     const int halfC = P.rot_C >> 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -49,7 +50,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, Acc acc, int
                 v *= P.scale;
                 if (row < rows && col_ok) {
                     if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
-                    P.out[(size_t)row * P.ldo + col] = v;
+                    outp[(size_t)row * P.ldo + col] = v;
                 }
             }
     }
@@ -80,11 +81,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const GemmProblem& P = G.p[blockIdx.y];
+    if ((int)blockIdx.z >= max(P.nbatch, 1)) return;
     // problem fields once into registers (re-reading the kernarg segment inside the k-loop costs a scalar-load
     // round trip per use)
-    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA = P.A + (size_t)blockIdx.z * P.sA;
     const float* __restrict__ pA2 = P.A2;
-    const float* __restrict__ pW = P.W;
+    const float* __restrict__ pW = P.W + (size_t)blockIdx.z * P.sW;
     const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
     const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
     if ((int)blockIdx.x >= tiles_n * tiles_m) return;
@@ -237,7 +239,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_nt_kernel(GemmBatch G)
                     for (int r = 0; r < 16; ++r) acc[i][j][0][r] += red[((((w + o) * TM + i) * TN + j) * 16 + r) * 64 + lane];
     }
 
-    gemm_epilogue<TM, TN>(P, [&](int i, int j) -> const f32x16& { return acc[i][j][0]; }, rows, ncols, row0, col0, wm, wn, lane);
+    gemm_epilogue<TM, TN>(P, [&](int i, int j) -> const f32x16& { return acc[i][j][0]; }, rows, ncols, row0, col0, wm, wn, lane,
+                          (size_t)blockIdx.z * P.sO);
 }
 
 template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
@@ -251,16 +254,17 @@ static int configure_cfg() {
 template <int TM, int TN, int WM, int WN, int WK, int BKC, int NBUF = 2>
 static int launch_cfg(const GemmBatch& g, hipStream_t st) {
     using GG = GemmGeom<TM, TN, WM, WN, WK, BKC, NBUF>;
-    int maxt = 0;
+    int maxt = 0, maxb = 1;
     for (int i = 0; i < g.n; ++i) {
         const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
         maxt = tl > maxt ? tl : maxt;
+        maxb = g.p[i].nbatch > maxb ? g.p[i].nbatch : maxb;
     }
     if (maxt == 0) return DR_OK;
     double flops = 0;
-    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
     ProfScope ps(PK_GEMM, flops, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC, NBUF>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, BKC, NBUF>), dim3(maxt, g.n, maxb), dim3(GG::NT), GG::SMEM_FLOATS * sizeof(float), st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -1145,6 +1149,7 @@ int gemm_wide_min_tiles() {
 
 // shapes / alignments the wide split kernel takes (everything else stays on the f32-MFMA kernels)
 static bool wide_ok(const GemmProblem& p) {
+    if (p.nbatch > 1) return false;
     if (!p.Wsplit || p.K % 8 || (p.A2 && p.K1 % 8) || p.ncols % 4 || p.ldo % 4) return false;
     if (((uintptr_t)p.out | (uintptr_t)p.addend | (uintptr_t)p.bias | (uintptr_t)p.Wsplit) & 15) return false;
     if ((p.epi & EPI_ROTARY) && (p.rot_C % 4 || ((uintptr_t)p.cosT | (uintptr_t)p.sinT) & 7)) return false;
@@ -1160,7 +1165,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         if (p.K % 4 || p.lda % 4 || (p.A2 && (p.K1 % 4 || p.lda2 % 4))) return DR_ENOSUP;
         if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2) & 15) return DR_ENOSUP;
         nL += (long)((p.rows + 127) / 128) * ((p.ncols + 63) / 64);
-        nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64);
+        nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64) * (p.nbatch > 1 ? p.nbatch : 1);
         const long tx = (long)((p.rows + 127) / 128) * ((p.ncols + 127) / 128);
         nX += tx;
         useful += (double)p.rows * p.ncols;
@@ -1187,6 +1192,8 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     static const int env_cfg = [] { const char* e = getenv("DR_GEMM_CFG"); return e ? atoi(e) : -1; }();   // tools/: tile experiments
     if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
     if (g_force_cfg >= 0) cfg = g_force_cfg;
+    for (int i = 0; i < g.n; ++i)
+        if (g.p[i].nbatch > 1 && cfg >= 20) return DR_ENOSUP;   // strided batches: f32-MFMA kernels only
     if (cfg >= 50 && cfg < 60) {
         for (int i = 0; i < g.n; ++i)
             if (!wide_ok(g.p[i])) return DR_ENOSUP;

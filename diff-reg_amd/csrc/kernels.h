@@ -38,6 +38,9 @@ struct GemmProblem {
     int epi;
     int rot_C;          // rotary: column c uses table index (c % rot_C) / 2
     float scale;        // applied last (1/sqrt(C) of matching.py:190)
+    // strided batch (f32-MFMA kernels only): instance z = blockIdx.z uses A + z sA, W + z sW, out + z sO (floats)
+    int nbatch;         // 0 or 1 = a single instance
+    long long sA, sW, sO;
 };
 
 struct GemmBatch {

@@ -252,20 +252,15 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     g.n = 1;
     int rc = launch_gemm(g, st);
     if (rc) return rc;
-    // sim[p] = a_p b_p^T : one NT GEMM per pair, up to 4 per launch
-    for (int p0 = 0; p0 < P; p0 += 4) {
-        memset(&g, 0, sizeof(g));
-        g.n = (P - p0) < 4 ? (P - p0) : 4;
-        for (int i = 0; i < g.n; ++i) {
-            GemmProblem& q = g.p[i];
-            const int pr = p0 + i;
-            q.A = ws.proj + (size_t)pr * N * C; q.W = ws.proj + ((size_t)PN + (size_t)pr * M) * C;
-            q.out = ws.sim + (size_t)pr * N * M; q.rows = N; q.ncols = M; q.K = C; q.K1 = C; q.lda = C; q.ldo = M;
-            q.epi = EPI_NONE; q.scale = 1.f;
-        }
-        rc = launch_gemm(g, st);
-        if (rc) return rc;
-    }
+    // sim[p] = a_p b_p^T : one NT GEMM per pair, all P pairs as one strided batch
+    memset(&g, 0, sizeof(g));
+    GemmProblem& q = g.p[0];
+    q.A = ws.proj; q.W = ws.proj + (size_t)PN * C; q.out = ws.sim;
+    q.rows = N; q.ncols = M; q.K = C; q.K1 = C; q.lda = C; q.ldo = M; q.epi = EPI_NONE; q.scale = 1.f;
+    q.nbatch = P; q.sA = (long long)N * C; q.sW = (long long)M * C; q.sO = (long long)N * M;
+    g.n = 1;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
     return DR_OK;
 }
 
