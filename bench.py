@@ -33,6 +33,9 @@ import torch  # noqa: E402
 
 HEAD_GAIN = 24.0
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA
+PEAK_MFMA_BF16_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
+# the split-operand GEMM spends six bf16 MFMA MACs per fp32 MAC: the ceiling of what it executes, in fp32-equivalent FLOP/s
+PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / 6.0
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -204,7 +207,8 @@ def main():
         "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
                                "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, P, nstreams),
                    "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
-                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32", "parallelism": "pairs sharded over %d GPU(s)" % world},
+                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32",
+                   "gemm_arithmetic": "fp32 in / fp32 out; each product as six bf16 MFMA products of hi/mid/lo operand splits, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)", "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
     }
 
@@ -239,7 +243,12 @@ def main():
                        "avg_us_per_launch": (v[1] / v[0] * 1e3) if v[0] else 0.0} for k, v in prof.items()}
             dom = max(prof, key=lambda k: prof[k][1])
             c, ms_, work = prof[dom]
-            if dom in ("gemm", "attention"):
+            if dom == "gemm_split":
+                ach = work / (ms_ * 1e-3) / 1e12
+                roof = dict(kernel="gemm_nt_wide_kernel (family gemm_split)", bound="mfma", achieved=ach, peak=PEAK_SPLIT_TFLOPS,
+                            unit="TFLOP/s", traffic=None, peak_basis="dense bf16 MFMA peak / 6 products per fp32 MAC",
+                            peak_f32_mfma=PEAK_MFMA_F32_TFLOPS, frac_vs_f32_mfma_peak=ach / PEAK_MFMA_F32_TFLOPS)
+            elif dom in ("gemm", "attention"):
                 roof = dict(kernel=dom, bound="mfma", achieved=work / (ms_ * 1e-3) / 1e12, peak=PEAK_MFMA_F32_TFLOPS,
                             unit="TFLOP/s", traffic=None)
             else:
@@ -248,7 +257,9 @@ def main():
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
-            roof["note"] = "dominant family by GPU time; work = algorithmic FLOPs (2*rows*cols*K per GEMM) or bytes"
+            roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "
+                            "the kernel computes each fp32 product as six bf16 MFMA products accumulated in fp32 "
+                            "(fp32-level accuracy, tests/test_ops_gpu.py::test_gemm_split_accuracy)")
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof
             result["kernel_families"] = fam

@@ -1065,7 +1065,7 @@ static int launch_wide8(const GemmBatch& g, hipStream_t st) {
     if (maxt == 0) return DR_OK;
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
-    ProfScope ps(PK_GEMM, flops, st);
+    ProfScope ps(PK_GEMM_SPLIT, flops, st);
     hipLaunchKernelGGL((gemm_nt_wide8_kernel<SUB, ABL>), dim3(maxt, g.n), dim3(512), SUB * GG::SMEM, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -1082,7 +1082,7 @@ static int launch_wide(const GemmBatch& g, hipStream_t st) {
     if (maxt == 0) return DR_OK;
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
-    ProfScope ps(PK_GEMM, flops, st);
+    ProfScope ps(PK_GEMM_SPLIT, flops, st);
     hipLaunchKernelGGL((gemm_nt_wide_kernel<ABL>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;

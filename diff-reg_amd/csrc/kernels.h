@@ -8,7 +8,7 @@ namespace dr {
 // optional per-kernel-family timing with HIP events on the launch stream (dr_prof_* in the C ABI);
 // costs one branch per launch when disabled.  Never enable inside a stream capture.
 // ---------------------------------------------------------------------------------------------
-enum ProfKind { PK_GEMM = 0, PK_ATTN, PK_LN, PK_PE, PK_SINKHORN, PK_PROCRUSTES, PK_STATE, PK_COUNT };
+enum ProfKind { PK_GEMM = 0, PK_ATTN, PK_LN, PK_PE, PK_SINKHORN, PK_PROCRUSTES, PK_STATE, PK_GEMM_SPLIT, PK_COUNT };
 extern bool g_prof_on;
 void prof_begin(int kind, double work, hipStream_t st);
 void prof_end(int kind, hipStream_t st);

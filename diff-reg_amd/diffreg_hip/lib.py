@@ -315,7 +315,7 @@ def top1_union(conf):
     return [out[p, :counts[p]] for p in range(P)]
 
 
-PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state")
+PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state", "gemm_split")
 
 
 def prof_enable(on=True):

@@ -81,10 +81,10 @@ int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* sr
 int dr_init(void);
 
 /* Per-kernel-family timing with HIP events recorded on the launch stream, for bench.py's roofline
- * line.  Families: 0 gemm, 1 attention, 2 layernorm, 3 position code, 4 sinkhorn, 5 procrustes,
- * 6 state (min / ddim / read-out).  work[k] = algorithmic FLOPs (gemm, attention) or bytes (others)
+ * line.  Families: 0 gemm (f32-input MFMA kernels), 1 attention, 2 layernorm, 3 position code, 4 sinkhorn,
+ * 5 procrustes, 6 state (min / ddim / read-out), 7 gemm_split (packed-weight split-operand kernels).  work[k] = algorithmic FLOPs (gemm, attention) or bytes (others)
  * summed over the recorded launches.  Do not enable during a stream capture. */
-#define DR_PROF_KINDS 7
+#define DR_PROF_KINDS 8
 void dr_prof_enable(int on);
 int dr_prof_collect(int* calls, double* ms, double* work);
 
