@@ -553,8 +553,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ pA2 = P.A2;
     const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
     const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // workgroup id -> tile, XCD-aware: ids are dealt round-robin to the 8 XCDs (each with its own L2), so the column
+    // tiles of one row block get ids 8 apart: they share an L2 and the A rows cross the fabric once, not tiles_n times
+    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x % (8 * tiles_n);
+    const int tm = grp * 8 + (rem & 7), tn = rem >> 3;
+    if (tm >= tiles_m) return;
     const int row0 = tm * BM, col0 = tn * BN;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nchunks = (K + BK - 1) / BK;
@@ -802,8 +805,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ pA2 = P.A2;
     const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
     const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x % (8 * tiles_n);     // XCD-aware, as in the 4-wave kernel
+    const int tm = grp * 8 + (rem & 7), tn = rem >> 3;
+    if (tm >= tiles_m) return;
     const int row0 = tm * BM, col0 = tn * BN;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w), wm = wu & 3, wn = wu >> 2;
@@ -1059,7 +1063,7 @@ static int launch_wide8(const GemmBatch& g, hipStream_t st) {
     using GG = WideGeom;
     int maxt = 0;
     for (int i = 0; i < g.n; ++i) {
-        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM + 7) / 8 * 8 * ((g.p[i].ncols + GG::BN - 1) / GG::BN);   // row blocks in groups of 8 (XCD map)
         maxt = tl > maxt ? tl : maxt;
     }
     if (maxt == 0) return DR_OK;
@@ -1076,7 +1080,7 @@ static int launch_wide(const GemmBatch& g, hipStream_t st) {
     using GG = WideGeom;
     int maxt = 0;
     for (int i = 0; i < g.n; ++i) {
-        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM + 7) / 8 * 8 * ((g.p[i].ncols + GG::BN - 1) / GG::BN);   // row blocks in groups of 8 (XCD map)
         maxt = tl > maxt ? tl : maxt;
     }
     if (maxt == 0) return DR_OK;
