@@ -255,6 +255,14 @@ def main():
                 roof = dict(kernel=dom, bound="hbm", achieved=work / (ms_ * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
                             traffic=None)
             roof["frac"] = roof["achieved"] / roof["peak"]
+            if dom == "gemm_split":
+                # PMC traffic of this kernel is collected on one named shape (separate rocprofv3 --pmc passes, the
+                # launches of a pass here are a mix of shapes): quoted beside the line, `traffic` itself stays null
+                tp = os.path.join(ROOT, "profiles", "r01_gemm_wide_pmc_traffic.json")
+                if os.path.exists(tp):
+                    tj = json.load(open(tp))
+                    roof["traffic_reference"] = {k: tj[k] for k in ("shape", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch",
+                                                                    "traffic_over_algorithmic", "command")}
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
             roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "
