@@ -422,6 +422,282 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Flash form on the bf16 pipe: the same workgroup / wave decomposition, but every fp32 product of QK^T and PV is
+// computed as in the wide GEMM (gemm.hip): operands written as hi + mid + lo bf16 (exact to 2^-27), the six
+// significant bf16 x bf16 products accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest first -- fp32-level
+// accuracy at 2.67x the f32-input MFMA rate.
+//   * K tile  -> LDS as [32 keys][3 planes][DPS k] bf16 (A operand of S^T = K Q^T: a lane reads 8 consecutive k)
+//   * V tile  -> LDS TRANSPOSED as [feature][3 planes][32 keys] bf16, keys in the order in which the score
+//                registers of a lane hold them (A operand of O^T = V^T P^T: a lane reads 8 consecutive keys of its
+//                feature); a thread stages a 4-key x 4-feature block, so the transposition is four 8-byte stores
+//   * Q stays in fp32 registers and is split k-step by k-step between the MFMAs; P is split from the score registers
+//   * K(kt+1) is written after the barrier that ends QK^T(kt), V(kt+1) after the one that ends PV(kt): two barriers
+//     per key tile, single K and V images (49 KB), staging registers for one of them at a time.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void asplit_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const af32x2 f = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, abf16x2));
+    const af32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, abf16x2));
+    const af32x2 r2 = {r.x - __uint_as_float(mid << 16), r.y - __uint_as_float(mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, abf16x2));
+}
+
+template <int KS, int NDT>
+struct FlashSplitGeom {
+    static constexpr int DPS = 16 * KS;                          // padded head dim (k-steps of 16)
+    static constexpr int KROW = 6 * DPS + 16;                    // bytes per key row of the K image (3 planes + pad)
+    static constexpr int KIMG = 32 * KROW;
+    static constexpr int VROW = 3 * 64 + 16;                     // bytes per feature row of the V^T image
+    static constexpr int VIMG = NDT * 32 * VROW;
+    static constexpr int OQS = NDT * 32 + 4;                     // floats per query row of the output transposition
+    static constexpr int OBYTES = 4 * 32 * OQS * 4;
+    static constexpr int SMEM = (KIMG + VIMG > OBYTES ? KIMG + VIMG : OBYTES) + 64;
+    static constexpr int KSLOTS = (32 * (DPS / 4) + 255) / 256;  // float4 staging slots per thread (K)
+    static constexpr int VGROUPS = 8 * (DPS / 4);                // 4-key x 4-feature blocks of a V tile (<= 256)
+};
+
+template <int KS, int NDT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_flash_split_kernel(AttnArgs A) {
+    using G = FlashSplitGeom<KS, NDT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    char* const Kimg = lds;
+    char* const Vimg = lds + G::KIMG;
+
+    int seg = blockIdx.z, qbase, kbase, Lq, Lk;
+    if (seg < A.nseg) {
+        qbase = A.q0 + seg * A.qstride; kbase = A.k0 + seg * A.kstride; Lq = A.Lq; Lk = A.Lk;
+    } else {
+        seg -= A.nseg;
+        qbase = A.q0b + seg * A.qstrideb; kbase = A.k0b + seg * A.kstrideb; Lq = A.Lqb; Lk = A.Lkb;
+    }
+    const int qb = blockIdx.x * 128;
+    if (qb >= Lq) return;
+    const int head = blockIdx.y, d = A.d;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, l31 = lane & 31;
+    const int nv4 = d >> 2;
+
+    // ---- Q of this lane's query in fp32: k-step s needs k = 16 s + 8 h .. + 7 (two float4), zero past d / past Lq
+    const int my_q = qb + w * 32 + l31;
+    const bool q_in = my_q < Lq;
+    const bool q_valid = q_in && (!A.qmask || A.qmask[qbase + my_q]);
+    float4 qf[KS][2];
+    {
+        const float* qrow = A.q + (size_t)(qbase + min(my_q, Lq - 1)) * A.ldq + head * d;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c4 = 4 * s + 2 * h + e;
+                float4 v = *reinterpret_cast<const float4*>(qrow + 4 * min(c4, nv4 - 1));
+                if (!(q_in && c4 < nv4)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                qf[s][e] = v;
+            }
+    }
+
+    // ---- staging maps ------------------------------------------------------------------------------------------
+    // K: slot = (key row r, float4 column c4) -> planes at Kimg + r KROW + plane 2 DPS + 8 c4 (4 bf16 = 8 bytes)
+    int krow[G::KSLOTS], kcol[G::KSLOTS], klds[G::KSLOTS];
+    bool kcv[G::KSLOTS], kact[G::KSLOTS];
+#pragma unroll
+    for (int j = 0; j < G::KSLOTS; ++j) {
+        const int sl = t + 256 * j, slc = min(sl, 32 * (G::DPS / 4) - 1);
+        const int r = slc / (G::DPS / 4), c4 = slc % (G::DPS / 4);
+        kact[j] = sl < 32 * (G::DPS / 4);
+        krow[j] = r; klds[j] = r * G::KROW + 8 * c4; kcv[j] = c4 < nv4;
+        kcol[j] = head * d + 4 * min(c4, nv4 - 1);
+    }
+    // V: block = (key quad kq = 0..7, feature quad c4): keys 4 kq .. 4 kq + 3 land at position
+    //    16 (kq >> 2) + 8 (kq & 1) + 4 ((kq >> 1) & 1) of rows 4 c4 .. 4 c4 + 3 (the order of a lane's score registers)
+    const bool vact = t < G::VGROUPS;
+    const int vkq = min(t, G::VGROUPS - 1) / (G::DPS / 4), vc4 = min(t, G::VGROUPS - 1) % (G::DPS / 4);
+    const bool vcv = vc4 < nv4;
+    const int vcol = head * d + 4 * min(vc4, nv4 - 1);
+    const int vlds = 4 * vc4 * G::VROW + 2 * (16 * (vkq >> 2) + 8 * (vkq & 1) + 4 * ((vkq >> 1) & 1));
+    float4 kreg[G::KSLOTS], vreg[4];
+    auto load_k = [&](int kt) {
+        const int lim = Lk - 1 - kt * 32;
+        const float* kb = A.k + (size_t)(kbase + kt * 32) * A.ldk;
+#pragma unroll
+        for (int j = 0; j < G::KSLOTS; ++j) kreg[j] = *reinterpret_cast<const float4*>(kb + (size_t)min(krow[j], lim) * A.ldk + kcol[j]);
+    };
+    auto load_v = [&](int kt) {
+        const int lim = Lk - 1 - kt * 32;
+        const float* vb = A.v + (size_t)(kbase + kt * 32) * A.ldv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vreg[e] = *reinterpret_cast<const float4*>(vb + (size_t)min(4 * vkq + e, lim) * A.ldv + vcol);
+    };
+    auto store_k = [&](int kt) {
+        const int lim = Lk - 1 - kt * 32;
+#pragma unroll
+        for (int j = 0; j < G::KSLOTS; ++j) {
+            if (!kact[j]) continue;
+            const bool ok = krow[j] <= lim && kcv[j];
+            const float4 v = kreg[j];
+            uint2 hi, mid, lo;
+            asplit_pair(ok ? v.x : 0.f, ok ? v.y : 0.f, hi.x, mid.x, lo.x);
+            asplit_pair(ok ? v.z : 0.f, ok ? v.w : 0.f, hi.y, mid.y, lo.y);
+            char* dst = Kimg + klds[j];
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + 2 * G::DPS) = mid;
+            *reinterpret_cast<uint2*>(dst + 4 * G::DPS) = lo;
+        }
+    };
+    auto store_v = [&](int kt) {
+        if (!vact) return;
+        const int lim = Lk - 1 - kt * 32;
+        float x[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = 4 * vkq + e <= lim && vcv;
+            x[e][0] = ok ? vreg[e].x : 0.f; x[e][1] = ok ? vreg[e].y : 0.f; x[e][2] = ok ? vreg[e].z : 0.f; x[e][3] = ok ? vreg[e].w : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            uint2 hi, mid, lo;
+            asplit_pair(x[0][f], x[1][f], hi.x, mid.x, lo.x);
+            asplit_pair(x[2][f], x[3][f], hi.y, mid.y, lo.y);
+            char* dst = Vimg + vlds + f * G::VROW;
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + 64) = mid;
+            *reinterpret_cast<uint2*>(dst + 128) = lo;
+        }
+    };
+
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nkt = (Lk + 31) / 32;
+    const float sc2 = A.scale * 1.4426950408889634f;
+
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) load_k(kt + 1);
+        // ---- S^T = K Q^T ----------------------------------------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const char* kp = Kimg + l31 * G::KROW + 16 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint4 qh, qm, ql;
+            asplit_pair(qf[s][0].x, qf[s][0].y, qh.x, qm.x, ql.x);
+            asplit_pair(qf[s][0].z, qf[s][0].w, qh.y, qm.y, ql.y);
+            asplit_pair(qf[s][1].x, qf[s][1].y, qh.z, qm.z, ql.z);
+            asplit_pair(qf[s][1].z, qf[s][1].w, qh.w, qm.w, ql.w);
+            const abf16x8 k0 = *reinterpret_cast<const abf16x8*>(kp + 32 * s);
+            const abf16x8 k1 = *reinterpret_cast<const abf16x8*>(kp + 2 * G::DPS + 32 * s);
+            const abf16x8 k2 = *reinterpret_cast<const abf16x8*>(kp + 4 * G::DPS + 32 * s);
+            const au32x4 qhv = {qh.x, qh.y, qh.z, qh.w}, qmv = {qm.x, qm.y, qm.z, qm.w}, qlv = {ql.x, ql.y, ql.z, ql.w};
+            const abf16x8 q0 = __builtin_bit_cast(abf16x8, qhv), q1 = __builtin_bit_cast(abf16x8, qmv), q2 = __builtin_bit_cast(abf16x8, qlv);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q0, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q2, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, sc, 0, 0, 0);
+        }
+        __syncthreads();                                         // every wave is done with the K image
+        if (more) {
+            store_k(kt + 1);
+            load_v(kt + 1);
+        }
+        // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float s = sc[r];
+            bool drop = kk >= Lk;                                // transformero.py:82
+            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            s = drop ? -INFINITY : s * sc2;
+            sc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float alpha = 1.f, psum = 0.f;
+        if (m_new == -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        } else {
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                sc[r] = p;
+                psum += p;
+            }
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        // ---- O^T += V^T P^T : k-step s contracts the keys of score registers 8 s .. 8 s + 7 -------------------
+        const char* vp = Vimg + l31 * G::VROW + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 ph, pm, pl;
+            asplit_pair(sc[8 * s + 0], sc[8 * s + 1], ph.x, pm.x, pl.x);
+            asplit_pair(sc[8 * s + 2], sc[8 * s + 3], ph.y, pm.y, pl.y);
+            asplit_pair(sc[8 * s + 4], sc[8 * s + 5], ph.z, pm.z, pl.z);
+            asplit_pair(sc[8 * s + 6], sc[8 * s + 7], ph.w, pm.w, pl.w);
+            const au32x4 phv = {ph.x, ph.y, ph.z, ph.w}, pmv = {pm.x, pm.y, pm.z, pm.w}, plv = {pl.x, pl.y, pl.z, pl.w};
+            const abf16x8 p0 = __builtin_bit_cast(abf16x8, phv), p1 = __builtin_bit_cast(abf16x8, pmv), p2 = __builtin_bit_cast(abf16x8, plv);
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) {
+                const char* vr = vp + i * 32 * G::VROW + 32 * s;
+                const abf16x8 v0 = *reinterpret_cast<const abf16x8*>(vr);
+                const abf16x8 v1 = *reinterpret_cast<const abf16x8*>(vr + 64);
+                const abf16x8 v2 = *reinterpret_cast<const abf16x8*>(vr + 128);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, p0, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p2, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p0, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p1, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                         // every wave is done with the V image
+        if (more) store_v(kt + 1);
+        // (the K image written above is read after this barrier, the V image after the next one)
+    }
+    __syncthreads();
+
+    // ---- out[q][f] = O^T[f][q] / l, through LDS; MFMA row l31 of tile i is feature 32 i + l31 ---------------------
+    float* ob = smem + w * 32 * G::OQS;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[l31 * G::OQS + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][r] * inv;
+    wave_lds_fence();
+    for (int idx = lane; idx < 32 * nv4; idx += 64) {
+        const int q = idx / nv4, c4 = idx % nv4;
+        const int qq = qb + w * 32 + q;
+        if (qq < Lq)
+            *reinterpret_cast<float4*>(A.out + (size_t)(qbase + qq) * A.ldo + head * d + 4 * c4) =
+                *reinterpret_cast<const float4*>(ob + q * G::OQS + 4 * c4);
+    }
+}
+
 template <int DG, int NDT>
 static int configure_attn() {
     using G = AttnGeom<DG, NDT>;
@@ -429,6 +705,9 @@ static int configure_attn() {
                                      (int)(G::SMEM_FLOATS * sizeof(float))));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(FlashGeom<DG, NDT>::SMEM_FLOATS * sizeof(float))));
+    constexpr int KS = (DG * 8 + 15) / 16;
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_split_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)FlashSplitGeom<KS, NDT>::SMEM));
     return DR_OK;
 }
 
@@ -441,7 +720,9 @@ int attention_configure() {
 }
 
 static int g_flash_min = -1;    // tests / tools: force the flash form from this many workgroups (-1 = default rule)
+static int g_attn_split = -1;   // tests / tools: 0 = f32-input MFMA flash kernel, 1 = split-operand one (-1 = default)
 void attention_force_flash_min(int n) { g_flash_min = n; }
+void attention_force_split(int on) { g_attn_split = on; }
 
 template <int DG, int NDT>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
@@ -457,6 +738,18 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     const int flash_min = g_flash_min >= 0 ? g_flash_min : flash_env;
     dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
     if ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0) {
+        static const int split_env = [] { const char* e = getenv("DR_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+        const int mode = g_attn_split >= 0 ? g_attn_split : split_env;     // 0 f32-input MFMA, 1 split operands
+        // d = 132 (4DMatch) needs 288 V staging blocks and 9 k-steps of Q in registers: more than two waves per SIMD
+        // allow -> f32 kernel.  (A hybrid with only PV split measured slower than both: 93 vs 84 / 108 us.)
+        if (DG <= 14 && mode == 1) {
+            constexpr int KS = (DG * 8 + 15) / 16;
+            using SG = FlashSplitGeom<KS, NDT>;
+            const size_t slds = (size_t)SG::SMEM;
+            hipLaunchKernelGGL((attention_flash_split_kernel<KS, NDT>), fgrid, dim3(256), slds, st, a);
+            DR_LAUNCH_CHECK();
+            return DR_OK;
+        }
         using FG = FlashGeom<DG, NDT>;
         const size_t flds = (size_t)FG::SMEM_FLOATS * sizeof(float);
         hipLaunchKernelGGL((attention_flash_kernel<DG, NDT>), fgrid, dim3(256), flds, st, a);

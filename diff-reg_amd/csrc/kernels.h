@@ -78,6 +78,7 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int attention_configure();
 void attention_force_flash_min(int n);
+void attention_force_split(int on);
 
 // ---------------------------------------------------------------------------------------------
 // row-wise ops

@@ -93,6 +93,7 @@ SIGNATURES.update({
     "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
     "dr_debug_gemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
+    "dr_debug_attention_split": (None, [c_int]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),

@@ -160,6 +160,8 @@ int dr_debug_procrustes_stamps(long long* h_out8);
 int dr_debug_gemm_stamps(long long* h_out256);
 /* attention: use the 128-query (flash) kernel from this many workgroups on; -1 = default rule (256) */
 void dr_debug_attention_config(int flash_min_workgroups);
+/* flash attention arithmetic: 1 = split-operand bf16 MFMA products (default), 0 = f32-input MFMA, -1 = default */
+void dr_debug_attention_split(int on);
 
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
  * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */

@@ -113,15 +113,18 @@ def test_attention_layer(variant, golden):
     g = golden(variant + "_attn_layer")
     cases = dict(self_full=(fs, fs, cs, ss, cs, ss, full[0], full[0]), cross_full=(fs, ft, cs, ss, ct, st, full[0], full[1]),
                  self_mask=(fs, fs, cs, ss, cs, ss, part[0], part[0]), cross_mask=(fs, ft, cs, ss, ct, st, part[0], part[1]))
-    for flash_min in (100000, 1):               # the 32-query kernel, then the 128-query (flash) kernel forced
+    # the 32-query kernel, then the 128-query (flash) kernel forced: on the f32-input MFMA and with split operands
+    for flash_min, split in ((100000, -1), (1, 0), (1, 1)):
         lib.raw().dr_debug_attention_config(flash_min)
+        lib.raw().dr_debug_attention_split(split)
         try:
             for name, (x, y, cx, sx, cy, sy, mx, my) in cases.items():
                 got = lib.attention_layer(tens, C, H, x.to(DEV), y.to(DEV), cx, sx, cy, sy, mx.to(DEV), my.to(DEV)).cpu()
                 err = np.abs(got[0].numpy() - g[name]).max()
-                assert err < 1e-4, (name, flash_min, err)          # north_star tolerance: 1e-4 fp32
+                assert err < 1e-4, (name, flash_min, split, err)          # north_star tolerance: 1e-4 fp32
         finally:
             lib.raw().dr_debug_attention_config(-1)
+            lib.raw().dr_debug_attention_split(-1)
     # two pairs in one call == two single calls
     _, p2 = pair(variant, 64, 48, 4)
     x2 = torch.cat([fs, p2["f_s"]]).to(DEV)
@@ -135,8 +138,9 @@ def test_attention_layer(variant, golden):
     assert (both[1] - ref2[0]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("Lx,Ly", [(200, 130), (128, 129), (33, 300)])
-def test_attention_flash_ragged(Lx, Ly):
+def test_attention_flash_ragged(Lx, Ly, split):
     """128-query kernel on lengths that are no multiple of its blocks (partial waves, partial key tiles, masks),
     two pairs per call, against the oracle layer."""
     from diffreg_hip import lib
@@ -157,10 +161,12 @@ def test_attention_flash_ragged(Lx, Ly):
     cy = torch.cat([half_tables(*q)[0] for q in pey]).to(DEV); sy = torch.cat([half_tables(*q)[1] for q in pey]).to(DEV)
     m2x, m2y = torch.cat([mx, mx]).to(DEV), torch.cat([my, my]).to(DEV)
     lib.raw().dr_debug_attention_config(1)
+    lib.raw().dr_debug_attention_split(split)
     try:
         got = lib.attention_layer(tens, C, H, x2, y2, cx, sx, cy, sy, m2x, m2y).cpu()
     finally:
         lib.raw().dr_debug_attention_config(-1)
+        lib.raw().dr_debug_attention_split(-1)
     for i in range(2):
         ref = orc.attention_layer(Wd, pre, xs[i], ys[i], pex[i], pey[i], mx, my, H)[0]
         valid = mx[0].bool()
