@@ -271,33 +271,17 @@ static int launch_cfg(const GemmBatch& g, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Split-operand variant: fp32 result from bf16 MFMAs.  Every fp32 operand x is written (round-to-nearest at each
+// Split-operand GEMM: fp32 result from bf16 MFMAs.  Every fp32 operand x is written (round-to-nearest at each
 // level) as hi + mid + lo, three bf16 numbers, exact to ~2^-27 |x|; the product keeps the six terms down to
 // 2^-18 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) and accumulates them in fp32 on v_mfma_f32_32x32x16_bf16.
 // bf16 x bf16 products are exact in fp32, so the dropped terms (<= 2^-26 relative) are below the rounding of the
 // fp32 accumulation itself: measured against an fp64 GEMM the result is as close as the f32-input MFMA kernel's
 // (tests/test_ops_gpu.py::test_gemm_split_accuracy).  Six bf16 MFMAs (32 cycles each, K = 16) replace eight
 // f32 MFMAs (64 cycles each, K = 2): 2.67x the f32-input MFMA rate.
-// The split happens once per staged element, on the way from the global-load registers into LDS, which holds the
-// three planes of a row side by side ([row][plane][BK] bf16, 16 B pad -> odd 16-B slot stride, conflict-free
-// ds_read_b128); a lane's fragment is 8 consecutive k of its row (operand map of the 32x32x16 MFMA).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-template <int TM, int TN, int WM, int WN, int BK, int NBUF>
-struct SplitGeom {
-    static constexpr int NW = WM * WN, NT = 64 * NW;
-    static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    static constexpr int PL = BK * 2;                           // bytes of one plane of one row
-    static constexpr int ROWB = 3 * PL + 16;                    // padded row stride (bytes)
-    static constexpr int S8 = BK / 8;                           // 8-float staging slots per row
-    static constexpr int A_SLOTS = (BM * S8 + NT - 1) / NT, B_SLOTS = (BN * S8 + NT - 1) / NT;
-    static constexpr int STAGE = (BM + BN) * ROWB;              // bytes per buffer
-    static constexpr int SMEM = NBUF * STAGE;
-    static constexpr int KSTEPS = BK / 16;
-};
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
     const f32x2 f = {x0, x1};
@@ -318,192 +302,6 @@ __device__ __forceinline__ void split8_store(char* dst, int plane_bytes, const f
     *reinterpret_cast<uint4*>(dst + plane_bytes) = mid;
     *reinterpret_cast<uint4*>(dst + 2 * plane_bytes) = lo;
 }
-
-template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split_kernel(GemmBatch G) {
-    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
-    constexpr int NT = GG::NT, BM = GG::BM, BN = GG::BN, ROWB = GG::ROWB, PL = GG::PL, S8 = GG::S8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    const GemmProblem& P = G.p[blockIdx.y];
-    const float* __restrict__ pA = P.A;
-    const float* __restrict__ pA2 = P.A2;
-    const float* __restrict__ pW = P.W;
-    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
-    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wn = w % WN, wm = w / WN;
-    const int nchunks = (K + BK - 1) / BK;
-
-    // staging slots of 8 consecutive k (K % 4 == 0: a slot is two float4, each all-valid or all-invalid)
-    float4 ra[GG::A_SLOTS][2], rb[GG::B_SLOTS][2];
-    const float* a1p[GG::A_SLOTS];
-    const float* a2p[GG::A_SLOTS];
-    const float* bp[GG::B_SLOTS];
-    int akc[GG::A_SLOTS], bkc[GG::B_SLOTS];
-    bool aok[GG::A_SLOTS], bok[GG::B_SLOTS];
-#pragma unroll
-    for (int s = 0; s < GG::A_SLOTS; ++s) {
-        const int slot = t + s * NT, r = slot / S8;
-        akc[s] = 8 * (slot % S8);
-        aok[s] = slot < BM * S8 && row0 + r < rows;
-        const int rc = min(row0 + r, rows - 1);
-        a1p[s] = pA + (size_t)rc * lda;
-        a2p[s] = pA2 ? pA2 + (size_t)rc * lda2 - K1 : a1p[s];
-    }
-#pragma unroll
-    for (int s = 0; s < GG::B_SLOTS; ++s) {
-        const int slot = t + s * NT, r = slot / S8;
-        bkc[s] = 8 * (slot % S8);
-        bok[s] = slot < BN * S8 && col0 + r < ncols;
-        bp[s] = pW + (size_t)min(col0 + r, ncols - 1) * K;
-    }
-    auto load_chunk = [&](int ch) {
-        const int k0 = ch * BK;
-#pragma unroll
-        for (int s = 0; s < GG::A_SLOTS; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int kc = min(k0 + akc[s] + 4 * q, K - 4);
-                ra[s][q] = *reinterpret_cast<const float4*>((kc < K1 ? a1p[s] : a2p[s]) + kc);
-            }
-#pragma unroll
-        for (int s = 0; s < GG::B_SLOTS; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                rb[s][q] = *reinterpret_cast<const float4*>(bp[s] + min(k0 + bkc[s] + 4 * q, K - 4));
-    };
-    auto store_chunk = [&](int ch) {
-        char* As = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE;
-        char* Bs = As + BM * ROWB;
-        const int k0 = ch * BK;
-#pragma unroll
-        for (int s = 0; s < GG::A_SLOTS; ++s) {
-            const int slot = t + s * NT;
-            if (slot < BM * S8) {
-                float4 u = ra[s][0], v = ra[s][1];
-                if (!(aok[s] && k0 + akc[s] < K)) u = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(aok[s] && k0 + akc[s] + 4 < K)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ABL == 1) {
-                    char* d = As + (slot / S8) * ROWB + akc[s] * 2;
-                    *reinterpret_cast<float4*>(d) = u; *reinterpret_cast<float4*>(d + PL) = v; *reinterpret_cast<float4*>(d + 2 * PL) = u;
-                } else
-                split8_store(As + (slot / S8) * ROWB + akc[s] * 2, PL, u, v, true);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < GG::B_SLOTS; ++s) {
-            const int slot = t + s * NT;
-            if (slot < BN * S8) {
-                float4 u = rb[s][0], v = rb[s][1];
-                if (!(bok[s] && k0 + bkc[s] < K)) u = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(bok[s] && k0 + bkc[s] + 4 < K)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ABL == 1) {
-                    char* d = Bs + (slot / S8) * ROWB + bkc[s] * 2;
-                    *reinterpret_cast<float4*>(d) = u; *reinterpret_cast<float4*>(d + PL) = v; *reinterpret_cast<float4*>(d + 2 * PL) = u;
-                } else
-                split8_store(Bs + (slot / S8) * ROWB + bkc[s] * 2, PL, u, v, true);
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    const int h = lane >> 5, l31 = lane & 31;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks && ABL != 2) load_chunk(ch + 1);
-        const char* As = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE + (wm * TM * 32 + l31) * ROWB + 16 * h;
-        const char* Bs = lds + (NBUF == 2 ? (ch & 1) : 0) * GG::STAGE + BM * ROWB + (wn * TN * 32 + l31) * ROWB + 16 * h;
-#pragma unroll
-        for (int ks = 0; ks < GG::KSTEPS; ++ks) {
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    a[i][p] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + p * PL + ks * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + p * PL + ks * 32);
-            // smallest terms first; consecutive MFMAs go to different accumulators
-#define DR_SPLIT_STEP(PA, PB)                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
-            if (ABL == 3) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(a[i][p]));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(b[j][p]));
-                continue;
-            }
-            DR_SPLIT_STEP(2, 0)
-            DR_SPLIT_STEP(0, 2)
-            DR_SPLIT_STEP(1, 1)
-            DR_SPLIT_STEP(1, 0)
-            DR_SPLIT_STEP(0, 1)
-            DR_SPLIT_STEP(0, 0)
-#undef DR_SPLIT_STEP
-        }
-        if (NBUF == 1) __syncthreads();
-        if (ch + 1 < nchunks) store_chunk(ch + 1);
-        __syncthreads();
-    }
-    gemm_epilogue<TM, TN>(P, [&](int i, int j) -> const f32x16& { return acc[i][j]; }, rows, ncols, row0, col0, wm, wn, lane);
-}
-
-template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
-static int configure_split() {
-    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_split_kernel<TM, TN, WM, WN, BK, NBUF, ABL>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM));
-    return DR_OK;
-}
-
-template <int TM, int TN, int WM, int WN, int BK, int NBUF, int ABL = 0>
-static int launch_split(const GemmBatch& g, hipStream_t st) {
-    using GG = SplitGeom<TM, TN, WM, WN, BK, NBUF>;
-    int maxt = 0;
-    for (int i = 0; i < g.n; ++i) {
-        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM) * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
-        maxt = tl > maxt ? tl : maxt;
-    }
-    if (maxt == 0) return DR_OK;
-    double flops = 0;
-    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
-    ProfScope ps(PK_GEMM, flops, st);
-    hipLaunchKernelGGL((gemm_nt_split_kernel<TM, TN, WM, WN, BK, NBUF, ABL>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
-    DR_LAUNCH_CHECK();
-    return DR_OK;
-}
-
-//                  TM TN WM WN BK NBUF
-#define SPL_128x128_1 2, 2, 2, 2, 32, 1   /* 53 KB */
-#define SPL_128x128_h 2, 2, 2, 2, 16, 2   /* 57 KB */
-#define SPL_128x64_2  2, 1, 2, 2, 32, 2   /* 80 KB */
-#define SPL_128x64_1  2, 1, 2, 2, 32, 1   /* 40 KB */
-#define SPL_64x64_1   1, 1, 2, 2, 32, 1   /* 27 KB */
-#define SPL_64x64_2   1, 1, 2, 2, 32, 2   /* 53 KB */
-#define SPL_256x64_1  2, 2, 4, 1, 32, 1   /* 256 x 64 tile, 4 waves stacked on rows: 67 KB */
-#define SPL_128x64_h  2, 1, 2, 2, 16, 2   /* 43 KB */
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1096,35 +894,13 @@ static int launch_wide(const GemmBatch& g, hipStream_t st) {
 #define CFG_SMALL  1, 1, 1, 1, 4, 128    /*  32 x  32 tile, k split over the 4 waves, deep chunks (latency-bound sizes) */
 #define CFG_MEDIUM 1, 1, 2, 2, 1, 64     /*  64 x  64 tile                                                            */
 #define CFG_LARGE  2, 1, 2, 2, 1, 32     /* 128 x  64 tile, 64 x 32 per wave                                          */
-#define CFG_XL     2, 2, 2, 2, 1, 32     /* 128 x 128 tile, 64 x 64 per wave (4 accumulator tiles)                    */
-#define CFG_L64    2, 1, 2, 2, 1, 64     /* experiment: 128 x 64 tile, 64-deep chunks (1 workgroup per CU)             */
-#define CFG_XL64   2, 2, 2, 2, 1, 64     /* experiment: 128 x 128 tile, 64-deep chunks                                 */
-#define CFG_L1B    2, 1, 2, 2, 1, 32, 1  /* 128 x  64 tile, single LDS buffer: 27 KB -> 5 workgroups per CU            */
-#define CFG_XL1B   2, 2, 2, 2, 1, 32, 1  /* 128 x 128 tile, single LDS buffer: 36 KB -> 4 workgroups per CU            */
 #define CFG_M1B    1, 1, 2, 2, 1, 32, 1  /*  64 x  64 tile, single LDS buffer: 18 KB -> 8 workgroups per CU            */
-#define CFG_M1B64  1, 1, 2, 2, 1, 64, 1  /*  64 x  64 tile, 64-deep chunks, single buffer: 35 KB -> 4 per CU             */
-#define CFG_LARGE8 1, 1, 4, 2, 1, 32     /* 128 x  64 tile, 8 waves of 32 x 32 (two per SIMD share the staged tiles)  */
 
 int gemm_configure() {
     int rc = configure_cfg<CFG_SMALL>();
     if (rc == DR_OK) rc = configure_cfg<CFG_MEDIUM>();
     if (rc == DR_OK) rc = configure_cfg<CFG_LARGE>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_LARGE8>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_XL>();
     if (rc == DR_OK) rc = configure_cfg<CFG_M1B>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_M1B64>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_L1B>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_XL1B>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_L64>();
-    if (rc == DR_OK) rc = configure_cfg<CFG_XL64>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x128_1>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x128_h>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_2>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_1>();
-    if (rc == DR_OK) rc = configure_split<SPL_64x64_1>();
-    if (rc == DR_OK) rc = configure_split<SPL_64x64_2>();
-    if (rc == DR_OK) rc = configure_split<SPL_256x64_1>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_h>();
     if (rc == DR_OK) rc = configure_wide<0>();
     if (rc == DR_OK) rc = configure_wide<1>();
     if (rc == DR_OK) rc = configure_wide<2>();
@@ -1134,16 +910,10 @@ int gemm_configure() {
     if (rc == DR_OK) rc = configure_wide8<2>();
     if (rc == DR_OK) rc = configure_wide8<2, 2>();
     if (rc == DR_OK) rc = configure_wide8<2, 3>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 1>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 2>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x64_1, 3>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 1>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 2>();
-    if (rc == DR_OK) rc = configure_split<SPL_128x128_1, 3>();
     return rc;
 }
 
-static int g_force_cfg = -1;   // tools/: force a configuration (0 small, 1 medium, 2 large)
+static int g_force_cfg = -1;   // tools / tests: force a configuration (0, 1, 2, 9: f32-MFMA tiles; 50..: wide split; 60..: 8-wave wide split)
 void gemm_force_config(int c) { g_force_cfg = c; }
 
 int gemm_wide_min_tiles() {
@@ -1162,18 +932,12 @@ static bool wide_ok(const GemmProblem& p) {
 
 int launch_gemm(const GemmBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 4) return DR_EINVAL;
-    long nL = 0, nM = 0, nX = 0;
-    double useful = 0, padded = 0;
+    long nM = 0;                    // 64 x 64 tiles of the launch
     for (int i = 0; i < g.n; ++i) {
         const GemmProblem& p = g.p[i];
         if (p.K % 4 || p.lda % 4 || (p.A2 && (p.K1 % 4 || p.lda2 % 4))) return DR_ENOSUP;
         if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2) & 15) return DR_ENOSUP;
-        nL += (long)((p.rows + 127) / 128) * ((p.ncols + 63) / 64);
         nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64) * (p.nbatch > 1 ? p.nbatch : 1);
-        const long tx = (long)((p.rows + 127) / 128) * ((p.ncols + 127) / 128);
-        nX += tx;
-        useful += (double)p.rows * p.ncols;
-        padded += (double)tx * 128 * 128;
     }
     // wide split-operand kernel: packed weights given and enough 128 x 224 tiles to occupy the chip
     long nW = 0;
@@ -1182,7 +946,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         wide = wide && wide_ok(g.p[i]);
         nW += (long)((g.p[i].rows + 127) / 128) * ((g.p[i].ncols + 223) / 224);
     }
-    static const int wide_min = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
+    const int wide_min = gemm_wide_min_tiles();
     // Launched alone, up to ~1.5 tiles per CU the 8-wave form (one workgroup per CU, two 16-chunks per barrier) is
     // 8-13 % faster (tools/gemm_split.py); inside the loop, where the engine keeps two batches in flight on two
     // streams, its 160 KB of LDS keeps the other stream's kernels off the CU and the 4-wave form wins by 2 %
@@ -1190,9 +954,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     static const int wide8_max = [] { const char* e = getenv("DR_GEMM_WIDE8_MAX"); return e ? atoi(e) : 0; }();
     if (wide && nW >= wide_min && g_force_cfg < 0) return nW <= wide8_max ? launch_wide8<2>(g, st) : launch_wide<0>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
-                                     // every configuration measured on the loop's shapes (tools/gemm_bench.py)
-    (void)nL;
-    (void)nX; (void)useful; (void)padded;              // 128 x 128 tiles (cfg 4) measured within noise of cfg 2: not auto-selected
+                                     // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
     static const int env_cfg = [] { const char* e = getenv("DR_GEMM_CFG"); return e ? atoi(e) : -1; }();   // tools/: tile experiments
     if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
     if (g_force_cfg >= 0) cfg = g_force_cfg;
@@ -1215,28 +977,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         if (cfg == 62) return launch_wide8<2, 2>(g, st);
         if (cfg == 63) return launch_wide8<2, 3>(g, st);
     }
-    if (cfg == 31) return launch_split<SPL_128x64_1, 1>(g, st);
-    if (cfg == 32) return launch_split<SPL_128x64_1, 2>(g, st);
-    if (cfg == 33) return launch_split<SPL_128x64_1, 3>(g, st);
-    if (cfg == 41) return launch_split<SPL_128x128_1, 1>(g, st);
-    if (cfg == 42) return launch_split<SPL_128x128_1, 2>(g, st);
-    if (cfg == 43) return launch_split<SPL_128x128_1, 3>(g, st);
-    if (cfg == 20) return launch_split<SPL_128x128_1>(g, st);
-    if (cfg == 21) return launch_split<SPL_128x128_h>(g, st);
-    if (cfg == 22) return launch_split<SPL_128x64_2>(g, st);
-    if (cfg == 23) return launch_split<SPL_128x64_1>(g, st);
-    if (cfg == 24) return launch_split<SPL_64x64_1>(g, st);
-    if (cfg == 25) return launch_split<SPL_64x64_2>(g, st);
-    if (cfg == 26) return launch_split<SPL_256x64_1>(g, st);
-    if (cfg == 27) return launch_split<SPL_128x64_h>(g, st);
-    if (cfg == 10) return launch_cfg<CFG_M1B64>(g, st);
     if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
-    if (cfg == 8) return launch_cfg<CFG_XL1B>(g, st);
-    if (cfg == 7) return launch_cfg<CFG_L1B>(g, st);
-    if (cfg == 6) return launch_cfg<CFG_XL64>(g, st);
-    if (cfg == 5) return launch_cfg<CFG_L64>(g, st);
-    if (cfg == 4) return launch_cfg<CFG_XL>(g, st);
-    if (cfg == 3) return launch_cfg<CFG_LARGE8>(g, st);
     if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
     if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
     return launch_cfg<CFG_SMALL>(g, st);

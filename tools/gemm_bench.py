@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from diffreg_hip import lib
 lib.ensure_init()
 dev = "cuda:0"
-CFGS = [int(c) for c in os.environ.get("CFGS", "0,1,2,3,-1").split(",")]
+CFGS = [int(c) for c in os.environ.get("CFGS", "0,1,2,9,-1").split(",")]
 shapes = [(16384, 432, 432), (16384, 432, 864), (4096, 432, 432), (4096, 864, 864), (4096, 432, 864), (256, 432, 432), (512, 432, 432), (512, 864, 864), (512, 432, 864), (256, 864, 864), (256, 256, 432),
           (2048, 432, 432), (2048, 864, 864), (8192, 432, 432), (8192, 864, 864), (8192, 432, 864), (16384, 864, 864)]
 for rows, ncols, K in shapes:

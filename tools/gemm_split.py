@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from diffreg_hip import lib
 lib.ensure_init()
 dev = "cuda:0"
-CFGS = [int(c) for c in os.environ.get("CFGS", "9,20,21,22,23,24,25,26,27").split(",")]
+CFGS = [int(c) for c in os.environ.get("CFGS", "9,50,60,61").split(",")]
 shapes = [(8192, 432, 432), (8192, 432, 864), (16384, 432, 432), (8192, 864, 864), (1000, 432, 436), (256, 432, 432)]
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
