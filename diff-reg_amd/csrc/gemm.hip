@@ -916,9 +916,11 @@ int gemm_configure() {
 static int g_force_cfg = -1;   // tools / tests: force a configuration (0, 1, 2, 9: f32-MFMA tiles; 50..: wide split; 60..: 8-wave wide split)
 void gemm_force_config(int c) { g_force_cfg = c; }
 
+static int g_wide_min = -1;      // tests: force the threshold (-1 = environment / default)
+void gemm_force_wide_min(int n) { g_wide_min = n; }
 int gemm_wide_min_tiles() {
     static const int v = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
-    return v;
+    return g_wide_min >= 0 ? g_wide_min : v;
 }
 
 // shapes / alignments the wide split kernel takes (everything else stays on the f32-MFMA kernels)

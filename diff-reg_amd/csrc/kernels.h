@@ -50,6 +50,7 @@ struct GemmBatch {
 
 int launch_gemm(const GemmBatch& g, hipStream_t st);
 size_t gemm_packed_weight_bytes(int ncols, int K);
+void gemm_force_wide_min(int n);
 int gemm_wide_min_tiles();   // launches with fewer 128 x 224 tiles stay on the f32-MFMA kernels
 int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t st);
 int gemm_configure();

@@ -325,6 +325,7 @@ int dr_init(void) {
 
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
+void dr_debug_gemm_wide_min(int tiles) { gemm_force_wide_min(tiles); }
 void dr_debug_attention_config(int flash_min_workgroups) { attention_force_flash_min(flash_min_workgroups); }
 void dr_debug_attention_split(int on) { attention_force_split(on); }
 int dr_debug_gemm_stamps(long long* h_out256) { return read_gemm_stamps(h_out256); }

@@ -153,6 +153,9 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
 
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c);
+/* launches with at least this many 128 x 224 tiles use the packed split-operand GEMM (default 128; -1 restores it).
+ * Set it BEFORE sizing a loop workspace: it decides whether the loop packs its weights. */
+void dr_debug_gemm_wide_min(int tiles);
 
 /* diagnostics for tools/: 8 wall-clock stamps (100 MHz ticks) of the phases of the last
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
