@@ -107,23 +107,55 @@ def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):
     ms = torch.ones(1, N, dtype=torch.bool)
     mt = torch.ones(1, M, dtype=torch.bool)
 
+    kept = []                                         # (seed, match_pred, inlier ratio) of the timed pairs: the parity sample
+
     def one(seed):
         p = synth.make_pair(N, M, v["C"], seed=seed)
         T = lambda a: torch.from_numpy(a)[None]
         t0 = time.perf_counter()
-        orc.denoise_loop(W, v, T(p["src_feats"]), T(p["tgt_feats"]), T(p["s_pcd"]), T(p["t_pcd"]), ms, mt, T(p["x_T"]),
-                         steps, mc, variant=variant)
-        return time.perf_counter() - t0
+        o = orc.denoise_loop(W, v, T(p["src_feats"]), T(p["tgt_feats"]), T(p["s_pcd"]), T(p["t_pcd"]), ms, mt, T(p["x_T"]),
+                             steps, mc, variant=variant)
+        dt = time.perf_counter() - t0
+        if "match_pred" in o:
+            kept.append((seed, o["match_pred"], orc.inlier_ratio(o["match_pred"], T(p["s_pcd"]), T(p["t_pcd"]), p["R_gt"], p["t_gt"])))
+        return dt
     t_start = time.perf_counter()
     times = [one(1000)]                               # warm-up pair (kept only if the budget is already spent)
     if time.perf_counter() - t_start < budget_s:
         times = []
+        kept.clear()
         while not times or (time.perf_counter() - t_start < budget_s and len(times) < 10):
             times.append(one(1001 + len(times)))
     med = float(np.median(times))
     return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d pairs of N=M=%d, %d denoise steps after 1 warm-up pair (median %.3f s/pair); "
-                       "oracle/diffreg_oracle.py on torch %s CPU" % (len(times), N, steps, med, torch.__version__))
+                       "oracle/diffreg_oracle.py on torch %s CPU" % (len(times), N, steps, med, torch.__version__)), kept
+
+
+def ir_fmr_parity(eng, variant, N, M, kept, device):
+    """The metric's parity leg: inlier ratio (3D/models/loss.py:383-410, thr 0.1) and feature-matching recall
+    (IR > 0.05, 3D/lib/tester.py:83-85) of the HIP loop's match_pred against the oracle's on the same synthetic pairs
+    (ground-truth pose of the generator)."""
+    from oracle import diffreg_oracle as orc
+    seeds = [k[0] for k in kept]
+    prs, inp = make_inputs(variant, len(seeds), N, M, seed0=seeds[0], device=device)
+    assert seeds == list(range(seeds[0], seeds[0] + len(seeds)))
+    out = eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)
+    torch.cuda.synchronize()
+    ml = eng.match_list(out)
+    ir_hip, ir_ref, jac = [], [], []
+    for i, (seed, mref, irr) in enumerate(kept):
+        p = prs[i]
+        mh = ml[i].cpu()
+        ir_hip.append(orc.inlier_ratio(mh, torch.from_numpy(p["s_pcd"])[None], torch.from_numpy(p["t_pcd"])[None], p["R_gt"], p["t_gt"]))
+        ir_ref.append(irr)
+        a, b = set(map(tuple, mh[:, 1:].tolist())), set(map(tuple, mref[:, 1:].tolist()))
+        jac.append(len(a & b) / max(1, len(a | b)))
+    ir_hip, ir_ref = np.array(ir_hip), np.array(ir_ref)
+    return dict(pairs=len(kept), ir_hip=float(ir_hip.mean()), ir_oracle=float(ir_ref.mean()),
+                max_abs_ir_diff=float(np.abs(ir_hip - ir_ref).max()), fmr_hip=float((ir_hip > 0.05).mean()),
+                fmr_oracle=float((ir_ref > 0.05).mean()), match_set_jaccard_min=float(min(jac)),
+                tolerance="IR / FMR within 0.1 (north_star)", note="synthetic scenes, generator ground truth; oracle = CPU restatement pinned to the reference")
 
 
 def main():
@@ -276,7 +308,9 @@ def main():
         if "roofline" not in result and "sinkhorn_roofline" in result:
             result["roofline"] = result["sinkhorn_roofline"]
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(variant, N, M, S, args.max_condition_num)
+            result["cpu_baseline"], kept = cpu_baseline(variant, N, M, S, args.max_condition_num)
+            if kept:
+                result["ir_fmr_parity"] = ir_fmr_parity(eng, variant, N, M, kept, dev)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

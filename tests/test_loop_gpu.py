@@ -179,6 +179,31 @@ def test_loop_against_oracle_fresh_seed(seed):
         assert_matrix_parity(out["conf_matrix_pred"][0].cpu().numpy(), ref["conf_matrix_pred"][0].numpy(), conf_f64, "conf")
 
 
+def test_inlier_ratio_and_fmr_parity():
+    """The metric's parity leg: inlier ratio (3D/models/loss.py:383-410) and FMR (IR > 0.05,
+    3D/lib/tester.py:83-85) of the HIP loop's match_pred against the oracle's on synthetic pairs with the generator's
+    ground-truth pose: within 0.1 (north_star); measured identical."""
+    variant, N, M, steps, mc = "3dmatch", 128, 128, 5, 200
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    eng = engine(variant, steps, mc)
+    seeds = (41, 42, 43, 44)
+    raws, ps = zip(*[pair(variant, N, M, s) for s in seeds])
+    cat = lambda k: torch.cat([q[k] for q in ps]).to(DEV)
+    out = eng.run(cat("f_s"), cat("f_t"), cat("p_s"), cat("p_t"), cat("x_T"))
+    ml = eng.match_list(out)
+    ms, mt = masks(N, M)
+    ir_hip, ir_ref = [], []
+    for i, (raw, p) in enumerate(zip(raws, ps)):
+        ref = orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc, variant=variant)
+        ir_ref.append(orc.inlier_ratio(ref["match_pred"], p["p_s"], p["p_t"], raw["R_gt"], raw["t_gt"]))
+        ir_hip.append(orc.inlier_ratio(ml[i].cpu(), p["p_s"], p["p_t"], raw["R_gt"], raw["t_gt"]))
+    ir_hip, ir_ref = np.array(ir_hip), np.array(ir_ref)
+    assert np.abs(ir_hip - ir_ref).max() <= 0.1, (ir_hip, ir_ref)
+    assert abs((ir_hip > 0.05).mean() - (ir_ref > 0.05).mean()) <= 0.1
+    assert ir_ref.mean() > 0.2            # the scenes do have true correspondences: the comparison is not vacuous
+
+
 def test_cfg3_shape_4dmatch_512():
     """BASELINE configs[2] shape (4DMatch, N = M = 512, C = 528, d_head = 132): tiles larger than the register-resident
     Sinkhorn / Procrustes paths, two pairs with different padding masks, 2 denoise steps, against the oracle."""
