@@ -890,6 +890,108 @@ static int launch_wide(const GemmBatch& g, hipStream_t st) {
     return DR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Latency form for the single-pair case (a few hundred rows: every GEMM of the loop is one short wave of workgroups
+// whose time is load latency, not arithmetic).  One 32 x 32 output tile per workgroup, 8 waves, the k range dealt to
+// the waves in groups of 8 (wave w: groups w, w + 8, ..); a lane's MFMA fragments are float4s of "its" row, so they
+// are loaded STRAIGHT from global memory into registers -- all of a wave's loads are in flight at once, there is no
+// LDS staging, no k loop with a barrier per chunk -- then 4 f32-input MFMAs per group, and one LDS pass adds the NW
+// partial tiles (NW = 8 or 16 waves by the length of k; a wave reduces and stores 16 / NW registers of the tile).
+template <int NW, int MAXG>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4))) void gemm_nt_direct_kernel(GemmBatch G) {
+    __shared__ float red[NW * 16 * 64];
+    const GemmProblem& P = G.p[blockIdx.y];
+    if ((int)blockIdx.z >= max(P.nbatch, 1)) return;
+    const float* __restrict__ pA = P.A + (size_t)blockIdx.z * P.sA;
+    const float* __restrict__ pA2 = P.A2;
+    const float* __restrict__ pW = P.W + (size_t)blockIdx.z * P.sW;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K;
+    const int tiles_n = (ncols + 31) / 32, tiles_m = (rows + 31) / 32;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int row0 = tm * 32, col0 = tn * 32;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ngroups = (K + 7) / 8;
+
+    const int ar = min(row0 + l31, rows - 1), bc = min(col0 + l31, ncols - 1);
+    const float* a1 = pA + (size_t)ar * P.lda;
+    const float* a2 = pA2 ? pA2 + (size_t)ar * P.lda2 - K1 : a1;
+    const float* bw = pW + (size_t)bc * K;
+    float4 fa[MAXG], fb[MAXG];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int k = 8 * (w + NW * i) + 4 * h;                 // K % 4 == 0: a float4 is all inside or all outside
+        const int kc = min(k, K - 4);
+        fa[i] = *reinterpret_cast<const float4*>((kc < K1 ? a1 : a2) + kc);
+        fb[i] = *reinterpret_cast<const float4*>(bw + kc);
+    }
+    __builtin_amdgcn_sched_barrier(0);                          // every load is issued before the first MFMA waits for one
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const bool ok = 8 * (w + NW * i) + 4 * h < K;           // groups past the end (and the k tail of the last one) add zeros
+        float4 a = fa[i];
+        if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = fb[i];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[1], 0, 0, 0);
+    }
+    (void)ngroups;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[0][r] + acc[1][r];
+    __syncthreads();
+    // wave w finishes registers (16 / NW) w ..: rows (r & 3) + 8 (r >> 2) + 4 h, column l31
+    const int halfC = P.rot_C >> 1;
+    const int col = col0 + l31;
+    const bool col_ok = col < ncols;
+    const int ridx = (P.epi & EPI_ROTARY) ? (col % P.rot_C) >> 1 : 0;
+    float* __restrict__ outp = P.out + (size_t)blockIdx.z * P.sO;
+#pragma unroll
+    for (int e = 0; e < 16 / NW; ++e) {
+        const int r = (16 / NW) * w + e;
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < NW; ++o) v += red[(o * 16 + r) * 64 + lane];
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (P.epi & EPI_ROTARY) {
+            const float other = __shfl_xor(v, 1);
+            if (row < rows && col_ok) {
+                const float c = P.cosT[(size_t)row * halfC + ridx], sn = P.sinT[(size_t)row * halfC + ridx];
+                const float sw = (col & 1) ? other : -other;
+                v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(sw, sn));
+            }
+        }
+        if (P.bias && col_ok) v += P.bias[col];
+        if (P.epi & EPI_RELU) v = fmaxf(v, 0.f);
+        v *= P.scale;
+        if (row < rows && col_ok) {
+            if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
+            outp[(size_t)row * P.ldo + col] = v;
+        }
+    }
+}
+
+template <int NW, int MAXG>
+static int launch_direct(const GemmBatch& g, hipStream_t st) {
+    int maxt = 0, maxb = 1;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = ((g.p[i].rows + 31) / 32) * ((g.p[i].ncols + 31) / 32);
+        maxt = tl > maxt ? tl : maxt;
+        maxb = g.p[i].nbatch > maxb ? g.p[i].nbatch : maxb;
+        flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
+    }
+    if (maxt == 0) return DR_OK;
+    ProfScope ps(PK_GEMM, flops, st);
+    hipLaunchKernelGGL((gemm_nt_direct_kernel<NW, MAXG>), dim3(maxt, g.n, maxb), dim3(64 * NW), 0, st, g);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
 //                 TM TN WM WN WK BKC
 #define CFG_SMALL  1, 1, 1, 1, 4, 128    /*  32 x  32 tile, k split over the 4 waves, deep chunks (latency-bound sizes) */
 #define CFG_MEDIUM 1, 1, 2, 2, 1, 64     /*  64 x  64 tile                                                            */
@@ -955,6 +1057,15 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     // (bench.py, DR_GEMM_WIDE8_MAX sweep) -- so it is opt-in.
     static const int wide8_max = [] { const char* e = getenv("DR_GEMM_WIDE8_MAX"); return e ? atoi(e) : 0; }();
     if (wide && nW >= wide_min && g_force_cfg < 0) return nW <= wide8_max ? launch_wide8<2>(g, st) : launch_wide<0>(g, st);
+    // latency form: few tiles (the whole launch is one short wave of workgroups) and a k range that fits the registers
+    int maxK = 0;
+    long n32 = 0;
+    for (int i = 0; i < g.n; ++i) {
+        maxK = g.p[i].K > maxK ? g.p[i].K : maxK;
+        n32 += (long)((g.p[i].rows + 31) / 32) * ((g.p[i].ncols + 31) / 32) * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
+    }
+    static const int direct_max = [] { const char* e = getenv("DR_GEMM_DIRECT_MAX"); return e ? atoi(e) : 1024; }();
+    if (g_force_cfg < 0 && n32 <= direct_max && maxK <= 16 * 8 * 7) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
     static const int env_cfg = [] { const char* e = getenv("DR_GEMM_CFG"); return e ? atoi(e) : -1; }();   // tools/: tile experiments
@@ -979,6 +1090,8 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         if (cfg == 62) return launch_wide8<2, 2>(g, st);
         if (cfg == 63) return launch_wide8<2, 3>(g, st);
     }
+    if (cfg == 11) return launch_direct<8, 7>(g, st);
+    if (cfg == 12) return launch_direct<16, 7>(g, st);
     if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
     if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
     if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
