@@ -612,6 +612,231 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-workgroup form of the stream kernel for tiles beyond the register-resident path (4DMatch 512 x 512,
+// 2D-3D 1024 x 2048: one workgroup per tile left 255 CUs idle and took 4.9 ms per call at 1024 x 2048).
+// A tile is cut into G row blocks, one 256-thread workgroup each; the same scaling iteration, split at the
+// points where a column sum needs every row block:
+//   phase 0   rho_i, E_ij = exp(z_ij - rho_i) -> workspace, a_i from b = 1, column partials sum_i E_ij a_i of the block
+//   phase 1   (iters - 1 times) b_j from the partials of all blocks; a_i = mu / (sum_j E_ij b_j + ..); new partials
+//   phase 2   b_j from the last partials; out_ij = E_ij a_i b_j e^-norm  (or the log form)
+// A wave keeps the row it works on in registers between the row sum and the column accumulation (one read of E per
+// phase), its column accumulators too (lane l owns columns l, l + 64, ..): CPL = columns per lane, M <= 64 CPL.
+// Launch boundaries are the grid-wide synchronisation; per-tile vectors (a, e^(alpha - rho), rho, the G x M partials,
+// the dustbin scalings) live in the workspace behind E.  Deterministic: no atomics, fixed summation order.
+// ---------------------------------------------------------------------------------------------
+struct SkGridArgs {
+    SkArgs k;
+    int G, R, phase, it;       // row blocks per tile, rows per block, phase, iteration index of phase 1
+    size_t tile_stride;        // workspace elements (of T) per tile
+};
+
+template <typename T>
+__host__ __device__ inline size_t sk_grid_tile_elems(int N, int M, int G, int iters) {
+    return (size_t)N * M + 3 * (size_t)N + 1 + (size_t)G * M + G + iters + 2 + 8;
+}
+
+template <typename TIn, typename T, typename TOut, int CPL>
+__global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
+    const SkArgs& A = GA.k;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = A.N, M = A.M, G = GA.G;
+    T* s_b = reinterpret_cast<T*>(smem);         // [M + 1]
+    T* s_col = s_b + (M + 1);                    // [4][M] per-wave column partials
+    T* s_scr = s_col + 4 * (size_t)M;            // [16]
+    __shared__ int s_cnt[2];
+
+    const int tile = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M;
+    T* base = reinterpret_cast<T*>(A.ws) + (size_t)tile * GA.tile_stride;
+    T* Ew = base;
+    T* g_a = Ew + (size_t)N * M;                 // [N + 1]
+    T* g_ed = g_a + (N + 1);                     // [N]
+    T* g_rho = g_ed + N;                         // [N]
+    T* g_cpart = g_rho + N;                      // [G][M]
+    T* g_dpart = g_cpart + (size_t)G * M;        // [G]
+    T* g_aN = g_dpart + G;                       // [iters + 1]: dustbin-row scaling after pass k
+    const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
+    const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
+    const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0;
+    const T alpha = (T)(*A.bin_score);
+
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        for (int i = t; i < N; i += 256) c0 += sm ? (sm[i] != 0) : 1;
+        for (int j = t; j < M; j += 256) c1 += tm ? (tm[j] != 0) : 1;
+        if (c0) atomicAdd(&s_cnt[0], c0);
+        if (c1) atomicAdd(&s_cnt[1], c1);
+    }
+    __syncthreads();
+    const int ms = s_cnt[0], ns = s_cnt[1];
+    const float normf = -logf((float)(ms + ns));                 // float32 marginals (quirk Q22)
+    const float lmuN = logf((float)ns) + normf, lnuM = logf((float)ms) + normf;
+    const T mu = t_exp<T>((T)normf), muN = t_exp<T>((T)lmuN), nu = mu, nuM = t_exp<T>((T)lnuM);
+    const T xmin = A.shift ? (T)A.shift[tile] : (T)0;
+    const int r0 = g * GA.R, r1 = min(N, r0 + GA.R);
+
+    // ---- b of the previous pass from the column partials of every block (phases 1, 2) ---------------------
+    T aN = muN / ((T)M + (T)1), bM = 1;
+    if (GA.phase > 0) {
+        aN = g_aN[GA.it - 1 + 0];                               // a_N the partials were built with
+        T dp = 0;
+        for (int q = 0; q < G; ++q) dp += g_dpart[q];
+        bM = nuM / (dp + aN);
+        for (int j = t; j < M; j += 256) {
+            T sacc = 0;
+            for (int q = 0; q < G; ++q) sacc += g_cpart[(size_t)q * M + j];
+            s_b[j] = nu / (sacc + aN);
+        }
+        if (t == 0) s_b[M] = bM;
+        __syncthreads();
+    }
+
+    if (GA.phase == 2) {
+        if (A.flags & DR_SK_OUT_LOG) {
+            TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * (N + 1) * (M + 1);
+            const T nrm = (T)normf;
+            const int re = (g == G - 1) ? N + 1 : r1;           // the last block also writes the dustbin row
+            for (int i = r0 + w; i < re; i += 4) {
+                const T ai = (i < N) ? g_a[i] : g_aN[GA.it - 1];
+                const T u = t_log<T>(ai) - (i < N ? g_rho[i] : alpha);
+                for (int j = lane; j <= M; j += WAVE) {
+                    T z = alpha;
+                    if (i < N && j < M) {
+                        z = (T)src[(size_t)i * M + j] - xmin;
+                        if (apply && ((sm && !sm[i]) || (tm && !tm[j]))) z = -(T)INFINITY;
+                    }
+                    dst[(size_t)i * (M + 1) + j] = (TOut)(z + u + t_log<T>(s_b[j]) - nrm);
+                }
+            }
+        } else {
+            TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M;
+            const T S = t_exp<T>(-(T)normf);
+            for (int i = r0 + w; i < r1; i += 4) {
+                const T ai = g_a[i] * S;
+                for (int j = lane; j < M; j += WAVE) dst[(size_t)i * M + j] = (TOut)(Ew[(size_t)i * M + j] * ai * s_b[j]);
+            }
+        }
+        return;
+    }
+
+    // ---- phases 0 / 1: rows of this block, one wave per row; the row stays in registers -----------------------
+    T bs = 0;
+    if (GA.phase == 1) {
+        for (int j = t; j < M; j += 256) bs += s_b[j];
+        bs = wave_sum(bs);
+        if (lane == 0) s_scr[w] = bs;
+        __syncthreads();
+        bs = s_scr[0] + s_scr[1] + s_scr[2] + s_scr[3];
+    }
+    const T aN_new = (GA.phase == 0) ? aN : muN / (bs + bM);
+    T cacc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) cacc[k] = 0;
+    T dacc = 0;
+    for (int i = r0 + w; i < r1; i += 4) {
+        T e[CPL];
+        T ai, ed;
+        if (GA.phase == 0) {
+            T m = alpha;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = lane + WAVE * k;
+                T v = -(T)INFINITY;
+                if (j < M) {
+                    v = (T)src[(size_t)i * M + j] - xmin;
+                    if (apply && ((sm && !sm[i]) || (tm && !tm[j]))) v = -(T)INFINITY;
+                }
+                e[k] = v;
+                m = v > m ? v : m;
+            }
+            m = wave_max(m);
+            T rs = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = lane + WAVE * k;
+                const T ex = (j < M) ? t_exp<T>(e[k] - m) : (T)0;
+                e[k] = ex;
+                if (j < M) Ew[(size_t)i * M + j] = ex;
+                rs += ex;
+            }
+            rs = wave_sum(rs);
+            ed = t_exp<T>(alpha - m);
+            ai = mu / (rs + ed);
+            if (lane == 0) { g_rho[i] = m; g_ed[i] = ed; g_a[i] = ai; }
+        } else {
+            T rs = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = lane + WAVE * k;
+                const T ex = (j < M) ? Ew[(size_t)i * M + j] : (T)0;
+                e[k] = ex;
+                rs += (j < M) ? ex * s_b[j] : (T)0;
+            }
+            rs = wave_sum(rs);
+            ed = g_ed[i];
+            ai = mu / (rs + ed * bM);
+            if (lane == 0) g_a[i] = ai;
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) cacc[k] += e[k] * ai;
+        dacc += ed * ai;                                        // same value in every lane
+    }
+    // column partials of the block: 4 waves -> LDS -> workspace
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = lane + WAVE * k;
+        if (j < M) s_col[(size_t)w * M + j] = cacc[k];
+    }
+    if (lane == 0) s_scr[8 + w] = dacc;
+    __syncthreads();
+    for (int j = t; j < M; j += 256)
+        g_cpart[(size_t)g * M + j] = s_col[j] + s_col[(size_t)M + j] + s_col[2 * (size_t)M + j] + s_col[3 * (size_t)M + j];
+    if (t == 0) {
+        g_dpart[g] = s_scr[8] + s_scr[9] + s_scr[10] + s_scr[11];
+        if (g == 0) g_aN[GA.it] = aN_new;                       // phase 0: it = 0; phase 1: it = 1 .. iters - 1
+        if (g == 0 && GA.phase == 0) g_a[N] = aN_new;
+    }
+}
+
+template <typename TIn, typename T, typename TOut, int CPL>
+static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
+    SkGridArgs ga;
+    ga.k = a; ga.G = G; ga.R = (a.N + G - 1) / G;
+    ga.tile_stride = sk_grid_tile_elems<T>(a.N, a.M, G, a.iters);
+    const size_t lds = ((size_t)5 * a.M + 1 + 16) * sizeof(T) + 16;
+    if (lds > 64 * 1024)
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_grid_kernel<TIn, T, TOut, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int ph = 0; ph <= a.iters; ++ph) {
+        ga.phase = ph == 0 ? 0 : (ph == a.iters ? 2 : 1);
+        ga.it = ph;                                              // phase 1/2 read g_aN[it - 1], phases 0/1 write g_aN[it]
+        hipLaunchKernelGGL((sk_grid_kernel<TIn, T, TOut, CPL>), dim3(G, a.B), dim3(256), lds, st, ga);
+        DR_LAUNCH_CHECK();
+    }
+    return DR_OK;
+}
+
+static int sk_grid_blocks(int B, int N) {
+    // enough workgroups for the chip, at least 8 rows (two per wave) per block, at most 32 blocks (each block reads
+    // the partials of all of them)
+    int G = (768 + B - 1) / B;
+    if (G > 32) G = 32;
+    if (G > (N + 7) / 8) G = (N + 7) / 8;
+    return G < 1 ? 1 : G;
+}
+
+static bool grid_path(int N, int M, int flags) { return !(flags & DR_SK_MINSHIFT) && M <= 64 * 32; }
+
+template <typename TIn, typename T, typename TOut>
+static int launch_grid(const SkArgs& a, hipStream_t st) {
+    const int G = sk_grid_blocks(a.B, a.N);
+    if (a.M <= 64 * 8) return launch_grid_cpl<TIn, T, TOut, 8>(a, G, st);
+    if (a.M <= 64 * 16) return launch_grid_cpl<TIn, T, TOut, 16>(a, G, st);
+    return launch_grid_cpl<TIn, T, TOut, 32>(a, G, st);
+}
+
 static size_t stream_lds_bytes(int N, int M, size_t esz) { return ((size_t)3 * N + M + 2 + 1024 + 32) * esz + 16; }
 
 template <typename TIn, typename T, typename TOut>
@@ -659,6 +884,14 @@ static bool reg_path(int N, int M, int flags) {
     return !(flags & (DR_SK_STRICT | DR_SK_OUT_LOG)) && N <= 256 && M <= 256;
 }
 
+// workspace of the non-register paths: E per tile (stream kernel), plus the per-tile vectors of the grid form
+// (sized for the largest iteration count the library is used with, so that the size does not depend on it)
+static size_t sk_workspace_need(int B, int N, int M, int esz, int flags, int iters) {
+    if (!grid_path(N, M, flags)) return (size_t)B * N * M * esz;
+    const int G = sk_grid_blocks(B, N);
+    return (size_t)B * sk_grid_tile_elems<float>(N, M, G, iters > 16 ? iters : 16) * esz;
+}
+
 template <typename TIn>
 static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const double* shift, const uint8_t* src_mask,
                              const uint8_t* tgt_mask, const float* bin_score, int iters, int flags, void* out, void* ws,
@@ -684,9 +917,17 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
         return launch_reg<TIn, double>(a, st);
     }
     const bool strict64 = in64 && (flags & DR_SK_STRICT);
-    const size_t need = (size_t)B * N * M * (strict64 ? 8 : 4);
+    const size_t need = sk_workspace_need(B, N, M, strict64 ? 8 : 4, flags, iters);
     if (!ws || ws_bytes < need) return DR_EWORKSPACE;
     a.vec_in = a.vec_out = 0;
+    if (grid_path(N, M, flags)) {
+        if (strict64) {
+            if (out32) return launch_grid<TIn, double, float>(a, st);
+            return launch_grid<TIn, double, double>(a, st);
+        }
+        if (out32) return launch_grid<TIn, float, float>(a, st);
+        return launch_grid<TIn, float, double>(a, st);
+    }
     if (strict64) {
         if (out32) return launch_stream<TIn, double, float>(a, st);
         return launch_stream<TIn, double, double>(a, st);
@@ -712,7 +953,7 @@ size_t dr_sinkhorn_workspace_bytes(int B, int N, int M, int elem_bytes, int flag
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     if (dr::reg_path(N, M, flags)) return 0;
     const bool strict64 = elem_bytes == 8 && (flags & DR_SK_STRICT);
-    return (size_t)B * N * M * (strict64 ? 8 : 4);
+    return dr::sk_workspace_need(B, N, M, strict64 ? 8 : 4, flags, 16);
 }
 
 int dr_sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,
