@@ -103,9 +103,12 @@ int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R,
 // ---------------------------------------------------------------------------------------------
 // top-K weighted Procrustes (procrustes.hip)
 // ---------------------------------------------------------------------------------------------
+// ws (optional, procrustes_workspace_bytes): lets tiles beyond 256 x 256 select their candidates with the whole chip
+size_t procrustes_workspace_bytes(int P, int N, int M);
 int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_pcd, const uint8_t* src_mask,
                       const uint8_t* tgt_mask, int P, int N, int M, int use_mask_len, float sample_rate, float max_cond,
-                      float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st);
+                      float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st,
+                      void* ws = nullptr, size_t ws_bytes = 0);
 
 int read_proc_stamps(long long* h_out);
 

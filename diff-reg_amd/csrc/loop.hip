@@ -286,6 +286,8 @@ struct LoopWs {
     uint8_t* tokmask;
     void* skws;
     size_t skws_bytes;
+    void* pws;
+    size_t pws_bytes;
     static size_t carve(Carver& c, LoopWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), NM = (size_t)P * N * M;
         DenoiseWs::carve(c, w.dw, P, N, M, cfg.C, cfg.n_layers);
@@ -307,6 +309,8 @@ struct LoopWs {
         size_t b = dr_sinkhorn_workspace_bytes(P, N, M, 4, 0);
         w.skws_bytes = a > b ? a : b;
         w.skws = w.skws_bytes ? (void*)c.take<char>(w.skws_bytes) : nullptr;
+        w.pws_bytes = procrustes_workspace_bytes(P, N, M);
+        w.pws = w.pws_bytes ? (void*)c.take<char>(w.pws_bytes) : nullptr;
         return c.off + 256;
     }
 };
@@ -548,7 +552,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         if (rc) return rc;
         // -- denoising_soft_procrustes (pipeline.py:304)
         rc = launch_procrustes(L.wconf, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
-                               cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st);
+                               cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
         if (rc) return rc;
         if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
         if (trace && trace->t_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->t_forwd + (size_t)k * P * 3, L.tf, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
@@ -598,7 +602,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = launch_f64_to_f32(conf, L.conf32, NM, st);
         if (rc) return rc;
         rc = launch_procrustes(L.conf32, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
-                               cfg->max_condition_num, R_final, t_final, L.Rf, L.tf, L.cond, L.ok, nullptr, st);
+                               cfg->max_condition_num, R_final, t_final, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
         if (rc) return rc;
     }
     return DR_OK;

@@ -26,6 +26,7 @@ struct F2Ws {
     double *x, *cond;
     int* ok;
     void* skws; size_t skws_bytes;
+    void* pws; size_t pws_bytes;
     static size_t carve(Carver2& c, F2Ws& w, const dr_loop2d3d_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), C = cfg.C, NM = (size_t)P * N * M, PM = (size_t)P * M, PN = (size_t)P * N;
         w.tok0 = c.take<float>(T * C); w.ta = c.take<float>(T * C); w.tb = c.take<float>(T * C);
@@ -42,6 +43,8 @@ struct F2Ws {
         size_t a = dr_sinkhorn_workspace_bytes(P, N, M, 8, strict), b = dr_sinkhorn_workspace_bytes(P, N, M, 4, 0);
         w.skws_bytes = a > b ? a : b;
         w.skws = w.skws_bytes ? (void*)c.take<char>(w.skws_bytes) : nullptr;
+        w.pws_bytes = procrustes_workspace_bytes(P, N, M);
+        w.pws = w.pws_bytes ? (void*)c.take<char>(w.pws_bytes) : nullptr;
         return c.off + 256;
     }
 };
@@ -211,7 +214,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
                           DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
         rc = launch_procrustes(L.wconf, s_pcd, t_pcd_da, src_mask, tgt_mask_da, P, N, M, 1, cfg->sample_rate, cfg->max_condition_num,
-                               L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st);
+                               L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
         if (rc) return rc;
         if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
         if (trace && trace->t_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->t_forwd + (size_t)k * P * 3, L.tf, (size_t)P * 12, hipMemcpyDeviceToDevice, st));

@@ -123,7 +123,17 @@ struct ProcArgs {
     int* topk_idx;            // optional [P, K] flat indices of the selected entries (index order)
     int N, M, K_fixed, use_mask_len;
     float sample_rate, max_cond;
+    // large tiles (N*M > 65536) with a workspace: candidates >= a lower bound of the K-th largest entry, compacted in
+    // index order by proc_compact_kernel into S slices of up to PC_CAP entries (nullptr = none: stream the tile)
+    unsigned* cellmax;        // [P, PC_NCELL] maxima of contiguous cells
+    unsigned* g_ckey;         // [P, S, PC_CAP]
+    int* g_cidx;              // [P, S, PC_CAP]
+    int* g_ccount;            // [P, S] entries >= the bound in the slice (may exceed PC_CAP: overflow)
+    int S, SL, CL;            // slices per tile, elements per slice, elements per cell
 };
+
+constexpr int PC_NCELL = 4096;   // cells per tile: the K-th largest cell maximum bounds the K-th largest entry from below
+constexpr int PC_CAP = 4096;     // candidate capacity of a slice (= the capacity of the final list)
 
 __device__ __forceinline__ float key_value(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
@@ -217,6 +227,85 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_w, int& total) {
     }
     total = tot;
     return base + incl - v;
+}
+
+// ---- large tiles: two multi-workgroup passes in front of the one-workgroup-per-pair kernel ---------------------------
+// (one workgroup streaming a 1024 x 2048 tile three times took 4.7 ms; these read it twice with the whole chip)
+__global__ __launch_bounds__(256) void proc_cellmax_kernel(ProcArgs A) {
+    const int pair = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int NM = A.N * A.M;
+    const float* conf = A.conf + (size_t)pair * NM;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int c = (blockIdx.x * 4 + w) * 4 + q;              // 16 cells per workgroup
+        if (c >= PC_NCELL) return;
+        const int e0 = c * A.CL, e1 = min(NM, e0 + A.CL);
+        unsigned m = 0;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const unsigned k = order_key(conf[e]);
+            m = k > m ? k : m;
+        }
+        m = wave_max(m);
+        if (lane == 0) A.cellmax[(size_t)pair * PC_NCELL + c] = m;  // 0 = empty cell
+    }
+}
+
+__global__ __launch_bounds__(1024) void proc_compact_kernel(ProcArgs A) {
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_pr[2];
+    __shared__ int s_w[16];
+    __shared__ int s_len[2];
+    const int pair = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+    const int N = A.N, M = A.M, NM = N * M;
+    const float* conf = A.conf + (size_t)pair * NM;
+    int K = A.K_fixed;
+    if (A.use_mask_len) {                                        // same rule as procrustes_kernel (quirk Q17)
+        if (t < 2) s_len[t] = 0;
+        __syncthreads();
+        int c0 = 0, c1 = 0;
+        for (int i = t; i < N; i += 1024) c0 += A.src_mask[(size_t)pair * N + i] != 0;
+        for (int j = t; j < M; j += 1024) c1 += A.tgt_mask[(size_t)pair * M + j] != 0;
+        if (c0) atomicAdd(&s_len[0], c0);
+        if (c1) atomicAdd(&s_len[1], c1);
+        __syncthreads();
+        const int mx = s_len[0] > s_len[1] ? s_len[0] : s_len[1];
+        K = (int)((float)mx * A.sample_rate);
+    }
+    if (K > NM) K = NM;
+    if (K > PK_MAX) K = PK_MAX;
+    const int ncell = (NM + A.CL - 1) / A.CL;                    // non-empty cells
+    unsigned L = 0, dummy;
+    if (K >= 1 && K <= ncell) {
+        unsigned cm[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cm[q] = A.cellmax[(size_t)pair * PC_NCELL + t + 1024 * q];
+        // L = the K-th largest cell maximum (all four digits: with millions of entries a 16-bit bucket admits far more
+        // than the list holds): >= K entries are >= L, typically a small multiple of K
+        radix_select<4>([&](auto&& f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f(cm[q], 0);
+        }, (unsigned)K, s_hist, s_pr, L, dummy);
+    }
+    // this slice, thread t owns a contiguous run (so that (thread, element) order is index order)
+    const int s0 = sl * A.SL, s1 = min(NM, s0 + A.SL);
+    const int CH = (A.SL + 1023) / 1024;
+    const int e0 = min(s1, s0 + t * CH), e1 = min(s1, e0 + CH);
+    int c = 0;
+    for (int e = e0; e < e1; ++e) {
+        const unsigned k = order_key(conf[e]);
+        c += (k >= L && k != 0u) ? 1 : 0;
+    }
+    int total;
+    int off = block_excl_scan(c, s_w, total);
+    unsigned* ck = A.g_ckey + ((size_t)pair * A.S + sl) * PC_CAP;
+    int* ci = A.g_cidx + ((size_t)pair * A.S + sl) * PC_CAP;
+    if (total <= PC_CAP) {
+        for (int e = e0; e < e1; ++e) {
+            const unsigned k = order_key(conf[e]);
+            if (k >= L && k != 0u) { ck[off] = k; ci[off] = e; ++off; }
+        }
+    }
+    if (t == 0) A.g_ccount[(size_t)pair * A.S + sl] = total;
 }
 
 // REG: the tile (N*M <= 65536) is read ONCE and kept as 64 ordered keys per thread.  !REG: every pass
@@ -315,7 +404,30 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         for_each([&](unsigned k, int) { tmax = k > tmax ? k : tmax; });
         unsigned L = 0, dummy;
         int ncand = NM;
-        if (K <= 1024) {
+        if (!REG && A.g_ckey) {
+            // candidates were compacted by proc_compact_kernel: concatenate the slices (index order)
+            int tot = 0;
+            bool over = false;
+            for (int q = 0; q < A.S; ++q) {
+                const int cq = A.g_ccount[(size_t)pair * A.S + q];
+                over = over || cq > PC_CAP;
+                tot += cq;
+            }
+            if (!over && tot <= CAND_MAX && tot >= K) {
+                ncand = tot;
+                for (int c = t; c < tot; c += 1024) {
+                    int q = 0, base = 0;
+                    for (;; ++q) {
+                        const int cq = A.g_ccount[(size_t)pair * A.S + q];
+                        if (c < base + cq) break;
+                        base += cq;
+                    }
+                    s_ckey[c] = A.g_ckey[((size_t)pair * A.S + q) * PC_CAP + (c - base)];
+                    s_cidx[c] = A.g_cidx[((size_t)pair * A.S + q) * PC_CAP + (c - base)];
+                }
+            }
+            __syncthreads();
+        } else if (K <= 1024) {
             // (threads whose slice is empty have tmax = 0 and are not enumerated; K <= #non-empty is
             //  guaranteed when K <= min(NM, 1024) because slices are filled round-robin)
             // two 8-bit digits suffice for a bound: L = the 16-bit bucket of the K-th largest thread maximum
@@ -467,9 +579,22 @@ int read_proc_stamps(long long* h_out) {
     return DR_OK;
 }
 
+static int proc_slices(long NM) {
+    long S = (NM + 16383) / 16384;
+    return (int)(S > 64 ? 64 : S);
+}
+
+size_t procrustes_workspace_bytes(int P, int N, int M) {
+    const long NM = (long)N * M;
+    if (P <= 0 || NM <= 65536) return 0;
+    const size_t S = proc_slices(NM);
+    return (size_t)P * (PC_NCELL * 4 + S * PC_CAP * 8 + S * 4) + 256;
+}
+
 int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_pcd, const uint8_t* src_mask,
                       const uint8_t* tgt_mask, int P, int N, int M, int use_mask_len, float sample_rate, float max_cond,
-                      float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st) {
+                      float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st,
+                      void* ws, size_t ws_bytes) {
     if (P <= 0) return DR_OK;
     if ((long)N * M > 0x7fffffffL) return DR_ENOSUP;
     ProcArgs a;
@@ -480,11 +605,28 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
     // K = int(int(max(len_s, len_t) * rate))  with float32 arithmetic (procrustes.py:63-65)
     a.K_fixed = (int)((float)(N > M ? N : M) * sample_rate);
     if (a.K_fixed > PK_MAX) return DR_ENOSUP;
+    a.cellmax = nullptr; a.g_ckey = nullptr; a.g_cidx = nullptr; a.g_ccount = nullptr; a.S = a.SL = a.CL = 0;
     ProfScope ps(PK_PROCRUSTES, (double)P * N * M * 4.0, st);
-    if ((long)N * M <= 65536)
+    const long NM = (long)N * M;
+    if (NM <= 65536) {
         hipLaunchKernelGGL(procrustes_kernel<true>, dim3(P), dim3(1024), 0, st, a);
-    else
+    } else {
+        if (ws && ws_bytes >= procrustes_workspace_bytes(P, N, M)) {
+            a.S = proc_slices(NM);
+            a.SL = (int)((NM + a.S - 1) / a.S);
+            a.CL = (int)((NM + PC_NCELL - 1) / PC_NCELL);
+            char* w8 = (char*)ws;
+            a.cellmax = (unsigned*)w8; w8 += (size_t)P * PC_NCELL * 4;
+            a.g_ckey = (unsigned*)w8; w8 += (size_t)P * a.S * PC_CAP * 4;
+            a.g_cidx = (int*)w8; w8 += (size_t)P * a.S * PC_CAP * 4;
+            a.g_ccount = (int*)w8;
+            hipLaunchKernelGGL(proc_cellmax_kernel, dim3(PC_NCELL / 16, P), dim3(256), 0, st, a);
+            DR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(proc_compact_kernel, dim3(a.S, P), dim3(1024), 0, st, a);
+            DR_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(procrustes_kernel<false>, dim3(P), dim3(1024), 0, st, a);
+    }
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

@@ -633,7 +633,28 @@ struct SkGridArgs {
 
 template <typename T>
 __host__ __device__ inline size_t sk_grid_tile_elems(int N, int M, int G, int iters) {
-    return (size_t)N * M + 3 * (size_t)N + 1 + (size_t)G * M + G + iters + 2 + 8;
+    return (size_t)N * M + 3 * (size_t)N + 1 + (size_t)G * M + G + iters + 2 + (size_t)M + 1 + 8;
+}
+
+// column sums over the row blocks, between two phases: cb[j] = sum_g cpart[g][j], cb[M] = sum_g dpart[g]
+template <typename T>
+__global__ __launch_bounds__(256) void sk_grid_reduce_kernel(SkGridArgs GA) {
+    const SkArgs& A = GA.k;
+    const int N = A.N, M = A.M, G = GA.G, tile = blockIdx.y;
+    T* base = reinterpret_cast<T*>(A.ws) + (size_t)tile * GA.tile_stride;
+    const T* g_cpart = base + (size_t)N * M + 3 * (size_t)N + 1;
+    const T* g_dpart = g_cpart + (size_t)G * M;
+    T* g_cb = const_cast<T*>(g_dpart) + G + (A.iters + 2);       // [M + 1]
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < M) {
+        T s = 0;
+        for (int q = 0; q < G; ++q) s += g_cpart[(size_t)q * M + j];
+        g_cb[j] = s;
+    } else if (j == M) {
+        T s = 0;
+        for (int q = 0; q < G; ++q) s += g_dpart[q];
+        g_cb[M] = s;
+    }
 }
 
 template <typename TIn, typename T, typename TOut, int CPL>
@@ -655,7 +676,8 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     T* g_rho = g_ed + N;                         // [N]
     T* g_cpart = g_rho + N;                      // [G][M]
     T* g_dpart = g_cpart + (size_t)G * M;        // [G]
-    T* g_aN = g_dpart + G;                       // [iters + 1]: dustbin-row scaling after pass k
+    T* g_aN = g_dpart + G;                       // [iters + 2]: dustbin-row scaling after pass k
+    const T* g_cb = g_aN + (A.iters + 2);        // [M + 1]: column sums over the blocks (sk_grid_reduce_kernel)
     const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
     const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
     const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0;
@@ -682,14 +704,8 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     T aN = muN / ((T)M + (T)1), bM = 1;
     if (GA.phase > 0) {
         aN = g_aN[GA.it - 1 + 0];                               // a_N the partials were built with
-        T dp = 0;
-        for (int q = 0; q < G; ++q) dp += g_dpart[q];
-        bM = nuM / (dp + aN);
-        for (int j = t; j < M; j += 256) {
-            T sacc = 0;
-            for (int q = 0; q < G; ++q) sacc += g_cpart[(size_t)q * M + j];
-            s_b[j] = nu / (sacc + aN);
-        }
+        bM = nuM / (g_cb[M] + aN);
+        for (int j = t; j < M; j += 256) s_b[j] = nu / (g_cb[j] + aN);
         if (t == 0) s_b[M] = bM;
         __syncthreads();
     }
@@ -812,6 +828,10 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
     for (int ph = 0; ph <= a.iters; ++ph) {
         ga.phase = ph == 0 ? 0 : (ph == a.iters ? 2 : 1);
         ga.it = ph;                                              // phase 1/2 read g_aN[it - 1], phases 0/1 write g_aN[it]
+        if (ph > 0) {
+            hipLaunchKernelGGL((sk_grid_reduce_kernel<T>), dim3((a.M + 1 + 255) / 256, a.B), dim3(256), 0, st, ga);
+            DR_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL((sk_grid_kernel<TIn, T, TOut, CPL>), dim3(G, a.B), dim3(256), lds, st, ga);
         DR_LAUNCH_CHECK();
     }
@@ -819,10 +839,10 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
 }
 
 static int sk_grid_blocks(int B, int N) {
-    // enough workgroups for the chip, at least 8 rows (two per wave) per block, at most 32 blocks (each block reads
-    // the partials of all of them)
+    // enough workgroups for the chip, at least 8 rows (two per wave) per block, at most 128 blocks (the column
+    // partials are G x M values per tile)
     int G = (768 + B - 1) / B;
-    if (G > 32) G = 32;
+    if (G > 128) G = 128;
     if (G > (N + 7) / 8) G = (N + 7) / 8;
     return G < 1 ? 1 : G;
 }
