@@ -126,13 +126,16 @@ struct DdimArgs {
     double sra, srm1, c, sigma;
     float sqrt_an;
 };
-int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st);
+// M, sm, tm (optional): minimum over the entries inside both masks only
+int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st, int M = 0, const uint8_t* sm = nullptr,
+                    const uint8_t* tm = nullptr);
 int launch_ddim(const DdimArgs& a, int P, hipStream_t st);
 int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st);
 int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t st);
 int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st);
 template <typename T>
-int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st);
+int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st, const uint8_t* sm = nullptr,
+                      const uint8_t* tm = nullptr);
 
 // sinkhorn.hip (internal form of dr_sinkhorn_*: `shift` = per-tile value subtracted first, nullable)
 int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,

@@ -518,7 +518,11 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     const size_t PN = (size_t)P * N, PM = (size_t)P * M, NM = (size_t)P * N * M;
     const uint8_t* tokmask = src_mask ? L.tokmask : nullptr;
     const int strict = (cfg->flags & DR_LOOP_STRICT_F64) ? DR_SK_STRICT : 0;
-    const int mflag = src_mask ? DR_SK_APPLY_MASK : 0;
+    // DR_LOOP_RAGGED: the masks are the true extents of pairs padded to (N, M); every pair gets its unpadded result
+    const bool ragged = (cfg->flags & DR_LOOP_RAGGED) && src_mask;
+    const int mflag = src_mask ? (DR_SK_APPLY_MASK | (ragged ? DR_SK_RAGGED : 0)) : 0;
+    const uint8_t* rsm = ragged ? src_mask : nullptr;
+    const uint8_t* rtm = ragged ? tgt_mask : nullptr;
 
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
@@ -543,7 +547,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         // -- x <- x - x.min() (3D only, pipeline.py:239); mask; Sinkhorn; exp; slice; float32 (pipeline.py:293-302)
         const double* shift = nullptr;
         if (!v4d) {
-            rc = launch_pair_min(L.x, P, N * M, L.dmin, st);
+            rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm);
             if (rc) return rc;
             shift = L.dmin;
         }
@@ -551,7 +555,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
                           DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
         // -- denoising_soft_procrustes (pipeline.py:304)
-        rc = launch_procrustes(L.wconf, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
+        rc = launch_procrustes(L.wconf, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, (v4d || ragged) ? 1 : 0, cfg->sample_rate,
                                cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
         if (rc) return rc;
         if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
@@ -587,13 +591,13 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = launch_sigmoid(L.x, conf, NM, st);                       // 4D/models/pipeline.py:192
         if (rc) return rc;
     } else {
-        rc = launch_pair_min(L.x, P, N * M, L.dmin, st);              // pipeline.py:264-272
+        rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm);  // pipeline.py:264-272
         if (rc) return rc;
         rc = sinkhorn_f64(P, N, M, L.x, L.dmin, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict,
                           conf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
         if (matches) {
-            rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st);
+            rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st, rsm, rtm);
             if (rc) return rc;
         }
     }
@@ -601,7 +605,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         // soft_procrustes on float32(conf): the well-defined value of pipeline.py:282 (quirk Q3)
         rc = launch_f64_to_f32(conf, L.conf32, NM, st);
         if (rc) return rc;
-        rc = launch_procrustes(L.conf32, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, v4d ? 1 : 0, cfg->sample_rate,
+        rc = launch_procrustes(L.conf32, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, (v4d || ragged) ? 1 : 0, cfg->sample_rate,
                                cfg->max_condition_num, R_final, t_final, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
         if (rc) return rc;
     }

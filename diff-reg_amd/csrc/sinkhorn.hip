@@ -212,7 +212,8 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
     }
     // lane-distributed per-row scalars: lane l holds the value of row row0 + ((l >> 2) & 15);
     // readlane(x, 4r) broadcasts row r into an SGPR when a whole-wave multiplier is needed.
-    const bool my_row_in = row0 + ((lane >> 2) & 15) < N;
+    const bool ragged = (A.flags & DR_SK_RAGGED) != 0;      // padded rows / columns do not exist (no mass, no dustbin share)
+    const bool my_row_in = row0 + ((lane >> 2) & 15) < N && (!ragged || ((rvalid >> ((lane >> 2) & 15)) & 1u));
     const float rho_l = fmaxf(alpha, reduce16(pm, OpMax()));
     constexpr float LOG2E = 1.4426950408889634f;
     // exp(alpha - rho_r): the dustbin-column entry of each row
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
 
     float bj[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) bj[c] = (col0 + c < M) ? 1.f : 0.f;
+    for (int c = 0; c < CPL; ++c) bj[c] = (col0 + c < M && (!ragged || cvalid[c])) ? 1.f : 0.f;
+    const bool tcol_in = t < M && (!ragged || !A.tgt_mask || A.tgt_mask[(size_t)tile * M + (t < M ? t : 0)]);
     float bM = 1.f;
     float a_l = 0.f;
     float aN = 0.f;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void sk_reg_kernel(SkArgs A) {
             float c = aN;
 #pragma unroll
             for (int k = 0; k < NW; ++k) c += s_colpart[k][t];
-            s_b[t] = (t < M) ? nu / c : 0.f;
+            s_b[t] = tcol_in ? nu / c : 0.f;
         } else if (t == MAXC) {
             float c = aN;
 #pragma unroll
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
     const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
     const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
     const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0;
+    const bool ragged = (A.flags & DR_SK_RAGGED) != 0;
     const T alpha = (T)(*A.bin_score);
 
     if (t < 2) s_cnt[t] = 0;
@@ -546,11 +549,11 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
             T ed = t_exp<T>(alpha - m);
             s_rho[i] = m;
             s_ed[i] = ed;
-            s_a[i] = mu / (rs + ed);
+            s_a[i] = (ragged && sm && !sm[i]) ? (T)0 : mu / (rs + ed);
         }
     }
-    if (t == 0) s_a[N] = muN / ((T)M + (T)1);
-    for (int j = t; j <= M; j += nthr) s_b[j] = 1;
+    if (t == 0) s_a[N] = muN / ((ragged ? (T)ns : (T)M) + (T)1);
+    for (int j = t; j <= M; j += nthr) s_b[j] = (ragged && j < M && tm && !tm[j]) ? (T)0 : (T)1;
     __syncthreads();
 
     for (int it = 0; it < A.iters; ++it) {
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
                 T rs = 0;
                 for (int j = lane; j < M; j += WAVE) rs += Ew[(size_t)i * M + j] * s_b[j];
                 rs = wave_sum(rs);
-                if (lane == 0) s_a[i] = mu / (rs + s_ed[i] * bM);
+                if (lane == 0) s_a[i] = (ragged && sm && !sm[i]) ? (T)0 : mu / (rs + s_ed[i] * bM);
             }
             if (t == 0) s_a[N] = muN / (bs + bM);
             __syncthreads();
@@ -586,7 +589,8 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
                 for (int i = g; i < N; i += 4) acc += Ew[(size_t)i * M + j] * s_a[i];
             s_part[g * 256 + jj] = acc;
             __syncthreads();
-            if (t < 256 && j < M) s_b[j] = nu / (s_part[jj] + s_part[256 + jj] + s_part[512 + jj] + s_part[768 + jj] + aN);
+            if (t < 256 && j < M)
+                s_b[j] = (ragged && tm && !tm[j]) ? (T)0 : nu / (s_part[jj] + s_part[256 + jj] + s_part[512 + jj] + s_part[768 + jj] + aN);
             __syncthreads();
         }
     }
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
     const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
     const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0;
+    const bool ragged = (A.flags & DR_SK_RAGGED) != 0;
     const T alpha = (T)(*A.bin_score);
 
     if (t < 2) s_cnt[t] = 0;
@@ -701,11 +706,11 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     const int r0 = g * GA.R, r1 = min(N, r0 + GA.R);
 
     // ---- b of the previous pass from the column partials of every block (phases 1, 2) ---------------------
-    T aN = muN / ((T)M + (T)1), bM = 1;
+    T aN = muN / ((ragged ? (T)ns : (T)M) + (T)1), bM = 1;
     if (GA.phase > 0) {
         aN = g_aN[GA.it - 1 + 0];                               // a_N the partials were built with
         bM = nuM / (g_cb[M] + aN);
-        for (int j = t; j < M; j += 256) s_b[j] = nu / (g_cb[j] + aN);
+        for (int j = t; j < M; j += 256) s_b[j] = (ragged && tm && !tm[j]) ? (T)0 : nu / (g_cb[j] + aN);
         if (t == 0) s_b[M] = bM;
         __syncthreads();
     }
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
             }
             rs = wave_sum(rs);
             ed = t_exp<T>(alpha - m);
-            ai = mu / (rs + ed);
+            ai = (ragged && sm && !sm[i]) ? (T)0 : mu / (rs + ed);
             if (lane == 0) { g_rho[i] = m; g_ed[i] = ed; g_a[i] = ai; }
         } else {
             T rs = 0;
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
             }
             rs = wave_sum(rs);
             ed = g_ed[i];
-            ai = mu / (rs + ed * bM);
+            ai = (ragged && sm && !sm[i]) ? (T)0 : mu / (rs + ed * bM);
             if (lane == 0) g_a[i] = ai;
         }
 #pragma unroll

@@ -8,10 +8,18 @@
 namespace dr {
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict__ x, int NM, double* __restrict__ out) {
+// sm / tm (nullable, [P,N] / [P,M]): the minimum runs over the entries inside both masks only (DR_LOOP_RAGGED)
+__global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict__ x, int NM, int M, const uint8_t* __restrict__ sm,
+                                                        const uint8_t* __restrict__ tm, double* __restrict__ out) {
     __shared__ double s[16];
     const double* p = x + (size_t)blockIdx.x * NM;
     double m = INFINITY;
+    if (sm) {
+        const uint8_t* s1 = sm + (size_t)blockIdx.x * (NM / M);
+        const uint8_t* t1 = tm + (size_t)blockIdx.x * M;
+        for (int e = threadIdx.x; e < NM; e += 1024)
+            if (s1[e / M] && t1[e % M]) m = fmin(m, p[e]);
+    } else
     for (int e = threadIdx.x; e < NM; e += 1024) m = fmin(m, p[e]);
     m = wave_min(m);
     if (lane_id() == 0) s[wave_id()] = m;
@@ -23,10 +31,11 @@ __global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict
     }
 }
 
-int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st) {
+int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st, int M, const uint8_t* sm, const uint8_t* tm) {
     if (P <= 0) return DR_OK;
     ProfScope ps(PK_STATE, (double)P * NM * 8.0, st);
-    hipLaunchKernelGGL(pair_min_kernel, dim3(P), dim3(1024), 0, st, x, NM, out);
+    if (!(sm && tm && M > 0)) { sm = tm = nullptr; M = 1; }
+    hipLaunchKernelGGL(pair_min_kernel, dim3(P), dim3(1024), 0, st, x, NM, M, sm, tm, out);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -114,17 +123,23 @@ constexpr int T1_MAX = 4096;   // N + M <= T1_MAX
 
 template <typename T>
 __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ conf, int N, int M, long long* __restrict__ out,
-                                                          int* __restrict__ count) {
+                                                          int* __restrict__ count, const uint8_t* __restrict__ smask,
+                                                          const uint8_t* __restrict__ tmask) {
     __shared__ unsigned s_key[T1_MAX];
     __shared__ int s_n;
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const T* c = conf + (size_t)pair * N * M;
+    // masks (nullable): rows / columns outside them do not exist (DR_LOOP_RAGGED)
+    const uint8_t* sm = smask ? smask + (size_t)pair * N : nullptr;
+    const uint8_t* tm = tmask ? tmask + (size_t)pair * M : nullptr;
     for (int i = t; i < T1_MAX; i += 1024) s_key[i] = 0xFFFFFFFFu;
     __syncthreads();
     // row arg-max: one wave per row
     for (int i = w; i < N; i += 16) {
+        if (sm && !sm[i]) continue;
         T best = -INFINITY; int bj = 0x7fffffff;
         for (int j = lane; j < M; j += 64) {
+            if (tm && !tm[j]) continue;
             const T v = c[(size_t)i * M + j];
             if (v > best || (v == best && j < bj) || bj == 0x7fffffff) { best = v; bj = j; }
         }
@@ -136,12 +151,14 @@ __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ 
     }
     // column arg-max: one thread per column (coalesced over j)
     for (int j = t; j < M; j += 1024) {
-        T best = c[j]; int bi = 0;
-        for (int i = 1; i < N; ++i) {
+        if (tm && !tm[j]) continue;
+        T best = -INFINITY; int bi = -1;
+        for (int i = 0; i < N; ++i) {
+            if (sm && !sm[i]) continue;
             const T v = c[(size_t)i * M + j];
-            if (v > best) { best = v; bi = i; }
+            if (v > best || bi < 0) { best = v; bi = i; }
         }
-        s_key[N + j] = (unsigned)(bi * M + j);
+        if (bi >= 0) s_key[N + j] = (unsigned)(bi * M + j);
     }
     __syncthreads();
     int n2 = 1;
@@ -177,14 +194,16 @@ __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st) {
+int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st, const uint8_t* sm,
+                      const uint8_t* tm) {
     if (P <= 0) return DR_OK;
     if (N + M > T1_MAX || (long)N * M >= 0xFFFFFFFFL) return DR_ENOSUP;
-    hipLaunchKernelGGL((top1_union_kernel<T>), dim3(P), dim3(1024), 0, st, conf, N, M, out, count);
+    if (!(sm && tm)) sm = tm = nullptr;
+    hipLaunchKernelGGL((top1_union_kernel<T>), dim3(P), dim3(1024), 0, st, conf, N, M, out, count, sm, tm);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
-template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t);
-template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t);
+template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
+template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
 
 }  // namespace dr

@@ -128,13 +128,15 @@ class DenoiseEngine:
         return b
 
     def run(self, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask=None, tgt_mask=None, noise=None, trace=False,
-            graph=False, _slot=0):
+            graph=False, _slot=0, ragged=False):
         """Run the loop for P pairs.  Returns a dict of device tensors (conf float64, x_final, matches list (3D),
-        R_final, t_final, and the per-step trace when asked)."""
+        R_final, t_final, and the per-step trace when asked).  ragged=True (with masks): the masks are the true extents
+        of pairs padded to (N, M) and every pair gets the result of its own unpadded run (DR_LOOP_RAGGED)."""
         P, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         masked = src_mask is not None
-        key = (P, N, M, masked, trace, bool(graph), _slot)
+        self.cfg.flags = (self.cfg.flags & ~2) | (2 if (ragged and masked) else 0)
+        key = (P, N, M, masked, trace, bool(graph), _slot, bool(ragged and masked))
         ent = self._graphs.get(key)
         if ent is None:
             b = self.make_buffers(P, N, M, masked=masked, trace=trace, private_ws=_slot > 0)
@@ -196,6 +198,38 @@ class DenoiseEngine:
         for st in self._streams[:n_streams]:
             cur.wait_stream(st)
         return outs
+
+    def run_ragged(self, pairs, noise=None, graph=False):
+        """Pairs of DIFFERENT sizes in one call: `pairs` is a list of dicts with src_feats [N_i,C], tgt_feats
+        [M_i,C], s_pcd [N_i,3], t_pcd [M_i,3], x_T [N_i,M_i] (device tensors).  They are padded to the largest extents,
+        run as one batch with DR_LOOP_RAGGED and cropped again: each entry of the returned list equals the pair's own
+        B = 1 run (the reference's pad-and-mask batching does not, quirk Q19)."""
+        P = len(pairs)
+        Ns = [int(q["src_feats"].shape[0]) for q in pairs]
+        Ms = [int(q["tgt_feats"].shape[0]) for q in pairs]
+        N, M, dev, C = max(Ns), max(Ms), self.device, self.C
+        fs, ft = torch.zeros(P, N, C, device=dev), torch.zeros(P, M, C, device=dev)
+        ps, pt = torch.zeros(P, N, 3, device=dev), torch.zeros(P, M, 3, device=dev)
+        xT = torch.zeros(P, N, M, device=dev)
+        sm, tm = torch.zeros(P, N, dtype=torch.bool, device=dev), torch.zeros(P, M, dtype=torch.bool, device=dev)
+        for i, q in enumerate(pairs):
+            n, m = Ns[i], Ms[i]
+            fs[i, :n] = q["src_feats"]; ft[i, :m] = q["tgt_feats"]; ps[i, :n] = q["s_pcd"]; pt[i, :m] = q["t_pcd"]
+            xT[i, :n, :m] = q["x_T"]; sm[i, :n] = True; tm[i, :m] = True
+        nz = None
+        if noise is not None:
+            nz = torch.zeros(self.steps, P, N, M, device=dev)
+            for i, z in enumerate(noise):
+                nz[:, i, :Ns[i], :Ms[i]] = z
+        out = self.run(fs, ft, ps, pt, xT, sm, tm, noise=nz, graph=graph, ragged=True)
+        res = []
+        cnt = out["match_count"].cpu().tolist() if "match_count" in out else None
+        for i in range(P):
+            r = dict(conf_matrix_pred=out["conf_matrix_pred"][i, :Ns[i], :Ms[i]], R_final=out["R_final"][i], t_final=out["t_final"][i])
+            if cnt is not None:
+                r["match_pred"] = out["matches_padded"][i, :cnt[i]]
+            res.append(r)
+        return res
 
     @staticmethod
     def match_list(out):

@@ -128,6 +128,7 @@ def ensure_init():
 
 
 SK_OUT_CONF, SK_OUT_LOG, SK_MINSHIFT, SK_APPLY_MASK, SK_OUT_F32, SK_STRICT = 0x0, 0x1, 0x2, 0x4, 0x8, 0x10
+SK_RAGGED = 0x20    # rows / columns outside the masks do not exist (a padded tile = its unpadded problem)
 
 
 def raw():
@@ -166,7 +167,7 @@ def mask_u8(m):
 
 
 def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift=False, apply_mask=False,
-             log_output=False, out_f32=False, strict=False, out=None):
+             log_output=False, out_f32=False, strict=False, ragged=False, out=None):
     """Batched Sinkhorn with dustbins on [B,N,M] fp32/fp64 scores.
 
     Returns conf [B,N,M] (= exp(log_optimal_transport(...))[:, :-1, :-1]) or, with log_output, the full
@@ -178,7 +179,8 @@ def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift
     if not f64 and scores.dtype != torch.float32:
         raise RuntimeError("sinkhorn: fp32 or fp64 scores only")
     flags = (SK_OUT_LOG if log_output else 0) | (SK_MINSHIFT if minshift else 0) | \
-            (SK_APPLY_MASK if apply_mask else 0) | (SK_OUT_F32 if (f64 and out_f32) else 0) | (SK_STRICT if strict else 0)
+            (SK_APPLY_MASK if apply_mask else 0) | (SK_OUT_F32 if (f64 and out_f32) else 0) | (SK_STRICT if strict else 0) | \
+            (SK_RAGGED if ragged else 0)
     odt = torch.float32 if (not f64 or out_f32) else torch.float64
     shape = (B, N + 1, M + 1) if log_output else (B, N, M)
     if out is None:

@@ -61,6 +61,10 @@ const char* dr_last_hip_error(void);  /* text of the last failing HIP call on th
 #define DR_SK_APPLY_MASK 0x4
 #define DR_SK_OUT_F32 0x8
 #define DR_SK_STRICT 0x10
+/* DR_SK_RAGGED (with masks): rows / columns outside the masks do not exist -- no marginal mass, no dustbin share --
+ * so a padded tile gives exactly the result of its unpadded (ms x ns) problem.  Without it padded rows / columns
+ * keep their marginal mass like the reference's batched call does (quirk Q19), which is NOT the B = 1 result. */
+#define DR_SK_RAGGED 0x20
 
 size_t dr_sinkhorn_workspace_bytes(int B, int N, int M, int elem_bytes, int flags);
 
@@ -179,6 +183,10 @@ int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, 
 #define DR_VARIANT_3DMATCH 0
 #define DR_VARIANT_4DMATCH 1
 #define DR_LOOP_STRICT_F64 0x1 /* run the fp64-state Sinkhorn calls in fp64 (streaming kernel) */
+/* Pairs of different sizes in one call: pad every pair to (N, M), pass the true extents as masks, and
+ * each pair gets exactly the result of its own unpadded B = 1 run: padded rows / columns are excluded from the
+ * Sinkhorn marginals (DR_SK_RAGGED), from x.min(), from the top-K rule (K from the true sizes) and from the read-out. */
+#define DR_LOOP_RAGGED 0x2
 
 typedef struct {
     int variant;               /* DR_VARIANT_*                                              */

@@ -179,6 +179,42 @@ def test_loop_against_oracle_fresh_seed(seed):
         assert_matrix_parity(out["conf_matrix_pred"][0].cpu().numpy(), ref["conf_matrix_pred"][0].numpy(), conf_f64, "conf")
 
 
+@pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
+def test_ragged_batch_equals_single_pairs(variant):
+    """Pairs of different sizes in one call: padded to the largest extents and run with
+    DR_LOOP_RAGGED, every pair reproduces its own unpadded B = 1 run (conf, final pose, match list) -- which the
+    reference's pad-and-mask batching does not (padded rows / columns keep marginal mass there)."""
+    steps, mc = 4, 200 if variant == "3dmatch" else 40
+    sizes = [(96, 80), (128, 128), (57, 121), (128, 40)]
+    eng = engine(variant, steps, mc)
+    ps = [pair(variant, n, m, 61 + i)[1] for i, (n, m) in enumerate(sizes)]
+    noises = [T(synth.step_noise(n, m, 61 + i, steps)).to(DEV) for i, (n, m) in enumerate(sizes)] if variant == "4dmatch" else None
+    items = [dict(src_feats=q["f_s"][0].to(DEV), tgt_feats=q["f_t"][0].to(DEV), s_pcd=q["p_s"][0].to(DEV), t_pcd=q["p_t"][0].to(DEV),
+                  x_T=q["x_T"][0].to(DEV)) for q in ps]
+    got = eng.run_ragged(items, noise=noises)
+    for i, q in enumerate(ps):
+        n, m = sizes[i]
+        kw = {}
+        if variant == "4dmatch":
+            ms, mt = masks(n, m)
+            kw = dict(src_mask=ms.to(DEV), tgt_mask=mt.to(DEV), noise=noises[i][:, None])
+        one = eng.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV), **kw)
+        dd = (got[i]["conf_matrix_pred"] - one["conf_matrix_pred"][0]).abs()
+        # (the batch and the single run pick different GEMM tilings, i.e. summation orders: fp32 rounding only.  The 4D
+        #  read-out sigmoid(x) does not pass through a final Sinkhorn and keeps the ill-conditioned entries of the loop
+        #  tests' docstring: same bar as there, <= 0.1 % of the entries beyond 1e-4)
+        if variant == "3dmatch":
+            assert dd.max().item() < 2e-6, (i, dd.max().item())
+        else:
+            assert (dd > 1e-4).double().mean().item() <= 1e-3, (i, dd.max().item())
+        assert (got[i]["R_final"] - one["R_final"][0]).abs().max().item() < 1e-4
+        assert (got[i]["t_final"] - one["t_final"][0]).abs().max().item() < 1e-4
+        if variant == "3dmatch":
+            a = set(map(tuple, got[i]["match_pred"].cpu().tolist()))
+            b = set(map(tuple, eng.match_list(one)[0].cpu().tolist()))
+            assert len(a ^ b) <= max(1, len(b) // 100), (i, len(a ^ b), len(b))    # flat rows may flip at 1e-7
+
+
 def test_inlier_ratio_and_fmr_parity():
     """The metric's parity leg: inlier ratio (3D/models/loss.py:383-410) and FMR (IR > 0.05,
     3D/lib/tester.py:83-85) of the HIP loop's match_pred against the oracle's on synthetic pairs with the generator's

@@ -86,6 +86,37 @@ def test_minshift_and_batch_of_different_masks():
     assert got64.dtype == torch.float64 and rel_err(got64, ref)[1] < 2e-5
 
 
+@pytest.mark.parametrize("N,M,nv,mv", [(128, 128, 100, 77), (256, 256, 201, 256), (96, 80, 33, 80), (300, 400, 257, 333),
+                                       (512, 512, 400, 511), (64, 1200, 50, 1111)])
+@pytest.mark.parametrize("dt,strict", [("f32", False), ("f64", False), ("f64", True)])
+def test_ragged_padded_tile_equals_unpadded_problem(N, M, nv, mv, dt, strict):
+    """DR_SK_RAGGED: a tile padded to (N, M) with masks gives exactly the Sinkhorn of its own (nv x mv) problem --
+    unlike the reference's pad-and-mask call, where padded rows / columns keep marginal mass (quirk Q19).  Every
+    kernel path: register-resident, multi-workgroup, strict fp64; conf and log output."""
+    from diffreg_hip import lib
+    dtype = torch.float32 if dt == "f32" else torch.float64
+    g = torch.Generator().manual_seed(N * 7 + M)
+    small = (torch.randn(2, nv, mv, generator=g) * 3).to(dtype)
+    big = torch.full((2, N, M), 5.0, dtype=dtype)            # garbage in the padding: must not matter
+    big[:, :nv, :mv] = small
+    sm = (torch.arange(N)[None] < nv).expand(2, N).contiguous()
+    tm = (torch.arange(M)[None] < mv).expand(2, M).contiguous()
+    a = torch.tensor(0.7)
+    ones_s, ones_t = torch.ones(2, nv, dtype=torch.bool), torch.ones(2, mv, dtype=torch.bool)
+    for log_output in (False, True):
+        ref = lib.sinkhorn(small.to(DEV), a, 3, ones_s.to(DEV), ones_t.to(DEV), apply_mask=True, strict=strict, log_output=log_output)
+        got = lib.sinkhorn(big.to(DEV), a, 3, sm.to(DEV), tm.to(DEV), apply_mask=True, strict=strict, ragged=True, log_output=log_output)
+        if log_output:
+            # valid block + dustbin row / column of the (nv+1) x (mv+1) problem sit at [:nv, :mv], [N, :mv], [:nv, M], [N, M]
+            gv = torch.cat([torch.cat([got[:, :nv, :mv], got[:, :nv, M:M + 1]], 2),
+                            torch.cat([got[:, N:N + 1, :mv], got[:, N:N + 1, M:M + 1]], 2)], 1)
+            assert (gv - ref).abs().max().item() < 2e-5
+        else:
+            assert (got[:, :nv, :mv] - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item() * 1e3)
+            assert got[:, nv:, :].abs().max().item() == 0 if nv < N else True
+            assert got[:, :, mv:].abs().max().item() == 0 if mv < M else True
+
+
 def test_extreme_scores_do_not_overflow():
     """the scaling form must survive what the log-domain reference survives (dustbins keep sums > 0)."""
     from diffreg_hip import lib
