@@ -87,6 +87,9 @@ class Pipeline(nn.Module):
         self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1))
         self._engine = None
         self.use_graph = True
+        # batches (B > 1) of padded pairs: False = the reference's pad-and-mask semantics (quirks Q8 / Q19: not the B = 1
+        # results, NaN in the 3D variant); True = every pair gets its own B = 1 result (DR_LOOP_RAGGED)
+        self.ragged_batches = False
 
     # -- engine lifetime: rebuilt whenever the weights may have moved / changed ----------------------
     def _apply(self, fn, *a, **k):
@@ -139,7 +142,8 @@ class Pipeline(nn.Module):
             noise = data["noise"] if "noise" in data else torch.randn(S, P, N, M, device=dev)
         all_valid = bool(src_mask.all()) and bool(tgt_mask.all())
         out = eng.run(src_feats.float(), tgt_feats.float(), s_pcd.float(), t_pcd.float(), x_T.float(),
-                      None if all_valid else src_mask, None if all_valid else tgt_mask, noise=noise, graph=self.use_graph)
+                      None if all_valid else src_mask, None if all_valid else tgt_mask, noise=noise, graph=self.use_graph,
+                      ragged=self.ragged_batches)
         conf = out["conf_matrix_pred"].clone()
         data.update({"conf_matrix_pred": conf})
         if self.variant == "3dmatch":
