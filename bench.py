@@ -244,7 +244,11 @@ def main():
         "conf_checksum": float(checksum.item()),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
+        # (N > 1: rank 0 still measures the roofline of its own GPU after the timed region; single-pair latency, the
+        #  Sinkhorn micro-benchmark and the CPU baseline are N = 1 only)
+        if world > 1:
+            args.no_single_pair = args.no_cpu_baseline = True
         # ---- single-pair latency (the literal "batch=1" of configs[1]) -------------------------------
         if not args.no_single_pair:
             prs1, inp1 = make_inputs(variant, 1, N, M, seed0=7000, device=dev)
@@ -303,7 +307,7 @@ def main():
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof
             result["kernel_families"] = fam
-        if not args.breakdown_only:
+        if not args.breakdown_only and world == 1:
             result["sinkhorn_roofline"] = sinkhorn_microbench(dev)
         if "roofline" not in result and "sinkhorn_roofline" in result:
             result["roofline"] = result["sinkhorn_roofline"]
@@ -314,6 +318,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()                      # the other ranks wait for rank 0's post-measurements before tearing down
         dist.destroy_process_group()
 
 
