@@ -68,6 +68,31 @@ def test_gemm_split_accuracy(rows, ncols, K, cfg):
         raw.dr_debug_gemm_config(-1)
 
 
+def test_gemm_split_dynamic_range():
+    """Split-operand GEMM on operands spanning 12 orders of magnitude (rows of x and of W scaled by 10^[-3, 3]): the
+    error of every output stays within fp32 rounding of ITS OWN row / column scale (the hi / mid / lo split is relative,
+    bf16 has the exponent range of fp32), like the f32-input MFMA kernel's."""
+    from diffreg_hip import lib
+    raw = lib.raw()
+    rows, ncols, K = 2048, 432, 432
+    g = torch.Generator().manual_seed(5)
+    sx = 10.0 ** (torch.rand(rows, 1, generator=g) * 6 - 3)
+    sw = 10.0 ** (torch.rand(ncols, 1, generator=g) * 6 - 3)
+    x = (torch.randn(rows, K, generator=g) * sx).to(DEV)
+    W = (torch.randn(ncols, K, generator=g) / K ** 0.5 * sw).to(DEV)
+    Wp = lib.pack_weight(W)
+    ref = x.double() @ W.double().T
+    scale = (sx.double() * sw.double().T).to(DEV)                # magnitude of out[r][c]
+    try:
+        raw.dr_debug_gemm_config(9)
+        e_base = ((lib.linear(x, W).double() - ref).abs() / scale).max().item()
+        raw.dr_debug_gemm_config(50)
+        e_split = ((lib.linear_packed(x, W, Wp).double() - ref).abs() / scale).max().item()
+    finally:
+        raw.dr_debug_gemm_config(-1)
+    assert e_split < 1e-5 and e_split <= 2.0 * e_base, (e_split, e_base)
+
+
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
 def test_vol_pe_and_rotary_linear(variant, golden):
     from diffreg_hip import lib
