@@ -215,6 +215,24 @@ def test_ragged_batch_equals_single_pairs(variant):
             assert len(a ^ b) <= max(1, len(b) // 100), (i, len(a ^ b), len(b))    # flat rows may flip at 1e-7
 
 
+def test_loop_is_bitwise_reproducible(batch_kernels):
+    """No float atomics, fixed reduction orders: two runs of the same batch (large-batch kernels forced, eager and
+    graph replay) give bit-identical matrices and poses."""
+    variant, N, M, steps = "3dmatch", 128, 128, 3
+    eng = engine(variant, steps, 200)
+    ps = [pair(variant, N, M, s)[1] for s in (71, 72, 73, 74)]
+    cat = lambda k: torch.cat([q[k] for q in ps]).to(DEV)
+    args = [cat(k) for k in ("f_s", "f_t", "p_s", "p_t", "x_T")]
+    outs = []
+    for graph in (False, False, True, True):
+        o = eng.run(*args, graph=graph)
+        torch.cuda.synchronize()
+        outs.append((o["conf_matrix_pred"].clone(), o["R_final"].clone(), o["x_final"].clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
 def test_inlier_ratio_and_fmr_parity():
     """The metric's parity leg: inlier ratio (3D/models/loss.py:383-410) and FMR (IR > 0.05,
     3D/lib/tester.py:83-85) of the HIP loop's match_pred against the oracle's on synthetic pairs with the generator's
