@@ -202,3 +202,126 @@ def make_pair_2d3d(N, M, seed, weights=None, overlap=0.6, tok_noise=0.05, dtype=
     return dict(s_pcd=base["s_pcd"], t_pcd_da=base["t_pcd"], img_pixels=pix.astype(dtype), img_feats=img_feats.astype(dtype),
                 img_dino=img_dino.astype(dtype), pcd_feats=pcd_feats.astype(dtype), x_T=base["x_T"],
                 gt_matches=base["gt_matches"], R_gt=base["R_gt"], t_gt=base["t_gt"])
+
+
+# ==========================================================================================
+# KPFCN backbone inputs: a stacked src|tgt cloud with the per-layer index
+# arrays the reference's collate function produces (3D/datasets/dataloader.py:13-68, 247-325):
+# grid-subsampled points per layer, radius neighbours (sorted by distance, padded with the
+# "shadow" index = number of support points), pools (layer l+1 queries -> layer l supports) and
+# upsamples (layer l queries -> layer l+1 supports, nearest first).  Brute-force numpy: the
+# point of these arrays is to be a fixed, reproducible input of the backbone, not a fast collate.
+# ==========================================================================================
+KPFCN_ARCH = ["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb", "resnetb_strided", "resnetb", "resnetb",
+              "resnetb_strided", "resnetb", "resnetb", "nearest_upsample", "unary", "nearest_upsample", "unary",
+              "nearest_upsample", "unary"]                       # 3D/configs/models.py:3-21
+KPFCN_CFG = dict(num_layers=4, in_points_dim=3, first_feats_dim=256, first_subsampling_dl=0.025, in_feats_dim=1,
+                 conv_radius=2.5, num_kernel_points=15, KP_extent=2.0, coarse_feature_dim=432)   # 3D/configs/test/3dmatch.yaml:3-26
+
+
+def _grid_subsample(pts, dl):
+    """barycentre of the points of every occupied voxel of size dl, voxels in lexicographic order"""
+    key = np.floor(pts / dl).astype(np.int64)
+    key -= key.min(0)
+    dims = key.max(0) + 1
+    lin = (key[:, 0] * dims[1] + key[:, 1]) * dims[2] + key[:, 2]
+    order = np.argsort(lin, kind="stable")
+    lin_s, pts_s = lin[order], pts[order]
+    starts = np.flatnonzero(np.r_[True, lin_s[1:] != lin_s[:-1]])
+    sums = np.add.reduceat(pts_s.astype(np.float64), starts, axis=0)
+    cnt = np.diff(np.r_[starts, len(lin_s)])[:, None]
+    return (sums / cnt).astype(np.float32)
+
+
+def _radius_neighbors(q, s, q_len, s_len, radius, limit):
+    """[len(q), limit] int64 indices into the stacked support cloud, nearest first, shadow index = len(s)"""
+    out = np.full((len(q), limit), len(s), dtype=np.int64)
+    q0 = s0 = 0
+    for ql, sl in zip(q_len, s_len):
+        qq, ss = q[q0:q0 + ql].astype(np.float64), s[s0:s0 + sl].astype(np.float64)
+        d2 = ((qq[:, None, :] - ss[None, :, :]) ** 2).sum(-1)
+        idx = np.argsort(d2, axis=1, kind="stable")[:, :limit]
+        dd = np.take_along_axis(d2, idx, 1)
+        idx = np.where(dd < radius * radius, idx + s0, len(s))
+        out[q0:q0 + ql, :idx.shape[1]] = idx
+        q0 += ql; s0 += sl
+    return out
+
+
+def make_kpfcn_batch(n_src=1400, n_tgt=1200, seed=0, limit=(28, 28, 30, 32)):
+    """points / neighbors / pools / upsamples / stack_lengths of a 4-layer KPFCN batch + features [N0,1] = 1"""
+    cfg = KPFCN_CFG
+    clouds = []
+    for c, n in enumerate((n_src, n_tgt)):
+        u = hash_uniform(seed, 40 + c, (n, 3), 0.0, 1.0)
+        # a folded sheet inside a 0.9 x 0.7 x 0.4 box: surface-like sampling, ~25-30 neighbours at the first radius
+        x, y = 0.9 * u[:, 0], 0.7 * u[:, 1]
+        z = 0.15 * np.sin(4.0 * x + c) * np.cos(3.0 * y) + 0.02 * u[:, 2] + 0.2
+        clouds.append(np.stack([x, y, z], 1).astype(np.float32))
+    dl = cfg["first_subsampling_dl"]
+    pts = [_grid_subsample(c, dl) for c in clouds]
+    points, lengths = [np.concatenate(pts)], [[len(p) for p in pts]]
+    for l in range(1, cfg["num_layers"]):
+        dl *= 2
+        pts = [_grid_subsample(p, dl) for p in pts]
+        points.append(np.concatenate(pts)); lengths.append([len(p) for p in pts])
+    neighbors, pools, upsamples = [], [], []
+    r = cfg["first_subsampling_dl"] * cfg["conv_radius"]
+    for l in range(cfg["num_layers"]):
+        neighbors.append(_radius_neighbors(points[l], points[l], lengths[l], lengths[l], r, limit[l]))
+        if l + 1 < cfg["num_layers"]:
+            pools.append(_radius_neighbors(points[l + 1], points[l], lengths[l + 1], lengths[l], r, limit[l]))
+            upsamples.append(_radius_neighbors(points[l], points[l + 1], lengths[l], lengths[l + 1], 2 * r, limit[l + 1]))
+        r *= 2
+    return dict(points=points, neighbors=neighbors, pools=pools, upsamples=upsamples, stack_lengths=lengths,
+                features=np.ones((len(points[0]), 1), np.float32))
+
+
+def make_kpfcn_weights(kernel_points, seed=3):
+    """state dict of models.backbone.KPFCN (3D/models/backbone.py:8-118) in the reference's names, hash-generated
+    (kaiming-like 1/sqrt(fan_in) scale); kernel_points[name] come from the reference's own disposition file."""
+    cfg = KPFCN_CFG
+    sd, ctr = {}, [0]
+
+    def w(shape, fan_in):
+        ctr[0] += 1
+        return (hash_uniform(seed, 1000 + ctr[0], shape) / np.sqrt(fan_in)).astype(np.float32)
+
+    def kpconv(pre, cin, cout):
+        sd[pre + "weights"] = w((cfg["num_kernel_points"], cin, cout), cin * 4)
+        sd[pre + "kernel_points"] = kernel_points[pre + "kernel_points"]
+
+    layer, in_dim, out_dim = 0, cfg["in_feats_dim"], cfg["first_feats_dim"]
+    skip_dims, bi = [], 0
+    for bi, block in enumerate(KPFCN_ARCH):
+        if any(t in block for t in ("pool", "strided", "upsample", "global")):
+            skip_dims.append(in_dim)
+        if "upsample" in block:
+            break
+        pre = "encoder_blocks.%d." % bi
+        if block == "simple":
+            kpconv(pre + "KPConv.", in_dim, out_dim // 2)
+        else:
+            if in_dim != out_dim // 4:
+                sd[pre + "unary1.mlp.weight"] = w((out_dim // 4, in_dim), in_dim)
+            kpconv(pre + "KPConv.", out_dim // 4, out_dim // 4)
+            sd[pre + "unary2.mlp.weight"] = w((out_dim, out_dim // 4), out_dim // 4)
+            if in_dim != out_dim:
+                sd[pre + "unary_shortcut.mlp.weight"] = w((out_dim, in_dim), in_dim)
+        in_dim = out_dim // 2 if "simple" in block else out_dim
+        if "pool" in block or "strided" in block:
+            layer += 1; out_dim *= 2
+    sd["coarse_out.weight"] = w((cfg["coarse_feature_dim"], in_dim // 2, 1), in_dim // 2)
+    sd["coarse_out.bias"] = w((cfg["coarse_feature_dim"],), 4.0)
+    start = bi
+    for di, block in enumerate(KPFCN_ARCH[start:]):
+        if di > 0 and "upsample" in KPFCN_ARCH[start + di - 1]:
+            in_dim += skip_dims[layer]
+        if block == "unary":
+            sd["decoder_blocks.%d.mlp.weight" % di] = w((out_dim, in_dim), in_dim)
+        in_dim = out_dim
+        if "upsample" in block:
+            layer -= 1; out_dim //= 2
+        if di == 1:
+            break                                                # the coarse phase returns after decoder block 1 (backbone.py:153-158)
+    return sd

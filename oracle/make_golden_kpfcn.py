@@ -1,0 +1,77 @@
+"""Mint the KPFCN golden vector by RUNNING THE REFERENCE backbone (build container only; needs /root/reference).
+
+    python oracle/make_golden_kpfcn.py      # writes tests/golden/kpfcn_coarse.npz
+
+models.backbone.KPFCN is imported from the reference tree where it lies (cwd = the tree root so that its kernel
+point disposition file resolves); shims: an attribute-dict config, a MagicMock for open3d.  Inputs (the synthetic
+stacked cloud with its neighbour / pool / upsample index arrays) and weights come from diffreg_hip.synth; the
+fixture stores the reference's kernel points (tiny), its coarse output and a few intermediate block outputs.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+TREE = "/root/reference/Diff-Reg-3dmatch"
+sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
+sys.path.insert(0, ROOT)
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def main():
+    import torch
+    from diffreg_hip import synth
+    sys.modules["open3d"] = MagicMock()
+    os.chdir(TREE)
+    sys.path.insert(0, TREE)
+    from models.backbone import KPFCN                                 # the reference implementation
+    cfg = AttrDict(dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), final_feats_dim=32, deform_radius=5.0,
+                        KP_influence="linear", aggregation_mode="sum", fixed_kernel_points="center", use_batch_norm=True,
+                        batch_norm_momentum=0.02, deformable=False, modulated=False, fine_feature_dim=264))
+    torch.manual_seed(0)
+    net = KPFCN(cfg).eval()
+    ref_sd = net.state_dict()
+    kp = {k: v.numpy().copy() for k, v in ref_sd.items() if k.endswith("kernel_points")}
+    sd = synth.make_kpfcn_weights(kp)
+    for k, v in sd.items():
+        assert tuple(ref_sd[k].shape) == tuple(v.shape), (k, ref_sd[k].shape, v.shape)
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected
+    used = ("encoder_blocks.", "decoder_blocks.1.", "coarse_out.")
+    assert all(not m.startswith(used) for m in missing), [m for m in missing if m.startswith(used)]
+    b = synth.make_kpfcn_batch()
+    tb = dict(points=[torch.from_numpy(p) for p in b["points"]], neighbors=[torch.from_numpy(p) for p in b["neighbors"]],
+              pools=[torch.from_numpy(p) for p in b["pools"]], upsamples=[torch.from_numpy(p) for p in b["upsamples"]],
+              stack_lengths=[torch.tensor(l) for l in b["stack_lengths"]], features=torch.from_numpy(b["features"]))
+    # intermediate outputs of the reference blocks, for localising a mismatch
+    inter = {}
+    hooks = [net.encoder_blocks[i].register_forward_hook(lambda m, a, o, i=i: inter.__setitem__("enc%d" % i, o.detach().numpy().copy()))
+             for i in (0, 1, 2, 10)]
+    with torch.no_grad():
+        out = net(tb, phase="coarse")
+    for h in hooks:
+        h.remove()
+    # also the restatement, run here against the reference before the fixture is written
+    from oracle import kpfcn_oracle as ko
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    mine = ko.kpfcn_coarse(tsd, tb)
+    err = (mine - out).abs().max().item()
+    print("reference coarse feats", tuple(out.shape), "abs max %.3f" % out.abs().max().item(), "| oracle - reference max abs %.2e" % err)
+    assert err < 2e-4 * max(1.0, out.abs().max().item())
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "kpfcn_coarse.npz"), coarse=out.numpy(),
+                        enc0=inter["enc0"][:64], enc1=inter["enc1"][:64], enc2=inter["enc2"][:64], enc10=inter["enc10"],
+                        **{"kp:" + k: v for k, v in kp.items()})
+    print("wrote", os.path.join(OUT, "kpfcn_coarse.npz"))
+
+
+if __name__ == "__main__":
+    main()

@@ -168,3 +168,24 @@ def test_2d3d_loop_matches_reference(golden, N, M, nv, mv, mv_da, steps, mc, see
     got = set(map(tuple, out["match_pred"][:, 1:].tolist()))
     want = set(zip(g["match_i"].tolist(), g["match_j"].tolist()))
     assert len(got ^ want) <= 0.05 * len(want)
+
+
+def kpfcn_inputs(golden):
+    """synthetic KPFCN batch + hash weights (+ the reference's kernel points from the fixture) as torch tensors"""
+    g = golden("kpfcn_coarse")
+    kp = {k[3:]: g[k] for k in g.files if k.startswith("kp:")}
+    sd = {k: T(v) for k, v in synth.make_kpfcn_weights(kp).items()}
+    b = synth.make_kpfcn_batch()
+    tb = dict(points=[T(p) for p in b["points"]], neighbors=[T(p) for p in b["neighbors"]], pools=[T(p) for p in b["pools"]],
+              upsamples=[T(p) for p in b["upsamples"]], features=T(b["features"]))
+    return g, sd, tb
+
+
+def test_kpfcn_backbone_matches_reference(golden):
+    """the restatement of KPFCN.forward(phase='coarse') against the output of the reference backbone
+    itself (oracle/make_golden_kpfcn.py) on the synthetic stacked cloud."""
+    from oracle import kpfcn_oracle as ko
+    g, sd, tb = kpfcn_inputs(golden)
+    out = ko.kpfcn_coarse(sd, tb)
+    assert tuple(out.shape) == g["coarse"].shape
+    assert np.abs(out.numpy() - g["coarse"]).max() < 2e-5
