@@ -356,6 +356,18 @@ int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, fl
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const float* W, const float* bias, float* out, int ldo,
+                     int epilogue, float scale, void* stream) {
+    if (rows < 0 || ncols <= 0 || K <= 0 || !x || !W || !out || lda < K || ldo < ncols || (epilogue & EPI_ROTARY)) return DR_EINVAL;
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& p = g.p[0];
+    p.A = x; p.W = W; p.bias = bias; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = lda; p.ldo = ldo;
+    p.epi = epilogue; p.scale = scale;
+    g.n = 1;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 size_t dr_packed_weight_bytes(int ncols, int K) { return (ncols > 0 && K > 0) ? gemm_packed_weight_bytes(ncols, K) : 0; }
 
 int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* stream) {

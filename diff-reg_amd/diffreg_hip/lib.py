@@ -85,6 +85,14 @@ SIGNATURES.update({
     "dr_pack_weight_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_linear_packed_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_float, c_void_p]),
+    "dr_linear_ex_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dr_kpconv_gather_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_void_p, c_int, c_void_p]),
+    "dr_col_stats_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_col_stats_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dr_norm_apply_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
+                                  c_int, c_void_p, c_int, c_void_p]),
+    "dr_gather_pool_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
@@ -232,6 +240,62 @@ def linear(x, W, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
     out = torch.empty(x.shape[0], W.shape[0], device=x.device)
     check(_lib.dr_linear_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(out), epilogue, ptr(cos), ptr(sin),
                              rot_C, float(scale), stream_of(x)))
+    return out
+
+
+def linear_ex(x, W, bias=None, epilogue=0, scale=1.0, K=None):
+    """x [rows, lda >= K] @ W[ncols, K]^T (+ bias) -> [rows, ncols]"""
+    ensure_init()
+    K = W.shape[1] if K is None else K
+    out = torch.empty(x.shape[0], W.shape[0], device=x.device)
+    check(_lib.dr_linear_ex_f32(x.shape[0], W.shape[0], K, ptr(x), x.stride(0), ptr(W), ptr(bias), ptr(out), out.stride(0), epilogue,
+                                float(scale), stream_of(x)))
+    return out
+
+
+def kpconv_gather(q_pts, s_pts, neighb_inds, x, kernel_points, extent):
+    """-> weighted features [Nq, ceil4(K*Cin)] (see dr_kpconv_gather_f32)"""
+    ensure_init()
+    Nq, H = neighb_inds.shape
+    K, Cin = kernel_points.shape[0], x.shape[1]
+    ld = (K * Cin + 3) // 4 * 4
+    out = torch.empty(Nq, ld, device=x.device)
+    check(_lib.dr_kpconv_gather_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()),
+                                    ptr(neighb_inds.contiguous()), ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent),
+                                    ptr(out), ld, stream_of(x)))
+    return out
+
+
+def col_stats(x):
+    """per-column mean and 1/sqrt(var + 1e-5) over the rows of x [N, C] (InstanceNorm1d of BatchNormBlock)"""
+    ensure_init()
+    N, C = x.shape
+    mean, rstd = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    wsb = _lib.dr_col_stats_workspace_bytes(N, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    check(_lib.dr_col_stats_f32(N, C, ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(ws), wsb, stream_of(x)))
+    return mean, rstd
+
+
+def norm_apply(a, stats_a, b=None, stats_b=None, slope=0.1, activate=True):
+    """act( norm(a) + [norm(b) | b | 0] )"""
+    ensure_init()
+    N, C = a.shape
+    out = torch.empty(N, C, device=a.device)
+    mb, rb = stats_b if stats_b is not None else (None, None)
+    check(_lib.dr_norm_apply_f32(N, C, ptr(a), a.stride(0), ptr(stats_a[0]), ptr(stats_a[1]), ptr(b), b.stride(0) if b is not None else 0,
+                                 ptr(mb), ptr(rb), float(slope), 1 if activate else 0, ptr(out), C, stream_of(a)))
+    return out
+
+
+def gather_pool(x, inds, first_only=False):
+    """max_pool / closest_pool over index lists [n2, H] (int64; indices >= len(x) read a zero row)"""
+    ensure_init()
+    n2, H = inds.shape
+    out = torch.empty(n2, x.shape[1], device=x.device)
+    inds = inds.contiguous()
+    check(_lib.dr_gather_pool_f32(n2, H, H, x.shape[1], ptr(x.contiguous()), x.shape[0], ptr(inds), 1 if first_only else 0, ptr(out),
+                                  stream_of(x)))
     return out
 
 

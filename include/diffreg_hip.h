@@ -121,6 +121,37 @@ int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* str
 int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
                          int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
 
+/* nn.Linear with a bias and explicit leading dimensions (x [rows, lda], out [rows, ldo]): the 1x1 Conv1d `coarse_out`
+ * of the backbone (3D/models/backbone.py:66, 155-156) and its UnaryBlocks (bias = NULL). */
+int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const float* W, const float* bias, float* out,
+                     int ldo, int epilogue, float scale, void* stream);
+
+/* ---- KPFCN backbone ops (3D/models/blocks.py) -------------------------------------------------------
+ * dr_kpconv_gather_f32: the gather / influence / neighbour-reduction half of KPConv.forward (blocks.py:288-375) with
+ *   the neighbour-count normalisation (blocks.py:390-393) folded in:
+ *     weighted[q][k*Cin + c] = (sum_h max(0, 1 - |s[nb[q][h]] - q_q - kp_k| / extent) * x[nb[q][h]][c]) / num_q
+ *   neighb_inds [Nq,H] int64 with the shadow index Ns (zero features, point at +1e6); num_q = max(1, #neighbours whose
+ *   feature sum is > 0).  The other half is ONE dr_linear_*: out = weighted @ W2^T with W2[co][k*Cin + c] =
+ *   weights[k][c][co] (the reference multiplies per kernel point and sums over K, blocks.py:382-387).
+ *   ld_weighted >= K*Cin (padding columns are zeroed).  K <= 16, H <= 64.
+ * dr_col_stats_f32 / dr_norm_apply_f32: BatchNormBlock with use_bn = InstanceNorm1d over the points of the stacked cloud
+ *   per channel, no affine, biased variance, eps 1e-5 (blocks.py:430-446): mean / rstd per column, then
+ *     out = act( (a - mean_a) rstd_a + [ (b - mean_b) rstd_b  |  b  |  0 ] ),  act = LeakyReLU(leaky_slope) or none
+ *   (UnaryBlock blocks.py:479-484; the residual sum of ResnetBottleneckBlock blocks.py:650-660).
+ * dr_gather_pool_f32: max_pool (first_only = 0) / closest_pool (first_only = 1) of blocks.py:56-87; indices >= n1 read
+ *   a zero row. */
+int dr_kpconv_gather_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts,
+                         const int64_t* neighb_inds, const float* x, const float* kernel_points, float extent,
+                         float* weighted, int ld_weighted, void* stream);
+size_t dr_col_stats_workspace_bytes(int N, int C);
+int dr_col_stats_f32(int N, int C, const float* x, int ldx, float* mean, float* rstd, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int dr_norm_apply_f32(int N, int C, const float* a, int lda, const float* mean_a, const float* rstd_a, const float* b,
+                      int ldb, const float* mean_b, const float* rstd_b, float leaky_slope, int activate, float* out,
+                      int ldo, void* stream);
+int dr_gather_pool_f32(int n2, int H, int ld_inds, int d, const float* x, int n1, const int64_t* inds, int first_only,
+                       float* out, void* stream);
+
 /* weights of one GeometryAttentionLayer in the reference state-dict layout ([out,in] row-major;
  * 3D/models/transformero.py:26-41): host struct of device pointers */
 typedef struct {

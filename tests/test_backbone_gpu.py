@@ -1,0 +1,61 @@
+"""the KPFCN backbone ops and the whole coarse phase through the C ABI, against the oracle and against
+the output of the reference backbone itself (tests/golden/kpfcn_coarse.npz).  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import kpfcn_oracle as ko
+from tests.helpers import T
+from tests.test_oracle_golden import kpfcn_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_kpconv_matches_oracle(golden):
+    from diffreg_hip import lib
+    g, sd, tb = kpfcn_inputs(golden)
+    cfg = synth.KPFCN_CFG
+    # layer-1 geometry with random features of 64 channels, then a strided one (pools), then Cin = 1
+    for q, s, idx, cin, layer in ((tb["points"][1], tb["points"][1], tb["neighbors"][1], 64, 1),
+                                  (tb["points"][2], tb["points"][1], tb["pools"][1], 96, 1),
+                                  (tb["points"][0], tb["points"][0], tb["neighbors"][0], 1, 0)):
+        x = T(synth.hash_normal(9, cin + len(s), (len(s), cin))).float()
+        Wk = T(synth.hash_uniform(10, cin, (cfg["num_kernel_points"], cin, 48))).float() / (cin * 4) ** 0.5
+        kp = sd["encoder_blocks.3.KPConv.kernel_points"] if layer == 1 else sd["encoder_blocks.0.KPConv.kernel_points"]
+        extent = cfg["first_subsampling_dl"] * 2 ** layer * cfg["KP_extent"]
+        ref = ko.kpconv(q, s, idx, x, Wk, kp, extent)
+        wf = lib.kpconv_gather(q.to(DEV), s.to(DEV), idx.to(DEV), x.to(DEV), kp.to(DEV), extent)
+        w2 = Wk.permute(2, 0, 1).reshape(48, -1)
+        w2 = torch.cat([w2, torch.zeros(48, (-w2.shape[1]) % 4)], 1).contiguous()
+        got = lib.linear_ex(wf, w2.to(DEV)).cpu()
+        assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_norm_and_pools_match_oracle():
+    from diffreg_hip import lib
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(700, 96, generator=g) * 3 + 1, torch.randn(700, 96, generator=g)
+    sa, sb = lib.col_stats(a.to(DEV)), lib.col_stats(b.to(DEV))
+    import torch.nn.functional as F
+    assert (lib.norm_apply(a.to(DEV), sa).cpu() - F.leaky_relu(ko.norm_block(a), 0.1)).abs().max().item() < 2e-5
+    assert (lib.norm_apply(a.to(DEV), sa, activate=False).cpu() - ko.norm_block(a)).abs().max().item() < 2e-5
+    ref = F.leaky_relu(ko.norm_block(a) + ko.norm_block(b), 0.1)
+    assert (lib.norm_apply(a.to(DEV), sa, b.to(DEV), sb).cpu() - ref).abs().max().item() < 2e-5
+    ref = F.leaky_relu(ko.norm_block(a) + b, 0.1)
+    assert (lib.norm_apply(a.to(DEV), sa, b.to(DEV), None).cpu() - ref).abs().max().item() < 2e-5
+    inds = torch.randint(0, 701, (300, 17), generator=g)            # 700 = shadow index
+    assert torch.equal(lib.gather_pool(a.to(DEV), inds.to(DEV)).cpu(), ko.max_pool(a, inds))
+    assert torch.equal(lib.gather_pool(a.to(DEV), inds.to(DEV), first_only=True).cpu(), ko.closest_pool(a, inds))
+
+
+def test_kpfcn_coarse_matches_reference(golden):
+    """the whole coarse phase on the GPU against the reference backbone's own output"""
+    from diffreg_hip.backbone import KPFCNEngine
+    g, sd, tb = kpfcn_inputs(golden)
+    eng = KPFCNEngine(sd, device=DEV)
+    out = eng.forward(tb).cpu().numpy()
+    assert out.shape == g["coarse"].shape
+    err = np.abs(out - g["coarse"]).max()
+    assert err < 1e-4 * max(1.0, np.abs(g["coarse"]).max()), err       # north_star tolerance: 1e-4 fp32
