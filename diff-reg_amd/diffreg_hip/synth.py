@@ -238,24 +238,27 @@ def _radius_neighbors(q, s, q_len, s_len, radius, limit):
     out = np.full((len(q), limit), len(s), dtype=np.int64)
     q0 = s0 = 0
     for ql, sl in zip(q_len, s_len):
-        qq, ss = q[q0:q0 + ql].astype(np.float64), s[s0:s0 + sl].astype(np.float64)
-        d2 = ((qq[:, None, :] - ss[None, :, :]) ** 2).sum(-1)
-        idx = np.argsort(d2, axis=1, kind="stable")[:, :limit]
-        dd = np.take_along_axis(d2, idx, 1)
-        idx = np.where(dd < radius * radius, idx + s0, len(s))
-        out[q0:q0 + ql, :idx.shape[1]] = idx
+        ss = s[s0:s0 + sl].astype(np.float64)
+        for c0 in range(0, ql, 1024):                            # query blocks: bounded memory for large clouds
+            qq = q[q0 + c0:q0 + min(ql, c0 + 1024)].astype(np.float64)
+            d2 = ((qq[:, None, :] - ss[None, :, :]) ** 2).sum(-1)
+            idx = np.argsort(d2, axis=1, kind="stable")[:, :limit]
+            dd = np.take_along_axis(d2, idx, 1)
+            idx = np.where(dd < radius * radius, idx + s0, len(s))
+            out[q0 + c0:q0 + c0 + len(qq), :idx.shape[1]] = idx
         q0 += ql; s0 += sl
     return out
 
 
-def make_kpfcn_batch(n_src=1400, n_tgt=1200, seed=0, limit=(28, 28, 30, 32)):
-    """points / neighbors / pools / upsamples / stack_lengths of a 4-layer KPFCN batch + features [N0,1] = 1"""
+def make_kpfcn_batch(n_src=1400, n_tgt=1200, seed=0, limit=(28, 28, 30, 32), extent=1.0):
+    """points / neighbors / pools / upsamples / stack_lengths of a 4-layer KPFCN batch + features [N0,1] = 1
+    (extent scales the sheet: the number of occupied voxels, hence of layer-0 points, grows with extent^2)"""
     cfg = KPFCN_CFG
     clouds = []
     for c, n in enumerate((n_src, n_tgt)):
         u = hash_uniform(seed, 40 + c, (n, 3), 0.0, 1.0)
         # a folded sheet inside a 0.9 x 0.7 x 0.4 box: surface-like sampling, ~25-30 neighbours at the first radius
-        x, y = 0.9 * u[:, 0], 0.7 * u[:, 1]
+        x, y = 0.9 * extent * u[:, 0], 0.7 * extent * u[:, 1]
         z = 0.15 * np.sin(4.0 * x + c) * np.cos(3.0 * y) + 0.02 * u[:, 2] + 0.2
         clouds.append(np.stack([x, y, z], 1).astype(np.float32))
     dl = cfg["first_subsampling_dl"]

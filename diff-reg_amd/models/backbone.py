@@ -1,0 +1,109 @@
+"""models.backbone -- drop-in for the reference's KPFCN backbone, coarse phase (3D/models/backbone.py:6-158), on the HIP
+ops of diffreg_hip.
+
+The module tree reproduces the reference's parameter names (encoder_blocks.{i}.KPConv.{weights,kernel_points},
+.unary1/.unary2/.unary_shortcut.mlp.weight, decoder_blocks.{i}.mlp.weight, coarse_out / coarse_in / fine_out), so the
+`backbone.*` part of a Diff-Reg checkpoint loads unchanged; the kernel point dispositions come from the checkpoint
+(the reference regenerates them from kernels/dispositions/*.ply, 3D/models/blocks.py:199-212).  forward(batch,
+phase='coarse') returns the coarse features exactly as the reference does; other phases / the training path are not
+accelerated (the reference's own fine branch is commented out upstream, backbone.py:161-180).
+"""
+import torch
+import torch.nn as nn
+
+
+def _get(cfg, k):
+    return cfg[k] if isinstance(cfg, dict) else getattr(cfg, k)
+
+
+class KPConv(nn.Module):                        # parameters of 3D/models/blocks.py:120-192
+    def __init__(self, K, cin, cout):
+        super().__init__()
+        self.weights = nn.Parameter(torch.zeros(K, cin, cout))
+        self.kernel_points = nn.Parameter(torch.zeros(K, 3), requires_grad=False)
+
+
+class UnaryBlock(nn.Module):                    # blocks.py:455-484 (its BatchNormBlock is an InstanceNorm1d without parameters)
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.mlp = nn.Linear(cin, cout, bias=False)
+
+
+class SimpleBlock(nn.Module):                   # blocks.py:518-572
+    def __init__(self, K, cin, cout):
+        super().__init__()
+        self.KPConv = KPConv(K, cin, cout // 2)
+
+
+class ResnetBottleneckBlock(nn.Module):         # blocks.py:575-660
+    def __init__(self, K, cin, cout):
+        super().__init__()
+        self.unary1 = UnaryBlock(cin, cout // 4) if cin != cout // 4 else nn.Identity()
+        self.KPConv = KPConv(K, cout // 4, cout // 4)
+        self.unary2 = UnaryBlock(cout // 4, cout)
+        self.unary_shortcut = UnaryBlock(cin, cout) if cin != cout else nn.Identity()
+
+
+class NearestUpsampleBlock(nn.Module):          # blocks.py:676-691 (no parameters)
+    pass
+
+
+class KPFCN(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        arch = list(_get(config, "architecture"))
+        K = _get(config, "num_kernel_points")
+        self.arch = arch
+        self.cfg = dict(num_layers=_get(config, "num_layers"), in_points_dim=3, first_feats_dim=_get(config, "first_feats_dim"),
+                        first_subsampling_dl=_get(config, "first_subsampling_dl"), in_feats_dim=_get(config, "in_feats_dim"),
+                        conv_radius=_get(config, "conv_radius"), num_kernel_points=K, KP_extent=_get(config, "KP_extent"),
+                        coarse_feature_dim=_get(config, "coarse_feature_dim"))
+        if _get(config, "KP_influence") != "linear" or _get(config, "aggregation_mode") != "sum" or _get(config, "deformable") \
+                or not _get(config, "use_batch_norm"):
+            raise NotImplementedError("only the shipped KPFCN configuration (linear influence, sum aggregation, rigid kernels, "
+                                      "use_batch_norm) is accelerated")
+        # ---- the reference's construction order (backbone.py:13-112), parameters only --------------------------------
+        layer, in_dim, out_dim = 0, _get(config, "in_feats_dim"), _get(config, "first_feats_dim")
+        self.encoder_blocks = nn.ModuleList()
+        skip_dims, start = [], 0
+        for bi, block in enumerate(arch):
+            if any(t in block for t in ("pool", "strided", "upsample", "global")):
+                skip_dims.append(in_dim)
+            if "upsample" in block:
+                start = bi
+                break
+            self.encoder_blocks.append(SimpleBlock(K, in_dim, out_dim) if "simple" in block else ResnetBottleneckBlock(K, in_dim, out_dim))
+            in_dim = out_dim // 2 if "simple" in block else out_dim
+            if "pool" in block or "strided" in block:
+                layer += 1; out_dim *= 2
+        cdim = _get(config, "coarse_feature_dim")
+        self.coarse_out = nn.Conv1d(in_dim // 2, cdim, kernel_size=1, bias=True)
+        self.coarse_in = nn.Conv1d(cdim, in_dim // 2, kernel_size=1, bias=True)
+        self.decoder_blocks = nn.ModuleList()
+        for di, block in enumerate(arch[start:]):
+            if di > 0 and "upsample" in arch[start + di - 1]:
+                in_dim += skip_dims[layer]
+            self.decoder_blocks.append(NearestUpsampleBlock() if "upsample" in block else UnaryBlock(in_dim, out_dim))
+            in_dim = out_dim
+            if "upsample" in block:
+                layer -= 1; out_dim //= 2
+        self.fine_out = nn.Conv1d(out_dim, _get(config, "fine_feature_dim"), kernel_size=1, bias=True)
+        self._engine = None
+        self._engine_key = None
+
+    def _get_engine(self, device):
+        from diffreg_hip.backbone import KPFCNEngine
+        key = (str(device), tuple(p._version for p in self.parameters()))
+        if self._engine is None or self._engine_key != key:
+            self._engine = KPFCNEngine(self.state_dict(), arch=self.arch, cfg=self.cfg, device=device)
+            self._engine_key = key
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, batch, phase="encode"):
+        if phase != "coarse":
+            raise NotImplementedError("only phase='coarse' exists (the reference's other branches are commented out, backbone.py:161-180)")
+        if self.training:
+            raise NotImplementedError("the training path of the backbone is outside the accelerated path")
+        dev = batch["points"][0].device
+        return self._get_engine(dev).forward(batch)

@@ -37,6 +37,7 @@ def main():
                         KP_influence="linear", aggregation_mode="sum", fixed_kernel_points="center", use_batch_norm=True,
                         batch_norm_momentum=0.02, deformable=False, modulated=False, fine_feature_dim=264))
     torch.manual_seed(0)
+    np.random.seed(0)                                                 # the reference rotates its kernel dispositions randomly
     net = KPFCN(cfg).eval()
     ref_sd = net.state_dict()
     kp = {k: v.numpy().copy() for k, v in ref_sd.items() if k.endswith("kernel_points")}
@@ -67,8 +68,11 @@ def main():
     print("reference coarse feats", tuple(out.shape), "abs max %.3f" % out.abs().max().item(), "| oracle - reference max abs %.2e" % err)
     assert err < 2e-4 * max(1.0, out.abs().max().item())
     os.makedirs(OUT, exist_ok=True)
+    keys = sorted(ref_sd.keys())
     np.savez_compressed(os.path.join(OUT, "kpfcn_coarse.npz"), coarse=out.numpy(),
-                        enc0=inter["enc0"][:64], enc1=inter["enc1"][:64], enc2=inter["enc2"][:64], enc10=inter["enc10"],
+                        enc0=inter["enc0"][:64], enc1=inter["enc1"][:64], enc2=inter["enc2"][:64], enc10=inter["enc10"][:, :256],
+                        # the reference module's parameter names and shapes (state-dict compatibility of models/backbone.py)
+                        sd_keys=np.array(keys), sd_shapes=np.array([";".join(map(str, ref_sd[k].shape)) for k in keys]),
                         **{"kp:" + k: v for k, v in kp.items()})
     print("wrote", os.path.join(OUT, "kpfcn_coarse.npz"))
 

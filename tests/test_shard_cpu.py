@@ -53,14 +53,35 @@ def test_single_process_gather_is_identity():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Diff-Reg-3dmatch"), reason="reference tree only exists in the build container")
-def test_models_overlay_resolves_backbone_in_reference_tree():
-    """our models.* shadow the hot-path modules; models.backbone still comes from the reference checkout."""
+def test_models_overlay_resolves_the_rest_in_reference_tree():
+    """our models.* shadow the hot-path modules (and the backbone, row f1); everything else (models.blocks, models.loss,
+    models.transformer.geotransformer, ...) still comes from the reference checkout."""
     import subprocess
     code = ("import sys; from unittest.mock import MagicMock; sys.modules['open3d']=MagicMock();"
             "sys.path.insert(0,'/root/reference/Diff-Reg-3dmatch'); sys.path.insert(0,%r);"
-            "import models.pipeline as p, models.backbone as b, models.transformer.geotransformer as g;"
+            "import models.pipeline as p, models.backbone as b, models.blocks as k, models.transformer.geotransformer as g;"
             "from models.transformer import RepositioningTransformer as R;"
-            "assert p.__file__.startswith(%r) and b.__file__.startswith('/root/reference') and R.__module__=='models.transformero';"
-            "print('ok')") % (os.path.join(ROOT, "diff-reg_amd"), ROOT)
+            "assert p.__file__.startswith(%r) and b.__file__.startswith(%r) and k.__file__.startswith('/root/reference') "
+            "and R.__module__=='models.transformero';"
+            "print('ok')") % (os.path.join(ROOT, "diff-reg_amd"), ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_backbone_overlay_state_dict_matches_reference():
+    """models/backbone.py exposes exactly the reference KPFCN's parameter names and shapes, so the
+    `backbone.*` part of a Diff-Reg checkpoint loads unchanged (names / shapes recorded from the reference module by
+    oracle/make_golden_kpfcn.py)."""
+    import importlib.util
+    import numpy as np
+    from diffreg_hip import synth
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("dr_models_backbone", os.path.join(here, "..", "diff-reg_amd", "models", "backbone.py"))
+    mb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mb)
+    cfg = dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), KP_influence="linear", aggregation_mode="sum", deformable=False,
+               use_batch_norm=True, fine_feature_dim=264)
+    mine = {k: tuple(v.shape) for k, v in mb.KPFCN(cfg).state_dict().items()}
+    g = np.load(os.path.join(here, "golden", "kpfcn_coarse.npz"))
+    ref = {str(k): tuple(int(v) for v in str(s).split(";") if v) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    assert mine == ref
