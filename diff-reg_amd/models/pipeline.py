@@ -3,9 +3,9 @@
 matching matrix -> conf_matrix_pred / match_pred / (R, t).
 
 The evaluation branch (`not self.training and not eval_flag`) runs entirely in libdiffreg_hip through
-diffreg_hip.engine.DenoiseEngine (one HIP-graph replay per forward).  The KPFCN backbone is out of
-scope: it is taken from the reference tree when that is importable
-(`models.backbone.KPFCN`), or injected with `backbone=`.  The training branch (row f3) is not built.
+diffreg_hip.engine.DenoiseEngine (one HIP-graph replay per forward).  The KPFCN backbone (SURVEY section 8
+row f1) is `models.backbone.KPFCN` of this overlay (HIP ops, the reference's state-dict layout), or whatever is
+injected with `backbone=`.  The training branch (row f3) is not built.
 """
 import math
 
@@ -51,7 +51,7 @@ def q_sample(x_start, t, noise=None, timesteps=1000):
 
 def _load_reference_backbone(kpfcn_config):
     try:
-        from models.backbone import KPFCN          # resolves in the reference tree (models/__init__ extends __path__)
+        from models.backbone import KPFCN          # the overlay's backbone (kpfcn_config must carry `architecture`, as main.py sets it)
     except Exception:                               # noqa: BLE001 - any import problem means "not available"
         return None
     return KPFCN(kpfcn_config)
