@@ -130,3 +130,43 @@ def test_pipeline_forward_matches_reference(golden, variant, N, M, nv, mv, steps
     # eval_flag=True (validation) skips the loop (pipeline.py:221)
     d2 = dict(data); d2.pop("conf_matrix_pred", None)
     assert "conf_matrix_pred" not in model(d2, eval_flag=True)
+
+
+def test_pipeline_end_to_end_with_overlay_backbone(golden):
+    """Rows f1 + a1: Pipeline(config) with its OWN backbone (models.backbone.KPFCN of the overlay) from the collate-style
+    input dict (stacked points, neighbour / pool / upsample indices) to conf_matrix_pred, against the oracle backbone
+    followed by the oracle loop."""
+    from models.pipeline import Pipeline
+    from oracle import kpfcn_oracle as ko
+    from tests.test_oracle_golden import kpfcn_inputs
+    variant, steps, mc = "3dmatch", 2, 200
+    g, bsd, tb = kpfcn_inputs(golden)
+    cfg = ref_like_config(variant, steps, mc)
+    cfg.kpfcn_config = to_attr(dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), KP_influence="linear", aggregation_mode="sum",
+                                    deformable=False, use_batch_norm=True, fine_feature_dim=264, coarse_level=-2))
+    model = Pipeline(cfg)
+    assert type(model.backbone).__module__.endswith("backbone") and hasattr(model.backbone, "encoder_blocks")
+    sd = model.state_dict()
+    W = weights(variant)
+    sd.update(W)
+    sd.update({"backbone." + k: v for k, v in bsd.items()})
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    b = synth.make_kpfcn_batch()
+    ns, nt = b["stack_lengths"][2]                                   # coarse_level = -2 -> layer 2
+    x_T = T(synth.hash_normal(77, 5, (1, ns, nt))).float()
+    data = {k: [t.to(DEV) for t in v] for k, v in tb.items() if isinstance(v, list)}
+    data["features"] = tb["features"].to(DEV)
+    data.update({"src_mask": torch.ones(1, ns, dtype=torch.bool, device=DEV), "tgt_mask": torch.ones(1, nt, dtype=torch.bool, device=DEV),
+                 "src_ind_coarse_split": torch.arange(ns, device=DEV), "tgt_ind_coarse_split": torch.arange(nt, device=DEV),
+                 "src_ind_coarse": torch.arange(ns, device=DEV), "tgt_ind_coarse": torch.arange(ns, ns + nt, device=DEV), "x_T": x_T.to(DEV)})
+    out = model(data)
+    conf = out["conf_matrix_pred"][0].cpu()
+    # oracle: backbone -> split -> loop
+    feats = ko.kpfcn_coarse(bsd, tb)
+    pts = tb["points"][2]
+    v = synth.VARIANTS[variant]
+    ms, mt = torch.ones(1, ns, dtype=torch.bool), torch.ones(1, nt, dtype=torch.bool)
+    ref = orc.denoise_loop(W, v, feats[None, :ns], feats[None, ns:], pts[None, :ns], pts[None, ns:], ms, mt, x_T, steps, mc, variant=variant)
+    d = (conf - ref["conf_matrix_pred"][0]).abs()
+    assert (d > 1e-4).double().mean().item() <= 1e-3, d.max().item()
