@@ -14,18 +14,20 @@ namespace dr {
 
 constexpr int KP_MAXK = 16, KP_MAXH = 64;
 
-// one wave per query point; lane l owns channels l, l + 64, ..
+// one wave per query point; lane l owns channels l, l + 64, .. (CPL of them); ONE pass over the neighbours' features:
+// a neighbour's K influences are read once (4 x ds_read_b128 from the [h][16] image) and applied to all the lane's
+// channels, and the per-neighbour feature sums of the normalisation are accumulated in the same pass
+template <int CPL>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int H, int Cin, int K, const float* __restrict__ q_pts,
                                                             const float* __restrict__ s_pts, const long long* __restrict__ nb,
                                                             const float* __restrict__ x, const float* __restrict__ kp, float extent,
                                                             float* __restrict__ wf, int ldw) {
-    __shared__ float s_w[4][KP_MAXK * KP_MAXH];     // influences [k][h] of the wave's query
+    __shared__ __attribute__((aligned(16))) float s_w[4][KP_MAXH * KP_MAXK];     // influences [h][k] of the wave's query
     __shared__ int s_idx[4][KP_MAXH];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= Nq) return;
     const float qx = q_pts[q * 3], qy = q_pts[q * 3 + 1], qz = q_pts[q * 3 + 2];
-    // influences: lane h computes the K weights of neighbour h (H <= 64)
     if (lane < H) {
         const long long id = nb[(size_t)q * H + lane];
         const bool shadow = id >= Ns || id < 0;
@@ -33,41 +35,54 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int 
         // the shadow point sits at +1e6 on every axis (blocks.py:288): its influence is 0
         const float nx = (shadow ? 1e6f : s_pts[id * 3]) - qx, ny = (shadow ? 1e6f : s_pts[id * 3 + 1]) - qy,
                     nz = (shadow ? 1e6f : s_pts[id * 3 + 2]) - qz;
-        for (int k = 0; k < K; ++k) {
-            const float dx = nx - kp[k * 3], dy = ny - kp[k * 3 + 1], dz = nz - kp[k * 3 + 2];
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            s_w[w][k * KP_MAXH + lane] = fmaxf(1.f - sqrtf(d2) / extent, 0.f);          // 'linear' influence (blocks.py:349)
+#pragma unroll
+        for (int k = 0; k < KP_MAXK; ++k) {
+            float wv = 0.f;
+            if (k < K) {
+                const float dx = nx - kp[k * 3], dy = ny - kp[k * 3 + 1], dz = nz - kp[k * 3 + 2];
+                wv = fmaxf(1.f - sqrtf(dx * dx + dy * dy + dz * dz) / extent, 0.f);       // 'linear' influence (blocks.py:349)
+            }
+            s_w[w][lane * KP_MAXK + k] = wv;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // neighbours with a positive feature sum (blocks.py:390-392): per neighbour, sum over all channels, in a fixed order
+    float acc[CPL][KP_MAXK];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int k = 0; k < KP_MAXK; ++k) acc[c][k] = 0.f;
     int num = 0;
     for (int h = 0; h < H; ++h) {
         const int id = s_idx[w][h];
+        if (id < 0) continue;                                       // zero features of the shadow row (blocks.py:369); uniform per wave
+        float wk[KP_MAXK];
+#pragma unroll
+        for (int k4 = 0; k4 < KP_MAXK / 4; ++k4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&s_w[w][h * KP_MAXK + 4 * k4]);
+            wk[4 * k4] = t4.x; wk[4 * k4 + 1] = t4.y; wk[4 * k4 + 2] = t4.z; wk[4 * k4 + 3] = t4.w;
+        }
         float part = 0.f;
-        if (id >= 0)
-            for (int c = lane; c < Cin; c += 64) part += x[(size_t)id * Cin + c];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + 64 * c;
+            const float xv = ch < Cin ? x[(size_t)id * Cin + ch] : 0.f;
+            part += xv;
+#pragma unroll
+            for (int k = 0; k < KP_MAXK; ++k) acc[c][k] = fmaf(wk[k], xv, acc[c][k]);
+        }
+        // neighbours with a positive feature sum (blocks.py:390-392), summed over all channels in a fixed order
         part = wave_sum(part);
         num += part > 0.f ? 1 : 0;
     }
     const float inv = 1.f / (float)(num > 1 ? num : 1);
-    // weighted features, KP_MAXK accumulators per owned channel
-    for (int c0 = lane; c0 < Cin; c0 += 64) {
-        float acc[KP_MAXK];
 #pragma unroll
-        for (int k = 0; k < KP_MAXK; ++k) acc[k] = 0.f;
-        for (int h = 0; h < H; ++h) {
-            const int id = s_idx[w][h];
-            if (id < 0) continue;                                   // zero features of the shadow row (blocks.py:369)
-            const float xv = x[(size_t)id * Cin + c0];
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < Cin)
 #pragma unroll
             for (int k = 0; k < KP_MAXK; ++k)
-                if (k < K) acc[k] = fmaf(s_w[w][k * KP_MAXH + h], xv, acc[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < KP_MAXK; ++k)
-            if (k < K) wf[(size_t)q * ldw + k * Cin + c0] = acc[k] * inv;
+                if (k < K) wf[(size_t)q * ldw + k * Cin + ch] = acc[c][k] * inv;
     }
     // zero the padding columns K*Cin .. ldw-1 (the GEMM reads whole float4s)
     for (int c = K * Cin + lane; c < ldw; c += 64) wf[(size_t)q * ldw + c] = 0.f;
@@ -76,9 +91,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int 
 int launch_kpconv_gather(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const long long* nb,
                          const float* x, const float* kp, float extent, float* wf, int ldw, hipStream_t st) {
     if (Nq <= 0) return DR_OK;
-    if (K > KP_MAXK || H > KP_MAXH || H < 1 || Cin < 1 || ldw < K * Cin) return DR_ENOSUP;
-    hipLaunchKernelGGL(kpconv_gather_kernel, dim3((Nq + 3) / 4), dim3(256), 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf,
-                       ldw);
+    if (K > KP_MAXK || H > KP_MAXH || H < 1 || Cin < 1 || Cin > 512 || ldw < K * Cin) return DR_ENOSUP;
+    const dim3 grid((Nq + 3) / 4), blk(256);
+    if (Cin <= 64) hipLaunchKernelGGL(kpconv_gather_kernel<1>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
+    else if (Cin <= 128) hipLaunchKernelGGL(kpconv_gather_kernel<2>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
+    else if (Cin <= 256) hipLaunchKernelGGL(kpconv_gather_kernel<4>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
+    else hipLaunchKernelGGL(kpconv_gather_kernel<8>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
