@@ -111,6 +111,12 @@ SIGNATURES.update({
     "dr_denoise_loop_2d3d_workspace_bytes": (c_size_t, [_P(Loop2D3DConfig), c_int, c_int, c_int]),
     "dr_denoise_loop_2d3d": (c_int, [_P(Loop2D3DConfig), _P(FusionWeights), c_int, c_int, c_int] + [c_void_p] * 16 +
                              [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
+    "dr_inlier_ratio_f32": (c_int, [c_int] * 4 + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p]),
+    "dr_nrfmr_f32": (c_int, [c_int] * 4 + [c_void_p] * 9 + [c_int, c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 4),
+    "dr_ransac_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_ransac_corr_f64": (c_int, [c_int] * 4 + [c_void_p] * 4 + [c_double, c_int, ctypes.c_uint64] + [c_void_p] * 7 +
+                           [c_size_t, c_void_p]),
+    "dr_registration_recall_f64": (c_int, [c_int] + [c_void_p] * 5 + [c_double, c_void_p, c_void_p, c_void_p]),
     "dr_denoiser_match_f32": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 9 +
                               [c_void_p, c_size_t, c_void_p]),
 })
@@ -381,6 +387,80 @@ def top1_union(conf):
     check(fn(P, N, M, ptr(conf), ptr(out), ptr(cnt), stream_of(conf)))
     counts = cnt.cpu().tolist()
     return [out[p, :counts[p]] for p in range(P)]
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation harness.  matches int64 [P,cap,3], count int32 [P] (the loop's own output layout)
+# ------------------------------------------------------------------------------------------------
+def _f32c(x, shape):
+    x = x.to(torch.float32).reshape(shape).contiguous()
+    return x
+
+
+def inlier_ratio(matches, count, s_pcd, t_pcd, rot, trn, inlier_thr, s2t_flow=None):
+    """-> (ir [P] float32, n_inlier [P] int32)   (MatchMotionLoss.compute_inlier_ratio, 3D/models/loss.py:383-410)"""
+    matches = matches.contiguous()
+    P, cap, _ = matches.shape
+    N, M = s_pcd.shape[1], t_pcd.shape[1]
+    dev = matches.device
+    ir = torch.empty(P, device=dev)
+    n_inl = torch.empty(P, dtype=torch.int32, device=dev)
+    flow = None if s2t_flow is None else _f32c(s2t_flow, (P, N, 3))
+    check(_lib.dr_inlier_ratio_f32(P, cap, N, M, ptr(matches), ptr(count.contiguous()), ptr(_f32c(s_pcd, (P, N, 3))),
+                                   ptr(_f32c(t_pcd, (P, M, 3))), ptr(_f32c(rot, (P, 9))), ptr(_f32c(trn, (P, 3))), ptr(flow),
+                                   float(inlier_thr), ptr(ir), ptr(n_inl), stream_of(matches)))
+    return ir, n_inl
+
+
+def nrfmr(matches, count, s_pcd, t_pcd, raw_pcd, raw_flow, raw_offsets, metric_index, q_offsets, max_q, rot, trn,
+          knn_radius=0.1, recall_thr=0.04, want_blended=False):
+    """-> (nrfmr [P] float32, n_recalled [P] int32[, blended [sum Q,3]])   (compute_nrfmr, 3D/lib/tester.py:150-210)"""
+    matches = matches.contiguous()
+    P, cap, _ = matches.shape
+    N, M = s_pcd.shape[1], t_pcd.shape[1]
+    dev = matches.device
+    out = torch.empty(P, device=dev)
+    n_rec = torch.empty(P, dtype=torch.int32, device=dev)
+    bl = torch.empty(metric_index.shape[0], 3, device=dev) if want_blended else None
+    check(_lib.dr_nrfmr_f32(P, cap, N, M, ptr(matches), ptr(count.contiguous()), ptr(_f32c(s_pcd, (P, N, 3))),
+                            ptr(_f32c(t_pcd, (P, M, 3))), ptr(_f32c(raw_pcd, (-1, 3))), ptr(_f32c(raw_flow, (-1, 3))),
+                            ptr(raw_offsets.contiguous()), ptr(metric_index.contiguous()), ptr(q_offsets.contiguous()), int(max_q),
+                            ptr(_f32c(rot, (P, 9))), ptr(_f32c(trn, (P, 3))), float(knn_radius), float(recall_thr), ptr(out),
+                            ptr(n_rec), ptr(bl), stream_of(matches)))
+    return (out, n_rec, bl) if want_blended else (out, n_rec)
+
+
+def ransac_corr(matches, count, s_pcd, t_pcd, distance_thr=0.05, iters=50000, seed=0, pair_ids=None):
+    """-> dict(rot [P,3,3], trn [P,3,1] float64, fitness [P], inlier_rmse [P], best_iter [P] int32)
+    (ransac_regist_coarse / Open3D correspondence RANSAC, 3D/models/loss.py:13-24, 347-379)"""
+    matches = matches.contiguous()
+    P, cap, _ = matches.shape
+    N, M = s_pcd.shape[1], t_pcd.shape[1]
+    dev = matches.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    rot, trn = torch.empty(P, 3, 3, **f64), torch.empty(P, 3, 1, **f64)
+    fit, rmse = torch.empty(P, **f64), torch.empty(P, **f64)
+    bi = torch.empty(P, dtype=torch.int32, device=dev)
+    wsb = _lib.dr_ransac_workspace_bytes(P, int(iters))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    ids = None if pair_ids is None else pair_ids.to(device=dev, dtype=torch.int64).contiguous()
+    check(_lib.dr_ransac_corr_f64(P, cap, N, M, ptr(matches), ptr(count.contiguous()), ptr(_f32c(s_pcd, (P, N, 3))),
+                                  ptr(_f32c(t_pcd, (P, M, 3))), float(distance_thr), int(iters), int(seed), ptr(ids), ptr(rot),
+                                  ptr(trn), ptr(fit), ptr(rmse), ptr(bi), ptr(ws), wsb, stream_of(matches)))
+    return dict(rot=rot, trn=trn, fitness=fit, inlier_rmse=rmse, best_iter=bi)
+
+
+def registration_recall(rot_est, trn_est, rot_gt, trn_gt, info, thr=0.2):
+    """-> (err [P] float64, success [P] int32)   (compute_registration_recall, 3D/models/loss.py:27-44, 415-448)"""
+    P = rot_est.shape[0]
+    dev = rot_est.device
+    err = torch.empty(P, dtype=torch.float64, device=dev)
+    ok = torch.empty(P, dtype=torch.int32, device=dev)
+    d = lambda x, s: x.to(torch.float64).reshape(s).contiguous()
+    check(_lib.dr_registration_recall_f64(P, ptr(d(rot_est, (P, 9))), ptr(d(trn_est, (P, 3))), ptr(_f32c(rot_gt, (P, 9))),
+                                          ptr(_f32c(trn_gt, (P, 3))), ptr(d(info, (P, 36))), float(thr), ptr(err), ptr(ok),
+                                          stream_of(rot_est)))
+    return err, ok
 
 
 PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state", "gemm_split")

@@ -32,6 +32,17 @@ def hash_u01(seed, stream, n):
     return ((z >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / (1 << 53))
 
 
+def hash_bits(seed, stream, n):
+    """n 53-bit integers (uint64): the integers under hash_u01.  The correspondence RANSAC samples with them
+    (csrc/metrics.hip::hash_bits is the same arithmetic on the device)."""
+    with np.errstate(over="ignore"):
+        base = _mix(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
+        idx = np.arange(n, dtype=np.uint64)
+        z = _mix(idx ^ base)
+        z = _mix(z + base)
+    return z >> np.uint64(11)
+
+
 def hash_uniform(seed, stream, shape, lo=-1.0, hi=1.0):
     n = int(np.prod(shape))
     return (lo + (hi - lo) * hash_u01(seed, stream, n)).reshape(shape)
@@ -328,3 +339,50 @@ def make_kpfcn_weights(kernel_points, seed=3):
         if di == 1:
             break                                                # the coarse phase returns after decoder block 1 (backbone.py:153-158)
     return sd
+
+
+# --------------------------------------------------------------------------------------------
+# evaluation-harness inputs: predicted matches, 4DMatch-style metric points, Redwood info matrices
+# --------------------------------------------------------------------------------------------
+def make_matches(pair, seed, inlier_frac=0.5, n_extra=0):
+    """A match_pred-like list [K,3] int64 (0, i, j) for a make_pair() scene: one row per source point (plus n_extra
+    rows that repeat source points, like the column arg-max half of the top-1 union), a fraction of the overlapping
+    points matched to their true partner, everything else to a hash-chosen target.  Sorted row-major like nonzero()."""
+    N, M = pair["s_pcd"].shape[0], pair["t_pcd"].shape[0]
+    j = (hash_u01(seed, 31, N + n_extra) * M).astype(np.int64)
+    i = np.concatenate([np.arange(N), (hash_u01(seed, 32, n_extra) * N).astype(np.int64)])
+    gt = pair["gt_matches"]
+    keep = hash_u01(seed, 33, len(gt)) < inlier_frac / max(len(gt) / N, 1e-9)
+    j[gt[keep, 0]] = gt[keep, 1]
+    key = np.unique(i * M + j)
+    return np.stack([np.zeros_like(key), key // M, key % M], 1).astype(np.int64)
+
+
+def make_metric_points(pair, seed, n_raw=2000, n_metric=600, flow_scale=0.05, dtype=np.float32):
+    """4DMatch-style extras for compute_nrfmr (3D/lib/tester.py:150-210): a raw source cloud scattered around the
+    superpoints, a smooth scene flow on it, the indices of the metric points, and the coarse flow of the superpoints."""
+    s = pair["s_pcd"].astype(np.float64)
+    N = len(s)
+    owner = (hash_u01(seed, 41, n_raw) * N).astype(np.int64)
+    raw = s[owner] + 0.04 * hash_normal(seed, 42, (n_raw, 3))
+    A = flow_scale * hash_normal(seed, 43, (3, 3))
+    b = flow_scale * hash_normal(seed, 44, (3,))
+    flow = lambda x: np.sin(x @ A.T) * 0.5 + b
+    metric_index = np.sort(np.argsort(hash_u01(seed, 45, n_raw))[:n_metric]).astype(np.int64)
+    return dict(raw_pcd=raw.astype(dtype), raw_flow=flow(raw).astype(dtype), metric_index=metric_index,
+                coarse_flow=flow(s).astype(dtype))
+
+
+def make_info(seed):
+    """A symmetric positive-definite 6x6 `gt.info` matrix of the Redwood registration benchmark (loss.py:27-44)."""
+    B = hash_normal(seed, 51, (6, 6))
+    return B @ B.T * 50.0 + 200.0 * np.eye(6)
+
+
+def deform_targets(pair, coarse_flow, dtype=np.float32):
+    """t_pcd of a non-rigid scene: the partners of the overlapping source points sit at R (s + flow) + t."""
+    tp = pair["t_pcd"].astype(np.float64).copy()
+    gt = pair["gt_matches"]
+    s = pair["s_pcd"].astype(np.float64) + coarse_flow.astype(np.float64)
+    tp[gt[:, 1]] = s[gt[:, 0]] @ pair["R_gt"].T + pair["t_gt"]
+    return tp.astype(dtype)

@@ -271,6 +271,62 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
                           float* tgt_out, float* conf, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Evaluation harness on device: the consumers of the loop's `match_pred`.
+ * Match layout everywhere below: `matches` int64 [P, cap, 3] rows (b, src index, tgt index), the first
+ * count[p] rows of segment p valid -- exactly what dr_denoise_loop / dr_top1_union_* write (cap = N+M).
+ * The reference's flat [K,3] list of one pair (B = 1, 3D/lib/tester.py:115) is P = 1, cap = K, count = {K};
+ * column 0 is not read (the segment is the pair).
+ */
+
+/* MatchMotionLoss.compute_inlier_ratio (3D/models/loss.py:383-410): warp the matched source points with the
+ * ground-truth pose (+ optional scene flow, the 4DMatch call of 3D/lib/tester.py:267), count matches closer
+ * than inlier_thr, float32 arithmetic.  rot [P,9], trn [P,3], s2t_flow [P,N,3] or NULL.
+ * out: ir [P] float32 (0 when a pair has fewer than 3 matches, loss.py:403-404), n_inlier [P] int32. */
+int dr_inlier_ratio_f32(int P, int cap, int N, int M, const int64_t* matches, const int32_t* count, const float* s_pcd,
+                        const float* t_pcd, const float* rot, const float* trn, const float* s2t_flow, float inlier_thr,
+                        float* ir, int32_t* n_inlier, void* stream);
+
+/* compute_nrfmr + blend_anchor_motion (3D/lib/tester.py:127-210; knn_point_np 3D/datasets/utils.py:23-40):
+ * the matches of a pair are motion anchors (t_pcd[j] - s_pcd[i] at s_pcd[i]); every metric point takes the
+ * inverse-distance blend of its 3 nearest anchors (anchors beyond knn_radius get distance 1e10), and counts as
+ * recalled when it lands within recall_thr of its ground-truth position rot (p + flow) + trn.
+ *   raw_pcd, raw_flow [sum R_p, 3]: the un-subsampled source clouds and their scene flow, pair p at rows
+ *   raw_offsets[p] .. raw_offsets[p+1];  metric_index int64 [sum Q_p] (indices into the pair's raw cloud), pair p at
+ *   q_offsets[p] .. q_offsets[p+1]  (int32 offsets, P+1 entries each; max_q = the largest Q_p).
+ * out: nrfmr [P] float32 (recalled / Q_p; 0 for a pair with fewer than 4 anchors, where the reference's
+ * np.argpartition(kth=3) raises); n_recalled [P] int32; blended [sum Q_p, 3] float32 or NULL (the blended motion). */
+int dr_nrfmr_f32(int P, int cap, int N, int M, const int64_t* matches, const int32_t* count, const float* s_pcd,
+                 const float* t_pcd, const float* raw_pcd, const float* raw_flow, const int32_t* raw_offsets,
+                 const int64_t* metric_index, const int32_t* q_offsets, int max_q, const float* rot, const float* trn,
+                 float knn_radius, float recall_thr, float* nrfmr, int32_t* n_recalled, float* blended, void* stream);
+
+/* MatchMotionLoss.ransac_regist_coarse -> ransac_pose_estimation (3D/models/loss.py:13-24, 347-379): Open3D 0.13.0
+ * (3D/eccv24_3d_env.yml:139) registration_ransac_based_on_correspondence with ransac_n = 3,
+ * TransformationEstimationPointToPoint(False), RANSACConvergenceCriteria(50000, 1000) (confidence clamps to 1: no
+ * early exit, all `iters` hypotheses are scored).  Hypothesis h of pair p samples three correspondences with
+ * replacement from a counter-based generator (splitmix64 of (seed, pair_ids[p], 3h + slot), restated in
+ * oracle/metrics_oracle.py -- Open3D's own generator is unseeded, the reference repeats the evaluation three times
+ * for that reason, tester.py:24), fits the rigid transform of the triple (Umeyama without scale, fp64), counts the
+ * correspondences closer than distance_thr and keeps the best (more inliers; then lower inlier RMSE; then lower h).
+ * Triples that repeat a source or a target point (rank-1 covariance: the roll angle is arbitrary) are skipped.
+ * out (fp64 like the reference's `torch.from_numpy(pose)`): rot [P,9], trn [P,3]; identity / zero when a pair has
+ * fewer than 3 matches (loss.py:363-366) or no hypothesis has an inlier; fitness [P], inlier_rmse [P] (optional),
+ * best_iter [P] int32 (optional, -1 = none).   pair_ids int64 [P] or NULL (= 0..P-1). */
+size_t dr_ransac_workspace_bytes(int P, int iters);
+int dr_ransac_corr_f64(int P, int cap, int N, int M, const int64_t* matches, const int32_t* count, const float* s_pcd,
+                       const float* t_pcd, double distance_thr, int iters, uint64_t seed, const int64_t* pair_ids,
+                       double* rot, double* trn, double* fitness, double* inlier_rmse, int32_t* best_iter,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* MatchMotionLoss.compute_registration_recall + computeTransformationErr (3D/models/loss.py:27-44, 415-448):
+ * e = [t, q_xyz] of inv(gt) * pred (q = unit quaternion of the rotation part, w >= 0; nibabel's mat2quat),
+ * err = e^T info e / info[0][0], success = err <= thr^2.  rot_est [P,9], trn_est [P,3] float64; rot_gt [P,9],
+ * trn_gt [P,3] float32; info [P,36] float64 (`gt_cov`).  out: err [P] float64, success [P] int32. */
+int dr_registration_recall_f64(int P, const double* rot_est, const double* trn_est, const float* rot_gt,
+                               const float* trn_gt, const double* info, double thr, double* err, int32_t* success,
+                               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
  * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)
  * with CrossModalFusionModule (EXP/fusion_module.py:61-107, vision3d/layers/transformer.py:58-301)

@@ -33,3 +33,24 @@ def sinkhorn_case(N, M, nv, mv, dtype):
     sc = T(3.0 * synth.hash_normal(1, N * 1000 + M, (1, N, M))).to(dtype)
     sm, tm = masks(N, M, nv, mv)
     return sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf")), sm, tm
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation-harness scenes; oracle/make_golden_metrics.py mints its vectors on exactly these inputs
+# ------------------------------------------------------------------------------------------------
+def metrics_scene(N, M, seed, inlier_frac=0.5, n_extra=100):
+    """torch CPU tensors in the layout of the reference's `data` dict (B = 1): rigid (3DMatch) and non-rigid (4DMatch)
+    targets, predicted matches, metric points, Redwood info matrix and pose estimates at growing distance from the truth."""
+    import math
+    p = synth.make_pair(N, M, 6, seed=seed)
+    mp = synth.make_metric_points(p, seed)
+    R, t = p["R_gt"], p["t_gt"]
+    est = []
+    for k, (ang, dt) in enumerate([(0.0, 0.0), (0.004, 0.01), (0.02, 0.05), (0.1, 0.3)]):
+        dR = synth._rodrigues(synth.hash_normal(seed, 60 + k, (3,)), ang)
+        est.append((T(dR @ R), T((t + dt * synth.hash_normal(seed, 70 + k, (3,))).reshape(3, 1))))   # float64 like Open3D's pose
+    return dict(s_pcd=T(p["s_pcd"])[None], t_pcd=T(p["t_pcd"])[None], t_pcd4=T(synth.deform_targets(p, mp["coarse_flow"]))[None],
+                rot=T(R.astype(np.float32))[None], trn=T(t.astype(np.float32).reshape(3, 1))[None],
+                matches=T(synth.make_matches(p, seed, inlier_frac, n_extra)), raw_pcd=T(mp["raw_pcd"]), raw_flow=T(mp["raw_flow"]),
+                metric_index=T(mp["metric_index"]), coarse_flow=T(mp["coarse_flow"]), info=synth.make_info(seed), est=est,
+                pair=p)
