@@ -11,7 +11,18 @@
 #include "kernels.h"
 #include "svd3.h"
 
+// The float32 metrics restate torch / numpy expressions operation by operation: no implicit fusing of a*b + c in this
+// file (contraction is switched off for everything below); every fused
+// multiply-add below is written as fma() / fmaf().
+#pragma clang fp contract(off)
+
 namespace dr {
+
+// plain float32 operations compiled under the pragma above (the header's __fmul_rn / __fadd_rn bodies are compiled
+// under the header's own contraction state and do get fused)
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 
 // ------------------------------------------------------------------------------------------------------------
 // counter-based sampling: the integer stream of diffreg_hip.synth.hash_bits (splitmix64 finaliser)
@@ -30,13 +41,13 @@ __device__ __forceinline__ uint64_t hash_bits(uint64_t base, uint64_t idx) { ret
 // R x + t the way a float32 matmul accumulates it (k ascending, fused), then the translation added
 __device__ __forceinline__ void warp_f32(const float* __restrict__ R, const float* __restrict__ t, float x, float y, float z,
                                          float& ox, float& oy, float& oz) {
-    ox = __fadd_rn(fmaf(R[2], z, fmaf(R[1], y, __fmul_rn(R[0], x))), t[0]);
-    oy = __fadd_rn(fmaf(R[5], z, fmaf(R[4], y, __fmul_rn(R[3], x))), t[1]);
-    oz = __fadd_rn(fmaf(R[8], z, fmaf(R[7], y, __fmul_rn(R[6], x))), t[2]);
+    ox = add_rn(fmaf(R[2], z, fmaf(R[1], y, mul_rn(R[0], x))), t[0]);
+    oy = add_rn(fmaf(R[5], z, fmaf(R[4], y, mul_rn(R[3], x))), t[1]);
+    oz = add_rn(fmaf(R[8], z, fmaf(R[7], y, mul_rn(R[6], x))), t[2]);
 }
 // sum of three squares as torch.sum / np.sum over an axis of length 3 form it: products first, then left to right
 __device__ __forceinline__ float sq3(float a, float b, float c) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(c, c));
+    return add_rn(add_rn(mul_rn(a, a), mul_rn(b, b)), mul_rn(c, c));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -58,11 +69,11 @@ __global__ __launch_bounds__(256) void inlier_kernel(const long long* __restrict
             float x0 = s[0], x1 = s[1], x2 = s[2];
             if (flow) {   // s_pcd + s2t_flow (loss.py:389)
                 const float* f = flow + ((size_t)pair * N + i) * 3;
-                x0 = __fadd_rn(x0, f[0]); x1 = __fadd_rn(x1, f[1]); x2 = __fadd_rn(x2, f[2]);
+                x0 = add_rn(x0, f[0]); x1 = add_rn(x1, f[1]); x2 = add_rn(x2, f[2]);
             }
             float wx, wy, wz;
             warp_f32(rot + (size_t)pair * 9, trn + (size_t)pair * 3, x0, x1, x2, wx, wy, wz);
-            inl = sq3(__fsub_rn(wx, y[0]), __fsub_rn(wy, y[1]), __fsub_rn(wz, y[2])) < thr2;
+            inl = sq3(sub_rn(wx, y[0]), sub_rn(wy, y[1]), sub_rn(wz, y[2])) < thr2;
         }
     }
     const unsigned long long b = __ballot(inl);
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void nrfmr_kernel(NrArgs A) {
         __syncthreads();
         if (active) {
             for (int k = 0; k < nk; ++k) {
-                const float d = sq3(__fsub_rn(s_a[k * 3], px), __fsub_rn(s_a[k * 3 + 1], py), __fsub_rn(s_a[k * 3 + 2], pz));
+                const float d = sq3(sub_rn(s_a[k * 3], px), sub_rn(s_a[k * 3 + 1], py), sub_rn(s_a[k * 3 + 2], pz));
                 if (d < d2) {       // ascending insertion; equal distances keep the earlier anchor first
                     if (d < d1) {
                         d2 = d1; i2 = i1;
@@ -145,24 +156,24 @@ __global__ __launch_bounds__(256) void nrfmr_kernel(NrArgs A) {
             const long long i = mt[(size_t)id[n] * 3 + 1], j = mt[(size_t)id[n] * 3 + 2];
             const bool okj = (unsigned long long)j < (unsigned long long)A.M;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) mo[n][c] = okj ? __fsub_rn(t_pcd[j * 3 + c], s_pcd[i * 3 + c]) : 0.f;   // tester.py:169
+            for (int c = 0; c < 3; ++c) mo[n][c] = okj ? sub_rn(t_pcd[j * 3 + c], s_pcd[i * 3 + c]) : 0.f;   // tester.py:169
         }
-        const float ws = __fadd_rn(__fadd_rn(w[0], w[1]), w[2]);
+        const float ws = add_rn(add_rn(w[0], w[1]), w[2]);
 #pragma unroll
         for (int n = 0; n < 3; ++n) w[n] = w[n] / ws;
         float bl[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            bl[c] = __fadd_rn(__fadd_rn(__fmul_rn(mo[0][c], w[0]), __fmul_rn(mo[1][c], w[1])), __fmul_rn(mo[2][c], w[2]));
+            bl[c] = add_rn(add_rn(mul_rn(mo[0][c], w[0]), mul_rn(mo[1][c], w[1])), mul_rn(mo[2][c], w[2]));
         if (A.blended) {
             float* o = A.blended + (size_t)(q0 + q) * 3;
             o[0] = bl[0]; o[1] = bl[1]; o[2] = bl[2];
         }
         float gx, gy, gz;
-        warp_f32(A.rot + (size_t)pair * 9, A.trn + (size_t)pair * 3, __fadd_rn(px, fx), __fadd_rn(py, fy), __fadd_rn(pz, fz), gx, gy,
+        warp_f32(A.rot + (size_t)pair * 9, A.trn + (size_t)pair * 3, add_rn(px, fx), add_rn(py, fy), add_rn(pz, fz), gx, gy,
                  gz);
-        const float e = sqrtf(sq3(__fsub_rn(__fadd_rn(px, bl[0]), gx), __fsub_rn(__fadd_rn(py, bl[1]), gy),
-                                  __fsub_rn(__fadd_rn(pz, bl[2]), gz)));
+        const float e = sqrtf(sq3(sub_rn(add_rn(px, bl[0]), gx), sub_rn(add_rn(py, bl[1]), gy),
+                                  sub_rn(add_rn(pz, bl[2]), gz)));
         hit = e < A.thr;
     }
     const unsigned long long b = __ballot(hit);

@@ -46,17 +46,22 @@ def inlier_ratio(match_pred, s_pcd, t_pcd, rot, trn, inlier_thr, s2t_flow=None):
 # ------------------------------------------------------------------------------------------
 # NR-FMR  (3D/lib/tester.py:127-210, 3D/datasets/utils.py:5-40)
 # ------------------------------------------------------------------------------------------
-def knn_point(k, reference_pts, query_pts):
-    """k nearest reference points of every query: (distances [Q,k] ascending, indices [Q,k])"""
+def knn_point(k, reference_pts, query_pts, stable=False):
+    """k nearest reference points of every query: (distances [Q,k] ascending, indices [Q,k]).
+    Equal distances (two matches that share a source point are two anchors at the same place) are ordered however
+    np.argpartition leaves them in the reference; stable=True states the HIP kernel's rule instead: lowest match row first."""
     d = np.sum((reference_pts[None, :, :] - query_pts[:, None, :]) ** 2, -1)
+    if stable:
+        idx = np.argsort(d, axis=1, kind="stable")[:, :k]
+        return np.sqrt(np.take_along_axis(d, idx, axis=1)), idx
     part = np.argpartition(d, k, axis=1)[:, :k]
     rows = np.arange(len(query_pts))[:, None]
     idx = part[rows, np.argsort(d[rows, part], axis=1)]
     return np.sqrt(np.take_along_axis(d, idx, axis=1)), idx
 
 
-def blend_anchor_motion(query_loc, reference_loc, reference_flow, knn=3, search_radius=0.1):
-    dist, idx = knn_point(knn, reference_loc, query_loc)
+def blend_anchor_motion(query_loc, reference_loc, reference_flow, knn=3, search_radius=0.1, stable=False):
+    dist, idx = knn_point(knn, reference_loc, query_loc, stable)
     dist[dist < 1e-10] = 1e-10
     far = dist > search_radius
     dist[far] = 1e+10
@@ -65,7 +70,7 @@ def blend_anchor_motion(query_loc, reference_loc, reference_flow, knn=3, search_
     return np.sum(reference_flow[idx] * w.reshape([-1, knn, 1]), axis=1), far.sum(axis=1) < 3
 
 
-def nrfmr(match_pred, s_pcd, t_pcd, raw_list, flow_list, metric_index_list, rot, trn, recall_thr=0.04):
+def nrfmr(match_pred, s_pcd, t_pcd, raw_list, flow_list, metric_index_list, rot, trn, recall_thr=0.04, stable=False):
     """-> (mean over pairs, per-pair recall list, per-pair blended motion list); all torch float32 like the reference"""
     per, blends = [], []
     for k in range(len(raw_list)):
@@ -74,7 +79,7 @@ def nrfmr(match_pred, s_pcd, t_pcd, raw_list, flow_list, metric_index_list, rot,
         m = match_pred[match_pred[:, 0] == k]
         anchors = s_pcd[k][m[:, 1]]
         motion = t_pcd[k][m[:, 2]] - anchors
-        bl, _ = blend_anchor_motion(pts.numpy(), anchors.numpy(), motion.numpy(), knn=3, search_radius=0.1)
+        bl, _ = blend_anchor_motion(pts.numpy(), anchors.numpy(), motion.numpy(), knn=3, search_radius=0.1, stable=stable)
         pred = pts + torch.from_numpy(bl).to(pts)
         dist = torch.sqrt(torch.sum((pred - gt) ** 2, dim=1))
         per.append((dist < recall_thr).float().sum() / len(dist))

@@ -30,6 +30,22 @@ def test_oracle_matches_reference_vectors(golden, N, M, seed):
         assert rr == g[tag + "rr_ok"][k]
 
 
+def test_stable_tie_rule_differs_only_on_tied_queries():
+    """matches that share a source point are anchors at the same place: the reference's 3-NN choice among them is whatever
+    np.argpartition leaves; the kernel's rule (lowest match row first) gives the same blend wherever no tie reaches the
+    third neighbour"""
+    sc = metrics_scene(256, 256, 3)
+    m = sc["matches"]
+    anchors = sc["s_pcd"][0][m[:, 1]].numpy()
+    motion = (sc["t_pcd4"][0][m[:, 2]] - sc["s_pcd"][0][m[:, 1]]).numpy()
+    q = sc["raw_pcd"][sc["metric_index"]].numpy()
+    a, _ = mo.blend_anchor_motion(q, anchors, motion)
+    b, _ = mo.blend_anchor_motion(q, anchors, motion, stable=True)
+    d = np.sort(np.sum((anchors[None] - q[:, None]) ** 2, -1), 1)
+    untied = (d[:, 0] != d[:, 1]) & (d[:, 1] != d[:, 2]) & (d[:, 2] != d[:, 3])
+    assert untied.sum() > 100 and np.array_equal(a[untied], b[untied])
+
+
 def test_mat2quat_identities():
     # the nibabel step has no reference vector (nibabel absent): check it as a quaternion of the rotation
     for k in range(20):
