@@ -18,6 +18,8 @@
 //  sk_stream_kernel  any size / strict input dtype / log output: E is kept in a global workspace
 //                    (L2/MALL resident), one workgroup per tile, same scaling iteration.
 #include "kernels.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace dr {
 
@@ -73,6 +75,64 @@ struct OpMax { __device__ __forceinline__ float operator()(float a, float b) con
 __device__ __forceinline__ float bcast_lane(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
+
+// streaming (non-temporal) global access of a lane's CPL values: a tile is read once and written once, so the big batched
+// launches mark both as streaming -- on MI355X a 1024-thread tile copy runs at 6.15 TB/s with `nt` on loads and stores
+// against 5.67 TB/s without (tools/_build/skx.hip).  Small launches keep the default policy: their consumer is the next
+// kernel of the loop and the tile is still in L2.
+typedef float sk_v4f __attribute__((ext_vector_type(4)));
+typedef float sk_v2f __attribute__((ext_vector_type(2)));
+typedef double sk_v2d __attribute__((ext_vector_type(2)));
+template <typename T, int CPL>
+struct NtIO;
+template <>
+struct NtIO<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4], double sh) {
+        const sk_v4f t = __builtin_nontemporal_load(reinterpret_cast<const sk_v4f*>(p));
+        const float s = (float)sh;
+        v[0] = t.x - s; v[1] = t.y - s; v[2] = t.z - s; v[3] = t.w - s;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        sk_v4f t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<sk_v4f*>(p));
+    }
+};
+template <>
+struct NtIO<double, 4> {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[4], double sh) {
+        const sk_v2d t0 = __builtin_nontemporal_load(reinterpret_cast<const sk_v2d*>(p));
+        const sk_v2d t1 = __builtin_nontemporal_load(reinterpret_cast<const sk_v2d*>(p + 2));
+        v[0] = (float)(t0.x - sh); v[1] = (float)(t0.y - sh); v[2] = (float)(t1.x - sh); v[3] = (float)(t1.y - sh);
+    }
+    static __device__ __forceinline__ void store(double* p, const float (&v)[4]) {
+        sk_v2d t0, t1; t0.x = (double)v[0]; t0.y = (double)v[1]; t1.x = (double)v[2]; t1.y = (double)v[3];
+        __builtin_nontemporal_store(t0, reinterpret_cast<sk_v2d*>(p));
+        __builtin_nontemporal_store(t1, reinterpret_cast<sk_v2d*>(p + 2));
+    }
+};
+template <>
+struct NtIO<float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2], double sh) {
+        const sk_v2f t = __builtin_nontemporal_load(reinterpret_cast<const sk_v2f*>(p));
+        const float s = (float)sh;
+        v[0] = t.x - s; v[1] = t.y - s;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+        sk_v2f t; t.x = v[0]; t.y = v[1];
+        __builtin_nontemporal_store(t, reinterpret_cast<sk_v2f*>(p));
+    }
+};
+template <>
+struct NtIO<double, 2> {
+    static __device__ __forceinline__ void load(const double* p, float (&v)[2], double sh) {
+        const sk_v2d t = __builtin_nontemporal_load(reinterpret_cast<const sk_v2d*>(p));
+        v[0] = (float)(t.x - sh); v[1] = (float)(t.y - sh);
+    }
+    static __device__ __forceinline__ void store(double* p, const float (&v)[2]) {
+        sk_v2d t; t.x = (double)v[0]; t.y = (double)v[1];
+        __builtin_nontemporal_store(t, reinterpret_cast<sk_v2d*>(p));
+    }
+};
 
 template <typename T, int CPL>
 struct VecIO;
@@ -345,33 +405,42 @@ __device__ __forceinline__ float wave_allsum_dpp(float v) {
     return bcast_lane(v, 0) + bcast_lane(v, 16) + bcast_lane(v, 32) + bcast_lane(v, 48);
 }
 
-template <typename TIn, typename TOut, int NW, int CPL>
-__global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
-    constexpr int RPW = 16, N = NW * RPW, M = 64 * CPL;
-    __shared__ __attribute__((aligned(16))) float s_colpart[NW][M];
-    __shared__ __attribute__((aligned(16))) float s_b[M + 4];
-    __shared__ float s_dust[NW];
+// launches of at least this many 256 x 256 tiles (128 MB in + 128 MB out: beyond the L2s and half the Infinity Cache)
+// stream their tiles with non-temporal loads and stores
+constexpr int SK_NT_MIN_TILES = 512;
 
-    const int tile = blockIdx.x, lane = lane_id(), w = wave_id(), t = threadIdx.x;
-    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
-    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
-    const float alpha = *A.bin_score;
-    const double sh = A.shift ? A.shift[tile] : 0.0;
-    constexpr float LOG2E = 1.4426950408889634f;
+// The tile lives in registers as float2 pairs of adjacent columns so that every pass is v_pk_fma_f32 / v_pk_mul_f32 (the
+// full-rate fp32 form of gfx950: two columns per lane per instruction): with one workgroup per CU nothing overlaps a tile's
+// compute phase with memory, so its instruction count is wall time of the batched launch.
+typedef float sk_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sk_f2 sk_fma2(sk_f2 a, sk_f2 b, sk_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ sk_f2 sk_splat(float v) { sk_f2 r; r.x = v; r.y = v; return r; }
 
-    float E[RPW][CPL];
+template <typename IO, typename T, int CPL>
+__device__ __forceinline__ void sk_load_row(const T* p, sk_f2 (&e)[CPL / 2], double sh) {
+    float tmp[CPL];
+    IO::load(p, tmp, sh);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) VecIO<TIn, CPL>::load(src + r * M, E[r], sh);
+    for (int k = 0; k < CPL / 2; ++k) { e[k].x = tmp[2 * k]; e[k].y = tmp[2 * k + 1]; }
+}
 
-    // row maxima -> rho (4 rows per lane), exponentials
-    float p[RPW], rho4[4], ed4[4], a4[4];
+// Everything between "the tile is in registers" and "a_i, b_j are final": row maxima, exponentials, `iters` scaling
+// iterations.  `after_max()` runs once the raw scores have been consumed (the persistent kernel issues its prefetch there).
+template <int NW, int CPL, typename Hook>
+__device__ __forceinline__ void sk_fast_tile(sk_f2 (&E)[16][CPL / 2], const float alpha, const int iters, float (*s_colpart)[64 * CPL],
+                                             float* s_b, float* s_dust, float (&a4)[4], sk_f2 (&bj)[CPL / 2], Hook&& after_max) {
+    constexpr int RPW = 16, N = NW * RPW, M = 64 * CPL, H = CPL / 2;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int lane = lane_id(), w = wave_id(), t = threadIdx.x;
+    float p[RPW], rho4[4], ed4[4];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        float m = E[r][0];
+        float m = fmaxf(E[r][0].x, E[r][0].y);
 #pragma unroll
-        for (int c = 1; c < CPL; ++c) m = fmaxf(m, E[r][c]);
+        for (int k = 1; k < H; ++k) m = fmaxf(m, fmaxf(E[r][k].x, E[r][k].y));
         p[r] = m;
     }
+    after_max();
     reduce16x4(p, rho4, OpMax());
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -380,48 +449,52 @@ __global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const float nrho = -bcast_lane(rho4[r & 3], 16 * (r >> 2)) * LOG2E;
+        const sk_f2 nrho = sk_splat(-bcast_lane(rho4[r & 3], 16 * (r >> 2)) * LOG2E);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) E[r][c] = __builtin_amdgcn_exp2f(fmaf(E[r][c], LOG2E, nrho));
+        for (int k = 0; k < H; ++k) {
+            const sk_f2 z = sk_fma2(E[r][k], sk_splat(LOG2E), nrho);
+            E[r][k].x = __builtin_amdgcn_exp2f(z.x);
+            E[r][k].y = __builtin_amdgcn_exp2f(z.y);
+        }
     }
-
     const float tot = (float)(N + M);
     const float mu = 1.f / tot, muN = (float)M / tot, nu = mu, nuM = (float)N / tot;
-    float bj[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) bj[c] = 1.f;
+    for (int k = 0; k < H; ++k) bj[k] = sk_splat(1.f);
     float bM = 1.f, aN = 0.f;
-
-    for (int it = 0; it < A.iters; ++it) {
+    for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            float s = E[r][0] * bj[0];
+            sk_f2 s = E[r][0] * bj[0];
 #pragma unroll
-            for (int c = 1; c < CPL; ++c) s = fmaf(E[r][c], bj[c], s);
-            p[r] = s;
+            for (int k = 1; k < H; ++k) s = sk_fma2(E[r][k], bj[k], s);
+            p[r] = s.x + s.y;
         }
         float rs4[4];
         reduce16x4(p, rs4, OpAdd());
 #pragma unroll
         for (int k = 0; k < 4; ++k) a4[k] = mu / fmaf(ed4[k], bM, rs4[k]);
-        float bs = bj[0];
+        sk_f2 bs2 = bj[0];
 #pragma unroll
-        for (int c = 1; c < CPL; ++c) bs += bj[c];
-        aN = muN / (wave_allsum_dpp(bs) + bM);
-        float cp[CPL];
+        for (int k = 1; k < H; ++k) bs2 += bj[k];
+        aN = muN / (wave_allsum_dpp(bs2.x + bs2.y) + bM);
+        sk_f2 cp[H];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) cp[c] = 0.f;
+        for (int k = 0; k < H; ++k) cp[k] = sk_splat(0.f);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const float ar = bcast_lane(a4[r & 3], 16 * (r >> 2));
+            const sk_f2 ar = sk_splat(bcast_lane(a4[r & 3], 16 * (r >> 2)));
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) cp[c] = fmaf(E[r][c], ar, cp[c]);
+            for (int k = 0; k < H; ++k) cp[k] = sk_fma2(E[r][k], ar, cp[k]);
         }
         float dpl = ed4[0] * a4[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) dpl = fmaf(ed4[k], a4[k], dpl);
         const float dp = bcast_lane(dpl, 0) + bcast_lane(dpl, 16) + bcast_lane(dpl, 32) + bcast_lane(dpl, 48);
-        VecIO<float, CPL>::store(&s_colpart[w][lane * CPL], cp);
+        float cpf[CPL];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { cpf[2 * k] = cp[k].x; cpf[2 * k + 1] = cp[k].y; }
+        VecIO<float, CPL>::store(&s_colpart[w][lane * CPL], cpf);
         if (lane == 0) s_dust[w] = dp;
         __syncthreads();
         if (t < M) {
@@ -436,17 +509,116 @@ __global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
             s_b[M] = nuM / c;
         }
         __syncthreads();
-        VecIO<float, CPL>::load(&s_b[lane * CPL], bj, 0.0);
+        float bf[CPL];
+        VecIO<float, CPL>::load(&s_b[lane * CPL], bf, 0.0);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { bj[k].x = bf[2 * k]; bj[k].y = bf[2 * k + 1]; }
         bM = s_b[M];
     }
+}
 
+// out row r = E[r] a_r b (N + M)
+template <typename IO, typename T, int CPL>
+__device__ __forceinline__ void sk_store_row(T* p, const sk_f2 (&e)[CPL / 2], const float ar_tot, const sk_f2 (&bj)[CPL / 2]) {
+    float o[CPL];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const float ar = bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot;
-        float o[CPL];
+    for (int k = 0; k < CPL / 2; ++k) {
+        const sk_f2 v = e[k] * sk_splat(ar_tot) * bj[k];
+        o[2 * k] = v.x; o[2 * k + 1] = v.y;
+    }
+    IO::store(p, o);
+}
+
+template <typename TIn, typename TOut, int NW, int CPL, bool NT>
+__global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
+    using InIO = typename std::conditional<NT, NtIO<TIn, CPL>, VecIO<TIn, CPL>>::type;
+    using OutIO = typename std::conditional<NT, NtIO<TOut, CPL>, VecIO<TOut, CPL>>::type;
+    constexpr int RPW = 16, N = NW * RPW, M = 64 * CPL;
+    __shared__ __attribute__((aligned(16))) float s_colpart[NW][M];
+    __shared__ __attribute__((aligned(16))) float s_b[M + 4];
+    __shared__ float s_dust[NW];
+
+    const int tile = blockIdx.x, lane = lane_id(), w = wave_id();
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
+    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (unsigned)(w * RPW * M + lane * CPL);
+    const float alpha = *A.bin_score;
+    const double sh = A.shift ? A.shift[tile] : 0.0;
+
+    sk_f2 E[RPW][CPL / 2], bj[CPL / 2];
+    float a4[4];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) o[c] = E[r][c] * ar * bj[c];
-        VecIO<TOut, CPL>::store(dst + r * M, o);
+    for (int r = 0; r < RPW; ++r) sk_load_row<InIO, TIn, CPL>(src + r * M, E[r], sh);
+    sk_fast_tile<NW, CPL>(E, alpha, A.iters, s_colpart, s_b, s_dust, a4, bj, [] {});
+    const float tot = (float)(N + M);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+        sk_store_row<OutIO, TOut, CPL>(dst + r * M, E[r], bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot, bj);
+}
+
+// ---------------------------------------------------------------------------------------------
+// persistent form of the fast kernel for big batches of 256 x 256 float tiles (the roofline micro-benchmark's regime):
+// a workgroup holds one tile in 64 VGPRs per thread, so only ONE workgroup fits a CU and nothing overlaps its compute
+// phase (exponentials + 3 iterations) with memory.  Here a workgroup walks over tiles g, g + G, ... and, while it
+// computes tile i, the first 8 of the 16 rows each wave owns in tile i + 1 are fetched by LDS-DMA (global_load_lds_dwordx4:
+// no VGPRs; one wave-instruction = one 1 KB tile row = the image the owning lanes read back with one ds_read_b128) into
+// 128 KB of LDS.  The other 8 rows are loaded into each row's registers right behind the store of that row in the epilogue,
+// so the HBM reads of the next tile run under the drain of the stores.
+// ---------------------------------------------------------------------------------------------
+// workgroups of the persistent form: one per CU; DR_SK_PERSIST_GRID=0 keeps the one-tile-per-workgroup kernel (tools)
+static int sk_persist_grid() {
+    static const int v = [] { const char* e = getenv("DR_SK_PERSIST_GRID"); return e ? atoi(e) : 256; }();
+    return v;
+}
+typedef __attribute__((address_space(3))) void sk_lds_void;
+typedef const __attribute__((address_space(1))) void sk_glb_void;
+constexpr int SKP_PRE = 8;                                        // rows per wave prefetched through LDS
+constexpr size_t SKP_LDS = 16 * 256 * 4 + 1040 + 64 + 16 * SKP_PRE * 1024;    // colpart + b + dust + prefetch image
+
+__global__ __launch_bounds__(1024) void sk_fast_persist_kernel(SkArgs A) {
+    constexpr int NW = 16, CPL = 4, RPW = 16, N = 256, M = 256;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*s_colpart)[M] = reinterpret_cast<float (*)[M]>(sk_smem);
+    float* s_b = reinterpret_cast<float*>(sk_smem + NW * M * 4);
+    float* s_dust = reinterpret_cast<float*>(sk_smem + NW * M * 4 + 1040);
+    char* s_pref = sk_smem + NW * M * 4 + 1040 + 64;
+
+    const int lane = lane_id(), w = wave_id();
+    const unsigned toff = (unsigned)(w * RPW * M + lane * CPL);
+    const float alpha = *A.bin_score;
+    const float tot = (float)(N + M);
+    char* my_pref = s_pref + w * SKP_PRE * 1024;                 // this wave's 8 rows (wave-uniform base)
+    const float* scores = reinterpret_cast<const float*>(A.scores);
+
+    sk_f2 E[RPW][CPL / 2], bj[CPL / 2];
+    float a4[4];
+    int tile = blockIdx.x;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) sk_load_row<NtIO<float, CPL>, float, CPL>(scores + (size_t)tile * N * M + toff + r * M, E[r], 0.0);
+    while (true) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < A.B;
+        const float* nsrc = scores + (size_t)(has_next ? next : tile) * N * M + toff;
+        // once the row maxima have consumed the raw scores, every value of this tile is in registers and the prefetch
+        // image is free again
+        sk_fast_tile<NW, CPL>(E, alpha, A.iters, s_colpart, s_b, s_dust, a4, bj, [&] {
+            if (has_next) {
+#pragma unroll
+                for (int r = 0; r < SKP_PRE; ++r)
+                    __builtin_amdgcn_global_load_lds((sk_glb_void*)(reinterpret_cast<const char*>(nsrc) + r * M * 4),
+                                                     (sk_lds_void*)(my_pref + r * 1024), 16, 0, 0);
+            }
+        });
+        float* dst = reinterpret_cast<float*>(A.out) + (size_t)tile * N * M + toff;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            sk_store_row<NtIO<float, CPL>, float, CPL>(dst + r * M, E[r], bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot, bj);
+            if (r >= SKP_PRE && has_next) sk_load_row<NtIO<float, CPL>, float, CPL>(nsrc + r * M, E[r], 0.0);
+        }
+        if (!has_next) break;
+#pragma unroll
+        for (int r = 0; r < SKP_PRE; ++r)
+            sk_load_row<VecIO<float, CPL>, float, CPL>(reinterpret_cast<const float*>(my_pref + r * 1024) + lane * CPL, E[r], 0.0);
+        tile = next;     // (no barrier: s_colpart / s_b are rewritten only behind the next tile's first barrier)
     }
 }
 
@@ -892,12 +1064,26 @@ template <typename TIn, typename TOut>
 static int launch_reg(const SkArgs& a, hipStream_t st) {
     const bool plain = a.vec_in && a.vec_out && !a.src_mask && !a.tgt_mask && !(a.flags & DR_SK_MINSHIFT);
     if (plain && a.N == 256 && a.M == 256) {
-        hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 16, 4>), dim3(a.B), dim3(1024), 0, st, a);
+        if (a.B >= SK_NT_MIN_TILES && std::is_same<TIn, float>::value && std::is_same<TOut, float>::value && !a.shift &&
+            sk_persist_grid() > 0) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_fast_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)SKP_LDS));
+                attr_done = true;
+            }
+            const int G = a.B < sk_persist_grid() ? a.B : sk_persist_grid();
+            hipLaunchKernelGGL(sk_fast_persist_kernel, dim3(G), dim3(1024), SKP_LDS, st, a);
+        } else if (a.B >= SK_NT_MIN_TILES && sizeof(TIn) == 4 && sizeof(TOut) == 4)   // (float64 tiles measured slower with nt)
+            hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 16, 4, true>), dim3(a.B), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 16, 4, false>), dim3(a.B), dim3(1024), 0, st, a);
         DR_LAUNCH_CHECK();
         return DR_OK;
     }
     if (plain && a.N == 128 && a.M == 128) {
-        hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 8, 2>), dim3(a.B), dim3(512), 0, st, a);
+        if (a.B >= 4 * SK_NT_MIN_TILES && sizeof(TIn) == 4 && sizeof(TOut) == 4)
+            hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 8, 2, true>), dim3(a.B), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((sk_fast_kernel<TIn, TOut, 8, 2, false>), dim3(a.B), dim3(512), 0, st, a);
         DR_LAUNCH_CHECK();
         return DR_OK;
     }

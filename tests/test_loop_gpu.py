@@ -128,9 +128,13 @@ def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, 
     assert_matrix_parity(conf, ref, conf_f64, "conf_matrix_pred")
     if variant == "3dmatch":
         # read-out entries are 1e-3..2e-2 (intrinsically flat): also hold them relatively
+        # (same rule as assert_matrix_parity: the HIP result may be as far from the float64 evaluation as twice the reference's
+        #  own float32 run is, hence up to three times that from the reference run itself)
         rel = np.abs(conf - ref) / np.maximum(ref, 1e-9)
+        rel_hip = np.abs(conf - conf_f64) / np.maximum(conf_f64, 1e-9)
         rel_ref = np.abs(ref - conf_f64) / np.maximum(conf_f64, 1e-9)
-        assert rel.max() <= max(1e-4, 2.0 * rel_ref.max()), (rel.max(), rel_ref.max())
+        assert rel_hip.max() <= max(1e-4, 2.0 * rel_ref.max()), (rel_hip.max(), rel_ref.max())
+        assert rel.max() <= max(1e-4, 3.0 * rel_ref.max()), (rel.max(), rel_ref.max())
         got = set(map(tuple, eng.match_list(out)[0].cpu().tolist()))
         srt = np.sort(ref, 1)
         am = ref.argmax(1)

@@ -155,6 +155,23 @@ def test_full_size_batch_properties():
         assert rel_err(conf[b:b + 1], ref)[1] < 2e-5
 
 
+@pytest.mark.parametrize("B", [512, 513, 777, 1300])
+def test_persistent_kernel_equals_per_tile_kernel(B):
+    """launches of >= 512 float tiles of 256 x 256 run the persistent LDS-prefetching kernel (one workgroup per CU walking
+    over tiles, non-temporal loads/stores); it must give the bits of the one-tile-per-workgroup kernel that smaller launches use"""
+    from diffreg_hip import lib
+    g = torch.Generator(device="cpu").manual_seed(B)
+    x = (torch.randn(B, 256, 256, generator=g) * 3).to(DEV)
+    a = torch.tensor(0.37, device=DEV)
+    big = lib.sinkhorn(x, a, 3)
+    small = torch.cat([lib.sinkhorn(x[i:i + 200].contiguous(), a, 3) for i in range(0, B, 200)])
+    assert torch.equal(big, small)
+    for b in (0, B - 1):
+        sm, tm = masks(256, 256)
+        ref = orc.sinkhorn_conf(x[b:b + 1].cpu(), torch.tensor(0.37), 3, sm, tm)
+        assert rel_err(big[b:b + 1], ref)[1] < 2e-5
+
+
 def test_bad_arguments():
     from diffreg_hip import lib
     with pytest.raises(RuntimeError):
