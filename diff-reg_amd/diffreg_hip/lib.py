@@ -117,6 +117,10 @@ SIGNATURES.update({
     "dr_ransac_corr_f64": (c_int, [c_int] * 4 + [c_void_p] * 4 + [c_double, c_int, ctypes.c_uint64] + [c_void_p] * 7 +
                            [c_size_t, c_void_p]),
     "dr_registration_recall_f64": (c_int, [c_int] + [c_void_p] * 5 + [c_double, c_void_p, c_void_p, c_void_p]),
+    "dr_grid_subsample_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_grid_subsample_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "dr_radius_neighbors_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_radius_neighbors_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "dr_denoiser_match_f32": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 9 +
                               [c_void_p, c_size_t, c_void_p]),
 })
@@ -461,6 +465,46 @@ def registration_recall(rot_est, trn_est, rot_gt, trn_gt, info, thr=0.2):
                                           ptr(_f32c(trn_gt, (P, 3))), ptr(d(info, (P, 36))), float(thr), ptr(err), ptr(ok),
                                           stream_of(rot_est)))
     return err, ok
+
+
+# ------------------------------------------------------------------------------------------------
+# collate-time ops: stacked clouds [n,3] float32 + lengths int32 [nb], all on the device
+# ------------------------------------------------------------------------------------------------
+def grid_subsample(points, lengths, dl):
+    """-> (sub_points [n,3] buffer, sub_lengths [nb] int32, total [1] int32, status [1] int32), asynchronous; the first
+    total[0] rows of the buffer are valid (cpp_subsampling.subsample_batch, grid_subsampling.cpp:4-211)"""
+    points = points.to(torch.float32).contiguous()
+    lengths = lengths.to(device=points.device, dtype=torch.int32).contiguous()
+    n, nb = points.shape[0], lengths.shape[0]
+    dev = points.device
+    out = torch.empty(max(n, 1), 3, device=dev)
+    ol = torch.empty(nb, dtype=torch.int32, device=dev)
+    tot = torch.empty(1, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = _lib.dr_grid_subsample_workspace_bytes(n, nb)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(_lib.dr_grid_subsample_f32(n, nb, ptr(points), ptr(lengths), float(dl), ptr(out), ptr(ol), ptr(tot), ptr(status), ptr(ws),
+                                     wsb, stream_of(points)))
+    return out, ol, tot, status
+
+
+def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit):
+    """-> (neighbors int64 [nq, limit], max_count [1] int32, status [1] int32), asynchronous
+    (cpp_neighbors.batch_query + [:, :limit], neighbors.cpp:210-333)"""
+    queries = queries.to(torch.float32).contiguous()
+    supports = supports.to(torch.float32).contiguous()
+    dev = queries.device
+    ql = q_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    sl = s_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    nq, ns, nb = queries.shape[0], supports.shape[0], ql.shape[0]
+    out = torch.empty(nq, limit, dtype=torch.int64, device=dev)
+    mc = torch.empty(1, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = _lib.dr_radius_neighbors_workspace_bytes(nq, ns, nb)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(_lib.dr_radius_neighbors_f32(nq, ns, nb, ptr(queries), ptr(supports), ptr(ql), ptr(sl), float(radius), int(limit), ptr(out),
+                                       ptr(mc), ptr(status), ptr(ws), wsb, stream_of(queries)))
+    return out, mc, status
 
 
 PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state", "gemm_split")

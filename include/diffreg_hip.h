@@ -327,6 +327,33 @@ int dr_registration_recall_f64(int P, const double* rot_est, const double* trn_e
                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Collate-time native code on device: the two C++ extensions the reference's data loader calls to build
+ * the KPFCN index arrays (3D/datasets/dataloader.py:13-68, 120-200).  Clouds are stacked: `lengths` int32 [nb] (device).
+ * Nothing synchronises; `status` (device int32) becomes 1 when a cloud spans more than 65 533 cells on an axis.
+ */
+
+/* cpp_subsampling.subsample_batch(points, batches_len, sampleDl) -> batch_grid_subsampling
+ * (cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:4-211, max_p = 0): barycentre of every occupied voxel,
+ * summed in float32 in input order (bit-exact).  out_points has room for n rows; the first out_total[0] are written, per
+ * cloud in ascending (iz, iy, ix) voxel order (the reference emits std::unordered_map iteration order; consumers are
+ * permutation-equivariant); out_lengths [nb]. */
+size_t dr_grid_subsample_workspace_bytes(int n, int nb);
+int dr_grid_subsample_f32(int n, int nb, const float* points, const int32_t* lengths, float dl, float* out_points,
+                          int32_t* out_lengths, int32_t* out_total, int32_t* status, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* cpp_neighbors.batch_query(queries, supports, q_batches, s_batches, radius)[:, :limit] -> batch_nanoflann_neighbors
+ * (cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:210-333) + the truncation of dataloader.py:64-65: for every query the
+ * supports of its own cloud with squared distance < radius^2 (float32, nanoflann's L2_Simple_Adaptor order of operations),
+ * nearest first (equal distances: lower index first; the reference's std::sort leaves them unspecified), as indices into the
+ * stacked supports, padded with ns.  out int64 [nq, limit] (limit <= 64); max_count[0] = the largest neighbourhood found
+ * (the reference's matrix is min(max_count, limit) wide: the caller slices). */
+size_t dr_radius_neighbors_workspace_bytes(int nq, int ns, int nb);
+int dr_radius_neighbors_f32(int nq, int ns, int nb, const float* queries, const float* supports, const int32_t* q_lengths,
+                            const int32_t* s_lengths, float radius, int limit, int64_t* out, int32_t* max_count, int32_t* status,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
  * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)
  * with CrossModalFusionModule (EXP/fusion_module.py:61-107, vision3d/layers/transformer.py:58-301)

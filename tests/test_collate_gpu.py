@@ -1,0 +1,98 @@
+"""GPU parity of the collate-time ops through the C ABI: dr_grid_subsample_f32, dr_radius_neighbors_f32 against
+oracle/collate_oracle.py and against the reference's own C++ (oracle/_ref, when built), and the device level loop against the
+index arrays the KPFCN backbone is tested with."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import synth
+from oracle import collate_oracle as co
+from tests.test_collate_oracle import scene, rows_equal_up_to_ties
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n_src,n_tgt,seed,dl", [(1400, 1200, 0, 0.05), (3000, 2500, 1, 0.05), (3000, 2500, 1, 0.1), (700, 900, 2, 0.2),
+                                                 (20000, 17000, 4, 0.03), (5, 3, 5, 0.05)])
+def test_grid_subsample_bit_exact(n_src, n_tgt, seed, dl):
+    from diffreg_hip.collate import batch_grid_subsampling_kpconv
+    P, L = scene(n_src, n_tgt, seed)
+    sp, sl = batch_grid_subsampling_kpconv(T(P), T(L), sampleDl=dl)
+    op, ol = co.grid_subsample_batch(P, L, dl)
+    assert sl.dtype == torch.int32 and np.array_equal(sl.cpu().numpy(), ol)
+    assert np.array_equal(sp.cpu().numpy(), op)               # same points, same order, same float32 bits
+    if co.ref_lib() is not None and n_src <= 3000:
+        rp, rl = co.ref_subsample_batch(P, L, dl)
+        assert np.array_equal(rp[co.canonical_order(rp, rl, P, L, dl)], sp.cpu().numpy())
+
+
+def test_grid_subsample_four_clouds_and_empty():
+    from diffreg_hip import lib
+    Pa, La = scene(900, 800, 6)
+    Pb, Lb = scene(500, 700, 7)
+    P, L = np.concatenate([Pa, Pb]), np.concatenate([La, [0], Lb]).astype(np.int32)      # an empty cloud in the middle
+    out, ol, tot, status = lib.grid_subsample(T(P), T(L), 0.06)
+    op, ol_ref = co.grid_subsample_batch(P, L, 0.06)
+    assert int(status) == 0 and int(tot) == len(op) and np.array_equal(ol.cpu().numpy(), ol_ref)
+    assert np.array_equal(out[:len(op)].cpu().numpy(), op)
+    # extent / cell beyond 65533 cells per axis is reported, not silently wrong
+    far = P.copy(); far[0, 0] += 1e4
+    _, _, _, st2 = lib.grid_subsample(T(far), T(L), 0.06)
+    assert int(st2) == 1
+
+
+@pytest.mark.parametrize("n_src,n_tgt,seed,dl,limit", [(1400, 1200, 0, 0.05, 40), (3000, 2500, 1, 0.1, 35), (20000, 17000, 4, 0.03, 38)])
+def test_radius_neighbors_vs_oracle_and_reference(n_src, n_tgt, seed, dl, limit):
+    from diffreg_hip.collate import batch_neighbors_kpconv
+    P, L = scene(n_src, n_tgt, seed)
+    sp, sl = co.grid_subsample_batch(P, L, dl)
+    for (Q, ql, S, sl_, r) in ((P, L, P, L, 1.25 * dl), (sp, sl, P, L, 1.25 * dl), (P, L, sp, sl, 2.5 * dl)):
+        got = batch_neighbors_kpconv(T(Q), T(S), T(ql), T(sl_), r, limit).cpu().numpy()
+        if len(Q) <= 6000:
+            want = co.radius_neighbors_batch(Q, S, ql, sl_, r)[:, :limit]
+            assert got.dtype == np.int64 and np.array_equal(got, want)          # the oracle breaks ties like the kernel
+        if co.ref_lib() is not None:
+            ref = co.ref_batch_query(Q, S, ql, sl_, r)[:, :limit]                # the reference's own kd-tree search
+            assert rows_equal_up_to_ties(ref.astype(np.int64), got, Q, S)
+
+
+def test_radius_neighbors_edge_cases():
+    from diffreg_hip import lib
+    P, L = scene(600, 500, 8)
+    # queries far outside the support cloud find nothing; the row is all padding
+    n0 = int(L[0])
+    Q = np.concatenate([P[:10] + 50.0, P[n0:n0 + 10]]).astype(np.float32)
+    out, mc, st = lib.radius_neighbors(T(Q), T(P), T(np.array([10, 10], np.int32)), T(L), 0.08, 16)
+    o = out.cpu().numpy()
+    assert (o[:10] == len(P)).all() and (o[10:, 0] == np.arange(n0, n0 + 10)).all()   # a support point is its own nearest neighbour
+    # a query never sees the other cloud of the pair
+    assert (o[10:] >= n0).all()
+    # untruncated width and truncation agree on the common columns
+    from diffreg_hip.collate import batch_neighbors_kpconv
+    a = batch_neighbors_kpconv(T(P), T(P), T(L), T(L), 0.08, 64).cpu().numpy()
+    b = batch_neighbors_kpconv(T(P), T(P), T(L), T(L), 0.08, 7).cpu().numpy()
+    assert b.shape[1] == 7 and np.array_equal(a[:, :7], b)
+    with pytest.raises(RuntimeError):
+        lib.radius_neighbors(torch.from_numpy(Q), torch.from_numpy(P), torch.tensor([10, 10]), torch.from_numpy(L), 0.08, 16)   # CPU tensors
+
+
+def test_level_loop_matches_cpu_collate_and_feeds_the_backbone():
+    """build_kpfcn_inputs (dataloader.py:120-211 on device) against the same loop run with the oracle, level by level"""
+    from diffreg_hip.collate import build_kpfcn_inputs
+    P, L = scene(1400, 1200, 0)
+    cfg = dict(architecture=synth.KPFCN_ARCH, first_subsampling_dl=0.05, conv_radius=2.5, deform_radius=5.0)
+    limits = [28, 28, 30, 32]
+    got = build_kpfcn_inputs(T(P), T(L), cfg, limits)
+    pts, lens, r_n = P, L, 0.05 * 2.5
+    for lvl in range(4):
+        assert np.array_equal(got["points"][lvl].cpu().numpy(), pts) and np.array_equal(got["stack_lengths"][lvl].cpu().numpy(), lens)
+        conv = co.radius_neighbors_batch(pts, pts, lens, lens, r_n)[:, :limits[lvl]]
+        assert np.array_equal(got["neighbors"][lvl].cpu().numpy(), conv)
+        if lvl == 3:
+            assert got["pools"][lvl].shape == (0, 1) and got["upsamples"][lvl].shape == (0, 1)
+            break
+        pp, pl = co.grid_subsample_batch(pts, lens, 2 * r_n / 2.5)
+        assert np.array_equal(got["pools"][lvl].cpu().numpy(), co.radius_neighbors_batch(pp, pts, pl, lens, r_n)[:, :limits[lvl]])
+        assert np.array_equal(got["upsamples"][lvl].cpu().numpy(), co.radius_neighbors_batch(pts, pp, lens, pl, 2 * r_n)[:, :limits[lvl]])
+        pts, lens, r_n = pp, pl, 2 * r_n
