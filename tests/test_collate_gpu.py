@@ -96,3 +96,22 @@ def test_level_loop_matches_cpu_collate_and_feeds_the_backbone():
         assert np.array_equal(got["pools"][lvl].cpu().numpy(), co.radius_neighbors_batch(pp, pts, pl, lens, r_n)[:, :limits[lvl]])
         assert np.array_equal(got["upsamples"][lvl].cpu().numpy(), co.radius_neighbors_batch(pts, pp, lens, pl, 2 * r_n)[:, :limits[lvl]])
         pts, lens, r_n = pp, pl, 2 * r_n
+
+
+def test_device_collate_feeds_the_backbone(golden):
+    """end of row f4 -> row f1: the index arrays built on the device drive the KPFCN coarse phase; same features as the
+    oracle backbone on the same arrays"""
+    from diffreg_hip.backbone import KPFCNEngine
+    from diffreg_hip.collate import build_kpfcn_inputs
+    from oracle import kpfcn_oracle as ko
+    from tests.test_oracle_golden import kpfcn_inputs
+    g, sd, tb = kpfcn_inputs(golden)
+    cfg = dict(architecture=synth.KPFCN_ARCH, first_subsampling_dl=synth.KPFCN_CFG["first_subsampling_dl"], conv_radius=2.5, deform_radius=5.0)
+    lengths = torch.as_tensor(np.asarray(synth.make_kpfcn_batch()["stack_lengths"][0]), dtype=torch.int32)
+    batch = build_kpfcn_inputs(tb["points"][0].cuda(), lengths.cuda(), cfg, [28, 28, 30, 32])
+    batch["features"] = torch.ones(len(tb["points"][0]), 1, device="cuda")
+    out = KPFCNEngine(sd, device="cuda:0").forward(batch).cpu()
+    cpu = {k: [t.cpu() for t in v] if isinstance(v, list) else v.cpu() for k, v in batch.items()}
+    ref = ko.kpfcn_coarse(sd, cpu)
+    assert out.shape == ref.shape and out.shape[0] == int(batch["stack_lengths"][-2].sum())   # coarse_level = -2
+    assert (out - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
