@@ -85,3 +85,36 @@ def build_kpfcn_inputs(points, lengths, config, neighborhood_limits):
         layer += 1
         layer_blocks = []
     return out
+
+
+def collate_fn_device(pairs, config, neighborhood_limits, coarse_level=-2):
+    """The inference half of collate_fn_3dmatch (dataloader.py:70-325) on device: `pairs` = [(src_pcd [n,3], tgt_pcd [m,3]
+    [, rot [3,3], trn [3,1]]), ...] (device tensors) -> the input dict of Pipeline.forward: the KPFCN index arrays
+    (build_kpfcn_inputs), `features` = ones, and the coarse-level masks / split indices of dataloader.py:213-262.
+    Ground-truth products of the collate (coarse_matches, correspondences, fine-level subsampling) belong to training and
+    metrics and are not built here."""
+    dev = pairs[0][0].device
+    pts, lens = [], []
+    for p in pairs:
+        pts += [p[0].to(torch.float32), p[1].to(torch.float32)]
+        lens += [p[0].shape[0], p[1].shape[0]]
+    points = torch.cat(pts)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
+    d = build_kpfcn_inputs(points, lengths, config, neighborhood_limits)
+    d["features"] = torch.ones(points.shape[0], 1, device=dev)                    # in_feats_dim = 1 (3DMatch: occupancy)
+    cnt = d["stack_lengths"][coarse_level].view(-1, 2).to(torch.int64)            # [B, 2] points of src / tgt at the coarse level
+    B = cnt.shape[0]
+    smax, tmax = int(cnt[:, 0].max()), int(cnt[:, 1].max())                       # one sync: the padded extents are shapes
+    ar_s, ar_t = torch.arange(smax, device=dev), torch.arange(tmax, device=dev)
+    d["src_mask"] = ar_s[None, :] < cnt[:, :1]
+    d["tgt_mask"] = ar_t[None, :] < cnt[:, 1:]
+    start = torch.cumsum(cnt.sum(1), 0) - cnt.sum(1)                               # first coarse row of every pair
+    rows = torch.arange(B, device=dev)[:, None]
+    d["src_ind_coarse_split"] = (ar_s[None, :] + rows * smax)[d["src_mask"]]
+    d["tgt_ind_coarse_split"] = (ar_t[None, :] + rows * tmax)[d["tgt_mask"]]
+    d["src_ind_coarse"] = (ar_s[None, :] + start[:, None])[d["src_mask"]]
+    d["tgt_ind_coarse"] = (ar_t[None, :] + (start + cnt[:, 0])[:, None])[d["tgt_mask"]]
+    if len(pairs[0]) >= 4:
+        d["batched_rot"] = torch.stack([p[2].to(torch.float32) for p in pairs])
+        d["batched_trn"] = torch.stack([p[3].to(torch.float32).reshape(3, 1) for p in pairs])
+    return d

@@ -115,3 +115,45 @@ def test_device_collate_feeds_the_backbone(golden):
     ref = ko.kpfcn_coarse(sd, cpu)
     assert out.shape == ref.shape and out.shape[0] == int(batch["stack_lengths"][-2].sum())   # coarse_level = -2
     assert (out - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_raw_clouds_to_conf_matrix_on_device(golden):
+    """rows f4 -> f1 -> a1 in one go: two raw clouds -> collate_fn_device -> Pipeline (overlay backbone + denoising loop) ->
+    conf_matrix_pred, against oracle backbone + oracle loop on the arrays the device collate produced (themselves held to the
+    collate oracle above)."""
+    from diffreg_hip.collate import collate_fn_device
+    from models.pipeline import Pipeline
+    from oracle import kpfcn_oracle as ko, diffreg_oracle as orc
+    from tests.test_oracle_golden import kpfcn_inputs
+    from tests.test_models_api_gpu import ref_like_config, to_attr
+    from tests.helpers import weights
+    variant, steps, mc = "3dmatch", 2, 200
+    g, bsd, tb = kpfcn_inputs(golden)
+    cfg = ref_like_config(variant, steps, mc)
+    kc = dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), KP_influence="linear", aggregation_mode="sum", deformable=False,
+              use_batch_norm=True, fine_feature_dim=264, coarse_level=-2, deform_radius=5.0)
+    cfg.kpfcn_config = to_attr(kc)
+    model = Pipeline(cfg)
+    sd = model.state_dict()
+    W = weights(variant)
+    sd.update(W)
+    sd.update({"backbone." + k: v for k, v in bsd.items()})
+    model.load_state_dict(sd)
+    model = model.to("cuda:0").eval()
+    L = synth.make_kpfcn_batch()["stack_lengths"][0]
+    P0 = tb["points"][0]
+    data = collate_fn_device([(P0[:L[0]].cuda(), P0[L[0]:].cuda())], kc, [28, 28, 30, 32])
+    ns, nt = [int(v) for v in data["stack_lengths"][-2]]
+    assert data["src_mask"].shape == (1, ns) and data["tgt_mask"].all() and torch.equal(data["tgt_ind_coarse"].cpu(), torch.arange(ns, ns + nt))
+    x_T = torch.from_numpy(synth.hash_normal(78, 5, (1, ns, nt))).float()
+    data["x_T"] = x_T.cuda()
+    cpu = {k: [t.cpu() for t in v] if isinstance(v, list) else v.cpu() for k, v in data.items()}
+    out = model(data)
+    conf = out["conf_matrix_pred"][0].cpu()
+    feats = ko.kpfcn_coarse(bsd, cpu)
+    pts = cpu["points"][2]
+    v = synth.VARIANTS[variant]
+    ms, mt = torch.ones(1, ns, dtype=torch.bool), torch.ones(1, nt, dtype=torch.bool)
+    ref = orc.denoise_loop(W, v, feats[None, :ns], feats[None, ns:], pts[None, :ns], pts[None, ns:], ms, mt, x_T, steps, mc, variant=variant)
+    d = (conf - ref["conf_matrix_pred"][0]).abs()
+    assert (d > 1e-4).double().mean().item() <= 1e-3, d.max().item()
