@@ -16,16 +16,16 @@ static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 void prof_begin(int kind, double work, hipStream_t st) {
     ProfRec r; r.kind = kind; r.work = work; r.a = get_event(); r.b = nullptr;
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
 }
 void prof_end(int kind, hipStream_t st) {
     for (size_t i = g_prof.size(); i-- > 0;)
-        if (g_prof[i].kind == kind && !g_prof[i].b) { g_prof[i].b = get_event(); hipEventRecord(g_prof[i].b, st); return; }
+        if (g_prof[i].kind == kind && !g_prof[i].b) { g_prof[i].b = get_event(); (void)hipEventRecord(g_prof[i].b, st); return; }
 }
 }  // namespace dr
 
@@ -40,7 +40,7 @@ int dr_prof_collect(int* calls, double* ms, double* work) {
     for (auto& r : g_prof) {
         if (r.b) {
             float t = 0.f;
-            hipEventElapsedTime(&t, r.a, r.b);
+            (void)hipEventElapsedTime(&t, r.a, r.b);
             calls[r.kind] += 1; ms[r.kind] += t; work[r.kind] += r.work;
             g_pool.push_back(r.b);
         }

@@ -183,7 +183,6 @@ __global__ __launch_bounds__(256) void nrfmr_kernel(NrArgs A) {
 // ------------------------------------------------------------------------------------------------------------
 // correspondence RANSAC
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RS_TILE = 512;     // correspondences staged per pass: 512 x 6 doubles = 24 KB of LDS
 constexpr int RS_BLOCK = 256;    // hypotheses per workgroup
 
 struct RsBest { double err; int cnt; int it; };
@@ -194,7 +193,7 @@ __device__ __forceinline__ bool rs_better(int c, double e, int it, int oc, doubl
 struct RsArgs {
     const long long* matches; const int* count; int cap, N, M;
     const float* s_pcd; const float* t_pcd; const long long* pair_ids;
-    double thr2; int iters; uint64_t seed; RsBest* blk; int nblk;
+    double thr2; int iters; uint64_t seed; RsBest* blk; int nblk; double* pts;
     double* rot; double* trn; double* fitness; double* rmse; int* best_iter;
 };
 
@@ -253,8 +252,23 @@ __device__ __forceinline__ bool rs_fit(const long long* __restrict__ mt, int K, 
     return true;
 }
 
+// the correspondences of every pair as fp64 point pairs [P, cap, 6] (x, y, z of the source, then of the target; NaN for
+// indices outside the clouds): written once, then read by every hypothesis of the pair
+__global__ __launch_bounds__(256) void ransac_gather_kernel(RsArgs A) {
+    const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= A.cap) return;
+    const long long* m = A.matches + ((size_t)pair * A.cap + k) * 3;
+    double* o = A.pts + ((size_t)pair * A.cap + k) * 6;
+    const long long i = m[1], j = m[2];
+    const bool okk = k < A.count[pair] && (unsigned long long)i < (unsigned long long)A.N && (unsigned long long)j < (unsigned long long)A.M;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = okk ? (double)A.s_pcd[((size_t)pair * A.N + i) * 3 + c] : (double)NAN;
+        o[3 + c] = okk ? (double)A.t_pcd[((size_t)pair * A.M + j) * 3 + c] : (double)NAN;
+    }
+}
+
 __global__ __launch_bounds__(RS_BLOCK) void ransac_eval_kernel(RsArgs A) {
-    __shared__ double s_pt[RS_TILE * 6];
     __shared__ RsBest s_best[RS_BLOCK / 64];
     const int pair = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int K = min(A.count[pair], A.cap);
@@ -280,27 +294,18 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_eval_kernel(RsArgs A) {
     }
     int cnt = 0;
     double err = 0.0;
-    for (int k0 = 0; k0 < K; k0 += RS_TILE) {
-        const int nk = min(RS_TILE, K - k0);
-        for (int k = t; k < nk; k += RS_BLOCK) {
-            const long long i = mt[(size_t)(k0 + k) * 3 + 1], j = mt[(size_t)(k0 + k) * 3 + 2];
-            const bool okk = (unsigned long long)i < (unsigned long long)A.N && (unsigned long long)j < (unsigned long long)A.M;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                s_pt[k * 6 + c] = okk ? (double)sp[i * 3 + c] : (double)NAN;
-                s_pt[k * 6 + 3 + c] = okk ? (double)tp[j * 3 + c] : (double)NAN;
-            }
-        }
-        __syncthreads();
-        for (int k = 0; k < nk; ++k) {
-            const double sx = s_pt[k * 6], sy = s_pt[k * 6 + 1], sz = s_pt[k * 6 + 2];
-            const double ex = fma(R[0][0], sx, fma(R[0][1], sy, fma(R[0][2], sz, tv[0]))) - s_pt[k * 6 + 3];
-            const double ey = fma(R[1][0], sx, fma(R[1][1], sy, fma(R[1][2], sz, tv[1]))) - s_pt[k * 6 + 4];
-            const double ez = fma(R[2][0], sx, fma(R[2][1], sy, fma(R[2][2], sz, tv[2]))) - s_pt[k * 6 + 5];
-            const double d2 = fma(ex, ex, fma(ey, ey, ez * ez));
-            if (d2 < A.thr2) { ++cnt; err += d2; }
-        }
-        __syncthreads();
+    // every lane scores the SAME correspondence at the same time: the point pair is wave-uniform, so it comes through the
+    // scalar cache into SGPRs (s_load_dwordx4) and feeds the FMAs as their scalar operand -- no LDS staging, no barriers
+    // (the LDS-broadcast form spent 3 ds_read_b128 per evaluation and kept the fp64 pipe at half rate)
+    const double* __restrict__ cp = A.pts + (size_t)pair * A.cap * 6;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        const double sx = cp[k * 6], sy = cp[k * 6 + 1], sz = cp[k * 6 + 2];
+        const double ex = fma(R[0][0], sx, fma(R[0][1], sy, fma(R[0][2], sz, tv[0]))) - cp[k * 6 + 3];
+        const double ey = fma(R[1][0], sx, fma(R[1][1], sy, fma(R[1][2], sz, tv[1]))) - cp[k * 6 + 4];
+        const double ez = fma(R[2][0], sx, fma(R[2][1], sy, fma(R[2][2], sz, tv[2]))) - cp[k * 6 + 5];
+        const double d2 = fma(ex, ex, fma(ey, ey, ez * ez));
+        if (d2 < A.thr2) { ++cnt; err += d2; }
     }
     int bc = valid ? cnt : -1, bi = valid ? it : 0x7fffffff;
     double be = valid ? err : 0.0;
@@ -466,9 +471,9 @@ int dr_nrfmr_f32(int P, int cap, int N, int M, const int64_t* matches, const int
     return DR_OK;
 }
 
-size_t dr_ransac_workspace_bytes(int P, int iters) {
-    if (P <= 0 || iters <= 0) return 0;
-    return (size_t)P * ((iters + RS_BLOCK - 1) / RS_BLOCK) * sizeof(RsBest);
+size_t dr_ransac_workspace_bytes(int P, int cap, int iters) {
+    if (P <= 0 || iters <= 0 || cap <= 0) return 0;
+    return (size_t)P * ((iters + RS_BLOCK - 1) / RS_BLOCK) * sizeof(RsBest) + (size_t)P * cap * 6 * sizeof(double);
 }
 
 int dr_ransac_corr_f64(int P, int cap, int N, int M, const int64_t* matches, const int32_t* count, const float* s_pcd,
@@ -478,14 +483,17 @@ int dr_ransac_corr_f64(int P, int cap, int N, int M, const int64_t* matches, con
     if (P < 0 || cap <= 0 || N <= 0 || M <= 0 || iters <= 0 || !(distance_thr > 0.0)) return DR_EINVAL;
     if (P == 0) return DR_OK;
     if (!matches || !count || !s_pcd || !t_pcd || !rot || !trn) return DR_EINVAL;
-    if (!workspace || workspace_bytes < dr_ransac_workspace_bytes(P, iters)) return DR_EWORKSPACE;
+    if (!workspace || workspace_bytes < dr_ransac_workspace_bytes(P, cap, iters)) return DR_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RsArgs A{};
     A.matches = (const long long*)matches; A.count = count; A.cap = cap; A.N = N; A.M = M;
     A.s_pcd = s_pcd; A.t_pcd = t_pcd; A.pair_ids = (const long long*)pair_ids;
     A.thr2 = distance_thr * distance_thr; A.iters = iters; A.seed = seed;
     A.blk = (RsBest*)workspace; A.nblk = (iters + RS_BLOCK - 1) / RS_BLOCK;
+    A.pts = (double*)((char*)workspace + (size_t)P * A.nblk * sizeof(RsBest));
     A.rot = rot; A.trn = trn; A.fitness = fitness; A.rmse = inlier_rmse; A.best_iter = best_iter;
+    hipLaunchKernelGGL(ransac_gather_kernel, dim3((cap + 255) / 256, P), dim3(256), 0, st, A);
+    DR_LAUNCH_CHECK();
     hipLaunchKernelGGL(ransac_eval_kernel, dim3(A.nblk, P), dim3(RS_BLOCK), 0, st, A);
     DR_LAUNCH_CHECK();
     hipLaunchKernelGGL(ransac_final_kernel, dim3(P), dim3(64), 0, st, A);

@@ -126,7 +126,6 @@ __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ 
                                                           int* __restrict__ count, const uint8_t* __restrict__ smask,
                                                           const uint8_t* __restrict__ tmask) {
     __shared__ unsigned s_key[T1_MAX];
-    __shared__ int s_n;
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const T* c = conf + (size_t)pair * N * M;
     // masks (nullable): rows / columns outside them do not exist (DR_LOOP_RAGGED)
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ 
             }
         }
         count[pair] = n;
-        s_n = n;
+
     }
 }
 

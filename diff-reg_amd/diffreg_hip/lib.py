@@ -113,7 +113,7 @@ SIGNATURES.update({
                              [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
     "dr_inlier_ratio_f32": (c_int, [c_int] * 4 + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p]),
     "dr_nrfmr_f32": (c_int, [c_int] * 4 + [c_void_p] * 9 + [c_int, c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 4),
-    "dr_ransac_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_ransac_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_ransac_corr_f64": (c_int, [c_int] * 4 + [c_void_p] * 4 + [c_double, c_int, ctypes.c_uint64] + [c_void_p] * 7 +
                            [c_size_t, c_void_p]),
     "dr_registration_recall_f64": (c_int, [c_int] + [c_void_p] * 5 + [c_double, c_void_p, c_void_p, c_void_p]),
@@ -445,7 +445,7 @@ def ransac_corr(matches, count, s_pcd, t_pcd, distance_thr=0.05, iters=50000, se
     rot, trn = torch.empty(P, 3, 3, **f64), torch.empty(P, 3, 1, **f64)
     fit, rmse = torch.empty(P, **f64), torch.empty(P, **f64)
     bi = torch.empty(P, dtype=torch.int32, device=dev)
-    wsb = _lib.dr_ransac_workspace_bytes(P, int(iters))
+    wsb = _lib.dr_ransac_workspace_bytes(P, cap, int(iters))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ids = None if pair_ids is None else pair_ids.to(device=dev, dtype=torch.int64).contiguous()
     check(_lib.dr_ransac_corr_f64(P, cap, N, M, ptr(matches), ptr(count.contiguous()), ptr(_f32c(s_pcd, (P, N, 3))),

@@ -312,7 +312,7 @@ int dr_nrfmr_f32(int P, int cap, int N, int M, const int64_t* matches, const int
  * out (fp64 like the reference's `torch.from_numpy(pose)`): rot [P,9], trn [P,3]; identity / zero when a pair has
  * fewer than 3 matches (loss.py:363-366) or no hypothesis has an inlier; fitness [P], inlier_rmse [P] (optional),
  * best_iter [P] int32 (optional, -1 = none).   pair_ids int64 [P] or NULL (= 0..P-1). */
-size_t dr_ransac_workspace_bytes(int P, int iters);
+size_t dr_ransac_workspace_bytes(int P, int cap, int iters);
 int dr_ransac_corr_f64(int P, int cap, int N, int M, const int64_t* matches, const int32_t* count, const float* s_pcd,
                        const float* t_pcd, double distance_thr, int iters, uint64_t seed, const int64_t* pair_ids,
                        double* rot, double* trn, double* fitness, double* inlier_rmse, int32_t* best_iter,
