@@ -602,7 +602,6 @@ __global__ __launch_bounds__(1024) void sk_fast_persist_kernel(SkArgs A) {
         // image is free again
         sk_fast_tile<NW, CPL>(E, alpha, A.iters, s_colpart, s_b, s_dust, a4, bj, [&] {
             if (has_next) {
-#pragma unroll
                 for (int r = 0; r < SKP_PRE; ++r)
                     __builtin_amdgcn_global_load_lds((sk_glb_void*)(reinterpret_cast<const char*>(nsrc) + r * M * 4),
                                                      (sk_lds_void*)(my_pref + r * 1024), 16, 0, 0);
