@@ -46,11 +46,69 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// float4 form for C % 4 == 0 with 16-byte aligned rows (every layer of the loop: C = 432 / 528 / 256): a row is C / 4 float4s,
+// one wave per row, NV = ceil(C / 256) 16-byte loads per lane instead of 16 predicated dword loads
+template <bool POSTADD, int NV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                            const float* __restrict__ b, const float* __restrict__ res,
+                                                            int ldres, float* __restrict__ out, int ldo, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, C4 = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)row * ldres) : nullptr;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (POSTADD && c < C4) { const float4 r = rr[c]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < C4) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 gg = reinterpret_cast<const float4*>(g)[c], bb = reinterpret_cast<const float4*>(b)[c];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * gg.x + bb.x; y.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+            y.z = (v[i].z - mean) * rstd * gg.z + bb.z; y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            if (!POSTADD && rr) { const float4 r = rr[c]; y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
+            reinterpret_cast<float4*>(out + (size_t)row * ldo)[c] = y;
+        }
+    }
+}
+
+template <bool POSTADD>
+static bool launch_layernorm_vec(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
+                                 int ldo, int rows, int C, hipStream_t st) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if ((C & 3) || (ldx & 3) || (ldo & 3) || (res && (ldres & 3)) || !al(x) || !al(out) || !al(g) || !al(b) || (res && !al(res)) || C > 768)
+        return false;
+    const dim3 grid((rows + 3) / 4), blk(256);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 1>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    else if (C <= 512) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 2>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    else hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 3>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    return true;
+}
+
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                      int ldo, int rows, int C, hipStream_t st) {
     if (C > 64 * LN_MAX_PER_LANE) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
     ProfScope ps(PK_LN, (double)rows * C * (res ? 12.0 : 8.0), st);
+    if (launch_layernorm_vec<false>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st)) { DR_LAUNCH_CHECK(); return DR_OK; }
     hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -61,6 +119,7 @@ int launch_layernorm_postadd(const float* x, int ldx, const float* g, const floa
     if (C > 64 * LN_MAX_PER_LANE || !res) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
     ProfScope ps(PK_LN, (double)rows * C * 12.0, st);
+    if (launch_layernorm_vec<true>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st)) { DR_LAUNCH_CHECK(); return DR_OK; }
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
     DR_LAUNCH_CHECK();
     return DR_OK;
