@@ -157,3 +157,37 @@ def test_raw_clouds_to_conf_matrix_on_device(golden):
     ref = orc.denoise_loop(W, v, feats[None, :ns], feats[None, ns:], pts[None, :ns], pts[None, ns:], ms, mt, x_T, steps, mc, variant=variant)
     d = (conf - ref["conf_matrix_pred"][0]).abs()
     assert (d > 1e-4).double().mean().item() <= 1e-3, d.max().item()
+
+
+def test_radius_neighbors_more_than_cap_points_in_the_ball():
+    """a dense clump: 300 supports inside one ball, more than the 64 candidates a lane keeps before ranking -- the kept set must
+    still be the `limit` nearest (the farthest kept candidate makes room), in order"""
+    from diffreg_hip import lib
+    clump = (0.01 * synth.hash_normal(3, 5, (300, 3))).astype(np.float32) + np.array([0.5, 0.5, 0.5], np.float32)
+    bg, _ = scene(500, 400, 9)
+    S = np.concatenate([clump, bg[:400]]).astype(np.float32)
+    sl = np.array([len(S)], np.int32)
+    Q = np.concatenate([clump[:20], bg[400:420]]).astype(np.float32)
+    ql = np.array([len(Q)], np.int32)
+    for limit in (64, 40):
+        out, mc, st = lib.radius_neighbors(T(Q), T(S), T(ql), T(sl), 0.06, limit)
+        want = co.radius_neighbors_batch(Q, S, ql, sl, 0.06)
+        assert int(mc) == want.shape[1] and want.shape[1] > 64
+        assert np.array_equal(out.cpu().numpy(), want[:, :limit])
+
+
+def test_grid_subsample_large_cloud_and_negative_coordinates():
+    """131 072-pair sort (six global bitonic levels), coordinates on both sides of the origin, a cell size that does not divide
+    the extent; against the reference's own C++ when it is built, else the oracle"""
+    from diffreg_hip.collate import batch_grid_subsampling_kpconv
+    u = synth.hash_uniform(11, 3, (90000, 3), -1.0, 1.0)
+    P = np.stack([3.1 * u[:, 0], 2.3 * u[:, 1], 0.4 * np.sin(2 * u[:, 0]) + 0.05 * u[:, 2]], 1).astype(np.float32)
+    L = np.array([50000, 40000], np.int32)
+    sp, sl = batch_grid_subsampling_kpconv(T(P), T(L), sampleDl=0.037)
+    if co.ref_lib() is not None:
+        rp, rl = co.ref_subsample_batch(P, L, 0.037)
+        assert np.array_equal(rl, sl.cpu().numpy())
+        assert np.array_equal(rp[co.canonical_order(rp, rl, P, L, 0.037)], sp.cpu().numpy())
+    else:
+        op, ol = co.grid_subsample_batch(P, L, 0.037)
+        assert np.array_equal(op, sp.cpu().numpy())
