@@ -34,8 +34,15 @@ import torch  # noqa: E402
 HEAD_GAIN = 24.0
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA
 PEAK_MFMA_BF16_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-# the split-operand GEMM spends six bf16 MFMA MACs per fp32 MAC: the ceiling of what it executes, in fp32-equivalent FLOP/s
-PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / 6.0
+# the split-operand GEMMs spend several 16-bit MFMA MACs per fp32 MAC: the ceiling of what they execute, in fp32-equivalent
+# FLOP/s.  Default: two fp16 planes, three products (the fp16 and bf16 dense MFMA peaks are the same); DR_GEMM_F16X2=0: three
+# bf16 planes, six products.
+F16X2 = os.environ.get("DR_GEMM_F16X2", "1") != "0"
+SPLIT_PRODUCTS = 3.0 if F16X2 else 6.0
+PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / SPLIT_PRODUCTS
+SPLIT_KERNEL = "gemm_nt_wide2_kernel" if F16X2 else "gemm_nt_wide_kernel"
+SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand splits (rows of both operands scaled by exact powers of two into fp16's range)"
+              if F16X2 else "six bf16 MFMA products of hi/mid/lo operand splits")
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -275,7 +282,7 @@ def main():
                                "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, P, nstreams),
                    "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
                    "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32",
-                   "gemm_arithmetic": "fp32 in / fp32 out; each product as six bf16 MFMA products of hi/mid/lo operand splits, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)", "parallelism": "pairs sharded over %d GPU(s)" % world},
+                   "gemm_arithmetic": "fp32 in / fp32 out; each product as %s, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)" % SPLIT_TEXT, "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
     }
 
@@ -316,8 +323,8 @@ def main():
             c, ms_, work = prof[dom]
             if dom == "gemm_split":
                 ach = work / (ms_ * 1e-3) / 1e12
-                roof = dict(kernel="gemm_nt_wide_kernel (family gemm_split)", bound="mfma", achieved=ach, peak=PEAK_SPLIT_TFLOPS,
-                            unit="TFLOP/s", traffic=None, peak_basis="dense bf16 MFMA peak / 6 products per fp32 MAC",
+                roof = dict(kernel="%s (family gemm_split)" % SPLIT_KERNEL, bound="mfma", achieved=ach, peak=PEAK_SPLIT_TFLOPS,
+                            unit="TFLOP/s", traffic=None, peak_basis="dense 16-bit MFMA peak / %d products per fp32 MAC" % SPLIT_PRODUCTS,
                             peak_f32_mfma=PEAK_MFMA_F32_TFLOPS, frac_vs_f32_mfma_peak=ach / PEAK_MFMA_F32_TFLOPS)
             elif dom in ("gemm", "attention"):
                 roof = dict(kernel=dom, bound="mfma", achieved=work / (ms_ * 1e-3) / 1e12, peak=PEAK_MFMA_F32_TFLOPS,
@@ -329,7 +336,7 @@ def main():
             if dom == "gemm_split":
                 # PMC traffic of this kernel is collected on one named shape (separate rocprofv3 --pmc passes, the
                 # launches of a pass here are a mix of shapes): quoted beside the line, `traffic` itself stays null
-                tp = os.path.join(ROOT, "profiles", "r01_gemm_wide_pmc_traffic.json")
+                tp = os.path.join(ROOT, "profiles", "r01_gemm_wide2_pmc_traffic.json" if F16X2 else "r01_gemm_wide_pmc_traffic.json")
                 if os.path.exists(tp):
                     tj = json.load(open(tp))
                     roof["traffic_reference"] = {k: tj[k] for k in ("shape", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch",
@@ -337,7 +344,7 @@ def main():
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
             roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "
-                            "the kernel computes each fp32 product as six bf16 MFMA products accumulated in fp32 "
+                            "the kernel computes each fp32 product as " + SPLIT_TEXT + " accumulated in fp32 "
                             "(fp32-level accuracy, tests/test_ops_gpu.py::test_gemm_split_accuracy)")
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof

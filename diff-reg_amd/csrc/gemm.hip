@@ -582,6 +582,335 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The wide kernel on a TWO-plane fp16 split -- the default packed GEMM (DR_GEMM_F16X2=0 / dr_debug_gemm_f16x2(0) select the
+// three-plane bf16 kernel above instead).
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi) keeps 22 significand bits; the three products hi*hi, hi*lo, lo*hi are
+// exact in fp32 and the dropped lo*lo is 2^-22 relative -- below the fp32 accumulation error of a K = 432 dot product
+// (tools/split_error_study.py: the same error as a float32 matmul for operands of scale 1 .. 30) -- at HALF the MFMA work
+// of the three-plane bf16 split.  fp16 has 5 exponent bits, so both operands are brought into its range by EXACT powers of
+// two that the epilogue undoes: every row of A by 2^s_r with s_r = 14 - floor(log2(max |row|)) (a pre-pass of the workgroup
+// over its 128 rows, while the first B chunk is in flight), every row of W (output column) by 2^s_c likewise at pack time.
+// Elements within 2^-17 of their row's maximum then keep 22 significand bits; smaller ones are rounded to 2^-39 of the row
+// maximum absolutely -- either way far inside the fp32 rounding of a dot product that contains the row's maximum.
+// Same structure as gemm_nt_wide_kernel: 128 x 224 tile, 4 waves, B by LDS-DMA, A split on the way into LDS, one barrier
+// per 16-deep k-chunk; rows of the LDS images are [hi 32 B | lo 32 B | pad 16 B] = 80 B (5 slots: odd, conflict-free).
+struct WideGeom2 {
+    static constexpr int TN = 7, NWV = 4, BK = 16;
+    static constexpr int NT = 64 * NWV, BM = 32 * NWV, BN = 32 * TN;
+    static constexpr int PL = BK * 2, ROWB = 2 * PL + 16;
+    static constexpr int A_BYTES = BM * ROWB;                          // 10,240
+    static constexpr int B_IMG = ((BN * ROWB + 1023) / 1024) * 1024;   // 18,432
+    static constexpr int B_DMAS = B_IMG / 1024;                        // 18 wave-instructions per chunk
+    static constexpr int STAGE = A_BYTES + B_IMG;                      // 28,672
+    static constexpr int EPI_BYTES = NWV * 32 * 136 * 4;               // the epilogue's transposition regions: 69,632
+    static constexpr int WORK = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    static constexpr int SMEM = WORK + BM * 4;                         // + 2^-s_r of the 128 rows: two workgroups per CU
+    static constexpr int TARGET_EXP = 14;                              // scaled row maxima land in [2^14, 2^15)
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 f = {x0, x1};
+    const f16x2 h = __builtin_convertvector(f, f16x2);                 // round to nearest even
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {x0 - hf.x, x1 - hf.y};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// exponent s with 2^14 <= m 2^s < 2^15 (0 for m = 0 / inf / nan), clamped so that 2^s and 2^-s are normal floats
+__device__ __forceinline__ int f16_scale_exp(float m) {
+    const unsigned bits = __float_as_uint(m);
+    const int e = (int)((bits >> 23) & 0xff) - 127;
+    const bool ok = m > 0.f && e < 128;
+    return ok ? min(max(WideGeom2::TARGET_EXP - e, -100), 100) : 0;
+}
+__device__ __forceinline__ float pow2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_wide2_kernel(GemmBatch G) {
+    using GG = WideGeom2;
+    constexpr int TN = GG::TN, BM = GG::BM, BN = GG::BN, ROWB = GG::ROWB, PL = GG::PL, BK = GG::BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const GemmProblem& P = G.p[blockIdx.y];
+    const float* __restrict__ pA = P.A;
+    const float* __restrict__ pA2 = P.A2;
+    const int rows = P.rows, ncols = P.ncols, K = P.K, K1 = pA2 ? P.K1 : P.K, lda = P.lda, lda2 = P.lda2;
+    const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (rows + BM - 1) / BM;
+    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x % (8 * tiles_n);      // XCD-aware map (see the 3-plane kernel)
+    const int tm = grp * 8 + (rem & 7), tn = rem >> 3;
+    if (tm >= tiles_m) return;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nchunks = (K + BK - 1) / BK;
+
+    const int ar = t >> 1, akc = 8 * (t & 1), alds = ar * ROWB + akc * 2;
+    const float* a1p = pA + (size_t)min(row0 + ar, rows - 1) * lda;
+    const float* a2p = pA2 ? pA2 + (size_t)min(row0 + ar, rows - 1) * lda2 - K1 : a1p;
+    float4 ra[2][2];
+    auto load_a = [&](int ch, float4 (&dst)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kc = min(ch * BK + akc + 4 * q, K - 4);
+            dst[q] = *reinterpret_cast<const float4*>((kc < K1 ? a1p : a2p) + kc);
+        }
+    };
+    const char* bsrc = reinterpret_cast<const char*>(P.Wsplit) + (size_t)tn * GG::B_IMG + lane * 16;
+    const size_t bstep = (size_t)tiles_n * GG::B_IMG;
+    auto dma_b = [&](int ch) {
+        const char* src = bsrc + (size_t)ch * bstep;
+        char* dst = lds + (ch & 1) * GG::STAGE + GG::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < (GG::B_DMAS + 3) / 4; ++i) {
+            const int ins = w + 4 * i;
+            if (ins < GG::B_DMAS)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + ins * 1024), (lds_void*)(dst + ins * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+    float* const s_rinv = reinterpret_cast<float*>(lds + GG::WORK);
+    float sc = 1.f;                                              // 2^s_r of this thread's row (set by the pre-pass below)
+    auto store_a = [&](int ch, const float4 (&src)[2]) {
+        const unsigned d = lds_base + (ch & 1) * GG::STAGE + alds;
+        uint4 hi, lo;
+        split_pair_f16(src[0].x * sc, src[0].y * sc, hi.x, lo.x);
+        split_pair_f16(src[0].z * sc, src[0].w * sc, hi.y, lo.y);
+        split_pair_f16(src[1].x * sc, src[1].y * sc, hi.z, lo.z);
+        split_pair_f16(src[1].z * sc, src[1].w * sc, hi.w, lo.w);
+        const u32x4 vh = {hi.x, hi.y, hi.z, hi.w}, vl = {lo.x, lo.y, lo.z, lo.w};
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:32" :: "v"(d), "v"(vh), "v"(vl) : "memory");
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // One k-chunk.  A column tile is 3 dependent MFMAs; gap G = 3 j + g (tile j, after its MFMA g):
+    //   G 0..4   one B DMA instruction each (wave w: instructions w, w + 4, ..)
+    //   G 5, 6   the two float4 of A(ch + 2)
+    //   G 9..12  split of A(ch + 1), one register pair per gap;  G 13 its two ds_write_b128
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto chunk = [&](int ch, float4 (&cur)[2], float4 (&nxt)[2]) __attribute__((always_inline)) {
+        const bool has_next = ch + 1 < nchunks;
+        const unsigned sbase = lds_base + (ch & 1) * GG::STAGE;
+        const unsigned Ab = sbase + (w * 32 + l31) * ROWB + 16 * h;
+        const unsigned Bb = sbase + GG::A_BYTES + l31 * ROWB + 16 * h;
+        const char* dsrc = bsrc + (size_t)(ch + 1) * bstep;
+        char* ddst = lds + ((ch + 1) & 1) * GG::STAGE + GG::A_BYTES;
+        const unsigned adst = lds_base + ((ch + 1) & 1) * GG::STAGE + alds;
+        uint4 hi, lo;
+        auto gap = [&](int Gi) __attribute__((always_inline)) {
+            if (Gi < 5) {
+                const int ins = wu + 4 * Gi;
+                if (has_next && ins < GG::B_DMAS)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(dsrc + ins * 1024), (lds_void*)(ddst + ins * 1024), 16, 0, 0);
+            } else if (Gi < 7) {
+                if (has_next) {
+                    const int kc = min((ch + 2) * BK + akc + 4 * (Gi - 5), K - 4);
+                    nxt[Gi - 5] = *reinterpret_cast<const float4*>((kc < K1 ? a1p : a2p) + kc);
+                }
+            } else if (Gi >= 9 && Gi < 13 && has_next) {
+                if (Gi == 9) split_pair_f16(cur[0].x * sc, cur[0].y * sc, hi.x, lo.x);
+                else if (Gi == 10) split_pair_f16(cur[0].z * sc, cur[0].w * sc, hi.y, lo.y);
+                else if (Gi == 11) split_pair_f16(cur[1].x * sc, cur[1].y * sc, hi.z, lo.z);
+                else split_pair_f16(cur[1].z * sc, cur[1].w * sc, hi.w, lo.w);
+            } else if (Gi == 13 && has_next) {
+                const u32x4 vh = {hi.x, hi.y, hi.z, hi.w}, vl = {lo.x, lo.y, lo.z, lo.w};
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:32" :: "v"(adst), "v"(vh), "v"(vl) : "memory");
+            }
+        };
+        u32x4 a[2], b[2][2];
+#define DR_LDS_READ2(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#pragma unroll
+        for (int p = 0; p < 2; ++p) DR_LDS_READ2(a[p], Ab, p * PL);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) DR_LDS_READ2(b[0][p], Bb, p * PL);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = j & 1;
+            if (j + 1 < TN) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) DR_LDS_READ2(b[cb ^ 1][p], Bb, (j + 1) * 32 * ROWB + p * PL);
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");          // all but the two reads just issued
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+            const f16x8 b0 = __builtin_bit_cast(f16x8, b[cb][0]), b1 = __builtin_bit_cast(f16x8, b[cb][1]);
+#define DR_MFMA_GAP2(X, Y, g)                                                   \
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X, Y, acc[j], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    gap(3 * j + g);                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first
+            DR_MFMA_GAP2(a1, b0, 0)
+            DR_MFMA_GAP2(a0, b1, 1)
+            DR_MFMA_GAP2(a0, b0, 2)
+#undef DR_MFMA_GAP2
+        }
+#undef DR_LDS_READ2
+    };
+
+    dma_b(0);
+    {   // max |row| -> the row's scale.  The producer of A usually left it behind (LayerNorm and this kernel's own epilogue
+        // write row maxima); otherwise a pre-pass over this thread's half of its row (independent loads, all in flight; a
+        // coalesced row-at-a-time sweep with a wave reduction per row measured slower: 89 vs 67 us at 32768 x 432 x 432).
+        float mx = 0.f;
+        if (P.amax) {
+            const int row = min(row0 + ar, rows - 1);
+            for (int q = 0; q < P.amax_parts; ++q) mx = fmaxf(mx, P.amax[(size_t)q * P.amax_stride + row]);
+            if (P.amax2) mx = fmaxf(mx, P.amax2[row]);
+        } else {
+            for (int ch = 0; ch < nchunks; ++ch) {
+                float4 v[2];
+                load_a(ch, v);
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0].x), fabsf(v[0].y)), fmaxf(fabsf(v[0].z), fabsf(v[0].w))));
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[1].x), fabsf(v[1].y)), fmaxf(fabsf(v[1].z), fabsf(v[1].w))));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1));                   // the two threads of a row
+        }
+        const int s = f16_scale_exp(mx);
+        sc = pow2i(s);
+        if ((t & 1) == 0) s_rinv[ar] = pow2i(-s);
+    }
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+    store_a(0, ra[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
+        chunk(c0, ra[1], ra[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c0 + 1 < nchunks) {
+            chunk(c0 + 1, ra[0], ra[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // epilogue through LDS, as in the 3-plane kernel (the wave's 32 x 224 strip in two passes); the weight scale is undone first
+    {
+        constexpr int EST = 136;
+        float* const ep = reinterpret_cast<float*>(lds) + w * 32 * EST;
+        const int epi = P.epi, halfC = P.rot_C >> 1, rotC = P.rot_C, ldo = P.ldo;
+        const float scale = P.scale;
+        const float* __restrict__ cinv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P.Wsplit) + (size_t)nchunks * bstep);
+        const float* __restrict__ bias = P.bias;
+        const float* __restrict__ addend = P.addend;
+        const float* __restrict__ cosT = P.cosT;
+        const float* __restrict__ sinT = P.sinT;
+        float* __restrict__ outp = P.out;
+        float omx[16];                                           // max |stored value| of row (2 it + lane / 32), this lane's columns
+#pragma unroll
+        for (int it = 0; it < 16; ++it) omx[it] = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int j0 = pass * 4, nt = pass ? TN - 4 : 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj >= nt) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EST + jj * 32 + l31] = acc[j0 + jj][r];
+            }
+            const int c4 = (lane & 31) * 4;
+            const int col = col0 + j0 * 32 + c4;
+            const bool col_ok = c4 < nt * 32 && col < ncols;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cf = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (bias && col_ok) bv = *reinterpret_cast<const float4*>(bias + col);
+            if (col_ok) cf = *reinterpret_cast<const float4*>(cinv + col);       // 2^-s_c of the four columns
+            const int ridx = (epi & EPI_ROTARY) ? (col % rotC) >> 1 : 0;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 2 + (lane >> 5), row = row0 + w * 32 + rl;
+                float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4);
+                if (row < rows && col_ok) {
+                    const float rf = s_rinv[w * 32 + rl];        // undo the operand scales: exact powers of two
+                    v.x = v.x * rf * cf.x; v.y = v.y * rf * cf.y; v.z = v.z * rf * cf.z; v.w = v.w * rf * cf.w;
+                    if (epi & EPI_ROTARY) {
+                        const float2 c = *reinterpret_cast<const float2*>(cosT + (size_t)row * halfC + ridx);
+                        const float2 sn = *reinterpret_cast<const float2*>(sinT + (size_t)row * halfC + ridx);
+                        const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+                        v.x = __fadd_rn(__fmul_rn(x0, c.x), __fmul_rn(-x1, sn.x));
+                        v.y = __fadd_rn(__fmul_rn(x1, c.x), __fmul_rn(x0, sn.x));
+                        v.z = __fadd_rn(__fmul_rn(x2, c.y), __fmul_rn(-x3, sn.y));
+                        v.w = __fadd_rn(__fmul_rn(x3, c.y), __fmul_rn(x2, sn.y));
+                    }
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (epi & EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    float* o = outp + (size_t)row * ldo + col;
+                    if (addend) {
+                        const float4 ad = *reinterpret_cast<const float4*>(addend + (size_t)row * ldo + col);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    *reinterpret_cast<float4*>(o) = v;
+                    omx[it] = fmaxf(omx[it], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                }
+            }
+        }
+        if (P.omax) {                                            // one partial maximum per row and 224-column tile
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                float m = omx[it];
+#pragma unroll
+                for (int d = 16; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));     // over the 32 lanes that share the row
+                const int row = row0 + w * 32 + it * 2 + (lane >> 5);
+                if ((lane & 31) == 0 && row < rows) P.omax[(size_t)tn * P.omax_stride + row] = m;
+            }
+        }
+    }
+}
+
+// W [ncols][K] fp32 -> per output column c the scale 2^s_c (stored as 2^-s_c behind the image) ...
+__global__ __launch_bounds__(256) void wcol_scale_kernel(const float* __restrict__ W, int ncols, int K, float* __restrict__ cinv) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= ncols) return;
+    float mx = 0.f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(W[(size_t)c * K + k]));
+    mx = wave_max(mx);
+    if (lane == 0) cinv[c] = pow2i(-f16_scale_exp(mx));
+}
+// ... and the two-plane fp16 image of W[c][:] * 2^s_c
+__global__ void pack_weights_f16_kernel(const float* __restrict__ W, char* __restrict__ out, int ncols, int K,
+                                        const float* __restrict__ cinv) {
+    using GG = WideGeom2;
+    const int nck = (K + 15) / 16, tiles_n = (ncols + GG::BN - 1) / GG::BN;
+    const size_t n = (size_t)nck * tiles_n * GG::BN * 2, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int half = (int)(i & 1);
+    size_t rest = i >> 1;
+    const int r = (int)(rest % GG::BN); rest /= GG::BN;
+    const int tn = (int)(rest % tiles_n), ch = (int)(rest / tiles_n);
+    const int col = tn * GG::BN + r, k = ch * 16 + half * 8;
+    const float sc = col < ncols ? 1.0f / cinv[col] : 1.f;            // (a power of two: exact)
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (col < ncols && k + e < K) ? W[(size_t)col * K + k + e] * sc : 0.f;
+    uint4 hi, lo;
+    split_pair_f16(x[0], x[1], hi.x, lo.x);
+    split_pair_f16(x[2], x[3], hi.y, lo.y);
+    split_pair_f16(x[4], x[5], hi.z, lo.z);
+    split_pair_f16(x[6], x[7], hi.w, lo.w);
+    char* d = out + ((size_t)ch * tiles_n + tn) * GG::B_IMG + (size_t)r * GG::ROWB + half * 16;
+    *reinterpret_cast<uint4*>(d) = hi;
+    *reinterpret_cast<uint4*>(d + GG::PL) = lo;
+}
+
+static int g_f16x2 = -1;         // -1 = environment (DR_GEMM_F16X2, default ON); set BEFORE the weights are packed
+void gemm_force_f16x2(int on) { g_f16x2 = on; }
+bool gemm_f16x2() {
+    static const int v = [] { const char* e = getenv("DR_GEMM_F16X2"); return e ? atoi(e) : 1; }();
+    return (g_f16x2 >= 0 ? g_f16x2 : v) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // 8-wave form of the wide kernel: same 128 x 224 workgroup tile, same LDS images and DMA, but the 7 column tiles
 // of a 32-row strip are shared by two waves (4 + 3 tiles; wave w: strip w & 3, half w >> 2, so the two halves of a
 // strip sit on the same SIMD and balance it).  A workgroup then has two waves per SIMD whose MFMA groups fill
@@ -829,7 +1158,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, char* __restric
     *reinterpret_cast<uint4*>(d + 2 * GG::PL) = lo;
 }
 
-size_t gemm_packed_weight_bytes(int ncols, int K) {
+size_t gemm_packed_weight_bytes(int ncols, int K) {      // (the three-plane image is the larger one: room for either)
     return (size_t)((K + 15) / 16) * ((ncols + WideGeom::BN - 1) / WideGeom::BN) * WideGeom::B_IMG;
 }
 
@@ -837,6 +1166,15 @@ int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t
     const size_t n = (size_t)((K + 15) / 16) * ((ncols + WideGeom::BN - 1) / WideGeom::BN) * WideGeom::BN * 2;
     if (n == 0) return DR_OK;
     // (the 16-byte row pads and the tail of each tile image are copied to LDS but never read as operands)
+    if (gemm_f16x2()) {
+        // image, then the ncols column factors 2^-s_c (the three-plane size that gemm_packed_weight_bytes reports has room)
+        float* cinv = reinterpret_cast<float*>((char*)out + (size_t)((K + 15) / 16) * ((ncols + WideGeom2::BN - 1) / WideGeom2::BN) * WideGeom2::B_IMG);
+        hipLaunchKernelGGL(wcol_scale_kernel, dim3((ncols + 3) / 4), dim3(256), 0, st, W, ncols, K, cinv);
+        DR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, (char*)out, ncols, K, cinv);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, (char*)out, ncols, K);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -886,6 +1224,27 @@ static int launch_wide(const GemmBatch& g, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
     hipLaunchKernelGGL((gemm_nt_wide_kernel<ABL>), dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+static int launch_wide2(const GemmBatch& g, hipStream_t st) {
+    using GG = WideGeom2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM));
+        attr_done = true;
+    }
+    int maxt = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = ((g.p[i].rows + GG::BM - 1) / GG::BM + 7) / 8 * 8 * ((g.p[i].ncols + GG::BN - 1) / GG::BN);
+        maxt = tl > maxt ? tl : maxt;
+    }
+    if (maxt == 0) return DR_OK;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
+    ProfScope ps(PK_GEMM_SPLIT, flops, st);
+    hipLaunchKernelGGL(gemm_nt_wide2_kernel, dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -1056,6 +1415,13 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     // streams, its 160 KB of LDS keeps the other stream's kernels off the CU and the 4-wave form wins by 2 %
     // (bench.py, DR_GEMM_WIDE8_MAX sweep) -- so it is opt-in.
     static const int wide8_max = [] { const char* e = getenv("DR_GEMM_WIDE8_MAX"); return e ? atoi(e) : 0; }();
+    // (weights packed in the two-plane fp16 mode can only be read by the two-plane kernel: whatever the tile count)
+    // (and only deep reductions: below K = 128 the 2^-22 representation error is not hidden by the accumulation's own
+    //  rounding -- those launches stay on the f32-input MFMA kernels, which read the fp32 weights)
+    bool deep = true;
+    for (int i = 0; i < g.n; ++i) deep = deep && g.p[i].K >= 128;
+    if (wide && deep && gemm_f16x2() && g_force_cfg < 0 && nW >= wide_min) return launch_wide2(g, st);
+    if (gemm_f16x2() && g_force_cfg < 0) wide = false;
     if (wide && nW >= wide_min && g_force_cfg < 0) return nW <= wide8_max ? launch_wide8<2>(g, st) : launch_wide<0>(g, st);
     // latency form: few tiles (the whole launch is one short wave of workgroups) and a k range that fits the registers
     int maxK = 0;
@@ -1073,6 +1439,12 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     if (g_force_cfg >= 0) cfg = g_force_cfg;
     for (int i = 0; i < g.n; ++i)
         if (g.p[i].nbatch > 1 && cfg >= 20) return DR_ENOSUP;   // strided batches: f32-MFMA kernels only
+    if (cfg >= 50 && cfg < 80 && (cfg >= 70 || gemm_f16x2())) {   // 70: the two-plane fp16 kernel; in that packing mode
+        for (int i = 0; i < g.n; ++i)                              // every packed configuration means it (the image is its)
+            if (!wide_ok(g.p[i])) return DR_ENOSUP;
+        if (!gemm_f16x2()) return DR_EINVAL;                       // (weights packed in the three-plane mode)
+        return launch_wide2(g, st);
+    }
     if (cfg >= 50 && cfg < 60) {
         for (int i = 0; i < g.n; ++i)
             if (!wide_ok(g.p[i])) return DR_ENOSUP;

@@ -41,6 +41,11 @@ struct GemmProblem {
     // strided batch (f32-MFMA kernels only): instance z = blockIdx.z uses A + z sA, W + z sW, out + z sO (floats)
     int nbatch;         // 0 or 1 = a single instance
     long long sA, sW, sO;
+    // two-plane fp16 kernel only (ignored elsewhere): max |A[r][:]| per row as `amax_parts` partial maxima
+    // amax[p * amax_stride + r] (nullptr: the kernel sweeps its rows itself), likewise for A2 (one part), and where to put
+    // the maxima of the OUTPUT rows: omax[tile_n * omax_stride + r], one part per 224-column tile (nullptr: not wanted)
+    const float* amax; const float* amax2; float* omax;
+    int amax_parts; long long amax_stride, omax_stride;
 };
 
 struct GemmBatch {
@@ -55,6 +60,7 @@ int gemm_wide_min_tiles();   // launches with fewer 128 x 224 tiles stay on the 
 int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t st);
 int gemm_configure();
 void gemm_force_config(int c);
+void gemm_force_f16x2(int on);   // experimental two-plane fp16 split (set before the weights are packed); -1 = environment
 int read_gemm_stamps(long long* h_out256);
 
 // ---------------------------------------------------------------------------------------------
@@ -85,8 +91,10 @@ void attention_force_split(int on);
 // row-wise ops
 // ---------------------------------------------------------------------------------------------
 // out[r] = (res ? res[r] : 0) + LayerNorm(x[r]) * g + b      (eps = 1e-5)
+// rowmax (optional): max |out[r][:]| per row, for the consumer GEMM's operand scaling
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
-                     int ldo, int rows, int C, hipStream_t st);
+                     int ldo, int rows, int C, hipStream_t st, float* rowmax = nullptr);
+int launch_rowmax(const float* x, int ldx, int rows, int C, float* rowmax, hipStream_t st);
 // post-LN form: out[r] = LayerNorm(x[r] + res[r]) * g + b   (vision3d AttentionLayer / AttentionOutput)
 int launch_layernorm_postadd(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                              int ldo, int rows, int C, hipStream_t st);

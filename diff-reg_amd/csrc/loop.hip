@@ -27,7 +27,12 @@ struct Carver {
 // buffers of one attention-layer evaluation over `T` token rows
 struct LayerWs {
     float *qkv, *att, *mrg, *msg, *hid, *g2;
+    float *msg_max, *hid_max;   // row maxima of msg [T] and of hid [tiles][T] (operand scaling of the fp16-split GEMM)
+    size_t T;
     static size_t carve(Carver& c, LayerWs& w, size_t T, int C) {
+        w.T = T;
+        w.msg_max = c.take<float>(T);
+        w.hid_max = c.take<float>(T * ((2 * C + 223) / 224));
         w.qkv = c.take<float>(T * 3 * C);
         w.att = c.take<float>(T * C);
         w.mrg = c.take<float>(T * C);
@@ -92,13 +97,18 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
                       const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
                       const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
                       hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr,
-                      const PackedLayer* pk = nullptr) {
+                      const PackedLayer* pk = nullptr, const float* xmax = nullptr, const float* ymax = nullptr,
+                      float* outmax = nullptr) {
+    // xmax / ymax: max |row| of xin / yin (indexed like their rows) when their producer left them; outmax: where to leave
+    // those of `out`.  Only the fp16-split GEMM reads them (a launch without them sweeps its rows itself).
     // kv_cached: K|V of the source rows were projected earlier ([tokens, 2C], rotary applied to K): skip them.
     // kv_store : project ONLY K|V of the source rows into this buffer and return (used to fill the cache).
     const int halfC = C / 2, d = C / H;
     GemmBatch g;
     memset(&g, 0, sizeof(g));
-    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot, const void* Wpk) {
+    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot, const void* Wpk,
+                    const float* inmax) {
+        p.amax = inmax ? inmax + r0 : nullptr; p.amax_parts = 1; p.amax_stride = 0;
         p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.Wsplit = Wpk; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
         p.rows = rows; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.lda2 = 0; p.ldo = 3 * C;
         p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
@@ -106,18 +116,18 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     };
     int rc;
     if (kv_store) {
-        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true, pk ? pk->k : nullptr);
-        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false, pk ? pk->v : nullptr);
+        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true, pk ? pk->k : nullptr, ymax);
+        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false, pk ? pk->v : nullptr, ymax);
         g.p[0].out = kv_store + (size_t)yr0 * 2 * C; g.p[0].ldo = 2 * C;
         g.p[1].out = kv_store + (size_t)yr0 * 2 * C + C; g.p[1].ldo = 2 * C;
         g.n = 2;
         return launch_gemm(g, st);
     }
-    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true, pk ? pk->q : nullptr);
+    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true, pk ? pk->q : nullptr, xmax);
     g.n = 1;
     if (!kv_cached) {
-        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true, pk ? pk->k : nullptr);
-        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false, pk ? pk->v : nullptr);
+        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true, pk ? pk->k : nullptr, ymax);
+        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false, pk ? pk->v : nullptr, ymax);
         g.n = 3;
     }
     rc = launch_gemm(g, st);
@@ -145,13 +155,16 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
-    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st);
+    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st,
+                          ws.msg_max + xr0);
     if (rc) return rc;
     // message = norm2(mlp(cat[x, message]))
     memset(&g, 0, sizeof(g));
     GemmProblem& h = g.p[0];
     h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.Wsplit = pk ? pk->mlp0 : nullptr; h.out = ws.hid + (size_t)xr0 * 2 * C;
     h.rows = xrows; h.ncols = 2 * C; h.K = 2 * C; h.K1 = C; h.lda = C; h.lda2 = C; h.ldo = 2 * C; h.epi = EPI_RELU; h.scale = 1.f;
+    if (xmax) { h.amax = xmax + xr0; h.amax_parts = 1; h.amax2 = ws.msg_max + xr0; }
+    h.omax = ws.hid_max + xr0; h.omax_stride = (long long)ws.T;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
@@ -159,12 +172,15 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     GemmProblem& o = g.p[0];
     o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.Wsplit = pk ? pk->mlp2 : nullptr; o.out = ws.g2 + (size_t)xr0 * C;
     o.rows = xrows; o.ncols = C; o.K = 2 * C; o.K1 = 2 * C; o.lda = 2 * C; o.ldo = C; o.epi = EPI_NONE; o.scale = 1.f;
+    // (hid's maxima exist only when the launch above ran on the fp16-split kernel: same rows, twice the column tiles, so
+    //  whenever THIS launch is one of its kind, that one was too)
+    o.amax = ws.hid_max + xr0; o.amax_parts = (2 * C + 223) / 224; o.amax_stride = (long long)ws.T;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
     // e = x + message
     return launch_layernorm(ws.g2 + (size_t)xr0 * C, C, W.norm2_w, W.norm2_b, xin + (size_t)xr0 * C, C, out + (size_t)xr0 * C, C,
-                            xrows, C, st);
+                            xrows, C, st, outmax ? outmax + xr0 : nullptr);
 }
 
 // workspace of one denoiser + matching-head evaluation
@@ -172,6 +188,7 @@ struct DenoiseWs {
     LayerWs lw;
     float *fa, *fb, *cosT, *sinT, *proj, *sim;
     float *tgt_l0, *kv_l1;      // step-invariant: layer-0 output of the tgt rows, layer-1 K|V of those rows
+    float *m_feat0, *m_fa, *m_fb, *m_tgt_l0;   // row maxima of feat0 / fa / fb / tgt_l0 (fp16-split GEMM operand scaling)
     PackedWeights pw;
     static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C, int n_layers) {
         const size_t T = (size_t)P * (N + M);
@@ -179,6 +196,7 @@ struct DenoiseWs {
         PackedWeights::carve(c, w.pw, n_layers, C, T);
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
+        w.m_feat0 = c.take<float>(T); w.m_fa = c.take<float>(T); w.m_fb = c.take<float>(T); w.m_tgt_l0 = c.take<float>(T);
         w.fa = c.take<float>(T * C);
         w.fb = c.take<float>(T * C);
         w.cosT = c.take<float>(T * (C / 2));
@@ -200,10 +218,10 @@ static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, i
     const Family self_t{PN, M, PN, M};
     const PackedLayer* pk0 = ws.pw.on ? &ws.pw.layer[0] : nullptr;
     int rc = layer_call(w.layers[0], C, H, P, feat0, PN, PM, feat0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                        ws.tgt_l0, st, nullptr, nullptr, pk0);
+                        ws.tgt_l0, st, nullptr, nullptr, pk0, ws.m_feat0, ws.m_feat0, ws.m_tgt_l0);
     if (rc || cfg.n_layers < 2) return rc;
     return layer_call(w.layers[1], C, H, P, nullptr, 0, 0, ws.tgt_l0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                      nullptr, st, nullptr, ws.kv_l1, ws.pw.on ? &ws.pw.layer[1] : nullptr);
+                      nullptr, st, nullptr, ws.kv_l1, ws.pw.on ? &ws.pw.layer[1] : nullptr, nullptr, ws.m_tgt_l0);
 }
 
 static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
@@ -212,34 +230,44 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     const int C = cfg.C, H = cfg.H, T = P * (N + M), PN = P * N, PM = P * M;
     const float* cur = feat0;
     float* bufs[2] = {ws.fa, ws.fb};
+    float* mbufs[2] = {ws.m_fa, ws.m_fb};
+    const float* cmax = ws.m_feat0;
     int which = 0;
     const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
     for (int l = 0; l < cfg.n_layers; ++l) {
         float* nxt = bufs[which];
+        float* nmax = mbufs[which];
         const PackedLayer* pk = ws.pw.on ? &ws.pw.layer[l] : nullptr;
         int rc;
         if (use_cache && l == 0) {
             // src half only; the tgt half comes from the cache
-            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
+            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
+                            cmax, cmax, nmax);
             if (rc) return rc;
             DR_HIP_CHECK(hipMemcpyAsync(nxt + (size_t)PN * C, ws.tgt_l0 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
+            DR_HIP_CHECK(hipMemcpyAsync(nmax + PN, ws.m_tgt_l0 + PN, (size_t)PM * 4, hipMemcpyDeviceToDevice, st));
         } else if (use_cache && l == 1) {
             rc = layer_call(w.layers[1], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st,
-                            ws.kv_l1, nullptr, pk);
+                            ws.kv_l1, nullptr, pk, cmax, cmax, nmax);
             if (rc) return rc;
-            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
+            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
+                            cmax, nmax, nmax);
             if (rc) return rc;
         } else if (l % 2 == 0) {
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st, nullptr, nullptr, pk);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st, nullptr, nullptr, pk,
+                            cmax, cmax, nmax);
             if (rc) return rc;
         } else {
             // src attends tgt, then tgt attends the UPDATED src (quirk Q11)
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
+                            cmax, cmax, nmax);
             if (rc) return rc;
-            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk);
+            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
+                            cmax, nmax, nmax);
             if (rc) return rc;
         }
         cur = nxt;
+        cmax = nmax;
         which ^= 1;
     }
     *final_feats = cur;
@@ -248,6 +276,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     memset(&g, 0, sizeof(g));
     GemmProblem& p = g.p[0];
     p.A = cur; p.W = w.src_proj; p.Wsplit = ws.pw.on ? ws.pw.src_proj : nullptr; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
+    p.amax = cmax; p.amax_parts = 1;
     p.epi = EPI_ROTARY; p.rot_C = C; p.cosT = ws.cosT; p.sinT = ws.sinT; p.scale = 1.0f / sqrtf((float)C);
     g.n = 1;
     int rc = launch_gemm(g, st);
@@ -330,6 +359,7 @@ int dr_init(void) {
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
 void dr_debug_gemm_wide_min(int tiles) { gemm_force_wide_min(tiles); }
+void dr_debug_gemm_f16x2(int on) { gemm_force_f16x2(on); }
 void dr_debug_attention_config(int flash_min_workgroups) { attention_force_flash_min(flash_min_workgroups); }
 void dr_debug_attention_split(int on) { attention_force_split(on); }
 int dr_debug_gemm_stamps(long long* h_out256) { return read_gemm_stamps(h_out256); }
@@ -491,6 +521,7 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
     const size_t PN = (size_t)P * N, PM = (size_t)P * M;
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
+    { const int rcm = launch_rowmax(L.feat0, C, (int)(PN + PM), C, L.dw.m_feat0, st); if (rcm) return rcm; }
     if (src_mask) {
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
@@ -538,6 +569,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
 
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
+    { const int rcm = launch_rowmax(L.feat0, C, (int)(PN + PM), C, L.dw.m_feat0, st); if (rcm) return rcm; }
     if (src_mask) {
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));

@@ -12,11 +12,13 @@ constexpr int LN_MAX_PER_LANE = 16;   // C <= 64 * 16
 template <bool POSTADD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                         const float* __restrict__ b, const float* __restrict__ res,
-                                                        int ldres, float* __restrict__ out, int ldo, int rows, int C) {
+                                                        int ldres, float* __restrict__ out, int ldo, int rows, int C,
+                                                        float* __restrict__ rowmax) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* xr = x + (size_t)row * ldx;
+    float ymax = 0.f;
     float v[LN_MAX_PER_LANE];
     float s = 0.f;
 #pragma unroll
@@ -42,8 +44,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float y = (v[i] - mean) * rstd * g[c] + b[c];
             if (!POSTADD && res) y += res[(size_t)row * ldres + c];
             out[(size_t)row * ldo + c] = y;
+            ymax = fmaxf(ymax, fabsf(y));
         }
     }
+    if (rowmax) { ymax = wave_max(ymax); if (lane == 0) rowmax[row] = ymax; }
 }
 
 // float4 form for C % 4 == 0 with 16-byte aligned rows (every layer of the loop: C = 432 / 528 / 256): a row is C / 4 float4s,
@@ -51,10 +55,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <bool POSTADD, int NV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                             const float* __restrict__ b, const float* __restrict__ res,
-                                                            int ldres, float* __restrict__ out, int ldo, int rows, int C) {
+                                                            int ldres, float* __restrict__ out, int ldo, int rows, int C,
+                                                            float* __restrict__ rowmax) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, C4 = C >> 2;
+    float ymax = 0.f;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (size_t)row * ldres) : nullptr;
     float4 v[NV];
@@ -86,30 +92,49 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
             y.z = (v[i].z - mean) * rstd * gg.z + bb.z; y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
             if (!POSTADD && rr) { const float4 r = rr[c]; y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
             reinterpret_cast<float4*>(out + (size_t)row * ldo)[c] = y;
+            ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))));
         }
     }
+    if (rowmax) { ymax = wave_max(ymax); if (lane == 0) rowmax[row] = ymax; }
+}
+
+// max |x[r][:]| per row (the external features entering the first layer)
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int ldx, int rows, int C, float* __restrict__ rowmax) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, fabsf(x[(size_t)row * ldx + c]));
+    m = wave_max(m);
+    if (lane == 0) rowmax[row] = m;
+}
+int launch_rowmax(const float* x, int ldx, int rows, int C, float* rowmax, hipStream_t st) {
+    if (rows <= 0) return DR_OK;
+    hipLaunchKernelGGL(rowmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, rows, C, rowmax);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
 }
 
 template <bool POSTADD>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
-                                 int ldo, int rows, int C, hipStream_t st) {
+                                 int ldo, int rows, int C, hipStream_t st, float* rowmax) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if ((C & 3) || (ldx & 3) || (ldo & 3) || (res && (ldres & 3)) || !al(x) || !al(out) || !al(g) || !al(b) || (res && !al(res)) || C > 768)
         return false;
     const dim3 grid((rows + 3) / 4), blk(256);
-    if (C <= 256) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 1>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
-    else if (C <= 512) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 2>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
-    else hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 3>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 1>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C, rowmax);
+    else if (C <= 512) hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 2>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C, rowmax);
+    else hipLaunchKernelGGL((layernorm_vec_kernel<POSTADD, 3>), grid, blk, 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C, rowmax);
     return true;
 }
 
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
-                     int ldo, int rows, int C, hipStream_t st) {
+                     int ldo, int rows, int C, hipStream_t st, float* rowmax) {
     if (C > 64 * LN_MAX_PER_LANE) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
     ProfScope ps(PK_LN, (double)rows * C * (res ? 12.0 : 8.0), st);
-    if (launch_layernorm_vec<false>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st)) { DR_LAUNCH_CHECK(); return DR_OK; }
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    if (launch_layernorm_vec<false>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st, rowmax)) { DR_LAUNCH_CHECK(); return DR_OK; }
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C, rowmax);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -119,8 +144,8 @@ int launch_layernorm_postadd(const float* x, int ldx, const float* g, const floa
     if (C > 64 * LN_MAX_PER_LANE || !res) return DR_ENOSUP;
     if (rows <= 0) return DR_OK;
     ProfScope ps(PK_LN, (double)rows * C * 12.0, st);
-    if (launch_layernorm_vec<true>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st)) { DR_LAUNCH_CHECK(); return DR_OK; }
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C);
+    if (launch_layernorm_vec<true>(x, ldx, g, b, res, ldres, out, ldo, rows, C, st, nullptr)) { DR_LAUNCH_CHECK(); return DR_OK; }
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, g, b, res, ldres, out, ldo, rows, C, (float*)nullptr);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

@@ -196,6 +196,10 @@ void dr_debug_gemm_wide_min(int tiles);
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
 int dr_debug_gemm_stamps(long long* h_out256);
+/* packed GEMMs: 1 = two-plane fp16 operand split with exact power-of-two row / column scaling (three MFMA products per
+ * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = environment DR_GEMM_F16X2 (default 1).
+ * Set before weights are packed: an image is only readable in the mode it was packed in. */
+void dr_debug_gemm_f16x2(int on);
 /* attention: use the 128-query (flash) kernel from this many workgroups on; -1 = default rule (256) */
 void dr_debug_attention_config(int flash_min_workgroups);
 /* flash attention arithmetic: 1 = split-operand bf16 MFMA products (default), 0 = f32-input MFMA, -1 = default */

@@ -84,17 +84,20 @@ def assert_matrix_parity(got, ref, f64, what):
     assert e_hip.max() <= max(1e-4, 2.0 * e_ref.max()), (what, e_hip.max(), e_ref.max())
 
 
-@pytest.fixture
-def batch_kernels():
-    """Force the kernels that large batches select -- packed split-operand GEMMs for every layer GEMM, the 128-query
-    (split-operand) attention -- onto the small golden cases, so that the whole loop is held to the reference with them."""
+@pytest.fixture(params=[1, 0], ids=["fp16x2", "bf16x3"])
+def batch_kernels(request):
+    """Force the kernels that large batches select -- packed split-operand GEMMs for every layer GEMM (both operand splits:
+    the default two-plane fp16 one and the three-plane bf16 one), the 128-query (split-operand) attention -- onto the small
+    golden cases, so that the whole loop is held to the reference with them."""
     from diffreg_hip import lib
     lib.ensure_init()
+    lib.raw().dr_debug_gemm_f16x2(request.param)
     lib.raw().dr_debug_gemm_wide_min(1)
     lib.raw().dr_debug_attention_config(1)
     yield
     lib.raw().dr_debug_gemm_wide_min(-1)
     lib.raw().dr_debug_attention_config(-1)
+    lib.raw().dr_debug_gemm_f16x2(-1)
 
 
 @pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", LOOPS)
