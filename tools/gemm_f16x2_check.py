@@ -1,5 +1,5 @@
-"""The experimental two-plane fp16 split GEMM (DR_GEMM_F16X2) beside the shipped three-plane bf16 split: error against
-float64 and time per launch at the loop's shapes."""
+"""The two-plane fp16 split GEMM (default) beside the three-plane bf16 split (DR_GEMM_F16X2=0): error against float64 and time
+per launch at the loop's shapes (stand-alone op: the fp16 kernel sweeps its rows for their maxima itself here)."""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
 import torch
@@ -45,7 +45,9 @@ for name, sx, sw in (("rows and columns x 10^[-3,3]", 10.0 ** (torch.rand(rows, 
     for mode in (0, 1):
         lib.raw().dr_debug_gemm_f16x2(mode)
         Wp = lib.pack_weight(W)
+        lib.raw().dr_debug_gemm_config(70 if mode else 50)     # 2048 rows are below the automatic threshold of the packed kernels
         y = lib.linear_packed(x, W, Wp)
+        lib.raw().dr_debug_gemm_config(-1)
         row["f16x2" if mode else "bf16x3"] = float(((y.double() - ref).abs() / scale).max())
     row["torch_fp32_matmul"] = float((((x @ W.T).double() - ref).abs() / scale).max())
     res[name] = row
