@@ -115,6 +115,32 @@ def test_gemm_split_dynamic_range(cfg, case):
     assert e_split < 1e-5 and e_split <= 2.0 * e_base, (e_split, e_base)
 
 
+def test_gemm_f16_split_degenerate_rows():
+    """rows / columns without a usable maximum get scale 1: all-zero rows of x and of W give exact zeros, a row holding inf or
+    nan gives non-finite outputs in that row only (as an fp32 GEMM would), everything else is unaffected"""
+    from diffreg_hip import lib
+    raw = lib.raw()
+    rows, ncols, K = 1024, 432, 432
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, K, generator=g)
+    W = torch.randn(ncols, K, generator=g) / K ** 0.5
+    x[5] = 0.0; x[17, 3] = float("inf"); x[40, 100] = float("nan"); W[7] = 0.0
+    x, W = x.to(DEV), W.to(DEV)
+    raw.dr_debug_gemm_f16x2(1)
+    try:
+        Wp = lib.pack_weight(W)
+        raw.dr_debug_gemm_config(70)
+        y = lib.linear_packed(x, W, Wp)
+    finally:
+        raw.dr_debug_gemm_config(-1)
+        raw.dr_debug_gemm_f16x2(-1)
+    assert (y[5] == 0).all() and (y[:, 7][torch.isfinite(y[:, 7])] == 0).all()
+    assert not torch.isfinite(y[17]).any() and not torch.isfinite(y[40]).any()
+    ok = torch.ones(rows, dtype=torch.bool, device=DEV); ok[[17, 40]] = False
+    ref = x[ok].double() @ W.double().T
+    assert torch.isfinite(y[ok]).all() and (y[ok].double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
 def test_vol_pe_and_rotary_linear(variant, golden):
     from diffreg_hip import lib
