@@ -206,3 +206,188 @@ template int launch_top1_union<float>(const float*, int, int, int, long long*, i
 template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
 
 }  // namespace dr
+
+// ---------------------------------------------------------------------------------------------
+// batch_mutual_topk_select (Diff-Reg-2d3d/vision3d/ops/mutual_topk_select.py:63-134): per batch element the entries that are
+// among the k best of their row and / or of their column (mutual: and / or), beyond a threshold, inside the row / column
+// masks; returned like torch.nonzero: (b, i, j) in row-major order with their scores.  Used by the fine matching behind the
+// 2D-3D loop (EXP/model.py:744-752: k = 2, threshold 0.75) on the patch-to-patch similarity of every node correspondence.
+// Equal scores: the lower index wins a place among the k best (torch.topk leaves ties unspecified).
+// Three kernels: selection bits + per-batch counts (one workgroup per batch element), scan of the counts, ordered write.
+// ---------------------------------------------------------------------------------------------
+namespace dr {
+
+constexpr int MT_MAX_K = 8;
+
+struct MtArgs {
+    const float* score; const uint8_t* rmask; const uint8_t* cmask; int B, N, M, k, largest, mutual, use_thr; float thr;
+    unsigned* bits; int words; int* counts; long long* out_idx; float* out_score; int* total; long long capacity;
+};
+
+__device__ __forceinline__ bool mt_before(float v, int i, float pv, int pi, bool largest) {   // (v, i) ranks before (pv, pi)
+    return largest ? (v > pv || (v == pv && i < pi)) : (v < pv || (v == pv && i < pi));
+}
+
+__global__ __launch_bounds__(256) void mt_select_kernel(MtArgs A) {
+    extern __shared__ unsigned mt_bits[];                 // row-side bits, then column-side bits (A.words each)
+    unsigned* rb = mt_bits; unsigned* cb = mt_bits + A.words;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float* S = A.score + (size_t)b * A.N * A.M;
+    const bool largest = A.largest != 0;
+    for (int i = t; i < 2 * A.words; i += 256) mt_bits[i] = 0u;
+    __syncthreads();
+    // rows: one wave per row, k rounds of "best entry after the previous pick"
+    for (int i = w; i < A.N; i += 4) {
+        float pv = 0.f; int pj = -1;
+        for (int r = 0; r < A.k && r < A.M; ++r) {
+            float bv = 0.f; int bj = 0x7fffffff;
+            for (int j = lane; j < A.M; j += 64) {
+                const float v = S[(size_t)i * A.M + j];
+                if (v != v) continue;                                     // (NaN never selected)
+                if (pj >= 0 && !mt_before(pv, pj, v, j, largest)) continue;   // already picked or ranks before the last pick
+                if (bj == 0x7fffffff || mt_before(v, j, bv, bj, largest)) { bv = v; bj = j; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float ov = __shfl_xor(bv, m); const int oj = __shfl_xor(bj, m);
+                if (oj != 0x7fffffff && (bj == 0x7fffffff || mt_before(ov, oj, bv, bj, largest))) { bv = ov; bj = oj; }
+            }
+            if (bj == 0x7fffffff) break;
+            if (lane == 0) { const int e = i * A.M + bj; atomicOr(&rb[e >> 5], 1u << (e & 31)); }
+            pv = bv; pj = bj;
+        }
+    }
+    // columns: one thread per column
+    for (int j = t; j < A.M; j += 256) {
+        float pv = 0.f; int pi = -1;
+        for (int r = 0; r < A.k && r < A.N; ++r) {
+            float bv = 0.f; int bi = 0x7fffffff;
+            for (int i = 0; i < A.N; ++i) {
+                const float v = S[(size_t)i * A.M + j];
+                if (v != v) continue;
+                if (pi >= 0 && !mt_before(pv, pi, v, i, largest)) continue;
+                if (bi == 0x7fffffff || mt_before(v, i, bv, bi, largest)) { bv = v; bi = i; }
+            }
+            if (bi == 0x7fffffff) break;
+            const int e = bi * A.M + j; atomicOr(&cb[e >> 5], 1u << (e & 31));
+            pv = bv; pi = bi;
+        }
+    }
+    __syncthreads();
+    // combine, threshold, masks -> global bits, count
+    int cnt = 0;
+    for (int wd = t; wd < A.words; wd += 256) {
+        unsigned m = A.mutual ? (rb[wd] & cb[wd]) : (rb[wd] | cb[wd]);
+        unsigned keep = 0u;
+        while (m) {
+            const int bit = __ffs(m) - 1; m &= m - 1;
+            const int e = wd * 32 + bit, i = e / A.M, j = e % A.M;
+            const float v = S[e];
+            bool ok = !A.use_thr || (largest ? v > A.thr : v < A.thr);
+            if (A.rmask && !A.rmask[(size_t)b * A.N + i]) ok = false;
+            if (A.cmask && !A.cmask[(size_t)b * A.M + j]) ok = false;
+            if (ok) keep |= 1u << bit;
+        }
+        A.bits[(size_t)b * A.words + wd] = keep;
+        cnt += __popc(keep);
+    }
+    __shared__ int s_cnt[4];
+    cnt = wave_sum(cnt);
+    if (lane == 0) s_cnt[w] = cnt;
+    __syncthreads();
+    if (t == 0) A.counts[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void mt_scan_kernel(int* counts, int B, int* total) {   // counts -> exclusive offsets
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < B ? counts[i] : 0;
+        int inc = v;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(inc, m); if (lane >= m) inc += o; }
+        __shared__ int s_w[4];
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int off = s_carry;
+        for (int k = 0; k < w; ++k) off += s_w[k];
+        if (i < B) counts[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(256) void mt_write_kernel(MtArgs A) {
+    __shared__ int s_w[4];
+    __shared__ int s_carry;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float* S = A.score + (size_t)b * A.N * A.M;
+    if (t == 0) s_carry = A.counts[b];                   // (exclusive offset of this batch element)
+    __syncthreads();
+    for (int w0 = 0; w0 < A.words; w0 += 256) {
+        const int wd = w0 + t;
+        unsigned m = wd < A.words ? A.bits[(size_t)b * A.words + wd] : 0u;
+        const int c = __popc(m);
+        int inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int off = s_carry;
+        for (int k = 0; k < w; ++k) off += s_w[k];
+        long long pos = off + inc - c;
+        while (m) {
+            const int bit = __ffs(m) - 1; m &= m - 1;
+            const int e = wd * 32 + bit;
+            if (pos < A.capacity) {
+                A.out_idx[pos * 3] = b; A.out_idx[pos * 3 + 1] = e / A.M; A.out_idx[pos * 3 + 2] = e % A.M;
+                A.out_score[pos] = S[e];
+            }
+            ++pos;
+        }
+        __syncthreads();
+        if (t == 255) s_carry = off + inc;
+        __syncthreads();
+    }
+}
+
+}  // namespace dr
+
+extern "C" {
+
+size_t dr_mutual_topk_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    const size_t words = ((size_t)N * M + 31) / 32;
+    return (size_t)B * words * 4 + (size_t)B * 4 + 256;
+}
+
+int dr_mutual_topk_select_f32(int B, int N, int M, const float* score, int k, int largest, int use_threshold, float threshold,
+                              int mutual, const uint8_t* row_masks, const uint8_t* col_masks, int64_t* out_idx, float* out_score,
+                              long long capacity, int32_t* total, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace dr;
+    if (B < 0 || N <= 0 || M <= 0 || k < 1 || k > MT_MAX_K || capacity < 0 || !total) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DR_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int32_t), st));
+    if (B == 0) return DR_OK;
+    if (!score || (capacity > 0 && (!out_idx || !out_score))) return DR_EINVAL;
+    const size_t words = ((size_t)N * M + 31) / 32;
+    if (words * 8 > 64 * 1024) return DR_ENOSUP;                       // both bit planes of one element live in LDS
+    if (!workspace || workspace_bytes < dr_mutual_topk_workspace_bytes(B, N, M)) return DR_EWORKSPACE;
+    MtArgs A{};
+    A.score = score; A.rmask = row_masks; A.cmask = col_masks; A.B = B; A.N = N; A.M = M; A.k = k; A.largest = largest; A.mutual = mutual;
+    A.use_thr = use_threshold; A.thr = threshold; A.bits = (unsigned*)workspace; A.words = (int)words;
+    A.counts = (int*)((char*)workspace + (size_t)B * words * 4); A.out_idx = (long long*)out_idx; A.out_score = out_score; A.total = total;
+    A.capacity = capacity;
+    hipLaunchKernelGGL(mt_select_kernel, dim3(B), dim3(256), words * 8, st, A);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(256), 0, st, A.counts, B, total);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mt_write_kernel, dim3(B), dim3(256), 0, st, A);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}

@@ -122,6 +122,9 @@ SIGNATURES.update({
     "dr_grid_subsample_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "dr_radius_neighbors_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_radius_neighbors_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 4 + [c_float, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "dr_mutual_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_mutual_topk_select_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int] + [c_void_p] * 4 +
+                                  [ctypes.c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dr_denoiser_match_f32": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 9 +
                               [c_void_p, c_size_t, c_void_p]),
 })
@@ -506,6 +509,31 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit):
     check(_lib.dr_radius_neighbors_f32(nq, ns, nb, ptr(queries), ptr(supports), ptr(ql), ptr(sl), float(radius), int(limit), ptr(out),
                                        ptr(mc), ptr(status), ptr(ws), wsb, stream_of(queries)))
     return out, mc, status
+
+
+def batch_mutual_topk_select(score_mat, k, row_masks=None, col_masks=None, largest=True, threshold=None, mutual=True):
+    """-> (batch_indices, row_indices, col_indices, scores) like vision3d.ops.batch_mutual_topk_select(..., reduce_result=True)
+    (Diff-Reg-2d3d/vision3d/ops/mutual_topk_select.py:63-134); a 2-D score_mat is one batch element (mutual_topk_select :7-60,
+    returns (row_indices, col_indices, scores)).  One host sync for the number of correspondences."""
+    two_d = score_mat.dim() == 2
+    s = (score_mat[None] if two_d else score_mat).to(torch.float32).contiguous()
+    B, N, M = s.shape
+    dev = s.device
+    cap = B * (min(N, M) if mutual else (N + M)) * k
+    idx = torch.empty(max(cap, 1), 3, dtype=torch.int64, device=dev)
+    sc = torch.empty(max(cap, 1), device=dev)
+    tot = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = _lib.dr_mutual_topk_workspace_bytes(B, N, M)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(_lib.dr_mutual_topk_select_f32(B, N, M, ptr(s), int(k), 1 if largest else 0, 0 if threshold is None else 1,
+                                         0.0 if threshold is None else float(threshold), 1 if mutual else 0, ptr(mask_u8(row_masks)),
+                                         ptr(mask_u8(col_masks)), ptr(idx), ptr(sc), cap, ptr(tot), ptr(ws), wsb, stream_of(s)))
+    n = int(tot.item())
+    assert n <= cap
+    idx, sc = idx[:n], sc[:n]
+    if two_d:
+        return idx[:, 1], idx[:, 2], sc
+    return idx[:, 0], idx[:, 1], idx[:, 2], sc
 
 
 PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state", "gemm_split")

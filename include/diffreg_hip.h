@@ -357,6 +357,16 @@ int dr_radius_neighbors_f32(int nq, int ns, int nb, const float* queries, const 
                             const int32_t* s_lengths, float radius, int limit, int64_t* out, int32_t* max_count, int32_t* status,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* batch_mutual_topk_select / mutual_topk_select (Diff-Reg-2d3d/vision3d/ops/mutual_topk_select.py:7-134; the fine matching
+ * behind the 2D-3D loop, EXP/model.py:744-752: k = 2, threshold 0.75, mutual): per batch element the entries among the k best of
+ * their row and (mutual) / or of their column, beyond `threshold` when use_threshold (> for largest, < otherwise), inside
+ * row_masks [B,N] / col_masks [B,M] (NULL = all).  out_idx int64 [capacity,3] rows (b, i, j) in torch.nonzero order, out_score
+ * [capacity]; total[0] = number selected (entries beyond capacity are counted, not written).  k <= 8, N*M <= 262144. */
+size_t dr_mutual_topk_workspace_bytes(int B, int N, int M);
+int dr_mutual_topk_select_f32(int B, int N, int M, const float* score, int k, int largest, int use_threshold, float threshold,
+                              int mutual, const uint8_t* row_masks, const uint8_t* col_masks, int64_t* out_idx, float* out_score,
+                              long long capacity, int32_t* total, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
  * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)

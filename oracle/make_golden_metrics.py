@@ -76,6 +76,20 @@ def main():
         out[tag + "rr_err"] = np.array(errs)
         out[tag + "rr_ok"] = np.array(oks)
         print(tag, "ir3d %.4f ir4d %.4f nrfmr %.4f rr %s" % (out[tag + "ir3d"][0], out[tag + "ir4d"][0], out[tag + "nrfmr"], oks))
+    # batch_mutual_topk_select of the 2D-3D tree (vision3d/ops/mutual_topk_select.py), loaded from the file where it lies
+    import importlib.util
+    torch.Tensor.cuda = lambda self, *a, **k: self            # the function hard-codes .cuda()
+    spec = importlib.util.spec_from_file_location("ref_mts", "/root/reference/Diff-Reg-2d3d/vision3d/ops/mutual_topk_select.py")
+    mts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mts)
+    from tests.helpers import topk_case
+    for name in ("patch64_k2_thr", "ragged_k3_or", "smallest_k1", "masked_k2"):
+        c = topk_case(name)
+        b, i, j, s = mts.batch_mutual_topk_select(c["score"], c["k"], row_masks=c["row_masks"], col_masks=c["col_masks"],
+                                                  largest=c["largest"], threshold=c["threshold"], mutual=c["mutual"])
+        out["mts_" + name + "_idx"] = torch.stack([b, i, j], 1).numpy()
+        out["mts_" + name + "_score"] = s.numpy()
+        print("mutual_topk", name, len(b))
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

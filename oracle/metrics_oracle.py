@@ -169,3 +169,25 @@ def registration_recall(R_est, t_est, rot_gt, trn_gt, infos, thr=0.2):
         errs.append(transformation_err(np.linalg.inv(gt) @ pr, np.asarray(infos[k])))
     errs = np.array(errs)
     return float((errs <= thr ** 2).sum()) / len(errs), errs
+
+
+# ------------------------------------------------------------------------------------------
+# batch_mutual_topk_select  (Diff-Reg-2d3d/vision3d/ops/mutual_topk_select.py:63-134; the fine matching behind the 2D-3D loop,
+# EXP/model.py:744-752).  Pinned by oracle/make_golden_metrics.py (the reference function run on hash-generated scores).
+# ------------------------------------------------------------------------------------------
+def batch_mutual_topk_select(score_mat, k, row_masks=None, col_masks=None, largest=True, threshold=None, mutual=True):
+    """score_mat [B,N,M] -> (batch_indices, row_indices, col_indices, scores), torch.nonzero order"""
+    B, N, M = score_mat.shape
+    rows = torch.zeros_like(score_mat, dtype=torch.bool)
+    rows.scatter_(2, score_mat.topk(k=k, largest=largest, dim=2)[1], True)
+    cols = torch.zeros_like(score_mat, dtype=torch.bool)
+    cols.scatter_(1, score_mat.topk(k=k, largest=largest, dim=1)[1], True)
+    corr = (rows & cols) if mutual else (rows | cols)
+    if threshold is not None:
+        corr = corr & (score_mat > threshold if largest else score_mat < threshold)
+    if row_masks is not None:
+        corr = corr & row_masks[:, :, None]
+    if col_masks is not None:
+        corr = corr & col_masks[:, None, :]
+    b, i, j = torch.nonzero(corr, as_tuple=True)
+    return b, i, j, score_mat[b, i, j]

@@ -54,3 +54,25 @@ def metrics_scene(N, M, seed, inlier_frac=0.5, n_extra=100):
                 matches=T(synth.make_matches(p, seed, inlier_frac, n_extra)), raw_pcd=T(mp["raw_pcd"]), raw_flow=T(mp["raw_flow"]),
                 metric_index=T(mp["metric_index"]), coarse_flow=T(mp["coarse_flow"]), info=synth.make_info(seed), est=est,
                 pair=p)
+
+
+def topk_case(name):
+    """score matrices of the fine-matching kind (cosine similarities of patch features: distinct values in [-1, 1]) for
+    batch_mutual_topk_select; the golden vectors of oracle/make_golden_metrics.py are minted on exactly these"""
+    spec = {"patch64_k2_thr": dict(B=40, N=64, M=64, k=2, largest=True, threshold=0.75, mutual=True, masked=False),      # EXP/model.py:744-752
+            "ragged_k3_or": dict(B=7, N=50, M=37, k=3, largest=True, threshold=None, mutual=False, masked=False),
+            "smallest_k1": dict(B=5, N=128, M=96, k=1, largest=False, threshold=0.1, mutual=True, masked=False),
+            "masked_k2": dict(B=12, N=64, M=48, k=2, largest=True, threshold=0.3, mutual=True, masked=True)}[name]
+    B, N, M = spec["B"], spec["N"], spec["M"]
+    seed = sum(map(ord, name))
+    f = synth.hash_normal(seed, 1, (B, N, 16)); g = synth.hash_normal(seed, 2, (B, M, 16))
+    g[:, :min(N, M)] = f[:, :min(N, M)] + 0.35 * g[:, :min(N, M)]          # correlated pairs: similarities close to 1 on a diagonal
+    f /= np.linalg.norm(f, axis=2, keepdims=True); g /= np.linalg.norm(g, axis=2, keepdims=True)
+    score = T(np.einsum("bnd,bmd->bnm", f, g).astype(np.float32))
+    if not spec["largest"]:
+        score = (1.0 - score) * 0.5
+    rm = cm = None
+    if spec["masked"]:
+        rm = T(synth.hash_u01(seed, 3, B * N).reshape(B, N) > 0.2)
+        cm = T(synth.hash_u01(seed, 4, B * M).reshape(B, M) > 0.2)
+    return dict(score=score, k=spec["k"], largest=spec["largest"], threshold=spec["threshold"], mutual=spec["mutual"], row_masks=rm, col_masks=cm)

@@ -192,3 +192,22 @@ def test_tester_style_api_end_to_end():
     ev = evaluate_pairs(seg, cnt, data["s_pcd"], data["t_pcd"], data["batched_rot"], data["batched_trn"],
                         torch.from_numpy(sc["info"])[None].cuda(), ransac_iters=5000)
     assert float(ev["fmr"]) == 1.0 and int(ev["rr_ok"]) == 1 and torch.equal(ev["rot"], rot)
+
+
+@pytest.mark.parametrize("name", ["patch64_k2_thr", "ragged_k3_or", "smallest_k1", "masked_k2"])
+def test_mutual_topk_select_vs_reference_vectors(golden, name):
+    """dr_mutual_topk_select_f32 against the reference's batch_mutual_topk_select (indices in torch.nonzero order, bit-exact)"""
+    from diffreg_hip import lib
+    from tests.helpers import topk_case
+    g = golden("metrics_ref")
+    c = topk_case(name)
+    dv = lambda x: None if x is None else x.cuda()
+    b, i, j, s = lib.batch_mutual_topk_select(c["score"].cuda(), c["k"], dv(c["row_masks"]), dv(c["col_masks"]), c["largest"], c["threshold"],
+                                              c["mutual"])
+    assert np.array_equal(torch.stack([b, i, j], 1).cpu().numpy(), g["mts_" + name + "_idx"])
+    assert np.array_equal(s.cpu().numpy(), g["mts_" + name + "_score"])
+    # the unbatched form (mutual_topk_select, vision3d/ops/mutual_topk_select.py:7-60) = one batch element
+    i1, j1, s1 = lib.batch_mutual_topk_select(c["score"][0].cuda(), c["k"], None if c["row_masks"] is None else None, None, c["largest"],
+                                              c["threshold"], c["mutual"])
+    want = mo.batch_mutual_topk_select(c["score"][:1], c["k"], None, None, c["largest"], c["threshold"], c["mutual"])
+    assert torch.equal(i1.cpu(), want[1]) and torch.equal(j1.cpu(), want[2]) and torch.equal(s1.cpu(), want[3])

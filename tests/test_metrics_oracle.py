@@ -99,3 +99,13 @@ def test_segment_matches_layout():
     seg, cnt = segment_matches(m, 3)
     assert cnt.tolist() == [2, 0, 3] and seg.shape == (3, 5, 3)
     assert torch.equal(seg[0, :2], m[:2]) and torch.equal(seg[2, :3], m[2:])
+
+
+@pytest.mark.parametrize("name", ["patch64_k2_thr", "ragged_k3_or", "smallest_k1", "masked_k2"])
+def test_mutual_topk_oracle_vs_reference_vectors(golden, name):
+    from tests.helpers import topk_case
+    g = golden("metrics_ref")
+    c = topk_case(name)
+    b, i, j, s = mo.batch_mutual_topk_select(c["score"], c["k"], c["row_masks"], c["col_masks"], c["largest"], c["threshold"], c["mutual"])
+    assert np.array_equal(torch.stack([b, i, j], 1).numpy(), g["mts_" + name + "_idx"])
+    assert np.array_equal(s.numpy(), g["mts_" + name + "_score"]) and len(b) > 0
