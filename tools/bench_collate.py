@@ -16,8 +16,10 @@ def cloud(n, seed):
     # a folded sheet in a 4 x 3 x 2.5 m room (surface-like, as a depth scan), 2.5 cm pre-voxelised like 3DMatch
     u = synth.hash_uniform(seed, 1, (n * 3, 3), 0.0, 1.0)
     P = np.stack([4 * u[:, 0], 3 * u[:, 1], 1.2 + 0.6 * np.sin(3 * u[:, 0]) * np.cos(2 * u[:, 1]) + 0.02 * u[:, 2]], 1).astype(np.float32)
-    sp, _ = co.ref_subsample_batch(P, np.array([len(P)], np.int32), 0.025) if co.ref_lib() else co.grid_subsample_batch(P, np.array([len(P)], np.int32), 0.025)
-    return sp[:n]
+    # (3DMatch clouds come pre-voxelised at 2.5 cm: done with the device op; the reference C++ only serves the cpu_baseline leg)
+    from diffreg_hip.collate import batch_grid_subsampling_kpconv
+    sp, _ = batch_grid_subsampling_kpconv(torch.from_numpy(P).cuda(), torch.tensor([len(P)], dtype=torch.int32).cuda(), sampleDl=0.025)
+    return sp[:n].cpu().numpy()
 A, B = cloud(n, 1), cloud(n, 2)
 P = np.concatenate([A, B]); L = np.array([len(A), len(B)], np.int32)
 cfg = dict(architecture=synth.KPFCN_ARCH, first_subsampling_dl=0.025, conv_radius=2.5, deform_radius=5.0)

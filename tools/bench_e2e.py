@@ -18,8 +18,10 @@ def cloud(n, seed, R=None, t=None):
     P = np.stack([2.2 * u[:, 0], 1.7 * u[:, 1], 1.2 + 0.5 * np.sin(3 * u[:, 0]) * np.cos(2 * u[:, 1]) + 0.02 * u[:, 2]], 1)
     if R is not None:
         P = P @ R.T + t
-    sp, _ = co.grid_subsample_batch(P.astype(np.float32), np.array([len(P)], np.int32), 0.025)
-    return sp[:n]
+    # (3DMatch clouds come pre-voxelised at 2.5 cm: done with the device op; the oracle only serves the cpu_baseline leg)
+    from diffreg_hip.collate import batch_grid_subsampling_kpconv
+    sp, _ = batch_grid_subsampling_kpconv(torch.from_numpy(P.astype(np.float32)).cuda(), torch.tensor([len(P)], dtype=torch.int32).cuda(), sampleDl=0.025)
+    return sp[:n].cpu().numpy()
 R = synth._rodrigues(np.array([0.2, 0.1, 1.0]), 0.3); t = np.array([0.1, -0.05, 0.02])
 A, B = cloud(n, 1), cloud(n, 1, R, t)                      # the same surface seen from a second pose
 g = np.load(os.path.join(ROOT, "tests", "golden", "kpfcn_coarse.npz"))
