@@ -20,6 +20,48 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---- plane-image output of one wave's 32 queries (see AttnArgs::pimg): ob[q * stride + f] holds out[q][f] ------------------
+typedef _Float16 ah16x2 __attribute__((ext_vector_type(2)));
+typedef float aff32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void attn_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const aff32x2 f = {x0, x1};
+    const ah16x2 hh = __builtin_convertvector(f, ah16x2);
+    hi = __builtin_bit_cast(unsigned, hh);
+    const aff32x2 hf = __builtin_convertvector(hh, aff32x2);
+    const aff32x2 r = {x0 - hf.x, x1 - hf.y};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ah16x2));
+}
+__device__ __forceinline__ float attn_key_bound(const AttnArgs& A, int kbase, int Lk, int lane) {
+    float bm = 0.f;
+    for (int k = lane; k < Lk; k += 64) bm = fmaxf(bm, A.kbnd[kbase + k]);
+    return wave_max(bm) * A.vnorm[0];
+}
+__device__ __forceinline__ void attn_store_planes(const AttnArgs& A, const float* ob, int stride, int grow0, int nq, int head, int d,
+                                                  float bound, int lane) {
+    const unsigned bits = __float_as_uint(bound);
+    const int e = (int)((bits >> 23) & 0xff) - 127;
+    const int s = (bound > 0.f && e < 128) ? min(max(14 - e, -100), 100) : 0;
+    const float sc = __uint_as_float((unsigned)(127 + s) << 23);
+    const int nu = A.p_dp >> 3;
+    if (head == 0 && lane < 32 && lane < nq) A.pbnd[grow0 + lane] = bound;
+    for (int idx = lane; idx < 32 * nu; idx += 64) {
+        const int q = idx / nu, u = idx % nu;
+        if (q >= nq) continue;
+        float x[8];
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) x[e8] = (8 * u + e8 < d) ? ob[q * stride + 8 * u + e8] * sc : 0.f;
+        uint4 hi, lo;
+        attn_split2(x[0], x[1], hi.x, lo.x); attn_split2(x[2], x[3], hi.y, lo.y);
+        attn_split2(x[4], x[5], hi.z, lo.z); attn_split2(x[6], x[7], hi.w, lo.w);
+        const int row = grow0 + q, side = row >= A.p_split ? 1 : 0, lrow = row - (side ? A.p_split : 0);
+        const int r = lrow & 127, swz = (r >> 2) & 3, kc = head * (A.p_dp >> 4) + (u >> 1);
+        char* dst = A.pimg[side] + (((size_t)(lrow >> 7) * A.p_nct + kc) * 128 + r) * 64;
+        *reinterpret_cast<uint4*>(dst + (((u & 1) ^ swz) << 4)) = hi;
+        *reinterpret_cast<uint4*>(dst + (((2 + (u & 1)) ^ swz) << 4)) = lo;
+    }
+}
+
 template <int DG, int NDT>
 struct AttnGeom {
     static constexpr int DP = DG * 8;            // padded head dim for the QK^T k-loop
@@ -413,6 +455,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (f < G::QS) ob[l31 * G::QS + f] = acc[i][r] * inv;
         }
     wave_lds_fence();
+    if (A.pimg[0]) {
+        attn_store_planes(A, ob, G::QS, qbase + qb + w * 32, Lq - (qb + w * 32), head, d, attn_key_bound(A, kbase, Lk, lane), lane);
+        return;
+    }
     for (int idx = lane; idx < 32 * nv4; idx += 64) {
         const int q = idx / nv4, c4 = idx % nv4;
         const int qq = qb + w * 32 + q;
@@ -689,6 +735,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) ob[l31 * G::OQS + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][r] * inv;
     wave_lds_fence();
+    if (A.pimg[0]) {
+        attn_store_planes(A, ob, G::OQS, qbase + qb + w * 32, Lq - (qb + w * 32), head, d, attn_key_bound(A, kbase, Lk, lane), lane);
+        return;
+    }
     for (int idx = lane; idx < 32 * nv4; idx += 64) {
         const int q = idx / nv4, c4 = idx % nv4;
         const int qq = qb + w * 32 + q;
@@ -737,7 +787,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const int flash_env = [] { const char* e = getenv("DR_ATTN_FLASH_MIN"); return e ? atoi(e) : 256; }();
     const int flash_min = g_flash_min >= 0 ? g_flash_min : flash_env;
     dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
-    if ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0) {
+    if (a.pimg[0] || ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0)) {
         static const int split_env = [] { const char* e = getenv("DR_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
         const int mode = g_attn_split >= 0 ? g_attn_split : split_env;     // 0 f32-input MFMA, 1 split operands
         // d = 132 (4DMatch) needs 288 V staging blocks and 9 k-steps of Q in registers: more than two waves per SIMD

@@ -81,6 +81,11 @@ struct AttnArgs {
     // second family of segments (self attention over src AND tgt in one launch); nseg2 may be 0
     int nseg2, q0b, qstrideb, Lqb, k0b, kstrideb, Lkb;
     float scale;          // 1/sqrt(d)
+    // plane-image output (pgemm.h) instead of `out`: rows < p_split go to pimg[0], the others (minus p_split) to pimg[1]; head h
+    // occupies the k range [h p_dp, h p_dp + d) of the image (p_dp = d rounded up to 16, the pad is written as zeros);
+    // bound of a query row = max over the segment's key rows of kbnd[row] * vnorm[0]  (|softmax V| <= max |V|), written to
+    // pbnd[row] by the head-0 workgroups
+    char* pimg[2]; int p_split, p_nct, p_dp; float* pbnd; const float* kbnd; const float* vnorm;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int attention_configure();

@@ -7,6 +7,7 @@
 // Linear layers / LayerNorm / rotary are row-wise, so the P pairs simply widen the GEMMs; only the
 // attention, the N x M matrices and the Procrustes fit know about pair boundaries.
 #include "kernels.h"
+#include "pgemm.h"
 #include <string.h>
 
 namespace dr {
@@ -83,6 +84,98 @@ struct PackedWeights {
         }
         if (rc == DR_OK) rc = launch_pack_weights(W.src_proj, C, C, src_proj, st);
         return rc;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Plane-image path of the layer GEMMs (pgemm.h): every activation that feeds a GEMM lives as an fp16 hi / lo plane image
+// written by its producer; LayerNorm happens in the epilogue of the GEMM in front of it; weights are packed once.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PrepackLayer {
+    PgW qkv, merge, mlp0, mlp2;     // q|k|v: 3 blocks; merge: k order padded per head; mlp0: 2 blocks
+    const float *lnB1, *lnB2;       // device scalars: bound of norm1 / norm2 outputs
+};
+struct Prepack {
+    static constexpr int MAXL = 16;
+    PrepackLayer L[MAXL];
+    PgW head;                        // src_proj
+    int dp;                          // head dim rounded up to 16
+    static bool supported(const dr_loop_config& cfg) {
+        return cfg.n_layers <= MAXL && pgemm_shape_ok(cfg.C) && cfg.C % cfg.H == 0 && (cfg.C / cfg.H) % 4 == 0;
+    }
+    // lays the images out in `buf` (nullptr: size only) and returns the byte count
+    static size_t carve(void* buf, const dr_loop_config& cfg, Prepack* pp) {
+        Carver c(buf, (size_t)-1);
+        const int C = cfg.C, d = C / cfg.H, dp = (d + 15) / 16 * 16, nC = C / 16;
+        if (pp) pp->dp = dp;
+        auto take = [&](int nblk, int nct, PgW* v) {
+            char* p = c.take<char>(pgemm_weight_bytes(nblk, nct));
+            if (pp && buf) pgemm_weight_view(p, nblk, nct, v);
+        };
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            PrepackLayer* L = pp ? &pp->L[l] : nullptr;
+            take(3, nC, L ? &L->qkv : nullptr);
+            take(1, cfg.H * dp / 16, L ? &L->merge : nullptr);
+            take(2, 2 * nC, L ? &L->mlp0 : nullptr);
+            take(1, 2 * nC, L ? &L->mlp2 : nullptr);
+            float* b = c.take<float>(2);
+            if (L && buf) { L->lnB1 = b; L->lnB2 = b + 1; }
+        }
+        take(1, nC, pp ? &pp->head : nullptr);
+        return c.off + 256;
+    }
+    static int fill(void* buf, const dr_loop_config& cfg, const dr_loop_weights& W, hipStream_t st) {
+        Prepack pp;
+        carve(buf, cfg, &pp);
+        const int C = cfg.C, d = C / cfg.H;
+        // q|k|v are three separate [C, C] tensors: pack them as three one-block images laid out back to back (the block stride
+        // of a 3-block image is exactly one 1-block image minus its tail, so pack block by block into the 3-block view)
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const dr_layer_weights& w = W.layers[l];
+            const PrepackLayer& L = pp.L[l];
+            int rc = pgemm_pack_weights_block(w.q_proj, C, C, C, C, L.qkv, 0, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.k_proj, C, C, C, C, L.qkv, 1, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.v_proj, C, C, C, C, L.qkv, 2, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.merge, C, C, d, pp.dp, L.merge, 0, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0, C, 2 * C, 2 * C, 2 * C, L.mlp0, 0, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0 + (size_t)C * 2 * C, C, 2 * C, 2 * C, 2 * C, L.mlp0, 1, st);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp2, C, 2 * C, 2 * C, 2 * C, L.mlp2, 0, st);
+            if (rc == DR_OK) rc = launch_ln_bound(w.norm1_w, w.norm1_b, C, (float*)L.lnB1, st);
+            if (rc == DR_OK) rc = launch_ln_bound(w.norm2_w, w.norm2_b, C, (float*)L.lnB2, st);
+            if (rc) return rc;
+        }
+        return pgemm_pack_weights_block(W.src_proj, C, C, C, C, pp.head, 0, st);
+    }
+};
+
+// a token tensor of the plane path: fp32 rows [T, C] (the residual stream; may be null), plane image (src part, then tgt
+// part, each padded to 128 rows) and per-row bounds [T]
+struct Tok {
+    float* f32; char* img; float* bnd;
+};
+struct PlanesWs {
+    bool on;
+    Tok feat0, fa, fb, tgt_l0;
+    char *att_img, *msg_img, *hid_img;
+    float *att_bnd, *msg_bnd, *hid_bnd;
+    size_t side_C, side_att, side_hid;      // byte offset of the tgt part inside an image of K = C / H dp / 2C
+    void* own_pack;                         // packed weights inside the workspace (used when the caller passed none)
+    static size_t img_bytes(int PN, int PM, int K) { return plane_image_bytes(PN, K) + plane_image_bytes(PM, K); }
+    static void carve(Carver& c, PlanesWs& w, const dr_loop_config& cfg, int P, int N, int M) {
+        const int C = cfg.C, PN = P * N, PM = P * M, T = PN + PM;
+        static const int min_rows = [] { const char* e = getenv("DR_PLANES_MIN_ROWS"); return e ? atoi(e) : 8192; }();
+        static const int enabled = [] { const char* e = getenv("DR_PLANES"); return e ? atoi(e) : 1; }();
+        w.on = enabled && Prepack::supported(cfg) && T >= min_rows;
+        if (!w.on) return;
+        const int dp = (C / cfg.H + 15) / 16 * 16;
+        w.side_C = plane_image_bytes(PN, C); w.side_att = plane_image_bytes(PN, cfg.H * dp); w.side_hid = plane_image_bytes(PN, 2 * C);
+        Tok* toks[4] = {&w.feat0, &w.fa, &w.fb, &w.tgt_l0};
+        for (Tok* t : toks) { t->f32 = nullptr; t->img = c.take<char>(img_bytes(PN, PM, C)); t->bnd = c.take<float>(T); }
+        w.att_img = c.take<char>(img_bytes(PN, PM, cfg.H * dp)); w.att_bnd = c.take<float>(T);
+        w.msg_img = c.take<char>(img_bytes(PN, PM, C)); w.msg_bnd = c.take<float>(T);
+        w.hid_img = c.take<char>(img_bytes(PN, PM, 2 * C)); w.hid_bnd = c.take<float>(T);
+        w.own_pack = c.take<char>(Prepack::carve(nullptr, cfg, nullptr));
     }
 };
 
@@ -183,6 +276,110 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
                             xrows, C, st, outmax ? outmax + xr0 : nullptr);
 }
 
+
+// ---- the plane path of one GeometryAttentionLayer call (transformero.py:43-96): five launches ---------------------------------
+enum { SIDE_SRC = 1, SIDE_TGT = 2, SIDE_BOTH = 3 };
+struct PlCtx {
+    const Prepack* pp; const PlanesWs* pw; const LayerWs* lw;
+    int C, H, P, N, M;
+    const float *cosT, *sinT;
+    const uint8_t* tokmask;
+};
+static PgW pgw_blocks(const PgW& v, int b0) {
+    PgW r = v;
+    r.img += (size_t)b0 * v.nct * pgemm_bn() * 64; r.cinv += (size_t)b0 * pgemm_bn(); r.wnorm += b0;
+    return r;
+}
+static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, const Tok& xin, int xs, const Tok& yin, int ys,
+                             const Tok& out, const Family& f1, const Family* f2, hipStream_t st, const float* kv_cached = nullptr,
+                             float* kv_store = nullptr) {
+    const int C = X.C, H = X.H, PN = X.P * X.N, PM = X.P * X.M, halfC = C / 2, d = C / H, nC = C / 16, dp = X.pp->dp;
+    const PrepackLayer& L = X.pp->L[l];
+    const PlanesWs& pw = *X.pw;
+    const LayerWs& ws = *X.lw;
+    auto r0 = [&](int side) { return side == SIDE_TGT ? PN : 0; };
+    auto nrows = [&](int side) { return side == SIDE_TGT ? PM : PN; };
+    auto at = [&](char* img, size_t side_off, int side) { return img + (side == SIDE_TGT ? side_off : 0); };
+    PgBatch g;
+    auto reset = [&]() { memset(&g, 0, sizeof(g)); };
+    auto add = [&]() -> PgProblem& { return g.p[g.n++]; };
+    auto for_sides = [&](int mask, auto fn) { for (int side = 1; side <= 2; ++side) if (mask & side) fn(side); };
+    int rc;
+
+    // ---- q | k | v projections + rotary -> fp32 rows (the attention kernel's operands)
+    auto proj = [&](const Tok& tin, int side, int b0, int nblk, float* o, int ldo, int rotm) {
+        PgProblem& p = add();
+        p.A0 = at(tin.img, pw.side_C, side); p.bnd0 = tin.bnd + r0(side); p.nc0 = nC;
+        p.W = pgw_blocks(L.qkv, b0); p.nblk = nblk; p.rows = nrows(side); p.C = C; p.mode = PG_F32;
+        p.out = o; p.ldo = ldo; p.blk_stride = C; p.rot_mask = rotm; p.rot_C = C; p.scale = 1.f;
+        p.cosT = X.cosT + (size_t)r0(side) * halfC; p.sinT = X.sinT + (size_t)r0(side) * halfC;
+    };
+    reset();
+    if (kv_store) {
+        for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_store + (size_t)r0(side) * 2 * C, 2 * C, 1); });
+        return launch_pgemm(g, st);
+    }
+    const bool self = xs == ys && xin.img == yin.img && !kv_cached;
+    if (self) {
+        for_sides(xs, [&](int side) { proj(xin, side, 0, 3, ws.qkv + (size_t)r0(side) * 3 * C, 3 * C, 3); });
+    } else {
+        for_sides(xs, [&](int side) { proj(xin, side, 0, 1, ws.qkv + (size_t)r0(side) * 3 * C, 3 * C, 1); });
+        if (!kv_cached) for_sides(ys, [&](int side) { proj(yin, side, 1, 2, ws.qkv + (size_t)r0(side) * 3 * C + C, 3 * C, 1); });
+    }
+    rc = launch_pgemm(g, st);
+    if (rc) return rc;
+
+    // ---- attention -> plane image of the heads' outputs (head h at k = h dp)
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = ws.qkv; a.k = ws.qkv + C; a.v = ws.qkv + 2 * C; a.out = nullptr;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.H = H; a.d = d;
+    if (kv_cached) { a.k = kv_cached; a.v = kv_cached + C; a.ldk = a.ldv = 2 * C; }
+    a.qmask = X.tokmask; a.kmask = X.tokmask;
+    a.nseg = X.P; a.q0 = f1.q0; a.qstride = f1.Lq; a.Lq = f1.Lq; a.k0 = f1.k0; a.kstride = f1.Lk; a.Lk = f1.Lk;
+    if (f2) { a.nseg2 = X.P; a.q0b = f2->q0; a.qstrideb = f2->Lq; a.Lqb = f2->Lq; a.k0b = f2->k0; a.kstrideb = f2->Lk; a.Lkb = f2->Lk; }
+    a.scale = 1.0f / sqrtf((float)d);
+    a.pimg[0] = pw.att_img; a.pimg[1] = pw.att_img + pw.side_att; a.p_split = PN; a.p_nct = H * dp / 16; a.p_dp = dp;
+    a.pbnd = pw.att_bnd; a.kbnd = yin.bnd; a.vnorm = L.qkv.wnorm + 2;
+    rc = launch_attention(a, st);
+    if (rc) return rc;
+
+    // ---- message = norm1(merge(o)) -> plane image
+    reset();
+    for_sides(xs, [&](int side) {
+        PgProblem& p = add();
+        p.A0 = at(pw.att_img, pw.side_att, side); p.bnd0 = pw.att_bnd + r0(side); p.nc0 = H * dp / 16;
+        p.W = L.merge; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN;
+        p.gamma = W.norm1_w; p.beta = W.norm1_b; p.lnB = L.lnB1;
+        p.pimg = at(pw.msg_img, pw.side_C, side); p.p_nct = nC; p.pbnd = pw.msg_bnd + r0(side);
+    });
+    rc = launch_pgemm(g, st);
+    if (rc) return rc;
+    // ---- hidden = relu(mlp0([x | message])) -> plane image
+    reset();
+    for_sides(xs, [&](int side) {
+        PgProblem& p = add();
+        p.A0 = at(xin.img, pw.side_C, side); p.bnd0 = xin.bnd + r0(side); p.nc0 = nC;
+        p.A1 = at(pw.msg_img, pw.side_C, side); p.bnd1 = pw.msg_bnd + r0(side); p.nc1 = nC;
+        p.W = L.mlp0; p.nblk = 2; p.rows = nrows(side); p.C = C; p.mode = PG_PLANES; p.relu = 1;
+        p.pimg = at(pw.hid_img, pw.side_hid, side); p.p_nct = 2 * nC; p.pbnd = pw.hid_bnd + r0(side);
+    });
+    rc = launch_pgemm(g, st);
+    if (rc) return rc;
+    // ---- out = x + norm2(mlp2(hidden)) -> fp32 rows (the residual stream) + plane image (the next GEMMs' operand)
+    reset();
+    for_sides(xs, [&](int side) {
+        PgProblem& p = add();
+        p.A0 = at(pw.hid_img, pw.side_hid, side); p.bnd0 = pw.hid_bnd + r0(side); p.nc0 = 2 * nC;
+        p.W = L.mlp2; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN;
+        p.gamma = W.norm2_w; p.beta = W.norm2_b; p.lnB = L.lnB2;
+        p.resid = xin.f32 + (size_t)r0(side) * C; p.ldr = C; p.bnd_res = xin.bnd + r0(side);
+        p.out = out.f32 + (size_t)r0(side) * C; p.ldo = C;
+        p.pimg = at(out.img, pw.side_C, side); p.p_nct = nC; p.pbnd = out.bnd + r0(side);
+    });
+    return launch_pgemm(g, st);
+}
+
 // workspace of one denoiser + matching-head evaluation
 struct DenoiseWs {
     LayerWs lw;
@@ -190,10 +387,15 @@ struct DenoiseWs {
     float *tgt_l0, *kv_l1;      // step-invariant: layer-0 output of the tgt rows, layer-1 K|V of those rows
     float *m_feat0, *m_fa, *m_fb, *m_tgt_l0;   // row maxima of feat0 / fa / fb / tgt_l0 (fp16-split GEMM operand scaling)
     PackedWeights pw;
-    static void carve(Carver& c, DenoiseWs& w, int P, int N, int M, int C, int n_layers) {
+    PlanesWs pl;
+    const Prepack* pp;          // packed weights of the plane path (set per call)
+    static void carve(Carver& c, DenoiseWs& w, const dr_loop_config& cfg, int P, int N, int M) {
+        const int C = cfg.C, n_layers = cfg.n_layers;
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
-        PackedWeights::carve(c, w.pw, n_layers, C, T);
+        PlanesWs::carve(c, w.pl, cfg, P, N, M);
+        if (w.pl.on) w.pw.on = false;                       // the plane path packs its own images
+        else PackedWeights::carve(c, w.pw, n_layers, C, T);
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
         w.m_feat0 = c.take<float>(T); w.m_fa = c.take<float>(T); w.m_fb = c.take<float>(T); w.m_tgt_l0 = c.take<float>(T);
@@ -203,6 +405,7 @@ struct DenoiseWs {
         w.sinT = c.take<float>(T * (C / 2));
         w.proj = c.take<float>(T * C);
         w.sim = c.take<float>((size_t)P * N * M);
+        if (w.pl.on) { w.pl.fa.f32 = w.fa; w.pl.fb.f32 = w.fb; w.pl.tgt_l0.f32 = w.tgt_l0; }
     }
 };
 
@@ -216,6 +419,12 @@ static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, i
                           const uint8_t* tokmask, DenoiseWs& ws, hipStream_t st) {
     const int C = cfg.C, H = cfg.H, PN = P * N, PM = P * M;
     const Family self_t{PN, M, PN, M};
+    if (ws.pl.on) {
+        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask};
+        int rc = layer_call_planes(X, w.layers[0], 0, ws.pl.feat0, SIDE_TGT, ws.pl.feat0, SIDE_TGT, ws.pl.tgt_l0, self_t, nullptr, st);
+        if (rc || cfg.n_layers < 2) return rc;
+        return layer_call_planes(X, w.layers[1], 1, ws.pl.tgt_l0, 0, ws.pl.tgt_l0, SIDE_TGT, ws.pl.tgt_l0, self_t, nullptr, st, nullptr, ws.kv_l1);
+    }
     const PackedLayer* pk0 = ws.pw.on ? &ws.pw.layer[0] : nullptr;
     int rc = layer_call(w.layers[0], C, H, P, feat0, PN, PM, feat0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
                         ws.tgt_l0, st, nullptr, nullptr, pk0, ws.m_feat0, ws.m_feat0, ws.m_tgt_l0);
@@ -228,6 +437,59 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
                             const uint8_t* tokmask, DenoiseWs& ws, const float** final_feats, hipStream_t st,
                             bool use_cache = false) {
     const int C = cfg.C, H = cfg.H, T = P * (N + M), PN = P * N, PM = P * M;
+    if (ws.pl.on) {
+        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask};
+        const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
+        const Tok* cur = &ws.pl.feat0;
+        const Tok* bufs[2] = {&ws.pl.fa, &ws.pl.fb};
+        int which = 0;
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const Tok* nxt = bufs[which];
+            int rc;
+            if (use_cache && l == 0) {
+                rc = layer_call_planes(X, w.layers[0], 0, *cur, SIDE_SRC, *cur, SIDE_SRC, *nxt, self_s, nullptr, st);
+                if (rc) return rc;
+                // the tgt half of layer 0 comes from the cache: rows, plane image and bounds
+                DR_HIP_CHECK(hipMemcpyAsync(nxt->f32 + (size_t)PN * C, ws.pl.tgt_l0.f32 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
+                DR_HIP_CHECK(hipMemcpyAsync(nxt->img + ws.pl.side_C, ws.pl.tgt_l0.img + ws.pl.side_C, plane_image_bytes(PM, C), hipMemcpyDeviceToDevice, st));
+                DR_HIP_CHECK(hipMemcpyAsync(nxt->bnd + PN, ws.pl.tgt_l0.bnd + PN, (size_t)PM * 4, hipMemcpyDeviceToDevice, st));
+            } else if (l % 2 == 0) {
+                rc = layer_call_planes(X, w.layers[l], l, *cur, SIDE_BOTH, *cur, SIDE_BOTH, *nxt, self_s, &self_t, st);
+                if (rc) return rc;
+            } else {
+                // src attends tgt, then tgt attends the UPDATED src (quirk Q11)
+                rc = layer_call_planes(X, w.layers[l], l, *cur, SIDE_SRC, *cur, SIDE_TGT, *nxt, cross_s, nullptr, st,
+                                       (use_cache && l == 1) ? ws.kv_l1 : nullptr);
+                if (rc) return rc;
+                rc = layer_call_planes(X, w.layers[l], l, *cur, SIDE_TGT, *nxt, SIDE_SRC, *nxt, cross_t, nullptr, st);
+                if (rc) return rc;
+            }
+            cur = nxt;
+            which ^= 1;
+        }
+        *final_feats = cur->f32;
+        // matching head: src_proj on BOTH sides (quirk Q1), rotary, / sqrt(C)
+        PgBatch g;
+        memset(&g, 0, sizeof(g));
+        for (int side = 1; side <= 2; ++side) {
+            PgProblem& p = g.p[g.n++];
+            const int r0 = side == SIDE_TGT ? PN : 0;
+            p.A0 = cur->img + (side == SIDE_TGT ? ws.pl.side_C : 0); p.bnd0 = cur->bnd + r0; p.nc0 = C / 16;
+            p.W = ws.pp->head; p.nblk = 1; p.rows = side == SIDE_TGT ? PM : PN; p.C = C; p.mode = PG_F32;
+            p.out = ws.proj + (size_t)r0 * C; p.ldo = C; p.blk_stride = 0; p.rot_mask = 1; p.rot_C = C; p.scale = 1.0f / sqrtf((float)C);
+            p.cosT = ws.cosT + (size_t)r0 * (C / 2); p.sinT = ws.sinT + (size_t)r0 * (C / 2);
+        }
+        int rc = launch_pgemm(g, st);
+        if (rc) return rc;
+        GemmBatch gs;
+        memset(&gs, 0, sizeof(gs));
+        GemmProblem& q = gs.p[0];
+        q.A = ws.proj; q.W = ws.proj + (size_t)PN * C; q.out = ws.sim;
+        q.rows = N; q.ncols = M; q.K = C; q.K1 = C; q.lda = C; q.ldo = M; q.epi = EPI_NONE; q.scale = 1.f;
+        q.nbatch = P; q.sA = (long long)N * C; q.sW = (long long)M * C; q.sO = (long long)N * M;
+        gs.n = 1;
+        return launch_gemm(gs, st);
+    }
     const float* cur = feat0;
     float* bufs[2] = {ws.fa, ws.fb};
     float* mbufs[2] = {ws.m_fa, ws.m_fb};
@@ -319,8 +581,9 @@ struct LoopWs {
     size_t pws_bytes;
     static size_t carve(Carver& c, LoopWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), NM = (size_t)P * N * M;
-        DenoiseWs::carve(c, w.dw, P, N, M, cfg.C, cfg.n_layers);
+        DenoiseWs::carve(c, w.dw, cfg, P, N, M);
         w.feat0 = c.take<float>(T * cfg.C);
+        if (w.dw.pl.on) w.dw.pl.feat0.f32 = w.feat0;
         w.wconf = c.take<float>(NM);
         w.x0 = c.take<float>(NM);
         w.conf32 = c.take<float>(NM);
@@ -344,6 +607,25 @@ struct LoopWs {
     }
 };
 
+// plane path, once per call: the packed weights (the caller's, or packed now into the workspace) and the plane image of the
+// external features with their row maxima as bounds
+static int planes_begin(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, DenoiseWs& ws, Prepack& pp,
+                        hipStream_t st) {
+    if (!ws.pl.on) return DR_OK;
+    void* buf = const_cast<void*>(w.prepacked);
+    if (!buf) {
+        buf = ws.pl.own_pack;
+        const int rc = Prepack::fill(buf, cfg, w, st);
+        if (rc) return rc;
+    }
+    Prepack::carve(buf, cfg, &pp);
+    ws.pp = &pp;
+    const int C = cfg.C, PN = P * N, PM = P * M;
+    int rc = launch_planes_from_f32(ws.pl.feat0.f32, C, PN, C, ws.pl.feat0.img, ws.pl.feat0.bnd, st);
+    if (rc == DR_OK) rc = launch_planes_from_f32(ws.pl.feat0.f32 + (size_t)PN * C, C, PM, C, ws.pl.feat0.img + ws.pl.side_C, ws.pl.feat0.bnd + PN, st);
+    return rc;
+}
+
 }  // namespace dr
 
 using namespace dr;
@@ -353,6 +635,7 @@ extern "C" {
 int dr_init(void) {
     int rc = attention_configure();
     if (rc == DR_OK) rc = gemm_configure();
+    if (rc == DR_OK) rc = pgemm_configure();
     return rc;
 }
 
@@ -497,6 +780,18 @@ static int check_cfg(const dr_loop_config* cfg, const dr_loop_weights* w, int P,
     return DR_OK;
 }
 
+size_t dr_loop_prepack_bytes(const dr_loop_config* cfg) {
+    if (!cfg || !Prepack::supported(*cfg)) return 0;
+    return Prepack::carve(nullptr, *cfg, nullptr);
+}
+
+int dr_loop_prepack(const dr_loop_config* cfg, const dr_loop_weights* w, void* packed, size_t packed_bytes, void* stream) {
+    if (!cfg || !w || !w->layers || !w->src_proj || !packed || ((uintptr_t)packed & 255)) return DR_EINVAL;
+    if (!Prepack::supported(*cfg)) return DR_ENOSUP;
+    if (packed_bytes < Prepack::carve(nullptr, *cfg, nullptr)) return DR_EWORKSPACE;
+    return Prepack::fill(packed, *cfg, *w, (hipStream_t)stream);
+}
+
 size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, int M) {
     if (!cfg || P < 1 || N < 1 || M < 1) return 0;
     Carver c(nullptr, 0);
@@ -527,6 +822,9 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
     }
     rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);
+    if (rc) return rc;
+    Prepack pp;
+    rc = planes_begin(*cfg, *w, P, N, M, L.dw, pp, st);
     if (rc) return rc;
     rc = fill_pe(*cfg, *w, P, N, M, s_pcd_warped, nullptr, nullptr, t_pcd, true, true, L.dw, st);
     if (rc) return rc;
@@ -577,6 +875,9 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     rc = launch_f32_to_f64(x_T, L.x, NM, st);     // exact widening; step 1 keeps float32 semantics
     if (rc) return rc;
     rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);  // split-operand images of the weights (the caller may have updated them)
+    if (rc) return rc;
+    Prepack pp;
+    rc = planes_begin(*cfg, *w, P, N, M, L.dw, pp, st);
     if (rc) return rc;
     // the target cloud never moves: its position code is computed once (the reference recomputes it
     // every step, transformero.py:166)

@@ -1,0 +1,70 @@
+// pgemm.h -- internal interface of the plane-image GEMM (pgemm.hip): the layer nn.Linears of the loop with BOTH operands
+// pre-split into fp16 hi / lo planes in global memory, so that the kernel streams them by LDS-DMA only.
+#pragma once
+#include "kernels.h"
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Plane image of an activation matrix X [rows, K], K % 16 == 0:
+//   [rb = row / 128][kc = k / 16][r = row % 128][64 bytes]   (a 128-row block of one 16-deep k-chunk is 8 KB contiguous: it
+//   is copied to LDS by eight 1 KB DMA instructions and IS the LDS image the MFMA fragments are read from)
+//   the 64 bytes of (row, kc) are four 16-byte units of 8 fp16: logical unit u = 0: hi k 0..7, 1: hi k 8..15, 2: lo k 0..7,
+//   3: lo k 8..15, stored at position u ^ ((r >> 2) & 3) (conflict-free ds_read_b128 of a 32-row fragment)
+//   values: hi = fp16(x 2^s), lo = fp16(x 2^s - hi) with s = 14 - floor(log2(bound[row])) (f16 range: |x| <= bound[row] is
+//   the producer's promise; bound is an upper bound, not the maximum: fp16 keeps 22 significand bits for every element
+//   within 2^-17 of it and 2^-40 bound absolutely below -- far inside the fp32 rounding of a dot product)
+// Rows are padded to a multiple of 128 (the pad rows are never stored from).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PI_BM = 128;
+inline size_t plane_image_bytes(size_t rows, int K) { return ((rows + PI_BM - 1) / PI_BM) * (size_t)(K / 16) * (PI_BM * 64); }
+
+// view of `nblk` consecutive column blocks of a packed weight image (pgemm_pack_weights)
+struct PgW {
+    const char* img;     // [nblk][nct][BN rows][64 B]   (rows >= C of a block are zero)
+    const float* cinv;   // [nblk][BN]  2^-s_c of every output column
+    const float* wnorm;  // [nblk]      max_c sum_k |W[c][k]|  (output bound = input bound * wnorm)
+    int nct;             // 16-deep k-chunks of the image (= those of the A operand)
+};
+
+enum { PG_F32 = 0, PG_PLANES = 1, PG_LN = 2 };
+
+struct PgProblem {
+    const char* A0; const char* A1;     // plane images of the A operand: [A0 | A1] along k (A1 may be null)
+    const float* bnd0; const float* bnd1; // their per-row bounds
+    int nc0, nc1;                       // 16-deep k-chunks of each
+    PgW W;
+    int nblk;                           // column blocks (of C columns each) this problem computes
+    int rows, C;
+    int mode;
+    // PG_F32: out[row][nb * blk_stride + col] = rot(acc) * scale     (PG_LN: optional fp32 copy of the result, nb = 0)
+    float* out; int ldo; int blk_stride;
+    const float* cosT; const float* sinT; int rot_mask; int rot_C; float scale;
+    // PG_PLANES / PG_LN: plane image of the output, column block nb -> chunks p_kc0 + nb * (C / 16) ..
+    char* pimg; int p_nct; int p_kc0; float* pbnd;
+    int relu;
+    // PG_LN: y = LayerNorm(acc) * gamma + beta (+ resid[row][col]);  bound = (bnd_res ? bnd_res[row] : 0) + *lnB
+    const float* gamma; const float* beta; const float* resid; int ldr; const float* bnd_res; const float* lnB;
+};
+struct PgBatch { PgProblem p[3]; int n; };
+
+bool pgemm_shape_ok(int C);                      // column-block widths the kernel is built for
+int pgemm_bn();                                  // rows of a packed weight block (448)
+int launch_pgemm(const PgBatch& g, hipStream_t st);
+int pgemm_configure();
+
+// packed weights: nblk blocks of C rows of W [nblk * C, K] (row-major) -> image + cinv + wnorm.
+// k order of the image: k' = (k / piece_len) * piece_pad + k % piece_len  (zero where k' % piece_pad >= piece_len);
+// piece_len = K, piece_pad = K for the identity.  nct = ceil(K / piece_len) * piece_pad / 16.
+size_t pgemm_weight_bytes(int nblk, int nct);    // image + cinv + wnorm, 256-aligned
+void pgemm_weight_view(void* buf, int nblk, int nct, PgW* view);
+int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st);
+int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st);
+
+// fp32 rows -> plane image with bound[row] = max |x[row][:]| (the external features entering the first layer)
+int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st);
+int launch_planes_to_f32(const char* img, const float* bnd, int rows, int K, float* out, int ldo, hipStream_t st);
+// *out = sqrt(C) max|gamma| + max|beta|: an upper bound of |LayerNorm(.) gamma + beta|
+int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hipStream_t st);
+
+}  // namespace dr

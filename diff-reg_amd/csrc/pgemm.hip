@@ -1,0 +1,725 @@
+// pgemm.hip -- the layer nn.Linears of the denoising loop (q/k/v/merge/mlp of 3D/models/transformero.py:26-96, src_proj of
+// 3D/models/matching.py:107) as a GEMM whose operands are BOTH pre-split fp16 hi / lo plane images in global memory.
+//
+// out = x W^T in fp32 accuracy from three fp16 MFMA products per fp32 MAC (hi*hi + hi*lo + lo*hi, fp32 accumulate; see
+// gemm.hip for the numerics of the two-plane split).  What changes against gemm_nt_wide2_kernel is where the planes come from:
+// the PRODUCER of an activation (this kernel's own epilogue, the attention kernel, planes_from_f32 for the external
+// features) writes them, scaled by an exact power of two from a per-row upper bound that is propagated analytically
+// (|x W^T| <= bound(x) max_c ||W_c||_1, |LayerNorm| <= sqrt(C) max|gamma| + max|beta|, |softmax V| <= max|V|), so that no
+// kernel ever sweeps a row for its maximum and the A operand streams by LDS-DMA exactly like the weights: no VGPR-held
+// requests, no VALU split, no in-order vmcnt chain between A loads and the B image.
+//
+// Geometry: a workgroup is 128 rows x one column block of up to 448 columns (the whole C = 432 row of one nn.Linear), 8 waves
+// as 4 (rows) x 2 (columns), a wave = 32 x 224 = 7 accumulator tiles of v_mfma_f32_32x32x16_f16; one workgroup per CU.
+// A stage = one 16-deep k-chunk = 8 KB of A + 28 KB of W, 36 one-KB DMA instructions dealt over the 8 waves; NST = 4 stages
+// ring in LDS (144 KB), the DMA of stage s + 3 is issued in the middle of stage s, ONE barrier per stage placed mid-stage:
+//   tiles 0..2 of stage s | wait: own DMAs of stage s + 1 landed | s_barrier | issue DMAs of stage s + 3 into the slot of
+//   stage s - 1 (every wave is past it) | tiles 3..6 | fragments of stage s + 1 are read during the last tile
+// so no MFMA ever waits behind a barrier for a fragment read, and a DMA has two stage times to land.
+// Full rows per workgroup make the epilogue the place where LayerNorm (+ residual) happens (merge -> norm1, mlp2 -> norm2 + x):
+// the accumulators are transposed through LDS so that a lane owns 56 columns of one row, the row statistics cross the two
+// column waves through LDS, and the result leaves as fp32 rows and / or as the plane image of the next GEMM.
+#include <cstdlib>
+#include <string.h>
+#include <type_traits>
+#include "pgemm.h"
+
+namespace dr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// x0, x1 -> packed (hi0, hi1), (lo0, lo1): hi = fp16(x) round to nearest even, lo = fp16(x - hi)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 f = {x0, x1};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {x0 - hf.x, x1 - hf.y};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+// exponent s with 2^14 <= m 2^s < 2^15 (0 for m = 0 / inf / nan), clamped so that 2^s and 2^-s are normal floats
+__device__ __forceinline__ int scale_exp(float m) {
+    const unsigned bits = __float_as_uint(m);
+    const int e = (int)((bits >> 23) & 0xff) - 127;
+    const bool ok = m > 0.f && e < 128;
+    return ok ? min(max(14 - e, -100), 100) : 0;
+}
+__device__ __forceinline__ float pow2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+}
+__device__ __forceinline__ float dpp_xor1f(float v) { return __uint_as_float(dpp_xor1(__float_as_uint(v))); }
+__device__ __forceinline__ float dpp_xor2f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xF, 0xF, true));   // [2, 3, 0, 1]
+}
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int TNW_, int NST_>
+struct PgGeom {
+    static constexpr int TNW = TNW_, NST = NST_;
+    static constexpr int BM = 128, BNW = 32 * TNW, BN = 2 * BNW;
+    static constexpr int A_ST = BM * 64, B_ST = BN * 64, STAGE = A_ST + B_ST;
+    static constexpr int NB = B_ST / 1024;                  // DMA instructions of the weight part of a stage (28)
+    static constexpr int NFULL = NB / 8, REM = NB % 8;      // every wave issues 1 (A) + NFULL, waves < REM one more
+    static constexpr int RING = NST * STAGE;
+    static constexpr int NI = BNW / 16;                     // float4 pieces of a row a lane holds after the transposition (14)
+    static constexpr int EP_S = (BNW - 48 + 63) / 64 * 64 + 48;   // row stride of the transposition, = 48 mod 64 floats: conflict-free float4 reads
+    static constexpr int EP_BYTES = 8 * 16 * EP_S * 4;
+    static constexpr int WORK = RING > EP_BYTES ? RING : EP_BYTES;
+    static constexpr int SMEM = WORK + 6 * 128 * 4;         // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128]
+    static constexpr int MID = (TNW - 1) / 2 - 1 < 0 ? 0 : (TNW - 1) / 2 - 1;   // the barrier sits after this tile (2 of 7)
+};
+
+#define PG_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#define PG_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
+
+__device__ long long g_pg_stamps[128];
+#define PG_STAMP(i) do { if (DBG && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_pg_stamps[i] = wall_clock64(); } while (0)
+
+template <int TNW, int NST, bool DBG = false, int ABL = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgemm_kernel(PgBatch G) {
+    using GG = PgGeom<TNW, NST>;
+    constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+
+    const PgProblem& P = G.p[blockIdx.y];
+    const int rows = P.rows, C = P.C, nblk = P.nblk, nc0 = P.nc0, nc1 = P.A1 ? P.nc1 : 0, nst = nc0 + nc1;
+    const int rbs = (rows + 127) >> 7;
+    // workgroup id -> (row block, column block), XCD-aware: ids are dealt round-robin to the 8 XCDs, so the column blocks of a
+    // row block get ids 8 apart: they share an L2 and the A rows cross the fabric once
+    const int grp = blockIdx.x / (8 * nblk), rem = blockIdx.x % (8 * nblk);
+    const int rb = grp * 8 + (rem & 7), nb = rem >> 3;
+    if (rb >= rbs) return;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w & 3, wn = w >> 2;
+
+    float* const s_fac = reinterpret_cast<float*>(lds + GG::WORK);   // 2^(s1 - s0) of the rows (two-segment A operand)
+    float* const s_rinv = s_fac + 128;                               // 2^-s of the rows (last segment)
+    float* const s_sum = s_rinv + 128;                               // [2][128] LayerNorm partial sums of the two column waves
+    float* const s_sq = s_sum + 256;                                 // [2][128] partial squares
+    if (t < 128) {
+        const int row = min(rb * 128 + t, rows - 1);
+        const int e0 = scale_exp(P.bnd0[row]);
+        int e1 = e0;
+        if (nc1 > 0) e1 = scale_exp(P.bnd1[row]);
+        s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
+        s_rinv[t] = pow2i(-e1);
+    }
+
+    // ---- fragment addresses: a lane reads 16 bytes = 8 k of "its" row; lane half h takes k 8 h .. 8 h + 7
+    const int sw = (l31 >> 2) & 3;
+    const unsigned offAh = (wm * 32 + l31) * 64 + ((h ^ sw) << 4), offAl = (wm * 32 + l31) * 64 + (((2 + h) ^ sw) << 4);
+    const unsigned offBh = A_ST + (wn * BNW + l31) * 64 + ((h ^ sw) << 4), offBl = A_ST + (wn * BNW + l31) * 64 + (((2 + h) ^ sw) << 4);
+
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    u32x4 fa0[2], fa1[2], fb[2][2];
+    PG_STAMP(0);
+
+    // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream but keep
+    // their DMA issue -- ~100 cycles of the wave's instruction stream per 1 KB instruction, ~500 per stage, as much again as its
+    // MFMA issue -- in OPPOSITE halves of a stage, with the stage's one barrier between the halves:
+    //   group 0 (wn = 0): tiles 0, 1 + its DMA pieces | barrier | tiles 2 .. 6            (issues stage s + 2)
+    //   group 1 (wn = 1): tiles 0 .. 4                | barrier | tiles 5, 6 + DMA pieces (issues stage s + 3)
+    // so one wave of the SIMD is MFMA-dense while its partner feeds the DMA (in lockstep both halves serialise: measured
+    // 2.2 us per stage pair against 1.04 us of staging alone and 1.2 us of MFMAs alone).  Pieces: group 1 copies the A block
+    // (8 instructions, the longer-latency stream: it has 1.5 stages to land) and the first WB_CNT weight instructions, group 0
+    // the rest of the weights (L2 hits; one stage to land).
+    auto run = [&](auto grp_t) __attribute__((always_inline)) {
+        constexpr int GRP = decltype(grp_t)::value;
+        constexpr int WB_CNT = (GG::NB + 8) / 2 - 8;                 // weight instructions of group 1
+        constexpr int NW0 = GG::NB - WB_CNT;                         // weight instructions of group 0
+        constexpr int NPIECE = GRP ? 2 + (WB_CNT + 3) / 4 : (NW0 + 3) / 4;
+        constexpr int NFULLP = GRP ? 2 + WB_CNT / 4 : NW0 / 4;       // pieces every wave of the group issues
+        constexpr int REMP = GRP ? WB_CNT % 4 : NW0 % 4;             // waves (local index) < REMP issue one more
+        constexpr int MFIRST = GRP ? 3 * (TNW - 2) : 0;              // gap (MFMA index) of the first DMA piece
+        constexpr int MBAR = GRP ? 3 * (TNW - 2) - 1 : 5;            // the barrier follows this MFMA
+        const int wl = w & 3;
+        const char* pa = P.A0 + (size_t)rb * nc0 * A_ST + lane * 16;
+        const char* pb = P.W.img + (size_t)nb * nst * GG::B_ST + lane * 16;
+        const char* const pa1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * A_ST + lane * 16 : nullptr;
+        int ti = 0;                                                  // next stage this wave issues
+        auto dma_piece = [&](int i) __attribute__((always_inline)) {
+            char* dst = lds + (ti % NST) * STAGE;
+            if (GRP) {
+                if (i < 2) {
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pa + (2 * wl + i) * 1024), (lds_void*)(dst + (2 * wl + i) * 1024), 16, 0, 0);
+                } else {
+                    const int ins = wl + 4 * (i - 2);
+                    if (i - 2 < WB_CNT / 4 || wl < REMP)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(pb + ins * 1024), (lds_void*)(dst + A_ST + ins * 1024), 16, 0, 0);
+                }
+            } else {
+                const int ins = WB_CNT + wl + 4 * i;
+                if (i < NW0 / 4 || wl < REMP)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pb + ins * 1024), (lds_void*)(dst + A_ST + ins * 1024), 16, 0, 0);
+            }
+        };
+        auto dma_advance = [&]() __attribute__((always_inline)) {
+            ++ti;
+            pb += GG::B_ST;
+            pa = (ti == nc0) ? pa1 : pa + A_ST;
+        };
+
+        // One stage.  PAR = index of the B fragment buffer tile 0 uses (the buffers alternate tile by tile, across stages too).
+        auto stage = [&](int s, auto par_t, u32x4 (&ac)[2], u32x4 (&an)[2]) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_t)::value;
+            const unsigned sb = lds_base + (unsigned)(s % NST) * STAGE, sbn = lds_base + (unsigned)((s + 1) % NST) * STAGE;
+            const unsigned Bh = sb + offBh, Bl = sb + offBl;
+            const bool has_next = s + 1 < nst;
+            const bool do_issue = ti < nst && ti <= s + (GRP ? NST - 1 : NST - 2);
+            if (s == nc0 && nc1 > 0) {
+                // second A segment starts: bring the accumulators from the scale of segment 0 to that of segment 1 (exact powers of two)
+                const unsigned fb0 = lds_base + GG::WORK + (wm * 32 + 4 * h) * 4;
+                u32x4 f[4];
+                PG_READ(f[0], fb0, 0); PG_READ(f[1], fb0, 32); PG_READ(f[2], fb0, 64); PG_READ(f[3], fb0, 96);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] *= __uint_as_float(f[r >> 2][r & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto gap = [&](int m) __attribute__((always_inline)) {
+                if (m >= MFIRST && m < MFIRST + NPIECE) {
+                    if (do_issue && ABL != 1) dma_piece(m - MFIRST);
+                }
+                if (m == MFIRST + NPIECE - 1 && do_issue) dma_advance();
+                if (m == MBAR) {
+                    if (has_next) {
+                        // own DMAs of stage s + 1 have landed (those of stage s + 2, issued later, may still fly)
+                        if (s + 2 < nst) {
+                            if (wl < REMP) PG_VMCNT(NFULLP + 1); else PG_VMCNT(NFULLP);
+                        } else {
+                            PG_VMCNT(0);
+                        }
+                    }
+                    if (ABL != 2) __builtin_amdgcn_s_barrier();
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                const int cb = (PAR + j) & 1;
+                if (ABL == 3) {
+                } else if (j + 1 < TNW) {
+                    PG_READ(fb[cb ^ 1][0], Bh, (j + 1) * 2048);
+                    PG_READ(fb[cb ^ 1][1], Bl, (j + 1) * 2048);
+                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                } else if (has_next) {
+                    PG_READ(an[0], sbn + offAh, 0);
+                    PG_READ(an[1], sbn + offAl, 0);
+                    PG_READ(fb[cb ^ 1][0], sbn + offBh, 0);
+                    PG_READ(fb[cb ^ 1][1], sbn + offBl, 0);
+                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);               // MFMAs must not be hoisted above the wait
+                const f16x8 ah = __builtin_bit_cast(f16x8, ac[0]), al = __builtin_bit_cast(f16x8, ac[1]);
+                const f16x8 bh = __builtin_bit_cast(f16x8, fb[cb][0]), bl = __builtin_bit_cast(f16x8, fb[cb][1]);
+#define PG_MFMA(X, Y, g)                                                        \
+    if (ABL != 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X, Y, acc[j], 0, 0, 0);      \
+    else asm volatile("" ::"v"(X), "v"(Y));                                     \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    gap(3 * j + g);                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+                PG_MFMA(al, bh, 0)                               // smallest terms first
+                PG_MFMA(ah, bl, 1)
+                PG_MFMA(ah, bh, 2)
+#undef PG_MFMA
+            }
+        };
+
+        // ---- prologue: stages 0 .. NST - 2 in flight, stage 0 landed
+#pragma unroll
+        for (int q2 = 0; q2 < NST - 1; ++q2) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) dma_piece(i);
+            dma_advance();
+        }
+        if (wl < REMP) PG_VMCNT((NST - 2) * (NFULLP + 1)); else PG_VMCNT((NST - 2) * NFULLP);
+        __builtin_amdgcn_s_barrier();
+        PG_READ(fa0[0], lds_base + offAh, 0);
+        PG_READ(fa0[1], lds_base + offAl, 0);
+        PG_READ(fb[0][0], lds_base + offBh, 0);
+        PG_READ(fb[0][1], lds_base + offBl, 0);
+        PG_STAMP(1);
+        for (int s = 0; s < nst; s += 2) {
+            stage(s, std::integral_constant<int, 0>{}, fa0, fa1);
+            if (s + 1 < nst) stage(s + 1, std::integral_constant<int, TNW & 1>{}, fa1, fa0);
+            if (DBG && s < 100) PG_STAMP(8 + (s >> 1));
+        }
+    };
+    if (wn == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    PG_STAMP(2);
+    __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
+    PG_STAMP(3);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // The MFMA result has a lane's 16 values in 16 different rows.  Each wave transposes its 32 x 224 strip in two rounds of
+    // 16 rows through a private [16][EP_S] float region; afterwards lane (lr = lane / 4, q = lane % 4) owns the float4s
+    // 16 i + 4 q (i = 0 .. 13) of row 16 round + lr: a row is in ONE lane quad, so row statistics are two DPP steps.
+    const int lr = lane >> 2, q = lane & 3;
+    float* const ep = reinterpret_cast<float*>(lds) + w * (16 * EP_S);
+    const float* cinv = P.W.cinv + (size_t)nb * BN + wn * BNW + l31;
+    float cv[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) cv[j] = cinv[32 * j];
+    float4 v[2][NI];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = 8 * rr + r8;
+                ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * EP_S + 32 * j + l31] = acc[j][r] * cv[j];
+            }
+        wave_fence();
+        const float rinv = s_rinv[wm * 32 + 16 * rr + lr];       // undo the operand scales: exact powers of two
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 x = *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
+            x.x *= rinv; x.y *= rinv; x.z *= rinv; x.w *= rinv;
+            v[rr][i] = x;
+        }
+        wave_fence();
+    }
+    PG_STAMP(4);
+    const int mode = P.mode;
+    const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
+    int grow[2];
+    grow[0] = rb * 128 + wm * 32 + lr;
+    grow[1] = grow[0] + 16;
+
+    if (mode == PG_LN) {
+        // nn.LayerNorm over the C columns of the block (biased variance, eps inside the sqrt; transformero.py:88-94)
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (colw + 16 * i < C) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
+            s += dpp_xor1f(s);
+            s += dpp_xor2f(s);
+            if (q == 0) s_sum[wn * 128 + wm * 32 + 16 * rr + lr] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int rl = wm * 32 + 16 * rr + lr;
+            mean[rr] = (s_sum[rl] + s_sum[128 + rl]) / (float)C;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (colw + 16 * i < C) {
+                    const float d0 = v[rr][i].x - mean[rr], d1 = v[rr][i].y - mean[rr], d2 = v[rr][i].z - mean[rr], d3 = v[rr][i].w - mean[rr];
+                    s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
+                }
+            s += dpp_xor1f(s);
+            s += dpp_xor2f(s);
+            if (q == 0) s_sq[wn * 128 + rl] = s;
+        }
+        __syncthreads();
+        const float* __restrict__ gam = P.gamma;
+        const float* __restrict__ bet = P.beta;
+        const float* __restrict__ res = P.resid;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int rl = wm * 32 + 16 * rr + lr;
+            rstd[rr] = 1.0f / sqrtf((s_sq[rl] + s_sq[128 + rl]) / (float)C + 1e-5f);
+            const bool rok = grow[rr] < rows;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int col = colw + 16 * i;
+                if (col < C) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gam + col), b4 = *reinterpret_cast<const float4*>(bet + col);
+                    float4 y;
+                    y.x = (v[rr][i].x - mean[rr]) * rstd[rr] * g4.x + b4.x; y.y = (v[rr][i].y - mean[rr]) * rstd[rr] * g4.y + b4.y;
+                    y.z = (v[rr][i].z - mean[rr]) * rstd[rr] * g4.z + b4.z; y.w = (v[rr][i].w - mean[rr]) * rstd[rr] * g4.w + b4.w;
+                    if (res && rok) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(res + (size_t)grow[rr] * P.ldr + col);
+                        y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
+                    }
+                    v[rr][i] = y;
+                    if (P.out && rok) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
+                }
+            }
+        }
+    } else if (mode == PG_F32) {
+        const bool rot = (P.rot_mask >> nb) & 1;
+        const int halfC = P.rot_C >> 1;
+        const float scale = P.scale;
+        float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if (grow[rr] >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int col = colw + 16 * i;
+                if (col < C) {
+                    float4 x = v[rr][i];
+                    if (rot) {
+                        // x cos + swap(x) sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
+                        const int ridx = (col % P.rot_C) >> 1;
+                        const float2 c = *reinterpret_cast<const float2*>(P.cosT + (size_t)grow[rr] * halfC + ridx);
+                        const float2 sn = *reinterpret_cast<const float2*>(P.sinT + (size_t)grow[rr] * halfC + ridx);
+                        const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+                        x.x = __fadd_rn(__fmul_rn(x0, c.x), __fmul_rn(-x1, sn.x));
+                        x.y = __fadd_rn(__fmul_rn(x1, c.x), __fmul_rn(x0, sn.x));
+                        x.z = __fadd_rn(__fmul_rn(x2, c.y), __fmul_rn(-x3, sn.y));
+                        x.w = __fadd_rn(__fmul_rn(x3, c.y), __fmul_rn(x2, sn.y));
+                    }
+                    x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+                    *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = x;
+                }
+            }
+        }
+        PG_STAMP(6);
+        return;
+    } else if (P.relu) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                v[rr][i].x = fmaxf(v[rr][i].x, 0.f); v[rr][i].y = fmaxf(v[rr][i].y, 0.f);
+                v[rr][i].z = fmaxf(v[rr][i].z, 0.f); v[rr][i].w = fmaxf(v[rr][i].w, 0.f);
+            }
+    }
+    PG_STAMP(5);
+    if (!P.pimg) return;
+
+    // ---- plane image of the result.  Piece i of lane q is columns 16 i + 4 q .. + 3 of chunk (wn BNW / 16 + i): the lanes
+    // q and q ^ 1 hold the two halves of one 16-byte unit; for even i the even lane stores the unit, for odd i the odd one.
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const bool rok = grow[rr] < rows;
+        const int rowc = min(grow[rr], rows - 1);
+        float bound;
+        if (mode == PG_LN) bound = (P.bnd_res ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
+        else bound = fmaxf(P.bnd0[rowc], nc1 > 0 ? P.bnd1[rowc] : 0.f) * P.W.wnorm[nb];
+        if (P.pbnd && rok && nb == 0 && wn == 0 && q == 0) P.pbnd[grow[rr]] = bound;
+        const float sc = pow2i(scale_exp(bound));
+        const int rl = wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;
+        char* const rowp = P.pimg + (((size_t)rb * P.p_nct + P.p_kc0 + nb * (C >> 4) + wn * (BNW >> 4)) * 128 + rl) * 64;
+        const unsigned uh = (unsigned)(((q >> 1) ^ swz) << 4), ul = (unsigned)(((2 + (q >> 1)) ^ swz) << 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (wn * BNW + 16 * i >= C) continue;
+            unsigned h0, l0, h1, l1;
+            split2(v[rr][i].x * sc, v[rr][i].y * sc, h0, l0);
+            split2(v[rr][i].z * sc, v[rr][i].w * sc, h1, l1);
+            const unsigned ph0 = dpp_xor1(h0), ph1 = dpp_xor1(h1), pl0 = dpp_xor1(l0), pl1 = dpp_xor1(l1);
+            if ((((i ^ q) & 1) == 0) && rok) {
+                const uint4 H = (q & 1) ? make_uint4(ph0, ph1, h0, h1) : make_uint4(h0, h1, ph0, ph1);
+                const uint4 L = (q & 1) ? make_uint4(pl0, pl1, l0, l1) : make_uint4(l0, l1, pl0, pl1);
+                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + uh) = H;
+                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + ul) = L;
+            }
+        }
+    }
+    PG_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weights: per output column c the scale 2^s_c and the L1 norm; then the image
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pg_wscale_kernel(const float* __restrict__ W, int nblk, int C, int K, int BN, float* __restrict__ cinv,
+                                                        float* __restrict__ wnorm) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= nblk * BN) return;
+    const int nb = idx / BN, c = idx % BN;
+    if (c >= C) { if (lane == 0) cinv[idx] = 1.f; return; }
+    const float* wr = W + (size_t)(nb * C + c) * K;
+    float mx = 0.f, l1 = 0.f;
+    for (int k = lane; k < K; k += 64) { const float a = fabsf(wr[k]); mx = fmaxf(mx, a); l1 += a; }
+    mx = wave_max(mx);
+    l1 = wave_sum(l1);
+    if (lane == 0) {
+        cinv[idx] = pow2i(-scale_exp(mx));
+        if (l1 == l1) atomicMax(reinterpret_cast<unsigned*>(wnorm + nb), __float_as_uint(l1 * 1.0001f));   // non-negative floats order as integers
+        else wnorm[nb] = l1;
+    }
+}
+__global__ __launch_bounds__(256) void pg_pack_kernel(const float* __restrict__ W, int nblk, int C, int K, int BN, int nct, int piece_len,
+                                                      int piece_pad, const float* __restrict__ cinv, char* __restrict__ img) {
+    const size_t n = (size_t)nblk * nct * BN * 2, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int half = (int)(idx & 1);
+    size_t rest = idx >> 1;
+    const int c = (int)(rest % BN); rest /= BN;
+    const int kc = (int)(rest % nct), nb = (int)(rest / nct);
+    const float sc = c < C ? 1.0f / cinv[nb * BN + c] : 0.f;          // (a power of two: exact)
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kp = kc * 16 + half * 8 + e, piece = kp / piece_pad, off = kp % piece_pad, k = piece * piece_len + off;
+        x[e] = (c < C && off < piece_len && k < K) ? W[(size_t)(nb * C + c) * K + k] * sc : 0.f;
+    }
+    uint4 hi, lo;
+    split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y); split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
+    char* d = img + (((size_t)nb * nct + kc) * BN + c) * 64;
+    const int swz = (c >> 2) & 3;
+    *reinterpret_cast<uint4*>(d + ((half ^ swz) << 4)) = hi;
+    *reinterpret_cast<uint4*>(d + (((2 + half) ^ swz) << 4)) = lo;
+}
+
+// fp32 rows -> plane image, bound = max |row| (one wave per row; K <= 1024)
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ x, int ldx, int rows, int K, char* __restrict__ img,
+                                                              float* __restrict__ bnd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int ng = K >> 3, nct = K >> 4;                              // 8-wide groups
+    float4 v[2][2];
+    float mx = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+            v[g][0] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 8 * gi);
+            v[g][1] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 8 * gi + 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[g][0].x), fabsf(v[g][0].y)), fmaxf(fabsf(v[g][0].z), fabsf(v[g][0].w))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[g][1].x), fabsf(v[g][1].y)), fmaxf(fabsf(v[g][1].z), fabsf(v[g][1].w))));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) bnd[row] = mx;
+    const float sc = pow2i(scale_exp(mx));
+    const int rb = row >> 7, r = row & 127, swz = (r >> 2) & 3;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+            uint4 hi, lo;
+            split2(v[g][0].x * sc, v[g][0].y * sc, hi.x, lo.x); split2(v[g][0].z * sc, v[g][0].w * sc, hi.y, lo.y);
+            split2(v[g][1].x * sc, v[g][1].y * sc, hi.z, lo.z); split2(v[g][1].z * sc, v[g][1].w * sc, hi.w, lo.w);
+            char* d = img + (((size_t)rb * nct + (gi >> 1)) * 128 + r) * 64;
+            *reinterpret_cast<uint4*>(d + (((gi & 1) ^ swz) << 4)) = hi;
+            *reinterpret_cast<uint4*>(d + (((2 + (gi & 1)) ^ swz) << 4)) = lo;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const char* __restrict__ img, const float* __restrict__ bnd, int rows, int K,
+                                                            float* __restrict__ out, int ldo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int ng = K >> 3, nct = K >> 4, rb = row >> 7, r = row & 127, swz = (r >> 2) & 3;
+    const float inv = pow2i(-scale_exp(bnd[row]));
+    for (int gi = lane; gi < ng; gi += 64) {
+        const char* d = img + (((size_t)rb * nct + (gi >> 1)) * 128 + r) * 64;
+        const f16x8 hi = *reinterpret_cast<const f16x8*>(d + (((gi & 1) ^ swz) << 4));
+        const f16x8 lo = *reinterpret_cast<const f16x8*>(d + (((2 + (gi & 1)) ^ swz) << 4));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[(size_t)row * ldo + 8 * gi + e] = ((float)hi[e] + (float)lo[e]) * inv;
+    }
+}
+__global__ __launch_bounds__(256) void ln_bound_kernel(const float* __restrict__ g, const float* __restrict__ b, int C, float* __restrict__ out) {
+    __shared__ float sg[4], sb[4];
+    float mg = 0.f, mb = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { mg = fmaxf(mg, fabsf(g[c])); mb = fmaxf(mb, fabsf(b[c])); }
+    mg = wave_max(mg); mb = wave_max(mb);
+    if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = mg; sb[threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mg = fmaxf(fmaxf(sg[0], sg[1]), fmaxf(sg[2], sg[3]));
+        mb = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
+        out[0] = (sqrtf((float)C) * mg + mb) * 1.0001f;
+    }
+}
+
+using G7 = PgGeom<7, 4>;
+
+}  // namespace
+
+bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G7::BN; }
+int pgemm_bn() { return G7::BN; }
+
+int pgemm_configure() {
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+    return DR_OK;
+}
+
+int launch_pgemm(const PgBatch& g, hipStream_t st) {
+    if (g.n < 1 || g.n > 3) return DR_EINVAL;
+    int maxt = 0;
+    double flops = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const PgProblem& p = g.p[i];
+        if (!pgemm_shape_ok(p.C) || p.rows < 1 || p.nblk < 1 || p.nc0 < 1 || p.nc0 + (p.A1 ? p.nc1 : 0) < G7::NST) return DR_ENOSUP;
+        if (p.W.nct != p.nc0 + (p.A1 ? p.nc1 : 0)) return DR_EINVAL;
+        const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk;
+        maxt = tl > maxt ? tl : maxt;
+        flops += 2.0 * p.rows * p.C * p.nblk * 16.0 * p.W.nct;
+    }
+    ProfScope ps(PK_GEMM_SPLIT, flops, st);
+    static const bool dbg = [] { const char* e = getenv("DR_PG_STAMPS"); return e && atoi(e) != 0; }();
+    static const int abl = [] { const char* e = getenv("DR_PG_ABL"); return e ? atoi(e) : 0; }();
+    if (dbg && abl == 1) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 1>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    else if (dbg && abl == 2) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 2>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    else if (dbg && abl == 3) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 3>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    else if (dbg && abl == 4) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 4>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    else if (dbg) hipLaunchKernelGGL((pgemm_kernel<7, 4, true>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    else hipLaunchKernelGGL((pgemm_kernel<7, 4>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+size_t pgemm_weight_bytes(int nblk, int nct) {
+    size_t b = (size_t)nblk * nct * G7::B_ST;              // image
+    b += (size_t)nblk * G7::BN * 4;                        // cinv
+    b += (size_t)nblk * 4;                                 // wnorm
+    return (b + 255) & ~(size_t)255;
+}
+void pgemm_weight_view(void* buf, int nblk, int nct, PgW* v) {
+    char* p = (char*)buf;
+    v->img = p;
+    v->cinv = reinterpret_cast<const float*>(p + (size_t)nblk * nct * G7::B_ST);
+    v->wnorm = v->cinv + (size_t)nblk * G7::BN;
+    v->nct = nct;
+}
+int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st) {
+    if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
+    const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
+    PgW v;
+    pgemm_weight_view(buf, nblk, nct, &v);
+    DR_HIP_CHECK(hipMemsetAsync((void*)v.wnorm, 0, (size_t)nblk * 4, st));
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((nblk * G7::BN + 3) / 4), dim3(256), 0, st, W, nblk, C, K, G7::BN, (float*)v.cinv, (float*)v.wnorm);
+    DR_LAUNCH_CHECK();
+    const size_t n = (size_t)nblk * nct * G7::BN * 2;
+    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, nblk, C, K, G7::BN, nct, piece_len, piece_pad,
+                       v.cinv, (char*)v.img);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+// one block (C rows of W [C, K]) into block `nb` of a view
+int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& v, int nb, hipStream_t st) {
+    if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
+    const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
+    if (nct != v.nct) return DR_EINVAL;
+    float* cinv = (float*)v.cinv + (size_t)nb * G7::BN;
+    float* wnorm = (float*)v.wnorm + nb;
+    char* img = (char*)v.img + (size_t)nb * nct * G7::B_ST;
+    DR_HIP_CHECK(hipMemsetAsync(wnorm, 0, 4, st));
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((G7::BN + 3) / 4), dim3(256), 0, st, W, 1, C, K, G7::BN, cinv, wnorm);
+    DR_LAUNCH_CHECK();
+    const size_t n = (size_t)nct * G7::BN * 2;
+    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, 1, C, K, G7::BN, nct, piece_len, piece_pad,
+                       (const float*)cinv, img);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st) {
+    if (K % 16 || K > 1024 || ldx % 4 || ((uintptr_t)x & 15)) return DR_ENOSUP;
+    if (rows < 1) return DR_OK;
+    hipLaunchKernelGGL(planes_from_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, rows, K, img, bnd);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int launch_planes_to_f32(const char* img, const float* bnd, int rows, int K, float* out, int ldo, hipStream_t st) {
+    if (K % 16) return DR_ENOSUP;
+    if (rows < 1) return DR_OK;
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, img, bnd, rows, K, out, ldo);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(ln_bound_kernel, dim3(1), dim3(256), 0, st, gamma, beta, C, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}  // namespace dr
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI of the plane-image ops (include/diffreg_hip.h)
+// ---------------------------------------------------------------------------------------------------------------------
+using namespace dr;
+
+extern "C" {
+
+/* diagnostics (DR_PG_STAMPS=1): 100 MHz wall-clock stamps of workgroup 0 of the last plane GEMM launch; synchronises */
+int dr_debug_pgemm_stamps(long long* h_out128) {
+    DR_HIP_CHECK(hipMemcpyFromSymbol(h_out128, HIP_SYMBOL(g_pg_stamps), sizeof(long long) * 128));
+    return DR_OK;
+}
+
+size_t dr_plane_image_bytes(int rows, int K) { return (rows > 0 && K > 0 && K % 16 == 0) ? plane_image_bytes((size_t)rows, K) : 0; }
+
+int dr_planes_from_f32(int rows, int K, const float* x, int ldx, void* image, float* bound, void* stream) {
+    if (rows < 0 || K <= 0 || !x || !image || !bound || ldx < K) return DR_EINVAL;
+    return launch_planes_from_f32(x, ldx, rows, K, (char*)image, bound, (hipStream_t)stream);
+}
+
+int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream) {
+    if (rows < 0 || K <= 0 || !out || !image || !bound || ldo < K) return DR_EINVAL;
+    return launch_planes_to_f32((const char*)image, bound, rows, K, out, ldo, (hipStream_t)stream);
+}
+
+static int plane_nct(int K, int piece_len, int piece_pad) { return (K + piece_len - 1) / piece_len * piece_pad / 16; }
+
+size_t dr_plane_weight_bytes(int nblk, int C, int K, int piece_len, int piece_pad) {
+    if (nblk < 1 || !pgemm_shape_ok(C) || K < 1 || piece_len < 1 || piece_pad < piece_len || piece_pad % 16) return 0;
+    return pgemm_weight_bytes(nblk, plane_nct(K, piece_len, piece_pad));
+}
+
+int dr_pack_weight_planes_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream) {
+    if (nblk < 1 || K < 1 || !W || !packed || ((uintptr_t)packed & 15)) return DR_EINVAL;
+    return pgemm_pack_weights(W, nblk, C, K, piece_len, piece_pad, packed, (hipStream_t)stream);
+}
+
+int dr_ln_bound_f32(int C, const float* gamma, const float* beta, float* out, void* stream) {
+    if (C < 1 || !gamma || !beta || !out) return DR_EINVAL;
+    return launch_ln_bound(gamma, beta, C, out, (hipStream_t)stream);
+}
+
+int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
+    if (!a || a->rows < 1 || a->nblk < 1 || !a->a0 || !a->bound0 || !a->packed || a->k0 % 16 || (a->a1 && (a->k1 % 16 || !a->bound1))) return DR_EINVAL;
+    if (a->mode < 0 || a->mode > 2) return DR_EINVAL;
+    PgBatch g;
+    memset(&g, 0, sizeof(g));
+    PgProblem& p = g.p[0];
+    p.A0 = (const char*)a->a0; p.bnd0 = a->bound0; p.nc0 = a->k0 / 16;
+    p.A1 = (const char*)a->a1; p.bnd1 = a->bound1; p.nc1 = a->a1 ? a->k1 / 16 : 0;
+    pgemm_weight_view((void*)a->packed, a->nblk, p.nc0 + p.nc1, &p.W);
+    p.nblk = a->nblk; p.rows = a->rows; p.C = a->C; p.mode = a->mode;
+    p.out = a->out; p.ldo = a->ldo; p.blk_stride = a->blk_stride;
+    p.cosT = a->cos_t; p.sinT = a->sin_t; p.rot_mask = a->rot_mask; p.rot_C = a->rot_C > 0 ? a->rot_C : a->C; p.scale = a->scale;
+    p.pimg = (char*)a->out_image; p.p_nct = a->out_image_k / 16; p.p_kc0 = a->out_k0 / 16; p.pbnd = a->out_bound;
+    p.relu = a->relu;
+    p.gamma = a->gamma; p.beta = a->beta; p.resid = a->resid; p.ldr = a->ldr; p.bnd_res = a->bound_resid; p.lnB = a->ln_bound;
+    if (p.mode == PG_F32 && (!p.out || p.ldo % 4 || p.blk_stride % 4 || ((uintptr_t)p.out & 15))) return DR_EINVAL;
+    if (p.mode == PG_F32 && p.rot_mask && (!p.cosT || !p.sinT || p.rot_C % 4)) return DR_EINVAL;
+    if (p.mode != PG_F32 && p.pimg && (!p.pbnd || a->out_image_k % 16 || a->out_k0 % 16 || a->out_k0 + a->nblk * a->C > a->out_image_k)) return DR_EINVAL;
+    if (p.mode == PG_LN && (!p.gamma || !p.beta || !p.lnB || a->nblk != 1 || (p.out && (p.ldo % 4 || ((uintptr_t)p.out & 15))) ||
+                            (p.resid && (p.ldr % 4 || ((uintptr_t)p.resid & 15))))) return DR_EINVAL;
+    if (p.mode != PG_F32 && !p.pimg && !p.out) return DR_EINVAL;
+    g.n = 1;
+    return launch_pgemm(g, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -33,7 +33,7 @@ def sampling_times(steps, timesteps=1000):
 class DenoiseEngine:
     def __init__(self, state, *, variant, C, H, voxel, origin, steps, sk_iters=3, sample_rate=1.0, max_condition_num=0.0,
                  n_layers=6, device="cuda:0", strict_f64=False, prefix_t="denoising_transformer.",
-                 prefix_m="denoising_coarse_matching."):
+                 prefix_m="denoising_coarse_matching.", prepack=True):
         """state: mapping name -> tensor in the reference state-dict layout."""
         lib.ensure_init()
         self.device = torch.device(device)
@@ -69,6 +69,14 @@ class DenoiseEngine:
         self.cfg = cfg
         self._ws = None
         self._graphs = {}
+        # the weights are immutable for the life of the engine: their plane images are packed once (dr_loop_prepack)
+        self._packed = None
+        nb = lib.raw().dr_loop_prepack_bytes(ctypes.byref(cfg))
+        if nb and prepack:
+            self._packed = torch.empty(nb, dtype=torch.uint8, device=dev)
+            lib.check(lib.raw().dr_loop_prepack(ctypes.byref(cfg), ctypes.byref(self.w), self._packed.data_ptr(), nb,
+                                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            self.w.prepacked = self._packed.data_ptr()
 
     # ------------------------------------------------------------------------------------------
     def _workspace(self, P, N, M):

@@ -47,7 +47,7 @@ class LoopConfig(ctypes.Structure):
 
 class LoopWeights(ctypes.Structure):
     _fields_ = [("layers", ctypes.POINTER(LayerWeights)), ("src_proj", c_void_p), ("bin_score", c_void_p),
-                ("pe_freq", c_void_p)]
+                ("pe_freq", c_void_p), ("prepacked", c_void_p)]
 
 
 class FusionLayerWeights(ctypes.Structure):
@@ -60,6 +60,20 @@ class FusionWeights(ctypes.Structure):
                [(n, c_void_p) for n in ("img_emb_w", "img_emb_b", "pcd_emb_w", "pcd_emb_b", "img_in_w", "img_in_b", "dino_w",
                                         "dino_b", "all_w", "all_b", "pcd_in_w", "pcd_in_b", "out_w", "out_b", "src_proj",
                                         "bin_score")]
+
+
+class PlanesLinear(ctypes.Structure):
+    """dr_planes_linear (include/diffreg_hip.h)"""
+    _fields_ = [("rows", c_int), ("C", c_int), ("nblk", c_int),
+                ("a0", c_void_p), ("bound0", c_void_p), ("k0", c_int),
+                ("a1", c_void_p), ("bound1", c_void_p), ("k1", c_int),
+                ("packed", c_void_p), ("mode", c_int),
+                ("out", c_void_p), ("ldo", c_int), ("blk_stride", c_int),
+                ("cos_t", c_void_p), ("sin_t", c_void_p), ("rot_mask", c_int), ("rot_C", c_int), ("scale", c_float),
+                ("out_image", c_void_p), ("out_image_k", c_int), ("out_k0", c_int), ("out_bound", c_void_p),
+                ("relu", c_int),
+                ("gamma", c_void_p), ("beta", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("bound_resid", c_void_p),
+                ("ln_bound", c_void_p)]
 
 
 class Loop2D3DConfig(ctypes.Structure):
@@ -85,6 +99,13 @@ SIGNATURES.update({
     "dr_pack_weight_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_linear_packed_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_float, c_void_p]),
+    "dr_plane_image_bytes": (c_size_t, [c_int, c_int]),
+    "dr_planes_from_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_planes_to_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dr_plane_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_ln_bound_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_linear_planes_f32": (c_int, [ctypes.POINTER(PlanesLinear), c_void_p]),
     "dr_linear_ex_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dr_kpconv_gather_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_void_p]),
@@ -102,10 +123,13 @@ SIGNATURES.update({
     "dr_debug_gemm_f16x2": (None, [c_int]),
     "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
     "dr_debug_gemm_stamps": (c_int, [c_void_p]),
+    "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_loop_prepack_bytes": (c_size_t, [_P(LoopConfig)]),
+    "dr_loop_prepack": (c_int, [_P(LoopConfig), _P(LoopWeights), c_void_p, c_size_t, c_void_p]),
     "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),
     "dr_denoise_loop": (c_int, [_P(LoopConfig), _P(LoopWeights), c_int, c_int, c_int] + [c_void_p] * 14 +
                         [_P(LoopTrace), c_void_p, c_size_t, c_void_p]),
@@ -186,6 +210,65 @@ def mask_u8(m):
     if m.dtype == torch.bool:
         return m.contiguous().view(torch.uint8)
     return (m != 0).contiguous().view(torch.uint8)
+
+
+# ---- plane images (two-plane fp16 operand images of the layer GEMMs) -------------------------------------------------
+PL_F32, PL_PLANES, PL_LN = 0, 1, 2
+
+
+def planes_from_f32(x):
+    """x [rows, K] fp32 -> (image uint8, bound [rows])"""
+    ensure_init()
+    x = x.contiguous()
+    rows, K = x.shape
+    img = torch.zeros(_lib.dr_plane_image_bytes(rows, K), dtype=torch.uint8, device=x.device)
+    bnd = torch.empty(rows, device=x.device)
+    check(_lib.dr_planes_from_f32(rows, K, ptr(x), K, ptr(img), ptr(bnd), stream_of(x)))
+    return img, bnd
+
+
+def planes_to_f32(img, bnd, rows, K):
+    out = torch.empty(rows, K, device=img.device)
+    check(_lib.dr_planes_to_f32(rows, K, ptr(img), ptr(bnd), ptr(out), K, stream_of(out)))
+    return out
+
+
+def pack_weight_planes(W, nblk, C, piece_len=None, piece_pad=None):
+    """W [nblk * C, K] -> packed image (uint8 tensor)"""
+    ensure_init()
+    W = W.contiguous()
+    K = W.shape[1]
+    piece_len = piece_len or K
+    piece_pad = piece_pad or K
+    nbytes = _lib.dr_plane_weight_bytes(nblk, C, K, piece_len, piece_pad)
+    if nbytes == 0:
+        raise RuntimeError("unsupported plane weight shape")
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=W.device)
+    check(_lib.dr_pack_weight_planes_f32(nblk, C, K, piece_len, piece_pad, ptr(W), ptr(buf), stream_of(W)))
+    return buf
+
+
+def ln_bound(gamma, beta):
+    out = torch.empty(1, device=gamma.device)
+    check(_lib.dr_ln_bound_f32(gamma.numel(), ptr(gamma), ptr(beta), ptr(out), stream_of(gamma)))
+    return out
+
+
+def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, k1=0, out=None, ldo=0, blk_stride=0, cos_t=None,
+                  sin_t=None, rot_mask=0, rot_C=0, scale=1.0, out_image=None, out_image_k=0, out_k0=0, out_bound=None, relu=False,
+                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None):
+    a = PlanesLinear()
+    a.rows, a.C, a.nblk = rows, C, nblk
+    dp = lambda t_: None if t_ is None else t_.data_ptr()
+    a.a0, a.bound0, a.k0 = dp(a0), dp(b0), k0
+    a.a1, a.bound1, a.k1 = dp(a1), dp(b1), k1
+    a.packed, a.mode = dp(packed), mode
+    a.out, a.ldo, a.blk_stride = dp(out), ldo, blk_stride
+    a.cos_t, a.sin_t, a.rot_mask, a.rot_C, a.scale = dp(cos_t), dp(sin_t), rot_mask, rot_C, scale
+    a.out_image, a.out_image_k, a.out_k0, a.out_bound = dp(out_image), out_image_k, out_k0, dp(out_bound)
+    a.relu = 1 if relu else 0
+    a.gamma, a.beta, a.resid, a.ldr, a.bound_resid, a.ln_bound = dp(gamma), dp(beta), dp(resid), ldr, dp(bound_resid), dp(lnb)
+    check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
 
 
 def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift=False, apply_mask=False,

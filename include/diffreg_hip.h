@@ -121,6 +121,47 @@ int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* str
 int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
                          int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Plane images: the layer nn.Linears of the loop with BOTH operands pre-split into fp16 hi / lo planes (the
+ * default path of dr_denoise_loop for C <= 448, C % 16 == 0; 3D/models/transformero.py:26-96).
+ * Image of X [rows, K] (K % 16 == 0, rows padded to a multiple of 128): [row / 128][k / 16][row % 128][64 bytes], the
+ * 64 bytes = 16-byte units (hi k 0..7 | hi k 8..15 | lo k 0..7 | lo k 8..15) stored at unit ^ ((row >> 2) & 3);
+ * hi = fp16(x 2^s), lo = fp16(x 2^s - hi), s = 14 - floor(log2(bound[row])) with bound[row] >= max |x[row][:]| (an
+ * upper bound that producers propagate analytically, so nobody sweeps a row for its maximum).  x = (hi + lo) 2^-s
+ * keeps 22 significand bits for |x| >= 2^-17 bound and is rounded to 2^-40 bound absolutely below.
+ * A 128-row block of one k-chunk is 8 KB contiguous and is the LDS image of the GEMM: operands stream by LDS-DMA.
+ */
+size_t dr_plane_image_bytes(int rows, int K);
+/* fp32 rows -> image, bound[row] = max |x[row][:]| (the external features entering the first layer) */
+int dr_planes_from_f32(int rows, int K, const float* x, int ldx, void* image, float* bound, void* stream);
+/* image -> fp32 rows (tests) */
+int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream);
+/* weights W [nblk * C, K] (nn.Linear layout; nblk stacked layers of C output columns each, C <= 448, C % 16 == 0) ->
+ * packed image + per-column scales + per-block L1 norms.  The k order of the image is
+ * k' = (k / piece_len) * piece_pad + k % piece_len (zeros where k' % piece_pad >= piece_len): piece_len = piece_pad = K for
+ * the identity; (d, round_up(d, 16)) for the merge projection behind the attention kernel's head-padded image. */
+size_t dr_plane_weight_bytes(int nblk, int C, int K, int piece_len, int piece_pad);
+int dr_pack_weight_planes_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream);
+/* *out = (sqrt(C) max|gamma| + max|beta|): upper bound of |LayerNorm(.) gamma + beta| (device scalar) */
+int dr_ln_bound_f32(int C, const float* gamma, const float* beta, float* out, void* stream);
+
+#define DR_PL_F32 0     /* out[row][nb * blk_stride + c] = rotary(acc) * scale                                      */
+#define DR_PL_PLANES 1  /* out_image (+ out_bound) = [relu](acc); bound = max(bound0, bound1) * ||W_nb||            */
+#define DR_PL_LN 2      /* y = LayerNorm(acc) gamma + beta [+ resid]; -> out (optional) and out_image (optional)    */
+typedef struct {
+    int rows, C, nblk;             /* out columns = nblk blocks of C                                                  */
+    const void* a0; const float* bound0; int k0;   /* A operand = [a0 | a1] along k (images + their bounds)           */
+    const void* a1; const float* bound1; int k1;   /* a1 may be NULL                                                  */
+    const void* packed;            /* dr_pack_weight_planes_f32 of W [nblk * C, k0 + k1] (same k order as the images)  */
+    int mode;                      /* DR_PL_*                                                                         */
+    float* out; int ldo; int blk_stride;
+    const float* cos_t; const float* sin_t; int rot_mask; int rot_C; float scale;   /* bit nb of rot_mask: rotary      */
+    void* out_image; int out_image_k; int out_k0; float* out_bound;   /* block nb -> columns out_k0 + nb * C ..        */
+    int relu;
+    const float* gamma; const float* beta; const float* resid; int ldr; const float* bound_resid; const float* ln_bound;
+} dr_planes_linear;
+int dr_linear_planes_f32(const dr_planes_linear* args, void* stream);
+
 /* nn.Linear with a bias and explicit leading dimensions (x [rows, lda], out [rows, ldo]): the 1x1 Conv1d `coarse_out`
  * of the backbone (3D/models/backbone.py:66, 155-156) and its UnaryBlocks (bias = NULL). */
 int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const float* W, const float* bias, float* out,
@@ -196,6 +237,7 @@ void dr_debug_gemm_wide_min(int tiles);
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
 int dr_debug_gemm_stamps(long long* h_out256);
+int dr_debug_pgemm_stamps(long long* h_out128);   /* with DR_PG_STAMPS=1: phase stamps of workgroup 0 of the last plane GEMM */
 /* packed GEMMs: 1 = two-plane fp16 operand split with exact power-of-two row / column scaling (three MFMA products per
  * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = environment DR_GEMM_F16X2 (default 1).
  * Set before weights are packed: an image is only readable in the mode it was packed in. */
@@ -240,7 +282,15 @@ typedef struct {
     const float* src_proj;     /* denoising_coarse_matching.src_proj.weight [C,C] (Q1)       */
     const float* bin_score;    /* device pointer to one float                                */
     const float* pe_freq;      /* device [C/6], see dr_vol_pe_f32                            */
+    const void* prepacked;     /* dr_loop_prepack image of THESE weights (device, 256-byte aligned) or NULL: the loop
+                                * then packs them into its workspace at every call (weights may change between calls) */
 } dr_loop_weights;
+
+/* The layer weights as fp16 hi / lo plane images + per-column scales + per-layer LayerNorm bounds, packed ONCE for the
+ * life of an engine (immutable weights): pass the buffer as dr_loop_weights.prepacked.  0 bytes = this configuration does
+ * not use the plane path (C > 448 or C % 16 != 0): leave prepacked NULL. */
+size_t dr_loop_prepack_bytes(const dr_loop_config* cfg);
+int dr_loop_prepack(const dr_loop_config* cfg, const dr_loop_weights* w, void* packed, size_t packed_bytes, void* stream);
 
 typedef struct {                /* all optional (NULL to skip); per-step records for parity tests */
     float* x0;                 /* [steps,P,N,M]  x_start of every step                       */
