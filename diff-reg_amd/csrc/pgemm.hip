@@ -76,7 +76,7 @@ struct PgGeom {
     static constexpr int EP_S = (BNW - 48 + 63) / 64 * 64 + 48;   // row stride of the transposition, = 48 mod 64 floats: conflict-free float4 reads
     static constexpr int EP_BYTES = 8 * 16 * EP_S * 4;
     static constexpr int WORK = RING > EP_BYTES ? RING : EP_BYTES;
-    static constexpr int SMEM = WORK + 6 * 128 * 4;         // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128]
+    static constexpr int SMEM = WORK + 6 * 128 * 4 + 2 * BN * 4;   // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta [2][BN]
     static constexpr int MID = (TNW - 1) / 2 - 1 < 0 ? 0 : (TNW - 1) / 2 - 1;   // the barrier sits after this tile (2 of 7)
 };
 
@@ -85,8 +85,10 @@ struct PgGeom {
 
 __device__ long long g_pg_stamps[128];
 #define PG_STAMP(i) do { if (DBG && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_pg_stamps[i] = wall_clock64(); } while (0)
+// cycle stamps (s_memtime) inside stage 10 of waves 0 and 4 of workgroup 0: slots 64 + 16 grp + i
+#define PG_CSTAMP(i) do { if (DBG && s == 10 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 255) == 0) g_pg_stamps[64 + 16 * GRP + (i)] = clock64(); } while (0)
 
-template <int TNW, int NST, bool DBG = false, int ABL = 0>
+template <int TNW, int NST, int MODE, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgemm_kernel(PgBatch G) {
     using GG = PgGeom<TNW, NST>;
     constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    u32x4 fa0[2], fa1[2], fb[2][2];
+    u32x4 fa0[2], fa1[2], fx[TNW / 2][2], fy[TNW - TNW / 2][2];
     PG_STAMP(0);
 
     // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream but keep
@@ -147,42 +149,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int NPIECE = GRP ? 2 + (WB_CNT + 3) / 4 : (NW0 + 3) / 4;
         constexpr int NFULLP = GRP ? 2 + WB_CNT / 4 : NW0 / 4;       // pieces every wave of the group issues
         constexpr int REMP = GRP ? WB_CNT % 4 : NW0 % 4;             // waves (local index) < REMP issue one more
-        constexpr int MFIRST = GRP ? 3 * (TNW - 2) : 0;              // gap (MFMA index) of the first DMA piece
-        constexpr int MBAR = GRP ? 3 * (TNW - 2) - 1 : 5;            // the barrier follows this MFMA
         const int wl = w & 3;
-        const char* pa = P.A0 + (size_t)rb * nc0 * A_ST + lane * 16;
-        const char* pb = P.W.img + (size_t)nb * nst * GG::B_ST + lane * 16;
-        const char* const pa1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * A_ST + lane * 16 : nullptr;
+        // DMA pieces of this wave (1 KB instructions; `ins` = index inside the A block / the weight block of a stage):
+        //   group 1: A instructions 2 wl, 2 wl + 1, then weight instructions st0 .. (WB_CNT dealt 3, 3, 2, 2)
+        //   group 0: weight instructions st0 .. (the other NB - WB_CNT dealt 5, 5, 4, 4)
+        // issued in the SGPR-base + VGPR-offset + immediate form: per piece an s_mov to M0 and the load, nothing else
+        const int st0 = GRP ? wl * (WB_CNT / 4) + min(wl, WB_CNT % 4) : WB_CNT + wl * (NW0 / 4) + min(wl, NW0 % 4);
+        const unsigned voffW = lane * 16 + st0 * 1024, voffW4 = voffW + 4096, voffA = lane * 16 + 2 * wl * 1024;
+        const char* ga = P.A0 + (size_t)rb * nc0 * A_ST;             // A block of stage ti (wave-uniform)
+        const char* gb = P.W.img + (size_t)nb * nst * GG::B_ST;      // weight block of stage ti
+        const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * A_ST : nullptr;
         int ti = 0;                                                  // next stage this wave issues
-        auto dma_piece = [&](int i) __attribute__((always_inline)) {
-            char* dst = lds + (ti % NST) * STAGE;
+        // (the instruction's immediate offset is added to the global address AND to the LDS address M0 + 16 lane)
+#define PG_DMA(ldsaddr, voff, gbase, imm)                                                                  \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(ldsaddr), "v"(voff), "s"(gbase), "i"(imm) : "memory")
+        auto dma_piece = [&](int p, unsigned dstb) __attribute__((always_inline)) {   // dstb = LDS address of the slot of stage ti
+            const unsigned m0w = dstb + A_ST + st0 * 1024;
             if (GRP) {
-                if (i < 2) {
-                    __builtin_amdgcn_global_load_lds((glb_void*)(pa + (2 * wl + i) * 1024), (lds_void*)(dst + (2 * wl + i) * 1024), 16, 0, 0);
-                } else {
-                    const int ins = wl + 4 * (i - 2);
-                    if (i - 2 < WB_CNT / 4 || wl < REMP)
-                        __builtin_amdgcn_global_load_lds((glb_void*)(pb + ins * 1024), (lds_void*)(dst + A_ST + ins * 1024), 16, 0, 0);
-                }
+                if (p < 2) { if (ABL != 6) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024); }
+                else if (ABL == 5) {}
+                else if (p - 2 < WB_CNT / 4 || wl < WB_CNT % 4) PG_DMA(m0w, voffW, gb, (p - 2) * 1024);
+            } else if (ABL == 5) {
             } else {
-                const int ins = WB_CNT + wl + 4 * i;
-                if (i < NW0 / 4 || wl < REMP)
-                    __builtin_amdgcn_global_load_lds((glb_void*)(pb + ins * 1024), (lds_void*)(dst + A_ST + ins * 1024), 16, 0, 0);
+                if (p < 4) { if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w, voffW, gb, (p & 3) * 1024); }
+                else if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w + 4096, voffW4, gb, 0);
             }
         };
         auto dma_advance = [&]() __attribute__((always_inline)) {
             ++ti;
-            pb += GG::B_ST;
-            pa = (ti == nc0) ? pa1 : pa + A_ST;
+            gb += GG::B_ST;
+            ga = (ti == nc0) ? ga1 : ga + A_ST;
         };
 
-        // One stage.  PAR = index of the B fragment buffer tile 0 uses (the buffers alternate tile by tile, across stages too).
-        auto stage = [&](int s, auto par_t, u32x4 (&ac)[2], u32x4 (&an)[2]) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_t)::value;
+        // One stage = two MFMA bursts with no wait inside: tiles 0 .. NT1 - 1 (fragment set X), then tiles NT1 .. TNW - 1 (set Y).
+        // The fragment reads of a burst are issued in the MFMA gaps of the burst BEFORE it (Y during burst 1; the next stage's
+        // A fragments and X during burst 2), so a read has a whole burst (~300 cycles alone, twice that beside the partner
+        // wave) to return and a wave parks only at the stage's barrier.  (With reads one tile ahead both waves of a SIMD sat in
+        // s_waitcnt lgkmcnt at the same time: 34 % of the wave cycles parked, the MFMA pipe 48 % busy.)
+        auto stage = [&](int s, auto steady_t, u32x4 (&ac)[2], u32x4 (&an)[2]) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_t)::value;   // every condition of the tail is known true
+            constexpr int NT1 = TNW / 2, NT2 = TNW - NT1, M1 = 3 * NT1;      // M1 = MFMAs of burst 1
             const unsigned sb = lds_base + (unsigned)(s % NST) * STAGE, sbn = lds_base + (unsigned)((s + 1) % NST) * STAGE;
-            const unsigned Bh = sb + offBh, Bl = sb + offBl;
-            const bool has_next = s + 1 < nst;
-            const bool do_issue = ti < nst && ti <= s + (GRP ? NST - 1 : NST - 2);
+            const unsigned Bh = sb + offBh, Bl = sb + offBl, Bhn = sbn + offBh, Bln = sbn + offBl;
+            const bool has_next = STEADY || s + 1 < nst;
+            const bool do_issue = STEADY || ti < nst;
+            const unsigned dstb = lds_base + (unsigned)(ti % NST) * STAGE;
             if (s == nc0 && nc1 > 0) {
                 // second A segment starts: bring the accumulators from the scale of segment 0 to that of segment 1 (exact powers of two)
                 const unsigned fb0 = lds_base + GG::WORK + (wm * 32 + 4 * h) * 4;
@@ -197,72 +208,101 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
             auto gap = [&](int m) __attribute__((always_inline)) {
-                if (m >= MFIRST && m < MFIRST + NPIECE) {
-                    if (do_issue && ABL != 1) dma_piece(m - MFIRST);
+                // ---- fragment reads of the next burst: two per gap, in the first gaps of the burst (the wait that ends the burst
+                // then finds them landed: the last read is >= 4 MFMAs old)
+                if (ABL != 3) {
+                    if (m < NT2) {                                       // set Y: tile NT1 + m
+                        PG_READ(fy[m][0], Bh, (NT1 + m) * 2048);
+                        PG_READ(fy[m][1], Bl, (NT1 + m) * 2048);
+                    } else if (m == M1 && has_next) {                    // next stage's A fragments
+                        PG_READ(an[0], sbn + offAh, 0);
+                        PG_READ(an[1], sbn + offAl, 0);
+                    } else if (m > M1 && m <= M1 + NT1 && has_next) {    // next stage's set X
+                        PG_READ(fx[m - M1 - 1][0], Bhn, (m - M1 - 1) * 2048);
+                        PG_READ(fx[m - M1 - 1][1], Bln, (m - M1 - 1) * 2048);
+                    }
                 }
-                if (m == MFIRST + NPIECE - 1 && do_issue) dma_advance();
-                if (m == MBAR) {
+                // ---- DMA pieces: group 0 in burst 1 (stage s + NST - 2), group 1 in burst 2 (stage s + NST - 1)
+                constexpr int MF = GRP ? M1 + 1 : 0, STEP = GRP ? 2 : 1;
+                if (m >= MF && m < MF + STEP * NPIECE && (m - MF) % STEP == 0) {
+                    if (do_issue && ABL != 1) dma_piece((m - MF) / STEP, dstb);
+                    if ((m - MF) / STEP == NPIECE - 1 && do_issue) dma_advance();
+                }
+                // ---- the stage's barrier, between the bursts
+                if (m == M1 - 1) {
+                    PG_CSTAMP(1);
                     if (has_next) {
                         // own DMAs of stage s + 1 have landed (those of stage s + 2, issued later, may still fly)
-                        if (s + 2 < nst) {
+                        if (STEADY || s + 2 < nst) {
                             if (wl < REMP) PG_VMCNT(NFULLP + 1); else PG_VMCNT(NFULLP);
                         } else {
                             PG_VMCNT(0);
                         }
                     }
+                    PG_CSTAMP(2);
                     if (ABL != 2) __builtin_amdgcn_s_barrier();
+                    PG_CSTAMP(3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set Y has arrived (issued during burst 1)
+                    PG_CSTAMP(4);
                 }
             };
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) {
-                const int cb = (PAR + j) & 1;
-                if (ABL == 3) {
-                } else if (j + 1 < TNW) {
-                    PG_READ(fb[cb ^ 1][0], Bh, (j + 1) * 2048);
-                    PG_READ(fb[cb ^ 1][1], Bl, (j + 1) * 2048);
-                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                } else if (has_next) {
-                    PG_READ(an[0], sbn + offAh, 0);
-                    PG_READ(an[1], sbn + offAl, 0);
-                    PG_READ(fb[cb ^ 1][0], sbn + offBh, 0);
-                    PG_READ(fb[cb ^ 1][1], sbn + offBl, 0);
-                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);               // MFMAs must not be hoisted above the wait
-                const f16x8 ah = __builtin_bit_cast(f16x8, ac[0]), al = __builtin_bit_cast(f16x8, ac[1]);
-                const f16x8 bh = __builtin_bit_cast(f16x8, fb[cb][0]), bl = __builtin_bit_cast(f16x8, fb[cb][1]);
+            const f16x8 ah = __builtin_bit_cast(f16x8, ac[0]), al = __builtin_bit_cast(f16x8, ac[1]);
 #define PG_MFMA(X, Y, g)                                                        \
     if (ABL != 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X, Y, acc[j], 0, 0, 0);      \
     else asm volatile("" ::"v"(X), "v"(Y));                                     \
     __builtin_amdgcn_sched_barrier(0);                                          \
     gap(3 * j + g);                                                             \
     __builtin_amdgcn_sched_barrier(0);
+            PG_CSTAMP(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // A fragments and set X of this stage (issued during the previous burst 2)
+            PG_CSTAMP(6);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, fx[j][0]), bl = __builtin_bit_cast(f16x8, fx[j][1]);
                 PG_MFMA(al, bh, 0)                               // smallest terms first
                 PG_MFMA(ah, bl, 1)
                 PG_MFMA(ah, bh, 2)
-#undef PG_MFMA
             }
+#pragma unroll
+            for (int j = NT1; j < TNW; ++j) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, fy[j - NT1][0]), bl = __builtin_bit_cast(f16x8, fy[j - NT1][1]);
+                PG_MFMA(al, bh, 0)
+                PG_MFMA(ah, bl, 1)
+                PG_MFMA(ah, bh, 2)
+            }
+#undef PG_MFMA
+            PG_CSTAMP(5);
         };
 
-        // ---- prologue: stages 0 .. NST - 2 in flight, stage 0 landed
+        // ---- prologue: group 1 puts stages 0 .. NST - 2 in flight, group 0 stages 0 .. NST - 3 (it issues stage s + NST - 2 in
+        // the first burst of stage s, group 1 stage s + NST - 1 in the second); stage 0 landed
 #pragma unroll
-        for (int q2 = 0; q2 < NST - 1; ++q2) {
+        for (int q2 = 0; q2 < NST - 2 + GRP; ++q2) {
+            const unsigned dstb = lds_base + (unsigned)q2 * STAGE;
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) dma_piece(i);
+            for (int i = 0; i < NPIECE; ++i) dma_piece(i, dstb);
             dma_advance();
         }
-        if (wl < REMP) PG_VMCNT((NST - 2) * (NFULLP + 1)); else PG_VMCNT((NST - 2) * NFULLP);
+        if (wl < REMP) PG_VMCNT((NST - 3 + GRP) * (NFULLP + 1)); else PG_VMCNT((NST - 3 + GRP) * NFULLP);
         __builtin_amdgcn_s_barrier();
         PG_READ(fa0[0], lds_base + offAh, 0);
         PG_READ(fa0[1], lds_base + offAl, 0);
-        PG_READ(fb[0][0], lds_base + offBh, 0);
-        PG_READ(fb[0][1], lds_base + offBl, 0);
+#pragma unroll
+        for (int j = 0; j < TNW / 2; ++j) {
+            PG_READ(fx[j][0], lds_base + offBh, j * 2048);
+            PG_READ(fx[j][1], lds_base + offBl, j * 2048);
+        }
         PG_STAMP(1);
-        for (int s = 0; s < nst; s += 2) {
-            stage(s, std::integral_constant<int, 0>{}, fa0, fa1);
-            if (s + 1 < nst) stage(s + 1, std::integral_constant<int, TNW & 1>{}, fa1, fa0);
+        int s = 0;
+        for (; s + 1 < nst - (NST - 1); s += 2) {                    // steady state: every stage issues, has a successor
+            stage(s, std::true_type{}, fa0, fa1);
+            stage(s + 1, std::true_type{}, fa1, fa0);
+            if (DBG && s < 100) PG_STAMP(8 + (s >> 1));
+        }
+        for (; s < nst; s += 2) {                                    // tail
+            stage(s, std::false_type{}, fa0, fa1);
+            if (s + 1 < nst) stage(s + 1, std::false_type{}, fa1, fa0);
             if (DBG && s < 100) PG_STAMP(8 + (s >> 1));
         }
     };
@@ -282,9 +322,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float cv[TNW];
 #pragma unroll
     for (int j = 0; j < TNW; ++j) cv[j] = cinv[32 * j];
-    float4 v[2][NI];
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    auto transpose_round = [&](int rr, float4 (&dst)[NI]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < TNW; ++j)
 #pragma unroll
@@ -298,19 +336,100 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < NI; ++i) {
             float4 x = *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
             x.x *= rinv; x.y *= rinv; x.z *= rinv; x.w *= rinv;
-            v[rr][i] = x;
+            dst[i] = x;
         }
         wave_fence();
-    }
-    PG_STAMP(4);
-    const int mode = P.mode;
+    };
     const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
     int grow[2];
     grow[0] = rb * 128 + wm * 32 + lr;
     grow[1] = grow[0] + 16;
+    constexpr int mode = MODE;                                  // (one instantiation per epilogue: each gets its own register allocation)
+
+    if (mode == PG_F32) {
+        const bool rot = (P.rot_mask >> nb) & 1;
+        const int halfC = P.rot_C >> 1;
+        const float scale = P.scale;
+        float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
+        // Every rotary table load precedes the wave's first store: vmcnt retires in order, so a load behind a store would wait
+        // for the store to reach memory (loading the tables piece by piece between the stores cost 37 us on the q|k|v launch).
+        // Order: tables 0 | round 0 -> rotated in place | tables 1 | round 1 | all stores.
+        float4 vv[2][NI];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float4 tb[NI];
+            if (rot) {
+                const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;
+                const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int col = min(colw + 16 * i, C - 4), ridx = (col % P.rot_C) >> 1;
+                    const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx);
+                    tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
+                }
+            }
+            transpose_round(rr, vv[rr]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float4 x = vv[rr][i];
+                if (rot) {
+                    // x cos + swap(x) sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
+                    const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+                    x.x = __fadd_rn(__fmul_rn(x0, tb[i].x), __fmul_rn(-x1, tb[i].z));
+                    x.y = __fadd_rn(__fmul_rn(x1, tb[i].x), __fmul_rn(x0, tb[i].z));
+                    x.z = __fadd_rn(__fmul_rn(x2, tb[i].y), __fmul_rn(-x3, tb[i].w));
+                    x.w = __fadd_rn(__fmul_rn(x3, tb[i].y), __fmul_rn(x2, tb[i].w));
+                }
+                x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+                vv[rr][i] = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // keep the stores below behind the loads of the next round
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if (grow[rr] >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int col = colw + 16 * i;
+                if (col < C && ABL != 7) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = vv[rr][i];
+            }
+        }
+        PG_STAMP(6);
+        return;
+    }
+    float4 v[2][NI];
+    transpose_round(0, v[0]);
+    transpose_round(1, v[1]);
+    PG_STAMP(4);
 
     if (mode == PG_LN) {
         // nn.LayerNorm over the C columns of the block (biased variance, eps inside the sqrt; transformero.py:88-94)
+        float* const s_gam = s_sq + 256;                         // gamma | beta of the block, staged once per workgroup
+        float* const s_bet = s_gam + BN;
+        for (int c = t; c < BN; c += 512) {
+            s_gam[c] = c < C ? P.gamma[c] : 0.f;
+            s_bet[c] = c < C ? P.beta[c] : 0.f;
+        }
+        // Residual rows: EVERY load is issued here, before the first store of this wave -- vmcnt retires in order, so a load
+        // behind a store waits for the store to reach memory (the interleaved form cost 40 us per launch).  Round 0 stays in
+        // registers, round 1 is parked in the wave's transposition region (free now).
+        const float* __restrict__ res = P.resid;
+        float4 r0[NI];
+        if (res) {
+            const float* rp1 = res + (size_t)min(grow[1], rows - 1) * P.ldr;
+            const float* rp0 = res + (size_t)min(grow[0], rows - 1) * P.ldr;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int col = colw + 16 * i;
+                const float4 x = col < C ? *reinterpret_cast<const float4*>(rp1 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(ep + lr * EP_S + 16 * i + 4 * q) = x;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int col = colw + 16 * i;
+                r0[i] = col < C ? *reinterpret_cast<const float4*>(rp0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         float mean[2], rstd[2];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -339,9 +458,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (q == 0) s_sq[wn * 128 + rl] = s;
         }
         __syncthreads();
-        const float* __restrict__ gam = P.gamma;
-        const float* __restrict__ bet = P.beta;
-        const float* __restrict__ res = P.resid;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int rl = wm * 32 + 16 * rr + lr;
@@ -351,12 +467,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < NI; ++i) {
                 const int col = colw + 16 * i;
                 if (col < C) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(gam + col), b4 = *reinterpret_cast<const float4*>(bet + col);
+                    const float4 g4 = *reinterpret_cast<const float4*>(s_gam + col), b4 = *reinterpret_cast<const float4*>(s_bet + col);
                     float4 y;
                     y.x = (v[rr][i].x - mean[rr]) * rstd[rr] * g4.x + b4.x; y.y = (v[rr][i].y - mean[rr]) * rstd[rr] * g4.y + b4.y;
                     y.z = (v[rr][i].z - mean[rr]) * rstd[rr] * g4.z + b4.z; y.w = (v[rr][i].w - mean[rr]) * rstd[rr] * g4.w + b4.w;
-                    if (res && rok) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(res + (size_t)grow[rr] * P.ldr + col);
+                    if (res) {
+                        const float4 r4 = rr == 0 ? r0[i] : *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
                     v[rr][i] = y;
@@ -364,37 +480,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-    } else if (mode == PG_F32) {
-        const bool rot = (P.rot_mask >> nb) & 1;
-        const int halfC = P.rot_C >> 1;
-        const float scale = P.scale;
-        float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (grow[rr] >= rows) continue;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int col = colw + 16 * i;
-                if (col < C) {
-                    float4 x = v[rr][i];
-                    if (rot) {
-                        // x cos + swap(x) sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
-                        const int ridx = (col % P.rot_C) >> 1;
-                        const float2 c = *reinterpret_cast<const float2*>(P.cosT + (size_t)grow[rr] * halfC + ridx);
-                        const float2 sn = *reinterpret_cast<const float2*>(P.sinT + (size_t)grow[rr] * halfC + ridx);
-                        const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
-                        x.x = __fadd_rn(__fmul_rn(x0, c.x), __fmul_rn(-x1, sn.x));
-                        x.y = __fadd_rn(__fmul_rn(x1, c.x), __fmul_rn(x0, sn.x));
-                        x.z = __fadd_rn(__fmul_rn(x2, c.y), __fmul_rn(-x3, sn.y));
-                        x.w = __fadd_rn(__fmul_rn(x3, c.y), __fmul_rn(x2, sn.y));
-                    }
-                    x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-                    *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = x;
-                }
-            }
-        }
-        PG_STAMP(6);
-        return;
     } else if (P.relu) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
@@ -552,14 +637,19 @@ using G7 = PgGeom<7, 4>;
 bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G7::BN; }
 int pgemm_bn() { return G7::BN; }
 
-int pgemm_configure() {
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM));
+template <int MODE>
+static int configure_mode() {
+#define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM))
+    PG_ATTR(false, 0); PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6);
+    PG_ATTR(true, 7);
+#undef PG_ATTR
     return DR_OK;
+}
+int pgemm_configure() {
+    int rc = configure_mode<PG_F32>();
+    if (rc == DR_OK) rc = configure_mode<PG_PLANES>();
+    if (rc == DR_OK) rc = configure_mode<PG_LN>();
+    return rc;
 }
 
 int launch_pgemm(const PgBatch& g, hipStream_t st) {
@@ -577,12 +667,27 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
     static const bool dbg = [] { const char* e = getenv("DR_PG_STAMPS"); return e && atoi(e) != 0; }();
     static const int abl = [] { const char* e = getenv("DR_PG_ABL"); return e ? atoi(e) : 0; }();
-    if (dbg && abl == 1) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 1>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
-    else if (dbg && abl == 2) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 2>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
-    else if (dbg && abl == 3) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 3>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
-    else if (dbg && abl == 4) hipLaunchKernelGGL((pgemm_kernel<7, 4, true, 4>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
-    else if (dbg) hipLaunchKernelGGL((pgemm_kernel<7, 4, true>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
-    else hipLaunchKernelGGL((pgemm_kernel<7, 4>), dim3(maxt, g.n), dim3(512), G7::SMEM, st, g);
+    const int mode = g.p[0].mode;
+    for (int i = 1; i < g.n; ++i)
+        if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
+    const dim3 grid(maxt, g.n), blk(512);
+#define PG_LAUNCH(MODE, DBGF, ABLV) hipLaunchKernelGGL((pgemm_kernel<7, 4, MODE, DBGF, ABLV>), grid, blk, G7::SMEM, st, g)
+#define PG_LAUNCH_DBG(MODE)                                  \
+    switch (abl) {                                           \
+        case 1: PG_LAUNCH(MODE, true, 1); break;             \
+        case 2: PG_LAUNCH(MODE, true, 2); break;             \
+        case 3: PG_LAUNCH(MODE, true, 3); break;             \
+        case 4: PG_LAUNCH(MODE, true, 4); break;             \
+        case 5: PG_LAUNCH(MODE, true, 5); break;             \
+        case 6: PG_LAUNCH(MODE, true, 6); break;             \
+        case 7: PG_LAUNCH(MODE, true, 7); break;             \
+        default: PG_LAUNCH(MODE, true, 0); break;            \
+    }
+    if (dbg) {
+        if (mode == PG_F32) { PG_LAUNCH_DBG(PG_F32) } else if (mode == PG_PLANES) { PG_LAUNCH_DBG(PG_PLANES) } else { PG_LAUNCH_DBG(PG_LN) }
+    } else if (mode == PG_F32) PG_LAUNCH(PG_F32, false, 0);
+    else if (mode == PG_PLANES) PG_LAUNCH(PG_PLANES, false, 0);
+    else PG_LAUNCH(PG_LN, false, 0);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

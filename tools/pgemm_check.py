@@ -92,6 +92,9 @@ if rows >= 4096:
     t = timeit(lambda: lib.linear_planes(rows, C, 1, img, bnd, C, pkm, lib.PL_F32, out=o2, ldo=C))
     print("F32 432x432: %.1f us, %.1f TFLOP/s" % (t, 2.0 * rows * C * C / t / 1e6))
     t = timeit(lambda: lib.linear_planes(rows, C, 3, img, bnd, C, pk, lib.PL_F32, out=out, ldo=3 * C, blk_stride=C, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C))
+    out3 = torch.empty(3, rows, C, device=dev)
+    t = timeit(lambda: lib.linear_planes(rows, C, 3, img, bnd, C, pk, lib.PL_F32, out=out3, ldo=C, blk_stride=rows * C, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C))
+    print("F32 q|k|v as three [T,C] matrices: %.1f us" % t)
     print("F32 q|k|v 432x1296: %.1f us, %.1f TFLOP/s" % (t, 2.0 * rows * C * 3 * C / t / 1e6))
     t = timeit(lambda: lib.linear_planes(rows, C, 1, img, bnd, C, pkm, lib.PL_LN, out_image=msg_img, out_image_k=C, out_bound=msg_b, gamma=g1, beta=b1, lnb=lnb))
     print("merge+LN -> planes: %.1f us, %.1f TFLOP/s" % (t, 2.0 * rows * C * C / t / 1e6))

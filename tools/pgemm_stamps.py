@@ -33,6 +33,10 @@ def stamps(name, f):
     print(name)
     print("  prologue wait %.2f | main loop %.2f | barrier %.2f | transpose %.2f | ln/f32 %.2f | end %.2f (us since start)" %
           (t[1] - t0, t[2] - t0, t[3] - t0, t[4] - t0, (t[5] if t[5] > t[4] else t[6]) - t0, t[6] - t0))
+    for gname, o in (("wave 0 (group 0)", 64), ("wave 4 (group 1)", 80)):
+        c = [buf[o + i] for i in range(7)]
+        print("  stage 10 %s cycles: start->frags %d | burst1 %d | vmcnt %d | barrier %d | lgkm %d | burst2 %d | total %d" %
+              (gname, c[6] - c[0], c[1] - c[6], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[5] - c[0]))
     print("  stage pairs (us):", " ".join("%.2f" % (st[i] - (st[i - 1] if i else t[1] - t0)) for i in range(14)))
 
 stamps("F32 432x432", lambda: lib.linear_planes(rows, C, 1, img, bnd, C, pkm, lib.PL_F32, out=o2, ldo=C))
