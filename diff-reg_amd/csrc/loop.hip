@@ -167,6 +167,8 @@ struct PlanesWs {
         static const int min_rows = [] { const char* e = getenv("DR_PLANES_MIN_ROWS"); return e ? atoi(e) : 8192; }();
         static const int enabled = [] { const char* e = getenv("DR_PLANES"); return e ? atoi(e) : 1; }();
         w.on = enabled && Prepack::supported(cfg) && T >= min_rows;
+        if (cfg.flags & DR_LOOP_PLANES_FORCE) w.on = Prepack::supported(cfg);
+        if (cfg.flags & DR_LOOP_PLANES_OFF) w.on = false;
         if (!w.on) return;
         const int dp = (C / cfg.H + 15) / 16 * 16;
         w.side_C = plane_image_bytes(PN, C); w.side_att = plane_image_bytes(PN, cfg.H * dp); w.side_hid = plane_image_bytes(PN, 2 * C);

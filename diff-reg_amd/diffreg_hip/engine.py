@@ -33,7 +33,7 @@ def sampling_times(steps, timesteps=1000):
 class DenoiseEngine:
     def __init__(self, state, *, variant, C, H, voxel, origin, steps, sk_iters=3, sample_rate=1.0, max_condition_num=0.0,
                  n_layers=6, device="cuda:0", strict_f64=False, prefix_t="denoising_transformer.",
-                 prefix_m="denoising_coarse_matching.", prepack=True):
+                 prefix_m="denoising_coarse_matching.", prepack=True, planes=None):
         """state: mapping name -> tensor in the reference state-dict layout."""
         lib.ensure_init()
         self.device = torch.device(device)
@@ -63,7 +63,8 @@ class DenoiseEngine:
         cfg.voxel = voxel
         cfg.origin[0], cfg.origin[1], cfg.origin[2] = origin
         cfg.sample_rate, cfg.max_condition_num = sample_rate, max_condition_num
-        cfg.flags = 1 if strict_f64 else 0
+        # planes: None = the size rule picks the GEMM path; True / False = DR_LOOP_PLANES_FORCE / DR_LOOP_PLANES_OFF
+        cfg.flags = (1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0)
         cfg.h_alphas_cumprod = self._ac.ctypes.data
         cfg.h_times = self._times.ctypes.data
         self.cfg = cfg

@@ -3,12 +3,12 @@ golden vectors and with the oracle.  Needs a GPU.
 
 Tolerances (north_star: matching matrix and (R,t) to 1e-4 fp32 on identical inputs):
   R_forwd, t_forwd: 1e-4 absolute against the reference at every step.
-  x_start / conf  : 1e-4 absolute against the reference on (almost) every entry.  The sharp synthetic
-      scenes make a handful of x_start entries ill-conditioned: the reference's OWN float32 CPU run is
-      1e-4..1e-2 away from a float64 evaluation of the same mathematics on those entries (measured:
-      tools/debug_loop.py, DESIGN.md "Parity").  For them the bar is that the HIP path is at least as
-      close to the float64 evaluation as the reference is:  |hip - f64| <= max(1e-4, 2 |ref - f64|),
-      and they must stay rare (<= 0.1 % of the entries).
+  x_start / conf  : a plain 1e-4 absolute against the reference on every entry EXCEPT the ones listed per fixture in
+      tests/golden/loop_exemptions.json (oracle/make_exemptions.py): the sharp synthetic scenes make a handful of x_start
+      entries ill-conditioned (0 .. 38 per fixture, none in any 3D conf_matrix_pred) -- there the reference's OWN float32
+      CPU run is 2.5e-5 .. 1e-2 away from a float64 evaluation of the same mathematics, which is the list's criterion, a
+      property of the fixture, not of the implementation under test.  For them the bar is that the HIP path is at least as
+      close to the float64 evaluation as the reference is:  |hip - f64| <= max(1e-4, 2 |ref - f64|).
 """
 import numpy as np
 import pytest
@@ -76,12 +76,41 @@ def f64_evaluation(variant, N, M, nv, mv, steps, mc, seed):
     return _F64[key]
 
 
-def assert_matrix_parity(got, ref, f64, what):
+TAU = 2.5e-5       # oracle/make_exemptions.py: an entry is exempt when the REFERENCE's own float32 value is further than this from float64
+_EXEMPT = None
+
+
+def exemptions(fixture, key):
+    """committed per-fixture exemption list (tests/golden/loop_exemptions.json): flat indices + the reference's deviation"""
+    global _EXEMPT
+    if _EXEMPT is None:
+        import json, os
+        _EXEMPT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loop_exemptions.json")))
+        assert _EXEMPT["tau"] == TAU
+    e = _EXEMPT["fixtures"][fixture][key]
+    return np.asarray(e["index"], dtype=np.int64)
+
+
+def assert_matrix_parity(got, ref, f64, what, exempt=None):
+    """Every entry within 1e-4 of the reference -- a plain bound -- except the listed ill-conditioned ones, where the
+    reference's own float32 run is more than TAU away from the float64 evaluation: those must be at least as close to float64
+    as twice the reference's distance.  `exempt`: flat indices from the committed list (golden fixtures) or None = the same
+    rule applied to (ref, f64) on the spot (cases that are not fixtures)."""
+    got, ref, f64 = (np.asarray(a, dtype=np.float64).ravel() for a in (got, ref, f64))
+    rule = np.nonzero(np.abs(ref - f64) > TAU)[0]
+    if exempt is None:
+        exempt = rule
+    else:
+        assert set(rule.tolist()) <= set(exempt.tolist()) or np.abs(ref - f64)[np.setdiff1d(rule, exempt)].max() < 1.2 * TAU, \
+            (what, "the committed exemption list does not cover the rule on this host")
+    plain = np.ones(got.size, dtype=bool)
+    plain[exempt] = False
     d = np.abs(got - ref)
-    bad = d > 1e-4
-    assert bad.mean() <= 1e-3, (what, "entries off by more than 1e-4:", int(bad.sum()))
-    e_hip, e_ref = np.abs(got - f64), np.abs(ref - f64)
-    assert e_hip.max() <= max(1e-4, 2.0 * e_ref.max()), (what, e_hip.max(), e_ref.max())
+    assert d[plain].max() <= 1e-4, (what, "non-exempt entry off by", d[plain].max(), "at", int(np.argmax(d * plain)))
+    if exempt.size:
+        e_hip, e_ref = np.abs(got - f64)[exempt], np.abs(ref - f64)[exempt]
+        assert (e_hip <= np.maximum(1e-4, 2.0 * e_ref)).all(), (what, float(e_hip.max()), float(e_ref.max()))
+        assert exempt.size <= 0.005 * got.size + 40, (what, "too many exempt entries", exempt.size)
 
 
 @pytest.fixture(params=[1, 0], ids=["fp16x2", "bf16x3"])
@@ -105,11 +134,18 @@ def test_loop_matches_reference_batch_kernels(golden, batch_kernels, variant, N,
     test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph=False)
 
 
+@pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", [c for c in LOOPS if c[0] == "3dmatch"])
+def test_loop_matches_reference_plane_path(golden, variant, N, M, nv, mv, steps, mc, seed, tag):
+    """the plane-image GEMM path (fp16 hi / lo operand images written by the producers, LayerNorm in the GEMM epilogue,
+    weights packed once) forced onto the small golden loops"""
+    test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph=False, planes=True)
+
+
 @pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", LOOPS)
 @pytest.mark.parametrize("graph", [False, True])
-def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph):
+def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph, planes=None):
     g = golden("%s_loop_%s" % (variant, tag))
-    eng = engine(variant, steps, mc)
+    eng = engine(variant, steps, mc, planes=planes)
     _, p = pair(variant, N, M, seed)
     ms, mt = masks(N, M, nv, mv)
     noise = T(synth.step_noise(N, M, seed, steps))[:, None].to(DEV) if variant == "4dmatch" else None
@@ -124,11 +160,12 @@ def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, 
     x0 = out["x0"][:, 0].cpu().numpy()
     x0_f64, conf_f64 = f64_evaluation(variant, N, M, nv, mv, steps, mc, seed)
     assert (np.abs(x0[:, :16, :16] - g["x0_corner"]) > 1e-4).mean() <= 1e-3
-    assert_matrix_parity(x0[-1], g["x0_last"], x0_f64, "x_start of the last step")
+    fx = "%s_loop_%s" % (variant, tag)
+    assert_matrix_parity(x0[-1], g["x0_last"], x0_f64, "x_start of the last step", exemptions(fx, "x0_last"))
     conf = out["conf_matrix_pred"][0].cpu().numpy()
     assert out["conf_matrix_pred"].dtype == torch.float64            # quirk Q2
     ref = g["conf"]
-    assert_matrix_parity(conf, ref, conf_f64, "conf_matrix_pred")
+    assert_matrix_parity(conf, ref, conf_f64, "conf_matrix_pred", exemptions(fx, "conf"))
     if variant == "3dmatch":
         # read-out entries are 1e-3..2e-2 (intrinsically flat): also hold them relatively
         # (same rule as assert_matrix_parity: the HIP result may be as far from the float64 evaluation as twice the reference's
