@@ -47,10 +47,10 @@ PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s mea
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
 
-def make_inputs(variant, P, N, M, seed0, device):
+def make_inputs(variant, P, N, M, seed0, device, seeds=None):
     from diffreg_hip import synth
     C = synth.VARIANTS[variant]["C"]
-    prs = [synth.make_pair(N, M, C, seed=seed0 + i) for i in range(P)]
+    prs = [synth.make_pair(N, M, C, seed=sd) for sd in (seeds if seeds is not None else range(seed0, seed0 + P))]
     st = lambda k: torch.from_numpy(np.stack([p[k] for p in prs])).to(device)
     return prs, dict(f_s=st("src_feats"), f_t=st("tgt_feats"), p_s=st("s_pcd"), p_t=st("t_pcd"), x_T=st("x_T"))
 
@@ -211,6 +211,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="shard this many pairs round-robin over the ranks (ranks may differ by one pair: BASELINE configs[3] = 64 "
+                         "pairs over 8 GPUs) instead of --pairs per rank")
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="TEST ONLY (tests/test_shard_cpu.py): a deterministic CPU stand-in replaces the engine and the device "
+                         "harness so that this file's multi-rank control path -- torchrun environment, barrier, max time over "
+                         "ranks, the metric-vector all_reduce -- runs under gloo on a box without a GPU; the line it prints "
+                         "carries \"data\": \"cpu-stub\" and is not a measurement")
     ap.add_argument("--breakdown-only", action="store_true",
                     help="run only the eager, event-timed passes of one batch (the command profiled with rocprofv3 for profiles/)")
     args = ap.parse_args()
@@ -218,72 +226,119 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = args.cpu_stub
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    from diffreg_hip import lib
-    variant, N, M, P, S = "3dmatch", args.n, args.n, args.pairs, args.denoise_steps
-    W, eng = make_engine(variant, S, args.max_condition_num, dev)
+        if not stub:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo" if stub else "nccl")
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    if not stub:
+        torch.cuda.set_device(dev)
+        from diffreg_hip import lib
+    from diffreg_hip import shard
+    variant, N, M, S = "3dmatch", args.n, args.n, args.denoise_steps
+    # the pairs of this rank: --pairs each (weak scaling), or a round-robin share of --total-pairs (ranks may differ by one)
+    pair_ids = shard.shard_pairs(args.total_pairs, rank, world) if args.total_pairs else list(range(rank * args.pairs, (rank + 1) * args.pairs))
+    P = len(pair_ids)
     use_graph = not args.no_graph
     nstreams = max(1, min(args.streams, P)) if use_graph else 1
     per = [P // nstreams + (1 if i < P % nstreams else 0) for i in range(nstreams)]
-    groups, inp = [], None
-    for gi, pg in enumerate(per):
-        _, ig = make_inputs(variant, pg, N, M, seed0=5000 + 1000 * rank + 100 * gi, device=dev)
-        inp = inp or ig
-        groups.append(dict(src_feats=ig["f_s"], tgt_feats=ig["f_t"], s_pcd=ig["p_s"], t_pcd=ig["p_t"], x_T=ig["x_T"]))
+    groups, inp, gt, off = [], None, [], 0
+    if stub:
+        eng = W = None
+    else:
+        W, eng = make_engine(variant, S, args.max_condition_num, dev)
+        for gi, pg in enumerate(per):
+            prs_g, ig = make_inputs(variant, pg, N, M, 0, dev, seeds=[5000 + i for i in pair_ids[off:off + pg]])
+            off += pg
+            inp = inp or ig
+            groups.append(dict(src_feats=ig["f_s"], tgt_feats=ig["f_t"], s_pcd=ig["p_s"], t_pcd=ig["p_t"], x_T=ig["x_T"]))
+            gt.append((torch.tensor(np.stack([p["R_gt"] for p in prs_g]), dtype=torch.float32, device=dev),
+                       torch.tensor(np.stack([p["t_gt"] for p in prs_g]), dtype=torch.float32, device=dev)))
 
     def run(graph):
+        """one pass over this rank's pairs -> list of per-batch outputs"""
+        if stub:
+            time.sleep(1e-3 * P)                      # stand-in for the loop: time proportional to the rank's pair count
+            return [None]
         if graph:
-            return eng.run_streams(groups, nstreams)[0]
-        return eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)
+            return eng.run_streams(groups, nstreams)
+        return [eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)]
+
+    def evaluate(outs):
+        """per-pair IR / FMR / RR of the last pass through the device harness -> three [P] tensors"""
+        if stub:                                      # deterministic functions of the GLOBAL pair index
+            ids = torch.tensor(pair_ids, dtype=torch.float64)
+            return (ids % 10) / 10.0, ((ids % 10) / 10.0 > 0.05).double(), (ids % 3 == 0).double()
+        from diffreg_hip import metrics as dmet
+        from diffreg_hip import synth
+        irs, fmrs, rrs, o = [], [], [], 0
+        for g_, out_, (Rg, tg) in zip(groups, outs, gt):
+            n = Rg.shape[0]
+            info = torch.stack([torch.as_tensor(synth.make_info(5000 + i), dtype=torch.float64) for i in pair_ids[o:o + n]]).to(dev)
+            ev = dmet.evaluate_pairs(out_["matches_padded"], out_["match_count"], g_["s_pcd"], g_["t_pcd"], Rg, tg, info=info,
+                                     pair_ids=torch.tensor(pair_ids[o:o + n]))
+            irs.append(ev["ir"].double()); fmrs.append(ev["fmr"].double()); rrs.append(ev["rr_ok"].double())
+            o += n
+        return torch.cat(irs), torch.cat(fmrs), torch.cat(rrs)
 
     if args.breakdown_only:
         use_graph = False
         args.no_single_pair = args.no_cpu_baseline = True
+    if stub:
+        args.no_single_pair = args.no_cpu_baseline = args.no_breakdown = True
     # the Sinkhorn roofline micro-benchmark (SURVEY 8d: batched tiles, HBM-bound) runs first: behind the MFMA-heavy loop the
     # same launch is 8 % slower (the chip is then at its power limit), which would measure the loop's heat, not the kernel
     sk_roof = None
-    if rank == 0 and world == 1 and not args.breakdown_only:
+    if rank == 0 and world == 1 and not args.breakdown_only and not stub:
         sk_roof = sinkhorn_microbench(dev)
         sk_roof["measured"] = "before the timed loop (HIP events, 20 launches after 0.3 s of warm-up launches)"
     for _ in range(max(args.warmup, 1)):
-        out = run(use_graph)
-    torch.cuda.synchronize()
+        outs = run(use_graph)
+    sync()
     # timed region: exactly K passes, bracketed by barrier + synchronize
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run(use_graph)
-    torch.cuda.synchronize()
+        outs = run(use_graph)
+    sync()
+    t_rank = time.perf_counter() - t0                                  # this rank's own time (before the closing barrier)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    checksum = out["conf_matrix_pred"].sum().reshape(1).double()
-    from diffreg_hip import shard
     elapsed = shard.max_over_ranks(elapsed, dev)                       # max over ranks
-    checksum = shard.gather_metrics(checksum, dev)                     # metric gather (RCCL over xGMI when N > 1)
-    total_pairs = world * P * args.steps
+    # the run's ONE collective on results (RCCL over xGMI when N > 1; SURVEY 8e, vision3d/utils/distributed.py:57-64):
+    # all_reduce(SUM) of [sum IR, sum FMR, sum RR, n_pairs, sum t] of the last pass, evaluated on the device harness
+    ir, fmr, rr = evaluate(outs)
+    gathered = shard.reduce_metrics(shard.metric_vector(ir, fmr, rr, t_rank).to(dev))
+    per_rank_s = shard.gather_per_rank(t_rank, dev)
+    per_rank_pairs = shard.gather_per_rank(P, dev)
+    checksum = torch.zeros(1, dtype=torch.float64) if stub else outs[0]["conf_matrix_pred"].sum().reshape(1).double()
+    checksum = shard.gather_metrics(checksum, dev)
+    total_pairs = int(gathered["n_pairs"]) * args.steps
     value = total_pairs / elapsed
+    out = outs[0]
 
     result = {
         "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "cpu-stub (control-path test, not a measurement)" if stub else "synthetic",
         "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
-                               "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, P, nstreams),
+                               "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, max(int(p) for p in per_rank_pairs), nstreams),
                    "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
                    "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32",
                    "gemm_arithmetic": "fp32 in / fp32 out; each product as %s, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)" % SPLIT_TEXT, "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
+        "metric_gather": dict(gathered, collective="all_reduce(SUM) of [sum IR, sum FMR, sum RR, n_pairs, sum t] (float64)",
+                              backend="gloo" if stub else ("nccl (RCCL)" if world > 1 else "none (1 rank)"),
+                              per_rank_pairs=[int(p) for p in per_rank_pairs],
+                              per_rank_pairs_per_s=[p * args.steps / t for p, t in zip(per_rank_pairs, per_rank_s)]),
     }
 
     if rank == 0:

@@ -28,7 +28,8 @@ LOOPS = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
          ("3dmatch", 96, 80, 96, 80, 5, 200, 12, "n96x80_s5_mc200"),
          ("3dmatch", 256, 256, 256, 256, 20, 200, 13, "n256_s20_mc200"),
          ("4dmatch", 128, 128, 112, 100, 5, 40, 21, "n128_s5_mc40_masked"),
-         ("4dmatch", 64, 96, 64, 96, 20, 40, 22, "n64x96_s20_mc40")]
+         ("4dmatch", 64, 96, 64, 96, 20, 40, 22, "n64x96_s20_mc40"),
+         ("4dmatch", 512, 512, 470, 391, 20, 40, 62, "n512_s20_mc40_masked")]
 
 
 def f64_eval(variant, N, M, nv, mv, steps, mc, seed):

@@ -265,6 +265,8 @@ def run_tree(variant):
     else:
         run_loop(128, 128, 112, 100, 5, 40, seed=21, tag="n128_s5_mc40_masked")
         run_loop(64, 96, 64, 96, 20, 40, seed=22, tag="n64x96_s20_mc40")
+        # BASELINE configs[2] at its stated size: one pair of the 8, 512 x 512 (padded from 470 x 391), 20 steps, masks, sigma*xi
+        run_loop(512, 512, 470, 391, 20, 40, seed=62, tag="n512_s20_mc40_masked")
 
 
 def run_2d3d():

@@ -46,6 +46,56 @@ def test_two_ranks_shard_and_gather():
         assert sums == pytest.approx(want) and tmax == 2.0
 
 
+def _run_bench_stub(nproc, extra):
+    """bench.py's own multi-rank control path (torchrun environment, barrier, max time over ranks, metric-vector all_reduce)
+    under gloo with the CPU stand-in engine (--cpu-stub)"""
+    import json
+    import subprocess
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--cpu-stub"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_rank_path_two_ranks_weak_scaling():
+    d = _run_bench_stub(2, ["--pairs", "6"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["data"].startswith("cpu-stub")
+    mg = d["metric_gather"]
+    ids = list(range(12))                                            # rank r owns pairs 6 r .. 6 r + 5
+    assert mg["n_pairs"] == 12 and mg["per_rank_pairs"] == [6, 6] and mg["backend"] == "gloo"
+    assert mg["sum_inlier_ratio"] == pytest.approx(sum((i % 10) / 10.0 for i in ids))
+    assert mg["sum_fmr"] == pytest.approx(sum(1.0 for i in ids if (i % 10) / 10.0 > 0.05))
+    assert mg["sum_registration_recall"] == pytest.approx(sum(1.0 for i in ids if i % 3 == 0))
+    # value = pairs of ALL ranks x steps / max-over-ranks time
+    assert d["value"] == pytest.approx(12 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+    assert len(mg["per_rank_pairs_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_pairs_per_s"])
+
+
+def test_bench_rank_path_ragged_shard():
+    """13 pairs round-robin over 2 ranks (7 + 6: BASELINE configs[3]-style sharding of a fixed set): the gather still counts
+    every pair once, and the slower rank (more pairs) sets the time"""
+    d = _run_bench_stub(2, ["--total-pairs", "13"])
+    mg = d["metric_gather"]
+    assert mg["n_pairs"] == 13 and sorted(mg["per_rank_pairs"]) == [6, 7]
+    assert mg["sum_inlier_ratio"] == pytest.approx(sum((i % 10) / 10.0 for i in range(13)))
+    assert mg["sum_registration_recall"] == pytest.approx(sum(1.0 for i in range(13) if i % 3 == 0))
+    assert d["value"] == pytest.approx(13 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+def test_metric_vector_of_evaluate_pairs_shaped_data():
+    """shard.metric_vector / reduce_metrics on the dict layout diffreg_hip.metrics.evaluate_pairs returns (ir, fmr, rr_ok [P])"""
+    from diffreg_hip import shard
+    ev = dict(ir=torch.tensor([0.5, 0.02, 0.3]), fmr=torch.tensor([1.0, 0.0, 1.0]), rr_ok=torch.tensor([1, 0, 0], dtype=torch.int32))
+    v = shard.metric_vector(ev["ir"], ev["fmr"], ev["rr_ok"], 2.5)
+    assert v.dtype == torch.float64 and v.tolist() == pytest.approx([0.82, 2.0, 1.0, 3.0, 2.5])
+    g = shard.reduce_metrics(v)
+    assert g["mean_inlier_ratio"] == pytest.approx(0.82 / 3) and g["fmr"] == pytest.approx(2 / 3) and g["n_pairs"] == 3
+
+
 def test_single_process_gather_is_identity():
     from diffreg_hip import shard
     assert shard.shard_pairs(5, 0, 1) == [0, 1, 2, 3, 4]
