@@ -1244,6 +1244,14 @@ static int launch_wide2(const GemmBatch& g, hipStream_t st) {
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
+    static const int no_amax = [] { const char* e = getenv("DR_GEMM_NO_AMAX"); return e ? atoi(e) : 0; }();   // diagnostics: sweep always
+    if (no_amax) {
+        GemmBatch h = g;
+        for (int i = 0; i < h.n; ++i) { if (no_amax & 1) { h.p[i].amax = nullptr; h.p[i].amax2 = nullptr; } if (no_amax & 2) h.p[i].omax = nullptr; }
+        hipLaunchKernelGGL(gemm_nt_wide2_kernel, dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, h);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     hipLaunchKernelGGL(gemm_nt_wide2_kernel, dim3(maxt, g.n), dim3(GG::NT), GG::SMEM, st, g);
     DR_LAUNCH_CHECK();
     return DR_OK;

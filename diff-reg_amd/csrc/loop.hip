@@ -110,8 +110,8 @@ struct Prepack {
         const int C = cfg.C, d = C / cfg.H, dp = (d + 15) / 16 * 16, nC = C / 16;
         if (pp) pp->dp = dp;
         auto take = [&](int nblk, int nct, PgW* v) {
-            char* p = c.take<char>(pgemm_weight_bytes(nblk, nct));
-            if (pp && buf) pgemm_weight_view(p, nblk, nct, v);
+            char* p = c.take<char>(pgemm_weight_bytes(C, nblk, nct));
+            if (pp && buf) pgemm_weight_view(p, C, nblk, nct, v);
         };
         for (int l = 0; l < cfg.n_layers; ++l) {
             PrepackLayer* L = pp ? &pp->L[l] : nullptr;
@@ -287,9 +287,9 @@ struct PlCtx {
     const float *cosT, *sinT;
     const uint8_t* tokmask;
 };
-static PgW pgw_blocks(const PgW& v, int b0) {
+static PgW pgw_blocks(const PgW& v, int b0, int C) {
     PgW r = v;
-    r.img += (size_t)b0 * v.nct * pgemm_bn() * 64; r.cinv += (size_t)b0 * pgemm_bn(); r.wnorm += b0;
+    r.img += (size_t)b0 * v.nct * pgemm_bn(C) * 64; r.cinv += (size_t)b0 * pgemm_bn(C); r.wnorm += b0;
     return r;
 }
 static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, const Tok& xin, int xs, const Tok& yin, int ys,
@@ -314,7 +314,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     auto proj = [&](const Tok& tin, int side, int b0, int nblk, float* o, int rotm) {
         PgProblem& p = add();
         p.A0 = at(tin.img, pw.side_C, side); p.bnd0 = tin.bnd + r0(side); p.nc0 = nC;
-        p.W = pgw_blocks(L.qkv, b0); p.nblk = nblk; p.rows = nrows(side); p.C = C; p.mode = PG_F32;
+        p.W = pgw_blocks(L.qkv, b0, C); p.nblk = nblk; p.rows = nrows(side); p.C = C; p.mode = PG_F32;
         p.out = o + (size_t)r0(side) * C; p.ldo = C; p.blk_stride = (int)TC; p.rot_mask = rotm; p.rot_C = C; p.scale = 1.f;
         p.cosT = X.cosT + (size_t)r0(side) * halfC; p.sinT = X.sinT + (size_t)r0(side) * halfC;
     };
@@ -353,7 +353,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     for_sides(xs, [&](int side) {
         PgProblem& p = add();
         p.A0 = at(pw.att_img, pw.side_att, side); p.bnd0 = pw.att_bnd + r0(side); p.nc0 = H * dp / 16;
-        p.W = L.merge; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN;
+        p.W = L.merge; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN; p.k_alg = C;
         p.gamma = W.norm1_w; p.beta = W.norm1_b; p.lnB = L.lnB1;
         p.pimg = at(pw.msg_img, pw.side_C, side); p.p_nct = nC; p.pbnd = pw.msg_bnd + r0(side);
     });
@@ -398,8 +398,13 @@ struct DenoiseWs {
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
         PlanesWs::carve(c, w.pl, cfg, P, N, M);
-        if (w.pl.on) w.pw.on = false;                       // the plane path packs its own images
-        else PackedWeights::carve(c, w.pw, n_layers, C, T);
+        // The round-1 packed path (per-call bf16 x 3 / fp16 x 2 images + gemm_nt_wide2_kernel with producer-side row maxima) is
+        // retired from the loop: the full-size configs[2] test (8 pairs x 20 steps at 512 x 512) showed it to be
+        // non-deterministic from a few thousand token rows on (run-to-run differences of O(1) in the refined features; the
+        // stand-alone op dr_linear_packed_f32 is unaffected and keeps the kernel).  Large calls run the plane path, which is
+        // bit-identical between a batch and its pairs' own runs; small ones the f32-input MFMA kernels.
+        w.pw.on = false;
+        (void)n_layers;
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
         w.m_feat0 = c.take<float>(T); w.m_fa = c.take<float>(T); w.m_fb = c.take<float>(T); w.m_tgt_l0 = c.take<float>(T);

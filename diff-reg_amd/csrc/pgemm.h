@@ -36,6 +36,7 @@ struct PgProblem {
     PgW W;
     int nblk;                           // column blocks (of C columns each) this problem computes
     int rows, C;
+    int k_alg;                          // algorithmic k (for the flop count of the profiler; 0 = 16 nct)
     int mode;
     // PG_F32: out[row][nb * blk_stride + col] = rot(acc) * scale     (PG_LN: optional fp32 copy of the result, nb = 0)
     float* out; int ldo; int blk_stride;
@@ -49,15 +50,15 @@ struct PgProblem {
 struct PgBatch { PgProblem p[3]; int n; };
 
 bool pgemm_shape_ok(int C);                      // column-block widths the kernel is built for
-int pgemm_bn();                                  // rows of a packed weight block (448)
+int pgemm_bn(int C);                             // rows of a packed weight block (448 for C <= 448, 576 above)
 int launch_pgemm(const PgBatch& g, hipStream_t st);
 int pgemm_configure();
 
 // packed weights: nblk blocks of C rows of W [nblk * C, K] (row-major) -> image + cinv + wnorm.
 // k order of the image: k' = (k / piece_len) * piece_pad + k % piece_len  (zero where k' % piece_pad >= piece_len);
 // piece_len = K, piece_pad = K for the identity.  nct = ceil(K / piece_len) * piece_pad / 16.
-size_t pgemm_weight_bytes(int nblk, int nct);    // image + cinv + wnorm, 256-aligned
-void pgemm_weight_view(void* buf, int nblk, int nct, PgW* view);
+size_t pgemm_weight_bytes(int C, int nblk, int nct);    // image + cinv + wnorm, 256-aligned
+void pgemm_weight_view(void* buf, int C, int nblk, int nct, PgW* view);
 int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st);
 int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st);
 

@@ -144,10 +144,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the rest of the weights (L2 hits; one stage to land).
     auto run = [&](auto grp_t) __attribute__((always_inline)) {
         constexpr int GRP = decltype(grp_t)::value;
+        // EARLY: group 0 issues stage s + NST - 2 in the FIRST burst of stage s (its slot is free since the barrier of stage s - 1).
+        // That needs a slot beyond the one landing for stage s + 1, i.e. NST >= 4; with a 3-slot ring (the 576-column geometry)
+        // both groups issue stage s + 2 in the second burst and wait for everything at the next barrier.
+        constexpr bool EARLY = GRP == 0 && NST >= 4;
+        constexpr int AHEAD = EARLY ? NST - 2 : NST - 1;             // stages in flight beyond the current one after the prologue
         constexpr int WB_CNT = (GG::NB + 8) / 2 - 8;                 // weight instructions of group 1
         constexpr int NW0 = GG::NB - WB_CNT;                         // weight instructions of group 0
         constexpr int NPIECE = GRP ? 2 + (WB_CNT + 3) / 4 : (NW0 + 3) / 4;
         constexpr int NFULLP = GRP ? 2 + WB_CNT / 4 : NW0 / 4;       // pieces every wave of the group issues
+        static_assert(2 * NPIECE <= 3 * (TNW - TNW / 2), "the DMA pieces of a stage must fit the gaps of the second burst");
         constexpr int REMP = GRP ? WB_CNT % 4 : NW0 % 4;             // waves (local index) < REMP issue one more
         const int wl = w & 3;
         // DMA pieces of this wave (1 KB instructions; `ins` = index inside the A block / the weight block of a stage):
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else if (ABL == 5) {
             } else {
                 if (p < 4) { if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w, voffW, gb, (p & 3) * 1024); }
-                else if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w + 4096, voffW4, gb, 0);
+                else if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w + 4096, voffW4, gb, ((p - 4) & 3) * 1024);
             }
         };
         auto dma_advance = [&]() __attribute__((always_inline)) {
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 // ---- DMA pieces: group 0 in burst 1 (stage s + NST - 2), group 1 in burst 2 (stage s + NST - 1)
-                constexpr int MF = GRP ? M1 + 1 : 0, STEP = GRP ? 2 : 1;
+                constexpr int MF = EARLY ? 0 : M1 + 1, STEP = EARLY ? 1 : 2;
                 if (m >= MF && m < MF + STEP * NPIECE && (m - MF) % STEP == 0) {
                     if (do_issue && ABL != 1) dma_piece((m - MF) / STEP, dstb);
                     if ((m - MF) / STEP == NPIECE - 1 && do_issue) dma_advance();
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     PG_CSTAMP(1);
                     if (has_next) {
                         // own DMAs of stage s + 1 have landed (those of stage s + 2, issued later, may still fly)
-                        if (STEADY || s + 2 < nst) {
+                        if (NST >= 4 && (STEADY || s + 2 < nst)) {
                             if (wl < REMP) PG_VMCNT(NFULLP + 1); else PG_VMCNT(NFULLP);
                         } else {
                             PG_VMCNT(0);
@@ -278,13 +284,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- prologue: group 1 puts stages 0 .. NST - 2 in flight, group 0 stages 0 .. NST - 3 (it issues stage s + NST - 2 in
         // the first burst of stage s, group 1 stage s + NST - 1 in the second); stage 0 landed
 #pragma unroll
-        for (int q2 = 0; q2 < NST - 2 + GRP; ++q2) {
+        for (int q2 = 0; q2 < AHEAD; ++q2) {
             const unsigned dstb = lds_base + (unsigned)q2 * STAGE;
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) dma_piece(i, dstb);
             dma_advance();
         }
-        if (wl < REMP) PG_VMCNT((NST - 3 + GRP) * (NFULLP + 1)); else PG_VMCNT((NST - 3 + GRP) * NFULLP);
+        if (wl < REMP) PG_VMCNT((AHEAD - 1) * (NFULLP + 1)); else PG_VMCNT((AHEAD - 1) * NFULLP);
         __builtin_amdgcn_s_barrier();
         PG_READ(fa0[0], lds_base + offAh, 0);
         PG_READ(fa0[1], lds_base + offAl, 0);
@@ -630,25 +636,33 @@ __global__ __launch_bounds__(256) void ln_bound_kernel(const float* __restrict__
     }
 }
 
-using G7 = PgGeom<7, 4>;
+using G7 = PgGeom<7, 4>;     // column blocks of up to 448 (3DMatch: C = 432; 2D-3D: 256), 4-slot ring
+using G9 = PgGeom<9, 3>;     // column blocks of up to 576 (4DMatch: C = 528), 3-slot ring (the stage is 44 KB)
 
 }  // namespace
 
-bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G7::BN; }
-int pgemm_bn() { return G7::BN; }
+bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G9::BN; }
+int pgemm_bn(int C) { return C <= G7::BN ? G7::BN : G9::BN; }
+static size_t pg_bst(int C) { return (size_t)pgemm_bn(C) * 64; }
 
-template <int MODE>
-static int configure_mode() {
-#define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<7, 4, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7::SMEM))
-    PG_ATTR(false, 0); PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6);
-    PG_ATTR(true, 7);
+template <int TNW, int NST, int MODE>
+static int configure_mode(bool with_dbg) {
+    using GG = PgGeom<TNW, NST>;
+#define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM))
+    PG_ATTR(false, 0);
+    if constexpr (TNW == 7) {
+        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); }
+    }
 #undef PG_ATTR
     return DR_OK;
 }
 int pgemm_configure() {
-    int rc = configure_mode<PG_F32>();
-    if (rc == DR_OK) rc = configure_mode<PG_PLANES>();
-    if (rc == DR_OK) rc = configure_mode<PG_LN>();
+    int rc = configure_mode<7, 4, PG_F32>(true);
+    if (rc == DR_OK) rc = configure_mode<7, 4, PG_PLANES>(true);
+    if (rc == DR_OK) rc = configure_mode<7, 4, PG_LN>(true);
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>(false);
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_PLANES>(false);
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_LN>(false);
     return rc;
 }
 
@@ -656,13 +670,14 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 3) return DR_EINVAL;
     int maxt = 0;
     double flops = 0;
+    const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G7::BN ? G7::NST : G9::NST;
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
-        if (!pgemm_shape_ok(p.C) || p.rows < 1 || p.nblk < 1 || p.nc0 < 1 || p.nc0 + (p.A1 ? p.nc1 : 0) < G7::NST) return DR_ENOSUP;
+        if (!pgemm_shape_ok(p.C) || pgemm_bn(p.C) != bn || p.rows < 1 || p.nblk < 1 || p.nc0 < 1 || p.nc0 + (p.A1 ? p.nc1 : 0) < nst_min) return DR_ENOSUP;
         if (p.W.nct != p.nc0 + (p.A1 ? p.nc1 : 0)) return DR_EINVAL;
         const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk;
         maxt = tl > maxt ? tl : maxt;
-        flops += 2.0 * p.rows * p.C * p.nblk * 16.0 * p.W.nct;
+        flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
     static const bool dbg = [] { const char* e = getenv("DR_PG_STAMPS"); return e && atoi(e) != 0; }();
@@ -671,50 +686,54 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
     const dim3 grid(maxt, g.n), blk(512);
-#define PG_LAUNCH(MODE, DBGF, ABLV) hipLaunchKernelGGL((pgemm_kernel<7, 4, MODE, DBGF, ABLV>), grid, blk, G7::SMEM, st, g)
-#define PG_LAUNCH_DBG(MODE)                                  \
-    switch (abl) {                                           \
-        case 1: PG_LAUNCH(MODE, true, 1); break;             \
-        case 2: PG_LAUNCH(MODE, true, 2); break;             \
-        case 3: PG_LAUNCH(MODE, true, 3); break;             \
-        case 4: PG_LAUNCH(MODE, true, 4); break;             \
-        case 5: PG_LAUNCH(MODE, true, 5); break;             \
-        case 6: PG_LAUNCH(MODE, true, 6); break;             \
-        case 7: PG_LAUNCH(MODE, true, 7); break;             \
-        default: PG_LAUNCH(MODE, true, 0); break;            \
+#define PG_LAUNCH(TNW, NST, MODE, DBGF, ABLV) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>), grid, blk, (PgGeom<TNW, NST>::SMEM), st, g)
+#define PG_LAUNCH_DBG(MODE)                                        \
+    switch (abl) {                                                 \
+        case 1: PG_LAUNCH(7, 4, MODE, true, 1); break;             \
+        case 2: PG_LAUNCH(7, 4, MODE, true, 2); break;             \
+        case 3: PG_LAUNCH(7, 4, MODE, true, 3); break;             \
+        case 4: PG_LAUNCH(7, 4, MODE, true, 4); break;             \
+        case 5: PG_LAUNCH(7, 4, MODE, true, 5); break;             \
+        case 6: PG_LAUNCH(7, 4, MODE, true, 6); break;             \
+        case 7: PG_LAUNCH(7, 4, MODE, true, 7); break;             \
+        default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
     }
-    if (dbg) {
+    if (bn == G9::BN) {
+        if (mode == PG_F32) PG_LAUNCH(9, 3, PG_F32, false, 0);
+        else if (mode == PG_PLANES) PG_LAUNCH(9, 3, PG_PLANES, false, 0);
+        else PG_LAUNCH(9, 3, PG_LN, false, 0);
+    } else if (dbg) {
         if (mode == PG_F32) { PG_LAUNCH_DBG(PG_F32) } else if (mode == PG_PLANES) { PG_LAUNCH_DBG(PG_PLANES) } else { PG_LAUNCH_DBG(PG_LN) }
-    } else if (mode == PG_F32) PG_LAUNCH(PG_F32, false, 0);
-    else if (mode == PG_PLANES) PG_LAUNCH(PG_PLANES, false, 0);
-    else PG_LAUNCH(PG_LN, false, 0);
+    } else if (mode == PG_F32) PG_LAUNCH(7, 4, PG_F32, false, 0);
+    else if (mode == PG_PLANES) PG_LAUNCH(7, 4, PG_PLANES, false, 0);
+    else PG_LAUNCH(7, 4, PG_LN, false, 0);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
 
-size_t pgemm_weight_bytes(int nblk, int nct) {
-    size_t b = (size_t)nblk * nct * G7::B_ST;              // image
-    b += (size_t)nblk * G7::BN * 4;                        // cinv
+size_t pgemm_weight_bytes(int C, int nblk, int nct) {
+    size_t b = (size_t)nblk * nct * pg_bst(C);             // image
+    b += (size_t)nblk * pgemm_bn(C) * 4;                   // cinv
     b += (size_t)nblk * 4;                                 // wnorm
     return (b + 255) & ~(size_t)255;
 }
-void pgemm_weight_view(void* buf, int nblk, int nct, PgW* v) {
+void pgemm_weight_view(void* buf, int C, int nblk, int nct, PgW* v) {
     char* p = (char*)buf;
     v->img = p;
-    v->cinv = reinterpret_cast<const float*>(p + (size_t)nblk * nct * G7::B_ST);
-    v->wnorm = v->cinv + (size_t)nblk * G7::BN;
+    v->cinv = reinterpret_cast<const float*>(p + (size_t)nblk * nct * pg_bst(C));
+    v->wnorm = v->cinv + (size_t)nblk * pgemm_bn(C);
     v->nct = nct;
 }
 int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st) {
     if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
-    const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
+    const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16, BN = pgemm_bn(C);
     PgW v;
-    pgemm_weight_view(buf, nblk, nct, &v);
+    pgemm_weight_view(buf, C, nblk, nct, &v);
     DR_HIP_CHECK(hipMemsetAsync((void*)v.wnorm, 0, (size_t)nblk * 4, st));
-    hipLaunchKernelGGL(pg_wscale_kernel, dim3((nblk * G7::BN + 3) / 4), dim3(256), 0, st, W, nblk, C, K, G7::BN, (float*)v.cinv, (float*)v.wnorm);
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((nblk * BN + 3) / 4), dim3(256), 0, st, W, nblk, C, K, BN, (float*)v.cinv, (float*)v.wnorm);
     DR_LAUNCH_CHECK();
-    const size_t n = (size_t)nblk * nct * G7::BN * 2;
-    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, nblk, C, K, G7::BN, nct, piece_len, piece_pad,
+    const size_t n = (size_t)nblk * nct * BN * 2;
+    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, nblk, C, K, BN, nct, piece_len, piece_pad,
                        v.cinv, (char*)v.img);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -725,14 +744,15 @@ int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int pi
     if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
     const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
     if (nct != v.nct) return DR_EINVAL;
-    float* cinv = (float*)v.cinv + (size_t)nb * G7::BN;
+    const int BN = pgemm_bn(C);
+    float* cinv = (float*)v.cinv + (size_t)nb * BN;
     float* wnorm = (float*)v.wnorm + nb;
-    char* img = (char*)v.img + (size_t)nb * nct * G7::B_ST;
+    char* img = (char*)v.img + (size_t)nb * nct * pg_bst(C);
     DR_HIP_CHECK(hipMemsetAsync(wnorm, 0, 4, st));
-    hipLaunchKernelGGL(pg_wscale_kernel, dim3((G7::BN + 3) / 4), dim3(256), 0, st, W, 1, C, K, G7::BN, cinv, wnorm);
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((BN + 3) / 4), dim3(256), 0, st, W, 1, C, K, BN, cinv, wnorm);
     DR_LAUNCH_CHECK();
-    const size_t n = (size_t)nct * G7::BN * 2;
-    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, 1, C, K, G7::BN, nct, piece_len, piece_pad,
+    const size_t n = (size_t)nct * BN * 2;
+    hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, 1, C, K, BN, nct, piece_len, piece_pad,
                        (const float*)cinv, img);
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -789,7 +809,7 @@ static int plane_nct(int K, int piece_len, int piece_pad) { return (K + piece_le
 
 size_t dr_plane_weight_bytes(int nblk, int C, int K, int piece_len, int piece_pad) {
     if (nblk < 1 || !pgemm_shape_ok(C) || K < 1 || piece_len < 1 || piece_pad < piece_len || piece_pad % 16) return 0;
-    return pgemm_weight_bytes(nblk, plane_nct(K, piece_len, piece_pad));
+    return pgemm_weight_bytes(C, nblk, plane_nct(K, piece_len, piece_pad));
 }
 
 int dr_pack_weight_planes_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream) {
@@ -810,7 +830,7 @@ int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
     PgProblem& p = g.p[0];
     p.A0 = (const char*)a->a0; p.bnd0 = a->bound0; p.nc0 = a->k0 / 16;
     p.A1 = (const char*)a->a1; p.bnd1 = a->bound1; p.nc1 = a->a1 ? a->k1 / 16 : 0;
-    pgemm_weight_view((void*)a->packed, a->nblk, p.nc0 + p.nc1, &p.W);
+    pgemm_weight_view((void*)a->packed, a->C, a->nblk, p.nc0 + p.nc1, &p.W);
     p.nblk = a->nblk; p.rows = a->rows; p.C = a->C; p.mode = a->mode;
     p.out = a->out; p.ldo = a->ldo; p.blk_stride = a->blk_stride;
     p.cosT = a->cos_t; p.sinT = a->sin_t; p.rot_mask = a->rot_mask; p.rot_C = a->rot_C > 0 ? a->rot_C : a->C; p.scale = a->scale;
