@@ -309,12 +309,16 @@ def test_cfg3_4dmatch_512_batch8_20_steps(golden):
       pair 0: the reference itself (tests/golden/4dmatch_loop_n512_s20_mc40_masked.npz, minted by oracle/make_golden.py),
               with its committed exemption list;
       pair 1: the oracle run here (float32) with the exemption rule applied to its float64 evaluation;
-      pairs 2..7: the batched result equals the pair's own B = 1 run."""
+      pairs 2..7: the batched result equals the pair's own B = 1 run through the same (plane) GEMM path to fp32 rounding (the
+              similarity GEMM, Sinkhorn and top-K kernels tile a batch differently).  The loop is a discontinuous function of
+              its matrices (top-K, the condition-number gate): a pair whose K-th and (K+1)-th confidences nearly tie at some
+              step parts ways between ANY two float32 evaluations from there on (seed 67 does at step 13 -- measured with
+              tools/debug_cfg3b.py -- and is not used)."""
     variant, N, M, steps, mc = "4dmatch", 512, 512, 20, 40
     v = synth.VARIANTS[variant]
     W = weights(variant)
-    eng = engine(variant, steps, mc)
-    cases = [(470, 391, 62), (512, 512, 61), (500, 480, 63), (512, 300, 64), (333, 512, 65), (450, 450, 66), (512, 511, 67), (400, 390, 68)]
+    eng = engine(variant, steps, mc, planes=True)        # (8 x 1024 token rows select the plane path anyway; the B = 1 runs below need the flag)
+    cases = [(470, 391, 62), (512, 512, 61), (500, 480, 63), (512, 300, 64), (333, 512, 65), (450, 450, 66), (512, 511, 69), (400, 390, 68)]
     prs = [pair(variant, N, M, c[2])[1] for c in cases]
     cat = lambda k: torch.cat([q[k] for q in prs]).to(DEV)
     ms = torch.stack([torch.arange(N) < c[0] for c in cases])

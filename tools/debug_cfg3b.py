@@ -11,7 +11,7 @@ variant, N, M, mc = "4dmatch", 512, 512, 40
 steps = int(os.environ.get("STEPS", "20"))
 v = synth.VARIANTS[variant]
 eng = DenoiseEngine(weights(variant), variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps,
-                    sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=DEV)
+                    sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=DEV, planes=True)
 cases = [(470, 391, 62), (512, 512, 61), (500, 480, 63), (512, 300, 64), (333, 512, 65), (450, 450, 66), (512, 511, 67), (400, 390, 68)][:int(os.environ.get("P", "8"))]
 prs = [pair(variant, N, M, c[2])[1] for c in cases]
 cat = lambda k: torch.cat([q[k] for q in prs]).to(DEV)
