@@ -37,12 +37,14 @@ PEAK_MFMA_BF16_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
 # the split-operand GEMMs spend several 16-bit MFMA MACs per fp32 MAC: the ceiling of what they execute, in fp32-equivalent
 # FLOP/s.  Default: two fp16 planes, three products (the fp16 and bf16 dense MFMA peaks are the same); DR_GEMM_F16X2=0: three
 # bf16 planes, six products.
-F16X2 = os.environ.get("DR_GEMM_F16X2", "1") != "0"
-SPLIT_PRODUCTS = 3.0 if F16X2 else 6.0
+# The layer GEMMs (dr::pgemm_kernel, csrc/pgemm.hip) run on fp16 hi / lo plane images of both operands: three fp16 MFMA products per
+# fp32 MAC (the fp16 and bf16 dense MFMA peaks are the same).
+SPLIT_PRODUCTS = 3.0
 PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / SPLIT_PRODUCTS
-SPLIT_KERNEL = "gemm_nt_wide2_kernel" if F16X2 else "gemm_nt_wide_kernel"
-SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand splits (rows of both operands scaled by exact powers of two into fp16's range)"
-              if F16X2 else "six bf16 MFMA products of hi/mid/lo operand splits")
+SPLIT_KERNEL = "pgemm_kernel"
+SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand planes (rows of both operands scaled by exact powers of two into fp16's range; "
+              "planes written by the producing kernels, both operands streamed by LDS-DMA)")
+LOOP_PMC = os.path.join(ROOT, "profiles", "r02_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -199,7 +201,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed passes of the hot path (K)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "128")),
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DIFFREG_BENCH_PAIRS", "256")),
                     help="independent scene pairs per pass and per GPU")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFREG_BENCH_STREAMS", "2")),
                     help="the pairs of a pass are split into this many batches, one captured graph each, replayed "
@@ -332,7 +334,7 @@ def main():
         "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
                                "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, max(int(p) for p in per_rank_pairs), nstreams),
                    "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
-                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32",
+                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32", "gemm_path": "plane images (csrc/pgemm.hip), weights packed once per engine",
                    "gemm_arithmetic": "fp32 in / fp32 out; each product as %s, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)" % SPLIT_TEXT, "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
         "metric_gather": dict(gathered, collective="all_reduce(SUM) of [sum IR, sum FMR, sum RR, n_pairs, sum t] (float64)",
@@ -388,14 +390,15 @@ def main():
                 roof = dict(kernel=dom, bound="hbm", achieved=work / (ms_ * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
                             traffic=None)
             roof["frac"] = roof["achieved"] / roof["peak"]
-            if dom == "gemm_split":
-                # PMC traffic of this kernel is collected on one named shape (separate rocprofv3 --pmc passes, the
-                # launches of a pass here are a mix of shapes): quoted beside the line, `traffic` itself stays null
-                tp = os.path.join(ROOT, "profiles", "r01_gemm_wide2_pmc_traffic.json" if F16X2 else "r01_gemm_wide_pmc_traffic.json")
-                if os.path.exists(tp):
-                    tj = json.load(open(tp))
-                    roof["traffic_reference"] = {k: tj[k] for k in ("shape", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch",
-                                                                    "traffic_over_algorithmic", "command")}
+            if dom == "gemm_split" and os.path.exists(LOOP_PMC):
+                # HBM bytes and MFMA-pipe utilisation of THIS kernel over the loop's own launches: separate rocprofv3 --pmc passes of
+                # `bench.py --breakdown-only` (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; per launch, averaged like `achieved`)
+                tj = json.load(open(LOOP_PMC))
+                roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = "profiles/r02_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
+                roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
+                roof["effective_clock_GHz_pmc"] = tj.get("derived", {}).get("effective_clock_GHz")
+                roof["avg_us_per_launch_pmc_run"] = tj.get("avg_us_per_launch_profiled")
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
             roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "

@@ -896,6 +896,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     if (rc) return rc;
 
     const double* ac = cfg->h_alphas_cumprod;
+    const float* fin = nullptr;
     for (int k = 0; k < cfg->steps; ++k) {
         const int tcur = cfg->h_times[k], tnext = cfg->h_times[k + 1];
         // -- x <- x - x.min() (3D only, pipeline.py:239); mask; Sinkhorn; exp; slice; float32 (pipeline.py:293-302)
@@ -919,7 +920,6 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = fill_pe(*cfg, *w, P, N, M, s_pcd, L.Rf, L.tf, t_pcd, true, false, L.dw, st);
         if (rc) return rc;
         // -- denoising_transformer + denoising_coarse_matching (pipeline.py:243-244)
-        const float* fin = nullptr;
         rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, &fin, st, true);
         if (rc) return rc;
         rc = sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0,
@@ -939,6 +939,22 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         if (rc) return rc;
     }
     if (x_final) DR_HIP_CHECK(hipMemcpyAsync(x_final, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
+    if (trace && (trace->feats_nopos || trace->feats_pos) && fin) {
+        // data["src_feats_nopos"] / ["src_feats"] (+ tgt) of the last Matching.forward (matching.py:177-187): src_proj on both
+        // sides (quirk Q1), without and with the rotary embedding of the last step's position code
+        for (int pos = 0; pos < 2; ++pos) {
+            float* dst = pos ? trace->feats_pos : trace->feats_nopos;
+            if (!dst) continue;
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            GemmProblem& p = g.p[0];
+            p.A = fin; p.W = w->src_proj; p.out = dst; p.rows = (int)(PN + PM); p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
+            p.epi = pos ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.cosT = L.dw.cosT; p.sinT = L.dw.sinT; p.scale = 1.f;
+            g.n = 1;
+            rc = launch_gemm(g, st);
+            if (rc) return rc;
+        }
+    }
 
     // -- read-out
     if (v4d) {

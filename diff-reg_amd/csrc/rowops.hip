@@ -275,4 +275,27 @@ int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R,
     return DR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// split_feats (3D/models/pipeline.py:350-379): dst[dst_index[i]][:] = src[src_index[i]][:] for i < n (rows of C floats;
+// the padded destination is zero-filled by the caller).  One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ sidx,
+                                                           const long long* __restrict__ didx, float* __restrict__ dst, int n, int C) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* s = src + (size_t)sidx[i] * C;
+    float* d = dst + (size_t)didx[i] * C;
+    for (int c = lane; c < C; c += 64) d[c] = s[c];
+}
 }  // namespace dr
+
+extern "C" int dr_scatter_rows_f32(int n, int C, const float* src, const int64_t* src_index, const int64_t* dst_index, float* dst,
+                                   void* stream) {
+    if (n < 0 || C < 1 || !src || !src_index || !dst_index || !dst) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, (const long long*)src_index,
+                       (const long long*)dst_index, dst, n, C);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}

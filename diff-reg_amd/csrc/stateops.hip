@@ -203,6 +203,103 @@ int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* c
     return DR_OK;
 }
 template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
+// ---------------------------------------------------------------------------------------------
+// Matching.get_match(conf, thr, mutual=True) (3D/models/matching.py:126-143; the read-out the 4DMatch tester applies to
+// conf_matrix_pred, 4D/lib/tester.py:266): entries that are > thr AND equal to their row maximum AND equal to their column
+// maximum (every tie counts, as the reference's `==` does), listed like nonzero(): ascending (b, i, j).  One workgroup per
+// pair: column maxima in LDS, then two sweeps over the rows (count per row -> exclusive scan -> ordered write).
+// ---------------------------------------------------------------------------------------------
+constexpr int MM_MAX = 4096;   // N, M <= MM_MAX
+
+template <typename T>
+__global__ __launch_bounds__(1024) void mutual_match_kernel(const T* __restrict__ conf, int N, int M, T thr, int mutual, int cap,
+                                                            long long* __restrict__ out, T* __restrict__ mconf, int* __restrict__ count,
+                                                            uint8_t* __restrict__ mask) {
+    __shared__ T s_col[MM_MAX];
+    __shared__ int s_cnt[MM_MAX + 1];
+    const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const T* c = conf + (size_t)pair * N * M;
+    for (int j = t; j < M; j += 1024) {
+        T best = -INFINITY;
+        if (mutual)
+            for (int i = 0; i < N; ++i) { const T v = c[(size_t)i * M + j]; best = v > best ? v : best; }
+        s_col[j] = best;
+    }
+    __syncthreads();
+    auto hit = [&](int i, int j, T rowmax) {
+        const T v = c[(size_t)i * M + j];
+        return v > thr && (!mutual || (v == rowmax && v == s_col[j]));
+    };
+    auto row_max = [&](int i) {
+        T best = -INFINITY;
+        if (mutual) {
+            for (int j = lane; j < M; j += 64) { const T v = c[(size_t)i * M + j]; best = v > best ? v : best; }
+            for (int m = 32; m >= 1; m >>= 1) { const T o = __shfl_xor(best, m); best = o > best ? o : best; }
+        }
+        return best;
+    };
+    for (int i = w; i < N; i += 16) {
+        const T rm = row_max(i);
+        int n = 0;
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int j = j0 + lane;
+            n += __popcll(__ballot(j < M && hit(i, j, rm)));
+        }
+        if (lane == 0) s_cnt[i] = n;
+    }
+    __syncthreads();
+    if (t == 0) {                                    // exclusive scan over the rows (N <= 4096: a few microseconds once per pair)
+        int acc = 0;
+        for (int i = 0; i < N; ++i) { const int n = s_cnt[i]; s_cnt[i] = acc; acc += n; }
+        s_cnt[N] = acc;
+        count[pair] = acc;                           // the TRUE count: > cap tells the caller that the list was truncated
+    }
+    __syncthreads();
+    long long* o = out + (size_t)pair * cap * 3;
+    for (int i = w; i < N; i += 16) {
+        const T rm = row_max(i);
+        int base = s_cnt[i];
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int j = j0 + lane;
+            const bool h = j < M && hit(i, j, rm);
+            const unsigned long long b = __ballot(h);
+            if (mask && j < M) mask[((size_t)pair * N + i) * M + j] = h ? 1 : 0;
+            if (h) {
+                const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                    o[pos * 3] = pair; o[pos * 3 + 1] = i; o[pos * 3 + 2] = j;
+                    if (mconf) mconf[(size_t)pair * cap + pos] = c[(size_t)i * M + j];
+                }
+            }
+            base += __popcll(b);
+        }
+    }
+}
+
+template <typename T>
+static int launch_mutual_match(const T* conf, int P, int N, int M, T thr, int mutual, int cap, long long* out, T* mconf, int* count,
+                               uint8_t* mask, hipStream_t st) {
+    if (P <= 0) return DR_OK;
+    if (N > MM_MAX || M > MM_MAX) return DR_ENOSUP;
+    hipLaunchKernelGGL((mutual_match_kernel<T>), dim3(P), dim3(1024), 0, st, conf, N, M, thr, mutual, cap, out, mconf, count, mask);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+}  // namespace dr
+extern "C" {
+int dr_mutual_match_f64(int P, int N, int M, const double* conf, double thr, int mutual, int cap, int64_t* matches, double* mconf,
+                        int32_t* count, uint8_t* mask, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || cap < 1 || !conf || !matches || !count) return DR_EINVAL;
+    return dr::launch_mutual_match<double>(conf, P, N, M, thr, mutual, cap, (long long*)matches, mconf, count, mask, (hipStream_t)stream);
+}
+int dr_mutual_match_f32(int P, int N, int M, const float* conf, float thr, int mutual, int cap, int64_t* matches, float* mconf,
+                        int32_t* count, uint8_t* mask, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || cap < 1 || !conf || !matches || !count) return DR_EINVAL;
+    return dr::launch_mutual_match<float>(conf, P, N, M, thr, mutual, cap, (long long*)matches, mconf, count, mask, (hipStream_t)stream);
+}
+}
+namespace dr {
+
 template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
 
 }  // namespace dr

@@ -4,6 +4,7 @@ the whole loop, and calls dr_denoise_loop through the C ABI.
 
 Mirrors the eval branch of Pipeline.forward (3D/models/pipeline.py:221-283, 4D/models/pipeline.py:156-197)
 for P independent scene pairs (the reference runs B = 1; P pairs are P independent B = 1 problems)."""
+import collections
 import ctypes
 import math
 
@@ -33,8 +34,10 @@ def sampling_times(steps, timesteps=1000):
 class DenoiseEngine:
     def __init__(self, state, *, variant, C, H, voxel, origin, steps, sk_iters=3, sample_rate=1.0, max_condition_num=0.0,
                  n_layers=6, device="cuda:0", strict_f64=False, prefix_t="denoising_transformer.",
-                 prefix_m="denoising_coarse_matching.", prepack=True, planes=None):
-        """state: mapping name -> tensor in the reference state-dict layout."""
+                 prefix_m="denoising_coarse_matching.", prepack=True, planes=None, cache_entries=4):
+        """state: mapping name -> tensor in the reference state-dict layout.
+        cache_entries: run() keeps static buffers (and, with graph=True, a captured HIP graph) per call shape; at most this many
+        shapes stay cached, least recently used first out (its buffers and graph are freed)."""
         lib.ensure_init()
         self.device = torch.device(device)
         self.variant, self.C, self.H, self.n_layers = variant, C, H, n_layers
@@ -69,7 +72,8 @@ class DenoiseEngine:
         cfg.h_times = self._times.ctypes.data
         self.cfg = cfg
         self._ws = None
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()
+        self._cache_entries = max(1, int(cache_entries))
         # the weights are immutable for the life of the engine: their plane images are packed once (dr_loop_prepack)
         self._packed = None
         nb = lib.raw().dr_loop_prepack_bytes(ctypes.byref(cfg))
@@ -80,10 +84,45 @@ class DenoiseEngine:
             self.w.prepacked = self._packed.data_ptr()
 
     # ------------------------------------------------------------------------------------------
+    GUARD = 64 * 1024          # bytes of 0xA5 on either side of every buffer when guard bands are on (tests)
+
+    def enable_guards(self, on=True):
+        """Tests: allocate every static buffer (inputs, outputs, workspace) between two 64 KiB bands of 0xA5 and let
+        check_guards() verify them -- an out-of-bounds write of any kernel of the loop shows up as a damaged band instead of
+        as a wrong value somewhere else.  Affects buffers allocated from now on."""
+        self._guard = bool(on)
+        self._guarded = []
+
+    def _alloc(self, shape, dtype=torch.float32, fill=None):
+        n = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            n *= int(d)
+        if not getattr(self, "_guard", False):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            if fill is not None:
+                t.fill_(fill)
+            return t
+        esz = torch.empty((), dtype=dtype).element_size()
+        nbytes = (n * esz + 255) // 256 * 256
+        raw = torch.full((self.GUARD + nbytes + self.GUARD,), 0xA5, dtype=torch.uint8, device=self.device)
+        t = raw[self.GUARD:self.GUARD + n * esz].view(dtype).view(shape)
+        if fill is not None:
+            t.fill_(fill)
+        self._guarded.append((raw, n * esz))
+        return t
+
+    def check_guards(self):
+        torch.cuda.synchronize(self.device)
+        for raw, nbytes in getattr(self, "_guarded", []):
+            lo, hi = raw[:self.GUARD], raw[self.GUARD + (nbytes + 255) // 256 * 256:]
+            if not (bool((lo == 0xA5).all()) and bool((hi == 0xA5).all())):
+                raise AssertionError("guard band damaged around a buffer of %d bytes" % nbytes)
+        return len(getattr(self, "_guarded", []))
+
     def _workspace(self, P, N, M):
         need = lib.raw().dr_denoise_loop_workspace_bytes(ctypes.byref(self.cfg), P, N, M)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = self._alloc(need, torch.uint8)
         return self._ws, need
 
     def denoise_match(self, src_feats, tgt_feats, s_pcd_warped, t_pcd, src_mask=None, tgt_mask=None):
@@ -103,10 +142,13 @@ class DenoiseEngine:
     def _enqueue(self, bufs):
         b = bufs
         tr = None
-        if b.get("trace"):
+        if b.get("trace") or "feats_nopos" in b:
             tr = lib.LoopTrace()
+        if b.get("trace"):
             tr.x0, tr.R_forwd, tr.t_forwd, tr.cond = (b["tr_x0"].data_ptr(), b["tr_R"].data_ptr(), b["tr_t"].data_ptr(),
                                                       b["tr_cond"].data_ptr())
+        if "feats_nopos" in b:
+            tr.feats_nopos, tr.feats_pos = b["feats_nopos"].data_ptr(), b["feats_pos"].data_ptr()
         lib.check(lib.raw().dr_denoise_loop(
             ctypes.byref(self.cfg), ctypes.byref(self.w), b["P"], b["N"], b["M"], lib.ptr(b["src_feats"]), lib.ptr(b["tgt_feats"]),
             lib.ptr(b["s_pcd"]), lib.ptr(b["t_pcd"]), lib.ptr(b["src_mask"]), lib.ptr(b["tgt_mask"]), lib.ptr(b["x_T"]),
@@ -114,62 +156,72 @@ class DenoiseEngine:
             lib.ptr(b["R_final"]), lib.ptr(b["t_final"]), ctypes.byref(tr) if tr is not None else None, lib.ptr(b["ws"]),
             b["ws_bytes"], lib.stream_of(b["conf"])))
 
-    def make_buffers(self, P, N, M, masked=False, trace=False, private_ws=False):
+    def make_buffers(self, P, N, M, masked=False, trace=False, private_ws=False, side_outputs=False):
         dev, C, S = self.device, self.C, self.steps
         ws, need = self._workspace(P, N, M)
         if private_ws:          # concurrent batches must not share scratch memory
-            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = self._alloc(need, torch.uint8)
+        A = self._alloc
         b = dict(P=P, N=N, M=M, ws=ws, ws_bytes=need, trace=trace,
-                 src_feats=torch.zeros(P, N, C, device=dev), tgt_feats=torch.zeros(P, M, C, device=dev),
-                 s_pcd=torch.zeros(P, N, 3, device=dev), t_pcd=torch.zeros(P, M, 3, device=dev),
-                 src_mask=torch.ones(P, N, dtype=torch.uint8, device=dev) if masked else None,
-                 tgt_mask=torch.ones(P, M, dtype=torch.uint8, device=dev) if masked else None,
-                 x_T=torch.zeros(P, N, M, device=dev),
-                 noise=torch.zeros(S, P, N, M, device=dev) if self.variant == "4dmatch" else None,
-                 conf=torch.empty(P, N, M, dtype=torch.float64, device=dev),
-                 x_final=torch.empty(P, N, M, dtype=torch.float64, device=dev),
-                 matches=torch.zeros(P, N + M, 3, dtype=torch.int64, device=dev) if self.variant == "3dmatch" else None,
-                 match_count=torch.zeros(P, dtype=torch.int32, device=dev) if self.variant == "3dmatch" else None,
-                 R_final=torch.empty(P, 3, 3, device=dev), t_final=torch.empty(P, 3, 1, device=dev))
+                 src_feats=A((P, N, C), fill=0), tgt_feats=A((P, M, C), fill=0),
+                 s_pcd=A((P, N, 3), fill=0), t_pcd=A((P, M, 3), fill=0),
+                 src_mask=A((P, N), torch.uint8, fill=1) if masked else None,
+                 tgt_mask=A((P, M), torch.uint8, fill=1) if masked else None,
+                 x_T=A((P, N, M), fill=0),
+                 noise=A((S, P, N, M), fill=0) if self.variant == "4dmatch" else None,
+                 conf=A((P, N, M), torch.float64),
+                 x_final=A((P, N, M), torch.float64),
+                 matches=A((P, N + M, 3), torch.int64, fill=0) if self.variant == "3dmatch" else None,
+                 match_count=A((P,), torch.int32, fill=0) if self.variant == "3dmatch" else None,
+                 R_final=A((P, 3, 3)), t_final=A((P, 3, 1)))
         if trace:
-            b.update(tr_x0=torch.empty(S, P, N, M, device=dev), tr_R=torch.empty(S, P, 3, 3, device=dev),
-                     tr_t=torch.empty(S, P, 3, 1, device=dev), tr_cond=torch.empty(S, P, dtype=torch.float64, device=dev))
+            b.update(tr_x0=A((S, P, N, M)), tr_R=A((S, P, 3, 3)), tr_t=A((S, P, 3, 1)), tr_cond=A((S, P), torch.float64))
+        if side_outputs:
+            b.update(feats_nopos=A((P * (N + M), C)), feats_pos=A((P * (N + M), C)))
         return b
 
     def run(self, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask=None, tgt_mask=None, noise=None, trace=False,
-            graph=False, _slot=0, ragged=False):
+            graph=False, _slot=0, ragged=False, side_outputs=False, borrow=False):
         """Run the loop for P pairs.  Returns a dict of device tensors (conf float64, x_final, matches list (3D),
         R_final, t_final, and the per-step trace when asked).  ragged=True (with masks): the masks are the true extents
-        of pairs padded to (N, M) and every pair gets the result of its own unpadded run (DR_LOOP_RAGGED)."""
+        of pairs padded to (N, M) and every pair gets the result of its own unpadded run (DR_LOOP_RAGGED).
+        side_outputs=True adds what Matching.forward leaves in `data` at the last step (src/tgt_feats, *_nopos).
+
+        Shapes are cached (static buffers + captured graph), at most `cache_entries` of them, least recently used first out.
+        With graph=True a shape runs eagerly the FIRST time it is seen and is captured when it comes again, so a stream of
+        ever-changing shapes (the reference tester: B = 1, N and M differ from pair to pair) never pays warm-up + capture for
+        a graph it will not replay.  The returned tensors are COPIES unless borrow=True (then they are the cached static
+        buffers, overwritten by the next run() of the same shape)."""
         P, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         masked = src_mask is not None
         self.cfg.flags = (self.cfg.flags & ~2) | (2 if (ragged and masked) else 0)
-        key = (P, N, M, masked, trace, bool(graph), _slot, bool(ragged and masked))
+        key = (P, N, M, masked, trace, _slot, bool(ragged and masked), bool(side_outputs))
         ent = self._graphs.get(key)
         if ent is None:
-            b = self.make_buffers(P, N, M, masked=masked, trace=trace, private_ws=_slot > 0)
-            g = None
-            if graph:
-                self._fill(b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise)
-                s = torch.cuda.Stream(device=self.device)
-                s.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(s):
-                    self._enqueue(b)                      # warm-up outside the capture
-                torch.cuda.current_stream(self.device).wait_stream(s)
-                torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._enqueue(b)
-            ent = (b, g)
+            ent = dict(b=self.make_buffers(P, N, M, masked=masked, trace=trace, private_ws=_slot > 0, side_outputs=side_outputs), g=None, uses=0)
             self._graphs[key] = ent
-        b, g = ent
+            while len(self._graphs) > self._cache_entries:
+                _, old = self._graphs.popitem(last=False)      # frees the graph and the buffers of the least recently used shape
+                old.clear()
+        else:
+            self._graphs.move_to_end(key)
+        b = ent["b"]
         self._fill(b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise)
-        if g is not None:
-            g.replay()
+        if graph and ent["g"] is None and ent["uses"] >= 1:
+            # second visit of this shape: capture (the earlier eager run was the warm-up)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(b)
+            ent["g"] = g
+        if graph and ent["g"] is not None:
+            ent["g"].replay()
         else:
             self._enqueue(b)
-        return self._collect(b)
+        ent["uses"] += 1
+        out = self._collect(b)
+        return out if borrow else {k: v.clone() for k, v in out.items()}
 
     def _fill(self, b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise):
         b["src_feats"].copy_(src_feats); b["tgt_feats"].copy_(tgt_feats)
@@ -187,6 +239,12 @@ class DenoiseEngine:
             out["matches_padded"], out["match_count"] = b["matches"], b["match_count"]
         if b["trace"]:
             out.update(x0=b["tr_x0"], R_forwd=b["tr_R"], t_forwd=b["tr_t"], cond=b["tr_cond"])
+        if "feats_nopos" in b:
+            P, N, M, C = b["P"], b["N"], b["M"], self.C
+            for name, t_ in (("nopos", b["feats_nopos"]), ("pos", b["feats_pos"])):
+                sfx = "_nopos" if name == "nopos" else ""
+                out["src_feats" + sfx] = t_[:P * N].view(P, N, C)
+                out["tgt_feats" + sfx] = t_[P * N:].view(P, M, C)
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -194,16 +252,18 @@ class DenoiseEngine:
         """Run several independent batches of pairs concurrently, one captured graph per batch, replayed on
         `n_streams` HIP streams so that the tails / small launches of one batch overlap the big launches of another.
         groups: list of dicts with the keyword arguments of run() (src_feats, tgt_feats, s_pcd, t_pcd, x_T, ...).
-        Returns the list of result dicts (buffers are per group and stay valid until the group is run again)."""
+        Returns the list of result dicts (borrowed: the static buffers of each group, valid until the group is run again).
+        The first pass of a group runs eagerly, the second captures its graph, later ones replay it."""
         cur = torch.cuda.current_stream(self.device)
         if not hasattr(self, "_streams") or len(self._streams) < n_streams:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self._cache_entries = max(self._cache_entries, len(groups) + 2)        # every group keeps its own slot
         outs = []
         for gi, kw in enumerate(groups):
             st = self._streams[gi % n_streams]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs.append(self.run(graph=True, _slot=gi, **kw))
+                outs.append(self.run(graph=True, _slot=gi, borrow=True, **kw))
         for st in self._streams[:n_streams]:
             cur.wait_stream(st)
         return outs
@@ -230,13 +290,14 @@ class DenoiseEngine:
             nz = torch.zeros(self.steps, P, N, M, device=dev)
             for i, z in enumerate(noise):
                 nz[:, i, :Ns[i], :Ms[i]] = z
-        out = self.run(fs, ft, ps, pt, xT, sm, tm, noise=nz, graph=graph, ragged=True)
+        out = self.run(fs, ft, ps, pt, xT, sm, tm, noise=nz, graph=graph, ragged=True, borrow=True)
         res = []
         cnt = out["match_count"].cpu().tolist() if "match_count" in out else None
         for i in range(P):
-            r = dict(conf_matrix_pred=out["conf_matrix_pred"][i, :Ns[i], :Ms[i]], R_final=out["R_final"][i], t_final=out["t_final"][i])
+            r = dict(conf_matrix_pred=out["conf_matrix_pred"][i, :Ns[i], :Ms[i]].clone(), R_final=out["R_final"][i].clone(),
+                     t_final=out["t_final"][i].clone())
             if cnt is not None:
-                r["match_pred"] = out["matches_padded"][i, :cnt[i]]
+                r["match_pred"] = out["matches_padded"][i, :cnt[i]].clone()
             res.append(r)
         return res
 

@@ -83,7 +83,8 @@ class Loop2D3DConfig(ctypes.Structure):
 
 
 class LoopTrace(ctypes.Structure):
-    _fields_ = [("x0", c_void_p), ("R_forwd", c_void_p), ("t_forwd", c_void_p), ("cond", c_void_p)]
+    _fields_ = [("x0", c_void_p), ("R_forwd", c_void_p), ("t_forwd", c_void_p), ("cond", c_void_p), ("feats_nopos", c_void_p),
+                ("feats_pos", c_void_p)]
 
 
 _P = ctypes.POINTER
@@ -126,6 +127,9 @@ SIGNATURES.update({
     "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
+    "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_mutual_match_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_mutual_match_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_loop_prepack_bytes": (c_size_t, [_P(LoopConfig)]),
@@ -269,6 +273,33 @@ def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, 
     a.relu = 1 if relu else 0
     a.gamma, a.beta, a.resid, a.ldr, a.bound_resid, a.ln_bound = dp(gamma), dp(beta), dp(resid), ldr, dp(bound_resid), dp(lnb)
     check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
+
+
+def scatter_rows(src, src_index, dst_index, dst):
+    """dst[dst_index[i]] = src[src_index[i]] (rows; split_feats of the reference)"""
+    ensure_init()
+    src = src.contiguous().float()
+    si, di = src_index.to(torch.int64).contiguous(), dst_index.to(torch.int64).contiguous()
+    assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[-1] == src.shape[-1]
+    check(_lib.dr_scatter_rows_f32(si.numel(), src.shape[-1], ptr(src), ptr(si), ptr(di), ptr(dst), stream_of(src)))
+    return dst
+
+
+def mutual_match(conf, thr=0.0, mutual=True, cap=None, want_mask=False):
+    """Matching.get_match on device: conf [P,N,M] float32 / float64 -> (matches [P,cap,3] int64, mconf [P,cap], count [P] int32,
+    mask [P,N,M] uint8 or None); rows beyond count[p] are undefined, count > cap means the list was truncated."""
+    ensure_init()
+    conf = conf.contiguous()
+    P, N, M = conf.shape
+    cap = cap or (N + M)
+    dev = conf.device
+    matches = torch.zeros(P, cap, 3, dtype=torch.int64, device=dev)
+    mconf = torch.zeros(P, cap, dtype=conf.dtype, device=dev)
+    count = torch.zeros(P, dtype=torch.int32, device=dev)
+    mask = torch.zeros(P, N, M, dtype=torch.uint8, device=dev) if want_mask else None
+    fn = _lib.dr_mutual_match_f64 if conf.dtype == torch.float64 else _lib.dr_mutual_match_f32
+    check(fn(P, N, M, ptr(conf), float(thr), 1 if mutual else 0, cap, ptr(matches), ptr(mconf), ptr(count), ptr(mask), stream_of(conf)))
+    return matches, mconf, count, mask
 
 
 def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift=False, apply_mask=False,

@@ -61,6 +61,18 @@ class Matching(nn.Module):
     @staticmethod
     @torch.no_grad()
     def get_match(conf_matrix, thr=0.0, mutual=True):
+        """(index [K,3], mconf [K], mask [B,N,M]) of matching.py:126-143.  On the device: dr_mutual_match_* (one kernel; the
+        read-out the 4DMatch tester applies to conf_matrix_pred, 4D/lib/tester.py:266); the list length K is data dependent, so
+        the per-pair counts are read once to size it."""
+        if conf_matrix.is_cuda and conf_matrix.dtype in (torch.float32, torch.float64) and max(conf_matrix.shape[1:]) <= 4096:
+            B, N, M = conf_matrix.shape
+            cap = N + M
+            seg, mc, cnt, mask = lib.mutual_match(conf_matrix, thr, mutual, cap=cap, want_mask=True)
+            if int(cnt.max()) > cap:                                   # more ties than any sane matrix has: exact, but slower
+                seg, mc, cnt, mask = lib.mutual_match(conf_matrix, thr, mutual, cap=N * M, want_mask=True)
+                cap = N * M
+            keep = torch.arange(cap, device=conf_matrix.device)[None, :] < cnt[:, None]
+            return seg[keep], mc[keep], mask.bool()
         mask = conf_matrix > thr
         if mutual:
             mask = mask * (conf_matrix == conf_matrix.max(dim=2, keepdim=True)[0]) \
@@ -83,12 +95,14 @@ class Matching(nn.Module):
         s_np = lib.linear(src_feats.reshape(B * N, C), W)
         t_np = lib.linear(tgt_feats.reshape(B * M, C), W)            # src_proj on both sides (Q1)
         data["src_feats_nopos"], data["tgt_feats_nopos"] = s_np.view(B, N, C), t_np.view(B, M, C)
-        s_rot = lib.linear(src_feats.reshape(B * N, C), W, epilogue=2, cos=cs, sin=ss, rot_C=C)
-        t_rot = lib.linear(tgt_feats.reshape(B * M, C), W, epilogue=2, cos=ct, sin=st, rot_C=C)
-        data["src_feats"], data["tgt_feats"] = s_rot.view(B, N, C), t_rot.view(B, M, C)
-        a = (s_rot / C ** 0.5).view(B, N, C)
-        b = (t_rot / C ** 0.5).view(B, M, C)
-        sim = torch.stack([lib.linear(a[i], b[i]) for i in range(B)])
+        # (the rotary form comes from the GEMM's epilogue: a second pass over the same small projection; inside the denoising
+        #  loop -- dr_denoise_loop -- neither copy is materialised per step)
+        s_rot = lib.linear(src_feats.reshape(B * N, C), W, epilogue=2, cos=cs, sin=ss, rot_C=C).view(B, N, C)
+        t_rot = lib.linear(tgt_feats.reshape(B * M, C), W, epilogue=2, cos=ct, sin=st, rot_C=C).view(B, M, C)
+        data["src_feats"], data["tgt_feats"] = s_rot, t_rot
+        a = s_rot / C ** 0.5
+        b = t_rot / C ** 0.5
+        sim = torch.stack([lib.linear(a[i], b[i]) for i in range(B)]) if B > 1 else lib.linear(a[0], b[0])[None]
         conf = lib.sinkhorn(sim, self.bin_score, self.skh_iters, src_mask, tgt_mask, apply_mask=src_mask is not None)
         coarse_match, _, _ = self.get_match(conf, self.confidence_threshold)
         return conf, coarse_match

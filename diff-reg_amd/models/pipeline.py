@@ -86,6 +86,9 @@ class Pipeline(nn.Module):
         self.register_buffer("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac))
         self.register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1))
         self._engine = None
+        # HIP-graph replay of the loop: pays off when (B, N, M) repeats (fixed-size batches); the engine runs a shape eagerly the
+        # first time and captures it when it comes again, and keeps at most 4 shapes, so variable-size evaluation (the reference
+        # tester: B = 1, N and M change with every pair) neither captures graphs it never replays nor grows without bound
         self.use_graph = True
         # batches (B > 1) of padded pairs: False = the reference's pad-and-mask semantics (quirks Q8 / Q19: not the B = 1
         # results, NaN in the 3D variant); True = every pair gets its own B = 1 result (DR_LOOP_RAGGED)
@@ -140,22 +143,32 @@ class Pipeline(nn.Module):
         noise = None
         if self.variant == "4dmatch":
             noise = data["noise"] if "noise" in data else torch.randn(S, P, N, M, device=dev)
-        all_valid = bool(src_mask.all()) and bool(tgt_mask.all())
+        # 3D: masks are all-true for B = 1 (the only well-defined case there, quirk Q8) and the mask-free kernels are the fast
+        # ones; deciding that needs the mask VALUES, i.e. one host read -- done once per batch on the two small bool tensors
+        # together.  4D always runs with its masks (they are part of the reference's semantics there).
+        use_masks = self.variant == "4dmatch" or self.ragged_batches or not bool(torch.logical_and(src_mask.all(), tgt_mask.all()))
         out = eng.run(src_feats.float(), tgt_feats.float(), s_pcd.float(), t_pcd.float(), x_T.float(),
-                      None if all_valid else src_mask, None if all_valid else tgt_mask, noise=noise, graph=self.use_graph,
-                      ragged=self.ragged_batches)
-        conf = out["conf_matrix_pred"].clone()
-        data.update({"conf_matrix_pred": conf})
+                      src_mask if use_masks else None, tgt_mask if use_masks else None, noise=noise, graph=self.use_graph,
+                      ragged=self.ragged_batches, side_outputs=True)
+        data.update({"conf_matrix_pred": out["conf_matrix_pred"]})
+        # what the reference's last denoiser / Matching.forward call leaves behind (transformero.py:172, matching.py:177-187)
+        data.update({"position_layers": {}, "src_feats": out["src_feats"], "tgt_feats": out["tgt_feats"],
+                     "src_feats_nopos": out["src_feats_nopos"], "tgt_feats_nopos": out["tgt_feats_nopos"]})
         if self.variant == "3dmatch":
-            ml = eng.match_list(out)
-            match_pred = torch.cat([torch.cat([torch.full_like(m[:, :1], b), m[:, 1:]], 1) for b, m in enumerate(ml)]) \
-                if P > 1 else ml[0].clone()
-            data.update({"match_pred": match_pred})
+            # match_pred = the flat [K, 3] (b, i, j) list of pipeline.py:275-280: the per-pair segments are compacted ON the
+            # device (column 0 already carries b = 0; the batch index is written in), its length K is data dependent like the
+            # reference's nonzero(), so one count read sizes the result
+            seg, cnt = out["matches_padded"], out["match_count"]
+            cap = seg.shape[1]
+            keep = torch.arange(cap, device=dev)[None, :] < cnt[:, None]
+            seg = seg.clone()
+            seg[:, :, 0] = torch.arange(P, device=dev)[:, None]
+            data.update({"match_pred": seg[keep]})
         if self.strict_reference:
             R = torch.eye(3, dtype=torch.float64, device=dev)[None].repeat(P, 1, 1)
             t = torch.zeros(P, 3, 1, dtype=torch.float64, device=dev)
         else:
-            R, t = out["R_final"].clone(), out["t_final"].clone()
+            R, t = out["R_final"], out["t_final"]
         data.update({"R_s2t_pred": R, "t_s2t_pred": t})
         return data
 
@@ -169,13 +182,16 @@ class Pipeline(nn.Module):
         src_mask, tgt_mask = data["src_mask"], data["tgt_mask"]
         b_size, src_max = src_mask.shape
         tgt_max = tgt_mask.shape[1]
-        src_feats = torch.zeros([b_size * src_max, geo_feats.shape[-1]]).type_as(geo_feats)
-        tgt_feats = torch.zeros([b_size * tgt_max, geo_feats.shape[-1]]).type_as(geo_feats)
-        src_pcd = torch.zeros([b_size * src_max, 3]).type_as(pcd)
-        tgt_pcd = torch.zeros([b_size * tgt_max, 3]).type_as(pcd)
-        src_feats[data["src_ind_coarse_split"]] = geo_feats[data["src_ind_coarse"]]
-        tgt_feats[data["tgt_ind_coarse_split"]] = geo_feats[data["tgt_ind_coarse"]]
-        src_pcd[data["src_ind_coarse_split"]] = pcd[data["src_ind_coarse"]]
-        tgt_pcd[data["tgt_ind_coarse_split"]] = pcd[data["tgt_ind_coarse"]]
+        from diffreg_hip import lib
+        C = geo_feats.shape[-1]
+        dev = geo_feats.device
+        src_feats = torch.zeros(b_size * src_max, C, device=dev)
+        tgt_feats = torch.zeros(b_size * tgt_max, C, device=dev)
+        src_pcd = torch.zeros(b_size * src_max, 3, device=dev)
+        tgt_pcd = torch.zeros(b_size * tgt_max, 3, device=dev)
+        lib.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], src_feats)     # dr_scatter_rows_f32
+        lib.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_feats)
+        lib.scatter_rows(pcd, data["src_ind_coarse"], data["src_ind_coarse_split"], src_pcd)
+        lib.scatter_rows(pcd, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_pcd)
         return (src_feats.view(b_size, src_max, -1), tgt_feats.view(b_size, tgt_max, -1), src_pcd.view(b_size, src_max, -1),
                 tgt_pcd.view(b_size, tgt_max, -1), src_mask, tgt_mask)

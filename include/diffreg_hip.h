@@ -252,6 +252,20 @@ void dr_debug_attention_split(int on);
 int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream);
 int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream);
 
+/* Pipeline.split_feats (3D/models/pipeline.py:350-379): dst[dst_index[i]][:] = src[src_index[i]][:], i < n, rows of C floats
+ * (the stacked coarse features / points of the backbone scattered into the zero-padded [B * N_max, C] tensors). */
+int dr_scatter_rows_f32(int n, int C, const float* src, const int64_t* src_index, const int64_t* dst_index, float* dst, void* stream);
+
+/* Matching.get_match(conf, thr, mutual) (3D/models/matching.py:126-143; what 4D/lib/tester.py:266 applies to conf_matrix_pred
+ * with thr = 0.55, mutual = True): entries > thr that are also their row's and their column's maximum (mutual; ties all count,
+ * like the reference's `==`), in nonzero() order.  matches [P, cap, 3] int64 rows (b, i, j), mconf [P, cap] (optional),
+ * count [P] = the TRUE number of hits (rows beyond cap are dropped: pass cap = N * M to be safe, min(N, M) + slack in
+ * practice), mask [P, N, M] uint8 (optional; the reference's third return value). */
+int dr_mutual_match_f64(int P, int N, int M, const double* conf, double thr, int mutual, int cap, int64_t* matches, double* mconf,
+                        int32_t* count, uint8_t* mask, void* stream);
+int dr_mutual_match_f32(int P, int N, int M, const float* conf, float thr, int mutual, int cap, int64_t* matches, float* mconf,
+                        int32_t* count, uint8_t* mask, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The whole reverse-diffusion loop of Pipeline.forward's eval branch
  * (3D/models/pipeline.py:221-283; 4D/models/pipeline.py:156-197) for P independent pairs, enqueued
@@ -302,6 +316,10 @@ typedef struct {                /* all optional (NULL to skip); per-step records
     float* R_forwd;            /* [steps,P,9]                                                */
     float* t_forwd;            /* [steps,P,3]                                                */
     double* cond;              /* [steps,P]                                                  */
+    /* the side effects Matching.forward leaves in `data` at the LAST step (3D/models/matching.py:177-187), token layout
+     * [P*N + P*M, C] (all src rows, then all tgt rows): src_proj(feats) and its rotary-embedded form (before the 1/sqrt(C)) */
+    float* feats_nopos;
+    float* feats_pos;
 } dr_loop_trace;
 
 size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, int M);

@@ -76,3 +76,25 @@ def topk_case(name):
         rm = T(synth.hash_u01(seed, 3, B * N).reshape(B, N) > 0.2)
         cm = T(synth.hash_u01(seed, 4, B * M).reshape(B, M) > 0.2)
     return dict(score=score, k=spec["k"], largest=spec["largest"], threshold=spec["threshold"], mutual=spec["mutual"], row_masks=rm, col_masks=cm)
+
+
+# ------------------------------------------------------------------------------------------------
+# guard bands: an output / workspace buffer between two 64 KiB bands of 0xA5
+# ------------------------------------------------------------------------------------------------
+GUARD = 64 * 1024
+
+
+def guarded(shape, dtype, device, fill=None):
+    """-> (tensor of `shape` living between two 0xA5 bands, check()): check() raises when a kernel wrote outside the tensor."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    esz = torch.empty((), dtype=dtype).element_size()
+    nbytes = (n * esz + 255) // 256 * 256
+    raw = torch.full((GUARD + nbytes + GUARD,), 0xA5, dtype=torch.uint8, device=device)
+    t = raw[GUARD:GUARD + n * esz].view(dtype).view(*shape)
+    if fill is not None:
+        t.fill_(fill)
+
+    def check():
+        torch.cuda.synchronize()
+        assert bool((raw[:GUARD] == 0xA5).all()) and bool((raw[GUARD + nbytes:] == 0xA5).all()), "guard band damaged"
+    return t, check

@@ -146,6 +146,7 @@ def test_loop_matches_reference_plane_path(golden, variant, N, M, nv, mv, steps,
 def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag, graph, planes=None):
     g = golden("%s_loop_%s" % (variant, tag))
     eng = engine(variant, steps, mc, planes=planes)
+    eng.enable_guards()                # every input / output / workspace buffer of the loop between two 64 KiB bands of 0xA5
     _, p = pair(variant, N, M, seed)
     ms, mt = masks(N, M, nv, mv)
     noise = T(synth.step_noise(N, M, seed, steps))[:, None].to(DEV) if variant == "4dmatch" else None
@@ -153,6 +154,7 @@ def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, 
     out = eng.run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV),
                   ms.to(DEV) if masked else None, mt.to(DEV) if masked else None, noise=noise, trace=True, graph=graph)
     torch.cuda.synchronize()
+    assert eng.check_guards() >= 10    # no kernel of the loop wrote outside its buffers
     Rf, tf = out["R_forwd"][:, 0].cpu().numpy(), out["t_forwd"][:, 0].cpu().numpy()
     assert np.abs(Rf - g["R_forwd"]).max() < 1e-4, np.abs(Rf - g["R_forwd"]).max(axis=(1, 2))
     assert np.abs(tf - g["t_forwd"]).max() < 1e-4, np.abs(tf - g["t_forwd"]).max(axis=(1, 2))

@@ -127,6 +127,24 @@ def test_pipeline_forward_matches_reference(golden, variant, N, M, nv, mv, steps
         model.strict_reference = True
         out2 = model(dict(data))
         assert torch.equal(out2["R_s2t_pred"].cpu().float(), torch.from_numpy(g["R_s2t_pred"]).float())
+    # side effects of the eval branch on `data`: the last Matching.forward leaves src_proj(feats) with and without the
+    # rotary embedding (matching.py:177-187), the denoiser an empty position_layers dict (transformero.py:172)
+    assert out["position_layers"] == {}
+    tr = []
+    v = synth.VARIANTS[variant]
+    orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc, variant=variant,
+                     noise=T(synth.step_noise(N, M, seed, steps))[:, None], trace=tr)
+    hs, ht, pe_s, pe_t = orc.denoiser(W, v, p["f_s"], p["f_t"], tr[-1]["warped"], p["p_t"].float(), ms, mt)
+    Wp = W["denoising_coarse_matching.src_proj.weight"]
+    for key, ref_t in (("src_feats_nopos", hs @ Wp.T), ("tgt_feats_nopos", ht @ Wp.T), ("src_feats", orc.rotary(hs @ Wp.T, *pe_s)),
+                       ("tgt_feats", orc.rotary(ht @ Wp.T, *pe_t))):
+        got = out[key].cpu()
+        assert got.shape == ref_t.shape
+        # (features of the LAST step: they carry the loop's accumulated float32 deviation in the warp -- measured 2e-5 in R after
+        #  5 steps, which is 1.4e-3 rad in the highest-frequency rotary angle at voxel 0.04 -- times the head gain of the
+        #  synthetic weights: 1e-3 of the largest entry without the position code, 1e-2 with it)
+        tol = (1e-3 if key.endswith("nopos") else 1e-2) * max(1.0, ref_t.abs().max().item())
+        assert (got - ref_t).abs().max().item() < tol, key
     # eval_flag=True (validation) skips the loop (pipeline.py:221)
     d2 = dict(data); d2.pop("conf_matrix_pred", None)
     assert "conf_matrix_pred" not in model(d2, eval_flag=True)
@@ -170,3 +188,61 @@ def test_pipeline_end_to_end_with_overlay_backbone(golden):
     ref = orc.denoise_loop(W, v, feats[None, :ns], feats[None, ns:], pts[None, :ns], pts[None, ns:], ms, mt, x_T, steps, mc, variant=variant)
     d = (conf - ref["conf_matrix_pred"][0]).abs()
     assert (d > 1e-4).double().mean().item() <= 1e-3, d.max().item()
+
+
+def test_get_match_on_device_equals_reference_rule():
+    """Matching.get_match(conf, thr, mutual=True) -- the 4DMatch tester's read-out of conf_matrix_pred (4D/lib/tester.py:266) --
+    through dr_mutual_match_f64 / _f32: index list in nonzero() order, confidences and mask equal to the torch statement of
+    3D/models/matching.py:126-143 (oracle.mutual_match), ties included."""
+    from models.matching import Matching
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float64, torch.float32):
+        conf = torch.rand(3, 70, 45, generator=g, dtype=dtype)
+        conf[0, 5, 7] = conf[0, 5, 9] = 2.0                    # a tie of two row maxima that are also column maxima
+        conf[1] = torch.sigmoid(8 * (conf[1] - 0.5))
+        for thr, mutual in ((0.55, True), (0.0, True), (0.9, False)):
+            idx, mc, mask = Matching.get_match(conf.to(DEV), thr, mutual)
+            m_ref = conf > thr
+            if mutual:
+                m_ref = m_ref & (conf == conf.max(dim=2, keepdim=True)[0]) & (conf == conf.max(dim=1, keepdim=True)[0])
+            i_ref = m_ref.nonzero()
+            assert torch.equal(idx.cpu(), i_ref) and torch.equal(mask.cpu(), m_ref)
+            assert torch.equal(mc.cpu(), conf[i_ref[:, 0], i_ref[:, 1], i_ref[:, 2]])
+
+
+def test_scatter_rows_is_split_feats():
+    from diffreg_hip import lib
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(50, 432, generator=g)
+    si = torch.randperm(50, generator=g)[:37]
+    di = torch.randperm(64, generator=g)[:37]
+    dst = torch.zeros(64, 432, device=DEV)
+    lib.scatter_rows(src.to(DEV), si.to(DEV), di.to(DEV), dst)
+    ref = torch.zeros(64, 432)
+    ref[di] = src[si]
+    assert torch.equal(dst.cpu(), ref)
+
+
+def test_engine_cache_is_bounded_and_results_are_copies():
+    """ADVICE (round 1): the per-shape cache of DenoiseEngine.run is an LRU of a few entries, a graph is captured only when a
+    shape repeats, and run() returns copies (a later run of the same shape does not overwrite results the caller holds)."""
+    from diffreg_hip.engine import DenoiseEngine
+    variant = "3dmatch"
+    v = synth.VARIANTS[variant]
+    eng = DenoiseEngine(weights(variant), variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=1,
+                        sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=200, n_layers=v["n_layers"], device=DEV,
+                        cache_entries=2)
+    outs = {}
+    for n in (32, 40, 48, 32, 32):
+        _, p = pair(variant, n, n, 7)
+        o = eng.run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV), graph=True)
+        outs.setdefault(n, []).append(o["conf_matrix_pred"])
+        assert len(eng._graphs) <= 2
+    key32 = [k for k in eng._graphs if k[1] == 32][0]
+    assert eng._graphs[key32]["g"] is not None and eng._graphs[key32]["uses"] == 2      # evicted once, seen twice since: captured
+    a, b, c = outs[32]
+    assert torch.equal(a, b) and torch.equal(b, c) and a.data_ptr() != b.data_ptr()
+    _, p2 = pair(variant, 32, 32, 8)
+    held = c.clone()
+    eng.run(p2["f_s"].to(DEV), p2["f_t"].to(DEV), p2["p_s"].to(DEV), p2["p_t"].to(DEV), p2["x_T"].to(DEV), graph=True)
+    assert torch.equal(c, held)                                                          # not overwritten

@@ -1,0 +1,128 @@
+"""Plane-image ops (include/diffreg_hip.h "Plane images"; csrc/pgemm.hip): the layer nn.Linears of the loop with both operands
+as fp16 hi / lo plane images, LayerNorm (+ residual) in the GEMM epilogue.  Against float64 products / torch LayerNorm; every
+output between guard bands.  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import lib
+from tests.helpers import guarded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max())
+
+
+def image_like(rows, K):
+    return guarded((lib.raw().dr_plane_image_bytes(rows, K),), torch.uint8, DEV, fill=0)
+
+
+@pytest.mark.parametrize("rows", [1, 127, 1000, 4096 + 33])
+@pytest.mark.parametrize("C", [432, 528, 256])
+def test_image_round_trip_and_bounds(rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * torch.rand(rows, 1, generator=g) * 7).to(DEV)
+    img, bnd = lib.planes_from_f32(x)
+    back = lib.planes_to_f32(img, bnd, rows, C)
+    assert rel(back, x.double()) < 3e-7                        # 22 significand bits relative to the row bound
+    assert torch.equal(bnd, x.abs().amax(1))
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 432), (300, 528), (129, 256)])
+def test_layer_chain_against_float64(rows, C):
+    """q|k|v with rotary (DR_PL_F32), merge + LayerNorm (DR_PL_LN), mlp0 on [x | msg] + ReLU (DR_PL_PLANES), mlp2 + LayerNorm +
+    residual (DR_PL_LN): one GeometryAttentionLayer's GEMMs (transformero.py:60-96) through the plane ops."""
+    torch.manual_seed(rows)
+    x = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
+    img, bnd = lib.planes_from_f32(x)
+    # ---- q | k | v, rotary on q and k, three [rows, C] matrices
+    W = torch.randn(3 * C, C, device=DEV) / C ** 0.5
+    pk = lib.pack_weight_planes(W, 3, C)
+    ang = torch.rand(rows, C // 2, device=DEV) * 6.28
+    cosT, sinT = ang.cos().contiguous(), ang.sin().contiguous()
+    out, chk = guarded((3, rows, C), torch.float32, DEV, fill=float("nan"))
+    lib.linear_planes(rows, C, 3, img, bnd, C, pk, lib.PL_F32, out=out, ldo=C, blk_stride=rows * C, cos_t=cosT, sin_t=sinT, rot_mask=3,
+                      rot_C=C, scale=0.5)
+    chk()
+    ref = x.double() @ W.double().t()
+
+    def rot(z):
+        e, o = z[:, 0::2], z[:, 1::2]
+        return torch.stack([e * cosT.double() - o * sinT.double(), o * cosT.double() + e * sinT.double()], -1).reshape(z.shape)
+    want = torch.stack([rot(ref[:, :C]), rot(ref[:, C:2 * C]), ref[:, 2 * C:]]) * 0.5
+    assert not torch.isnan(out).any() and rel(out, want) < 2e-6
+    # ---- merge + norm1 -> image only
+    g1, b1 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+    Wm = torch.randn(C, C, device=DEV) / C ** 0.5
+    lnb = lib.ln_bound(g1, b1)
+    msg_img, chk_i = image_like(rows, C)
+    msg_b, chk_b = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 1, img, bnd, C, lib.pack_weight_planes(Wm, 1, C), lib.PL_LN, out_image=msg_img, out_image_k=C, out_bound=msg_b,
+                      gamma=g1, beta=b1, lnb=lnb)
+    chk_i(); chk_b()
+    refm = torch.nn.functional.layer_norm(x.double() @ Wm.double().t(), (C,), g1.double(), b1.double())
+    assert rel(lib.planes_to_f32(msg_img, msg_b, rows, C), refm) < 3e-6
+    assert bool((msg_b >= refm.abs().amax(1).float()).all())           # the analytic bound holds
+    # ---- mlp0 on [x | msg], ReLU -> image of 2C columns
+    W1 = torch.randn(2 * C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    hid_img, chk_h = image_like(rows, 2 * C)
+    hid_b, chk_hb = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 2, img, bnd, C, lib.pack_weight_planes(W1, 2, C), lib.PL_PLANES, a1=msg_img, b1=msg_b, k1=C, out_image=hid_img,
+                      out_image_k=2 * C, out_bound=hid_b, relu=True)
+    chk_h(); chk_hb()
+    refh = torch.relu(torch.cat([x.double(), refm], 1) @ W1.double().t())
+    assert rel(lib.planes_to_f32(hid_img, hid_b, rows, 2 * C), refh) < 4e-6 and bool((hid_b >= refh.abs().amax(1).float()).all())
+    # ---- mlp2 + norm2 + residual -> fp32 rows and image
+    W2 = torch.randn(C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    o32, chk_o = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+    o_img, chk_oi = image_like(rows, C)
+    o_b, _ = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 1, hid_img, hid_b, 2 * C, lib.pack_weight_planes(W2, 1, C), lib.PL_LN, out=o32, ldo=C, out_image=o_img,
+                      out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, resid=x, ldr=C, bound_resid=bnd, lnb=lnb)
+    chk_o(); chk_oi()
+    refo = x.double() + torch.nn.functional.layer_norm(refh @ W2.double().t(), (C,), g1.double(), b1.double())
+    assert rel(o32, refo) < 2e-6 and rel(lib.planes_to_f32(o_img, o_b, rows, C), refo) < 2e-6
+    assert bool((o_b >= refo.abs().amax(1).float()).all())
+
+
+def test_head_padded_k_order():
+    """the merge projection behind the attention kernel's image: head h at k = 112 h (d = 108 padded to 112, zeros in the pad)"""
+    rows, C = 700, 432
+    torch.manual_seed(0)
+    att = torch.randn(rows, C, device=DEV)
+    attp = torch.zeros(rows, 448, device=DEV)
+    for hh in range(4):
+        attp[:, 112 * hh:112 * hh + 108] = att[:, 108 * hh:108 * (hh + 1)]
+    aimg, ab = lib.planes_from_f32(attp)
+    Wm = torch.randn(C, C, device=DEV) / C ** 0.5
+    out, chk = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+    lib.linear_planes(rows, C, 1, aimg, ab, 448, lib.pack_weight_planes(Wm, 1, C, piece_len=108, piece_pad=112), lib.PL_F32, out=out, ldo=C)
+    chk()
+    assert rel(out, att.double() @ Wm.double().t()) < 2e-6
+
+
+def test_degenerate_rows_stay_in_their_rows():
+    """zero rows, rows 1e-6 and 1e8 times the others, and a row with inf / nan: every other row keeps fp32-level accuracy (the
+    per-row power-of-two scaling isolates rows; nothing is shared across rows in the GEMM or the LayerNorm epilogue)"""
+    rows, C = 384, 432
+    torch.manual_seed(1)
+    x = torch.randn(rows, C, device=DEV)
+    x[3] = 0.0
+    x[10] *= 1e-6
+    x[11] *= 1e8
+    x[200, 5] = float("inf")
+    x[201, 7] = float("nan")
+    img, bnd = lib.planes_from_f32(x)
+    W = torch.randn(C, C, device=DEV) / C ** 0.5
+    out = torch.empty(rows, C, device=DEV)
+    lib.linear_planes(rows, C, 1, img, bnd, C, lib.pack_weight_planes(W, 1, C), lib.PL_F32, out=out, ldo=C)
+    ref = x.double() @ W.double().t()
+    good = torch.ones(rows, dtype=torch.bool, device=DEV)
+    good[200] = good[201] = False
+    err = (out.double() - ref).abs()[good] / ref.abs().amax(1, keepdim=True).clamp_min(1e-30)[good]
+    assert float(err.max()) < 3e-6
+    assert torch.equal(out[3], torch.zeros(C, device=DEV))
+    assert not torch.isfinite(out[200]).all() and not torch.isfinite(out[201]).all()
