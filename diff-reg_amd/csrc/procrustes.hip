@@ -352,6 +352,11 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
                 });
             }
             __syncthreads();
+        } else {
+            // K > 1024 (thin tiles such as 2048 x 2, or a large sample_rate): the per-thread maxima do not bound the K-th largest
+            // entry, so no candidate list is built -- take the full-tile radix path whatever the tile's size (without this the
+            // list would be read uninitialised when N M <= CAND_MAX)
+            ncand = CAND_MAX + 1;
         }
         PROC_STAMP(2);
         unsigned tau = 0, remaining = 0;

@@ -20,6 +20,10 @@ def segment_matches(match_pred, B):
     a host sync (cap = K)."""
     K = match_pred.shape[0]
     dev = match_pred.device
+    # the reference's functions take the rows in any order; ranks inside a pair need them grouped by b: stable sort (a no-op
+    # for lists that nonzero() produced)
+    order = torch.argsort(match_pred[:, 0], stable=True)
+    match_pred = match_pred[order]
     b = match_pred[:, 0]
     count = torch.bincount(b, minlength=B)[:B]
     start = torch.cumsum(count, 0) - count

@@ -65,6 +65,21 @@ def test_inlier_ratio_batched_and_edge_cases():
         lib.inlier_ratio(matches, count, stack("s_pcd"), stack("t_pcd"), stack("rot"), stack("trn"), 0.1)   # CPU tensors
 
 
+def test_segment_matches_accepts_any_row_order():
+    """MatchMetrics takes the flat [K, 3] (b, i, j) list in ANY row order, like the reference's compute_inlier_ratio
+    (an unsorted list used to scatter to wrong slots)"""
+    from diffreg_hip.metrics import segment_matches
+    g = torch.Generator().manual_seed(2)
+    B, K = 4, 37
+    mp = torch.stack([torch.randint(0, B, (K,), generator=g), torch.randint(0, 50, (K,), generator=g), torch.randint(0, 60, (K,), generator=g)], 1)
+    mp[mp[:, 0] == 2, 0] = 3                                          # one pair without matches
+    seg, cnt = segment_matches(mp.cuda(), B)
+    for b in range(B):
+        rows = mp[mp[:, 0] == b]                                       # stable: the original relative order inside a pair
+        assert int(cnt[b]) == len(rows)
+        assert torch.equal(seg[b, :len(rows)].cpu(), rows)
+
+
 @pytest.mark.parametrize("N,M,seed", CASES)
 def test_nrfmr_vs_reference_vectors(golden, N, M, seed):
     from diffreg_hip import lib

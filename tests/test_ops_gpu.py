@@ -292,6 +292,23 @@ def test_procrustes_degenerate_and_batch():
     assert torch.equal(Rf[1].cpu(), torch.eye(3)) and torch.equal(tf[1].cpu(), torch.zeros(3, 1))
 
 
+def test_procrustes_thin_tile_more_than_1024_selected():
+    """K = max(N, M) * sample_rate > 1024 on a tile of <= 4096 entries (neither candidate list was built and
+    the fit read an uninitialised list): N = 2048, M = 2 selects 2048 of the 4096 entries."""
+    from diffreg_hip import lib
+    P, N, M = 2, 2048, 2
+    g = torch.Generator().manual_seed(4)
+    conf = torch.rand(P, N, M, generator=g)
+    ps = torch.rand(P, N, 3, generator=g)
+    pt = torch.rand(P, M, 3, generator=g)
+    sm, tm = torch.ones(P, N, dtype=torch.bool), torch.ones(P, M, dtype=torch.bool)
+    R, t, Rf, tf, cond, ok = lib.procrustes(conf.to(DEV), ps.to(DEV), pt.to(DEV), sm.to(DEV), tm.to(DEV), 1.0, 1e9)
+    for b in range(P):
+        r = orc.procrustes(conf[b:b + 1], ps[b:b + 1], pt[b:b + 1], sm[b:b + 1], tm[b:b + 1], 1.0, 1e9)
+        np.testing.assert_allclose(R[b].cpu().numpy(), r[0][0].numpy(), atol=1e-4)
+        np.testing.assert_allclose(t[b].cpu().numpy(), r[1][0].numpy(), atol=1e-4)
+
+
 @pytest.mark.parametrize("N,M", [(128, 128), (96, 80), (256, 256), (33, 500)])
 def test_top1_union(N, M):
     from diffreg_hip import lib
