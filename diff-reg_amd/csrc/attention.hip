@@ -748,6 +748,223 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Flash form on fp16 hi / lo plane images (the plane path of the loop, pgemm.h): Q, K, V arrive as the images the q|k|v GEMM's
+// epilogue wrote (rotary applied, heads padded to p_dp = 16 KS features, one power-of-two scale per query row / per key group),
+// so nothing is split on the VALU except P, and every fp32 product of Q K^T and P V is THREE fp16 MFMAs (hi*hi + hi*lo + lo*hi)
+// instead of the six bf16 ones of attention_flash_split_kernel:
+//   * a K tile (32 keys x KS chunks x 64 B) and a V tile land in LDS by LDS-DMA -- 28 one-KB instructions per tile, issued one tile
+//     ahead into the other buffer, one barrier per tile; the image's own layout IS the LDS layout;
+//   * S^T = K Q^T: K fragments by ds_read_b128 (the image's unit swizzle makes them conflict-free), Q fragments (both planes of
+//     all KS chunks: 8 KS registers) are loaded once per wave straight from the image;
+//   * O^T = V^T P^T: V is stored key-major, its A fragments (feature rows, 8 keys each) come out of ds_read_b64_tr_b16, two 4-key
+//     blocks per fragment in the order in which a lane's score registers hold the keys, so P goes from registers into the MFMA;
+//   * the scales: S = (K' Q'^T) 2^-(sk + sq) in fp32 behind the MFMA, O = (V'^T P^T) 2^-sv at the end (exact powers of two).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 ah16x8 __attribute__((ext_vector_type(8)));
+typedef short as16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void a_lds_void;
+typedef __attribute__((address_space(3))) as16x4 a_lds_s4;
+
+template <int KS, int NDT>
+struct AttnPlGeom {
+    static constexpr int KCH = 2048;                             // a K chunk: 32 keys x 64 B
+    static constexpr int VCH = 2048 + 32;                        // a V chunk, shifted by 32 B per chunk: the two 16-lane groups of a
+                                                                 // transposed read (features 0..15 / 16..31) then hit disjoint banks
+    static constexpr int KIMG = KS * KCH, VIMG = KS * VCH, BUF = KIMG + VIMG;
+    static constexpr int OQS = NDT * 32 + 4;
+    static constexpr int OBYTES = 4 * 32 * OQS * 4;
+    static constexpr int SMEM = (2 * BUF > OBYTES ? 2 * BUF : OBYTES) + 64;
+};
+
+__device__ __forceinline__ int attn_scale_exp(float bound) {
+    const unsigned bits = __float_as_uint(bound);
+    const int e = (int)((bits >> 23) & 0xff) - 127;
+    return (bound > 0.f && e < 128) ? min(max(14 - e, -100), 100) : 0;
+}
+
+template <int KS, int NDT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_planes_kernel(AttnArgs A) {
+    using G = AttnPlGeom<KS, NDT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds_base = (unsigned)(size_t)(a_lds_void*)lds;
+
+    int seg = blockIdx.z, qbase, kbase, Lq, Lk;
+    if (seg < A.nseg) {
+        qbase = A.q0 + seg * A.qstride; kbase = A.k0 + seg * A.kstride; Lq = A.Lq; Lk = A.Lk;
+    } else {
+        seg -= A.nseg;
+        qbase = A.q0b + seg * A.qstrideb; kbase = A.k0b + seg * A.kstrideb; Lq = A.Lqb; Lk = A.Lkb;
+    }
+    const int qb = blockIdx.x * 128;
+    if (qb >= Lq) return;
+    const int head = blockIdx.y, d = A.d, nct = A.p_nct;
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    // ---- scales: one per query row, one per key group (uniform over the segment's keys)
+    const float kb_bound = A.kgb[kbase], vb_bound = A.vgb[kbase];   // (every key row of a group carries the group's bound)
+    const int my_q = qb + w * 32 + l31;
+    const bool q_in = my_q < Lq;
+    const int qrow = qbase + min(my_q, Lq - 1);
+    const bool q_valid = q_in && (!A.qmask || A.qmask[qrow]);
+    const float sfac = A.scale * 1.4426950408889634f *
+                       __uint_as_float((unsigned)(127 - attn_scale_exp(A.qbnd[qrow]) - attn_scale_exp(kb_bound)) << 23);
+    const float vinv = __uint_as_float((unsigned)(127 - attn_scale_exp(vb_bound)) << 23);
+
+    // ---- Q fragments: both planes of the KS chunks of this lane's query, straight from the image
+    au32x4 qh[KS], ql[KS];
+    {
+        const int side = qrow >= A.p_split ? 1 : 0, lrow = qrow - (side ? A.p_split : 0), r = lrow & 127, swq = (r >> 2) & 3;
+        const char* qp = A.qimg[side] + (((size_t)(lrow >> 7) * nct + KS * head) * 128 + r) * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qh[s] = *reinterpret_cast<const au32x4*>(qp + (size_t)s * 8192 + ((h ^ swq) << 4));
+            ql[s] = *reinterpret_cast<const au32x4*>(qp + (size_t)s * 8192 + (((2 + h) ^ swq) << 4));
+        }
+    }
+    // ---- K / V staging: instruction `ins` of a tile: ins < 2 KS -> K, else V; chunk (ins / 2), rows 16 (ins & 1) + lane / 4
+    const int kside = kbase >= A.p_split ? 1 : 0, klrow0 = kbase - (kside ? A.p_split : 0);
+    const char* const kimg = A.kimg[kside];
+    const char* const vimg = A.vimg[kside];
+    auto stage = [&](int kt, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < (4 * KS + 3) / 4; ++i) {
+            const int ins = w + 4 * i;
+            if (ins < 4 * KS) {
+                const bool isv = ins >= 2 * KS;
+                const int j = ins - (isv ? 2 * KS : 0), chunk = j >> 1, half = j & 1;
+                const int key = min(kt * 32 + half * 16 + (lane >> 2), Lk - 1), lrow = klrow0 + key;
+                const char* src = (isv ? vimg : kimg) + (((size_t)(lrow >> 7) * nct + KS * head + chunk) * 128 + (lrow & 127)) * 64 + (lane & 3) * 16;
+                const unsigned dst = lds_base + b * G::BUF + (isv ? G::KIMG + chunk * G::VCH : chunk * G::KCH) + half * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+            }
+        }
+    };
+    // swizzle of the key rows a lane touches: position of logical unit u of row r is u ^ ((r >> 2) & 3); tiles are 32 rows, so
+    // it does not depend on the tile
+    const int swk = ((klrow0 + l31) >> 2) & 3;                  // K fragment row l31
+    // V fragments: lane g16 = l31 & 15 of a 16-lane group supplies row (g16 >> 2) of a 4-key block, feature quarter (g16 & 3)
+    const int g16 = l31 & 15, vq = g16 >> 2, vp = g16 & 3;
+    unsigned voff[2][2][2];                                      // [k-step][block a / b][hi / lo]: byte offset inside a chunk
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int krow = 16 * s + 8 * blk + 4 * h + vq, sw = ((klrow0 + krow) >> 2) & 3;
+            voff[s][blk][0] = krow * 64 + (((vp >> 1) ^ sw) << 4) + (vp & 1) * 8;
+            voff[s][blk][1] = krow * 64 + (((2 + (vp >> 1)) ^ sw) << 4) + (vp & 1) * 8;
+        }
+    int vchunk[NDT];                                             // chunk of feature tile i for this lane (features beyond p_dp: the last chunk again, results unused)
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) vchunk[i] = min(2 * i + (l31 >> 4), KS - 1) * G::VCH;
+
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nkt = (Lk + 31) / 32;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int b = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // own DMA instructions of tile kt have landed ...
+        __syncthreads();                                         // ... and everybody's; everybody is done with the other buffer
+        if (kt + 1 < nkt) stage(kt + 1, b ^ 1);
+        const char* kb = lds + b * G::BUF + l31 * 64;
+        const char* vb = lds + b * G::BUF + G::KIMG;
+        // ---- S^T = K Q^T
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const ah16x8 kh = *reinterpret_cast<const ah16x8*>(kb + s * G::KCH + ((h ^ swk) << 4));
+            const ah16x8 kl = *reinterpret_cast<const ah16x8*>(kb + s * G::KCH + (((2 + h) ^ swk) << 4));
+            const ah16x8 q_h = __builtin_bit_cast(ah16x8, qh[s]), q_l = __builtin_bit_cast(ah16x8, ql[s]);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, q_h, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_l, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_h, sc, 0, 0, 0);
+        }
+        // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float s = sc[r];
+            bool drop = kk >= Lk;                                // transformero.py:82
+            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            s = drop ? -INFINITY : s * sfac;
+            sc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float alpha = 1.f, psum = 0.f;
+        if (m_new == -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        } else {
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                sc[r] = p;
+                psum += p;
+            }
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        // ---- O^T += V^T P^T : k-step s contracts the keys of score registers 8 s .. 8 s + 7
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 ph, pl;
+            attn_split2(sc[8 * s + 0], sc[8 * s + 1], ph.x, pl.x);
+            attn_split2(sc[8 * s + 2], sc[8 * s + 3], ph.y, pl.y);
+            attn_split2(sc[8 * s + 4], sc[8 * s + 5], ph.z, pl.z);
+            attn_split2(sc[8 * s + 6], sc[8 * s + 7], ph.w, pl.w);
+            const au32x4 phv = {ph.x, ph.y, ph.z, ph.w}, plv = {pl.x, pl.y, pl.z, pl.w};
+            const ah16x8 p_h = __builtin_bit_cast(ah16x8, phv), p_l = __builtin_bit_cast(ah16x8, plv);
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) {
+                const unsigned base = lds_base + b * G::BUF + G::KIMG + vchunk[i];
+                auto tr = [&](unsigned off) {
+                    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s4*)(size_t)(base + off));
+                };
+                const as16x4 ha = tr(voff[s][0][0]), hb = tr(voff[s][1][0]), la = tr(voff[s][0][1]), lb = tr(voff[s][1][1]);
+                typedef short as16x8 __attribute__((ext_vector_type(8)));
+                const as16x8 vh8 = {ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+                const as16x8 vl8 = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+                const ah16x8 v_h = __builtin_bit_cast(ah16x8, vh8), v_l = __builtin_bit_cast(ah16x8, vl8);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h, acc[i], 0, 0, 0);
+            }
+        }
+        (void)vb;
+    }
+    __syncthreads();
+
+    // ---- out[q][f] = O^T[f][q] 2^-sv / l, through LDS, then the plane image of the merge projection's operand
+    float* ob = smem + w * 32 * G::OQS;
+    const float inv = vinv / l_run;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[l31 * G::OQS + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][r] * inv;
+    wave_lds_fence();
+    attn_store_planes(A, ob, G::OQS, qbase + qb + w * 32, Lq - (qb + w * 32), head, d, vb_bound, lane);
+}
+
 template <int DG, int NDT>
 static int configure_attn() {
     using G = AttnGeom<DG, NDT>;
@@ -758,6 +975,8 @@ static int configure_attn() {
     constexpr int KS = (DG * 8 + 15) / 16;
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_split_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)FlashSplitGeom<KS, NDT>::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)AttnPlGeom<KS, NDT>::SMEM));
     return DR_OK;
 }
 
@@ -787,6 +1006,15 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const int flash_env = [] { const char* e = getenv("DR_ATTN_FLASH_MIN"); return e ? atoi(e) : 256; }();
     const int flash_min = g_flash_min >= 0 ? g_flash_min : flash_env;
     dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
+    if (a.qimg[0]) {
+        // plane-image operands (the plane path of the loop): fp16 hi / lo products, DMA-fed tiles
+        constexpr int KS = (DG * 8 + 15) / 16;
+        if (a.p_dp != 16 * KS || !a.pimg[0]) return DR_EINVAL;
+        const size_t plds = AttnPlGeom<KS, NDT>::SMEM;
+        hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     if (a.pimg[0] || ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0)) {
         static const int split_env = [] { const char* e = getenv("DR_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
         const int mode = g_attn_split >= 0 ? g_attn_split : split_env;     // 0 f32-input MFMA, 1 split operands
@@ -812,7 +1040,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t st) {
-    if (a.d % 4 || a.ldq % 4 || a.ldk % 4 || a.ldv % 4) return DR_ENOSUP;
+    if (a.d % 4 || (!a.qimg[0] && (a.ldq % 4 || a.ldk % 4 || a.ldv % 4))) return DR_ENOSUP;
     if (a.nseg + a.nseg2 <= 0) return DR_OK;
     if (a.d <= 64) return launch_attn<8, 2>(a, st);       // 2D-3D: d = 64
     if (a.d <= 112) return launch_attn<14, 4>(a, st);     // 3DMatch: d = 108

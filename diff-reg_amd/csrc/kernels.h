@@ -86,6 +86,12 @@ struct AttnArgs {
     // bound of a query row = max over the segment's key rows of kbnd[row] * vnorm[0]  (|softmax V| <= max |V|), written to
     // pbnd[row] by the head-0 workgroups
     char* pimg[2]; int p_split, p_nct, p_dp; float* pbnd; const float* kbnd; const float* vnorm;
+    // plane-image INPUT (attention_planes_kernel): q / k / v as images of p_nct chunks (head h at k = h p_dp), written by the
+    // q|k|v GEMM's epilogue with the rotary embedding applied; same side split as pimg.  qbnd, kgb, vgb: bounds per token row;
+    // all key rows of a segment carry ONE bound (the GEMM wrote the bound of the row's group: a pair's side), read at the
+    // segment's first key row
+    const char* qimg[2]; const char* kimg[2]; const char* vimg[2];
+    const float* qbnd; const float* kgb; const float* vgb;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int attention_configure();

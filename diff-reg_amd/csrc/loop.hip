@@ -102,7 +102,9 @@ struct Prepack {
     PgW head;                        // src_proj
     int dp;                          // head dim rounded up to 16
     static bool supported(const dr_loop_config& cfg) {
-        return cfg.n_layers <= MAXL && pgemm_shape_ok(cfg.C) && cfg.C % cfg.H == 0 && (cfg.C / cfg.H) % 4 == 0;
+        if (!(cfg.n_layers <= MAXL && pgemm_shape_ok(cfg.C) && cfg.C % cfg.H == 0 && (cfg.C / cfg.H) % 4 == 0)) return false;
+        const int dp = (cfg.C / cfg.H + 15) / 16 * 16;                 // the head-padded q | k | v block must fit the column block too
+        return pgemm_shape_ok(cfg.H * dp) && pgemm_bn(cfg.H * dp) == pgemm_bn(cfg.C) && (dp == 64 || dp == 112 || dp == 144);
     }
     // lays the images out in `buf` (nullptr: size only) and returns the byte count
     static size_t carve(void* buf, const dr_loop_config& cfg, Prepack* pp) {
@@ -115,7 +117,7 @@ struct Prepack {
         };
         for (int l = 0; l < cfg.n_layers; ++l) {
             PrepackLayer* L = pp ? &pp->L[l] : nullptr;
-            take(3, nC, L ? &L->qkv : nullptr);
+            take(3, nC, L ? &L->qkv : nullptr);            // (C' = H dp output columns per block: same image size, C' <= BN)
             take(1, cfg.H * dp / 16, L ? &L->merge : nullptr);
             take(2, 2 * nC, L ? &L->mlp0 : nullptr);
             take(1, 2 * nC, L ? &L->mlp2 : nullptr);
@@ -134,9 +136,11 @@ struct Prepack {
         for (int l = 0; l < cfg.n_layers; ++l) {
             const dr_layer_weights& w = W.layers[l];
             const PrepackLayer& L = pp.L[l];
-            int rc = pgemm_pack_weights_block(w.q_proj, C, C, C, C, L.qkv, 0, st);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.k_proj, C, C, C, C, L.qkv, 1, st);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.v_proj, C, C, C, C, L.qkv, 2, st);
+            // q | k | v: output columns padded per head (d -> dp) so that the images the GEMM writes start every head at a k-chunk
+            const int Cq = cfg.H * pp.dp;
+            int rc = pgemm_pack_weights_block(w.q_proj, Cq, C, C, C, L.qkv, 0, st, d, pp.dp);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.k_proj, Cq, C, C, C, L.qkv, 1, st, d, pp.dp);
+            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.v_proj, Cq, C, C, C, L.qkv, 2, st, d, pp.dp);
             if (rc == DR_OK) rc = pgemm_pack_weights_block(w.merge, C, C, d, pp.dp, L.merge, 0, st);
             if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0, C, 2 * C, 2 * C, 2 * C, L.mlp0, 0, st);
             if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0 + (size_t)C * 2 * C, C, 2 * C, 2 * C, 2 * C, L.mlp0, 1, st);
@@ -159,6 +163,10 @@ struct PlanesWs {
     Tok feat0, fa, fb, tgt_l0;
     char *att_img, *msg_img, *hid_img;
     float *att_bnd, *msg_bnd, *hid_bnd;
+    char *qkv_img, *kvc_img;                 // q | k | v images (three images of H dp columns, back to back); cached k | v of layer 1
+    float *qkv_bnd, *kvc_bnd;                // [3][T] / [2][T]
+    float* grp_x;                            // [2 P] bound of x per key group (src groups, then tgt groups)
+    size_t qkv_stride;                       // bytes from the q image to the k image (= to the next: v)
     size_t side_C, side_att, side_hid;      // byte offset of the tgt part inside an image of K = C / H dp / 2C
     void* own_pack;                         // packed weights inside the workspace (used when the caller passed none)
     static size_t img_bytes(int PN, int PM, int K) { return plane_image_bytes(PN, K) + plane_image_bytes(PM, K); }
@@ -177,6 +185,10 @@ struct PlanesWs {
         w.att_img = c.take<char>(img_bytes(PN, PM, cfg.H * dp)); w.att_bnd = c.take<float>(T);
         w.msg_img = c.take<char>(img_bytes(PN, PM, C)); w.msg_bnd = c.take<float>(T);
         w.hid_img = c.take<char>(img_bytes(PN, PM, 2 * C)); w.hid_bnd = c.take<float>(T);
+        w.qkv_stride = (img_bytes(PN, PM, cfg.H * dp) + 255) & ~(size_t)255;
+        w.qkv_img = c.take<char>(3 * w.qkv_stride); w.qkv_bnd = c.take<float>(3 * (size_t)T);
+        w.kvc_img = c.take<char>(2 * w.qkv_stride); w.kvc_bnd = c.take<float>(2 * (size_t)T);
+        w.grp_x = c.take<float>(2 * (size_t)P);
         w.own_pack = c.take<char>(Prepack::carve(nullptr, cfg, nullptr));
     }
 };
@@ -307,44 +319,63 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     auto add = [&]() -> PgProblem& { return g.p[g.n++]; };
     auto for_sides = [&](int mask, auto fn) { for (int side = 1; side <= 2; ++side) if (mask & side) fn(side); };
     int rc;
+    bool rc_ok = true;
 
-    // ---- q | k | v projections + rotary -> fp32 rows (the attention kernel's operands), each of q, k, v its own [T, C] matrix:
-    // a workgroup then writes 128 contiguous rows (221 KB) instead of a third of each 5 KB row of an interleaved [T, 3C] buffer
-    const size_t TC = (size_t)(PN + PM) * C;
-    auto proj = [&](const Tok& tin, int side, int b0, int nblk, float* o, int rotm) {
+    // ---- q | k | v projections + rotary -> three plane images of H dp columns (head h at k = h dp): the attention kernel's
+    // operands.  q keeps a scale per row; all keys of a pair's side share ONE scale (k, v blocks take the bound of the row's group).
+    const int T = PN + PM, Cq = H * dp, nq = Cq / 16;
+    const bool cached = kv_cached != nullptr;            // (the plane path keeps the cached K | V as images: kvc_img / kvc_bnd)
+    char* const kv_img = kv_store ? pw.kvc_img : pw.qkv_img + pw.qkv_stride;
+    float* const kv_bnd = kv_store ? pw.kvc_bnd : pw.qkv_bnd + T;
+    if (!cached) {
+        // bound of the keys' source rows per group (pair x side)
+        for (int side = 1; side <= 2 && rc_ok; ++side)
+            if (ys & side) rc_ok = launch_group_max(yin.bnd + r0(side), X.P, side == SIDE_TGT ? X.M : X.N, pw.grp_x + (side == SIDE_TGT ? X.P : 0), st) == DR_OK;
+        if (!rc_ok) return DR_ELAUNCH;
+    }
+    auto proj = [&](const Tok& tin, int side, int b0, int nblk, char* img, float* bnd, int rotm, int grpm) {
         PgProblem& p = add();
         p.A0 = at(tin.img, pw.side_C, side); p.bnd0 = tin.bnd + r0(side); p.nc0 = nC;
-        p.W = pgw_blocks(L.qkv, b0, C); p.nblk = nblk; p.rows = nrows(side); p.C = C; p.mode = PG_F32;
-        p.out = o + (size_t)r0(side) * C; p.ldo = C; p.blk_stride = (int)TC; p.rot_mask = rotm; p.rot_C = C; p.scale = 1.f;
+        p.W = pgw_blocks(L.qkv, b0, C); p.nblk = nblk; p.rows = nrows(side); p.C = Cq; p.k_alg = C; p.mode = PG_PLANES;
+        p.rot_mask = rotm; p.rot_C = C; p.rot_piece_len = d; p.rot_piece_pad = dp; p.scale = 1.f;
         p.cosT = X.cosT + (size_t)r0(side) * halfC; p.sinT = X.sinT + (size_t)r0(side) * halfC;
+        p.pimg = at(img, pw.side_att, side); p.p_nct = nq; p.pbnd = bnd + r0(side);
+        p.pimg_blk_stride = (long long)pw.qkv_stride; p.pbnd_blk_stride = T;
+        p.grp_bnd = pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_TGT ? X.P : 0; p.grp_rows = side == SIDE_TGT ? X.M : X.N;
     };
     reset();
     if (kv_store) {
-        for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_store, 1); });
+        for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_img, kv_bnd, 1, 3); });
         return launch_pgemm(g, st);
     }
-    const bool self = xs == ys && xin.img == yin.img && !kv_cached;
+    const bool self = xs == ys && xin.img == yin.img && !cached;
     if (self) {
-        for_sides(xs, [&](int side) { proj(xin, side, 0, 3, ws.qkv, 3); });
+        for_sides(xs, [&](int side) { proj(xin, side, 0, 3, pw.qkv_img, pw.qkv_bnd, 3, 6); });
     } else {
-        for_sides(xs, [&](int side) { proj(xin, side, 0, 1, ws.qkv, 1); });
-        if (!kv_cached) for_sides(ys, [&](int side) { proj(yin, side, 1, 2, ws.qkv + TC, 1); });
+        for_sides(xs, [&](int side) { proj(xin, side, 0, 1, pw.qkv_img, pw.qkv_bnd, 1, 0); });
+        if (!cached) for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_img, kv_bnd, 1, 3); });
     }
     rc = launch_pgemm(g, st);
     if (rc) return rc;
 
-    // ---- attention -> plane image of the heads' outputs (head h at k = h dp)
+    // ---- attention on the images -> plane image of the heads' outputs (head h at k = h dp)
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = ws.qkv; a.k = ws.qkv + TC; a.v = ws.qkv + 2 * TC; a.out = nullptr;
-    a.ldq = a.ldk = a.ldv = C; a.ldo = C; a.H = H; a.d = d;
-    if (kv_cached) { a.k = kv_cached; a.v = kv_cached + TC; }
+    a.H = H; a.d = d;
     a.qmask = X.tokmask; a.kmask = X.tokmask;
     a.nseg = X.P; a.q0 = f1.q0; a.qstride = f1.Lq; a.Lq = f1.Lq; a.k0 = f1.k0; a.kstride = f1.Lk; a.Lk = f1.Lk;
     if (f2) { a.nseg2 = X.P; a.q0b = f2->q0; a.qstrideb = f2->Lq; a.Lqb = f2->Lq; a.k0b = f2->k0; a.kstrideb = f2->Lk; a.Lkb = f2->Lk; }
     a.scale = 1.0f / sqrtf((float)d);
-    a.pimg[0] = pw.att_img; a.pimg[1] = pw.att_img + pw.side_att; a.p_split = PN; a.p_nct = H * dp / 16; a.p_dp = dp;
-    a.pbnd = pw.att_bnd; a.kbnd = yin.bnd; a.vnorm = L.qkv.wnorm + 2;
+    a.pimg[0] = pw.att_img; a.pimg[1] = pw.att_img + pw.side_att; a.p_split = PN; a.p_nct = nq; a.p_dp = dp;
+    a.pbnd = pw.att_bnd;
+    {
+        const char* kimg = cached ? pw.kvc_img : pw.qkv_img + pw.qkv_stride;
+        const float* kb = cached ? pw.kvc_bnd : pw.qkv_bnd + T;
+        a.qimg[0] = pw.qkv_img; a.qimg[1] = pw.qkv_img + pw.side_att;
+        a.kimg[0] = kimg; a.kimg[1] = kimg + pw.side_att;
+        a.vimg[0] = kimg + pw.qkv_stride; a.vimg[1] = kimg + pw.qkv_stride + pw.side_att;
+        a.qbnd = pw.qkv_bnd; a.kgb = kb; a.vgb = kb + T;
+    }
     rc = launch_attention(a, st);
     if (rc) return rc;
 
@@ -365,7 +396,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         PgProblem& p = add();
         p.A0 = at(xin.img, pw.side_C, side); p.bnd0 = xin.bnd + r0(side); p.nc0 = nC;
         p.A1 = at(pw.msg_img, pw.side_C, side); p.bnd1 = pw.msg_bnd + r0(side); p.nc1 = nC;
-        p.W = L.mlp0; p.nblk = 2; p.rows = nrows(side); p.C = C; p.mode = PG_PLANES; p.relu = 1;
+        p.W = L.mlp0; p.nblk = 2; p.rows = nrows(side); p.C = C; p.mode = PG_PLANES; p.relu = 1; p.scale = 1.f;
         p.pimg = at(pw.hid_img, pw.side_hid, side); p.p_nct = 2 * nC; p.pbnd = pw.hid_bnd + r0(side);
     });
     rc = launch_pgemm(g, st);

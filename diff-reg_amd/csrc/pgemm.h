@@ -41,8 +41,12 @@ struct PgProblem {
     // PG_F32: out[row][nb * blk_stride + col] = rot(acc) * scale     (PG_LN: optional fp32 copy of the result, nb = 0)
     float* out; int ldo; int blk_stride;
     const float* cosT; const float* sinT; int rot_mask; int rot_C; float scale;
+    int rot_piece_len, rot_piece_pad;   // head-padded output columns (pack out_len / out_pad): table index of column c' (0: identity)
     // PG_PLANES / PG_LN: plane image of the output, column block nb -> chunks p_kc0 + nb * (C / 16) ..
     char* pimg; int p_nct; int p_kc0; float* pbnd;
+    long long pimg_blk_stride; long long pbnd_blk_stride;   // != 0: every column block writes its OWN image / bound array (q | k | v)
+    // PG_PLANES bound of block nb: bit nb of grp_mask set -> grp_bnd[grp_first + row / grp_rows] instead of the row's own bound
+    const float* grp_bnd; int grp_mask, grp_first, grp_rows;
     int relu;
     // PG_LN: y = LayerNorm(acc) * gamma + beta (+ resid[row][col]);  bound = (bnd_res ? bnd_res[row] : 0) + *lnB
     const float* gamma; const float* beta; const float* resid; int ldr; const float* bnd_res; const float* lnB;
@@ -60,10 +64,12 @@ int pgemm_configure();
 size_t pgemm_weight_bytes(int C, int nblk, int nct);    // image + cinv + wnorm, 256-aligned
 void pgemm_weight_view(void* buf, int C, int nblk, int nct, PgW* view);
 int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st);
-int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st);
+int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st, int out_len = 0,
+                             int out_pad = 0);
+int launch_group_max(const float* bnd, int ngroups, int grp_rows, float* out, hipStream_t st);
 
 // fp32 rows -> plane image with bound[row] = max |x[row][:]| (the external features entering the first layer)
-int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st);
+int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st, const float* bnd_in = nullptr);
 int launch_planes_to_f32(const char* img, const float* bnd, int rows, int K, float* out, int ldo, hipStream_t st);
 // *out = sqrt(C) max|gamma| + max|beta|: an upper bound of |LayerNorm(.) gamma + beta|
 int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hipStream_t st);

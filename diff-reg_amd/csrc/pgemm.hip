@@ -352,15 +352,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     grow[1] = grow[0] + 16;
     constexpr int mode = MODE;                                  // (one instantiation per epilogue: each gets its own register allocation)
 
-    if (mode == PG_F32) {
-        const bool rot = (P.rot_mask >> nb) & 1;
-        const int halfC = P.rot_C >> 1;
+    float4 v[2][NI];
+    bool rot = false;
+    if (mode != PG_LN) {
+        rot = (P.rot_mask >> nb) & 1;
+        const int halfC = P.rot_C >> 1, rpad = P.rot_piece_pad, rlen = P.rot_piece_len;
         const float scale = P.scale;
-        float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
         // Every rotary table load precedes the wave's first store: vmcnt retires in order, so a load behind a store would wait
         // for the store to reach memory (loading the tables piece by piece between the stores cost 37 us on the q|k|v launch).
         // Order: tables 0 | round 0 -> rotated in place | tables 1 | round 1 | all stores.
-        float4 vv[2][NI];
+        // Head-padded outputs (rot_piece_pad > 0: column c' = pad (c / len) + c % len of the image is column c of the nn.Linear):
+        // the table index follows the nn.Linear's column.
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             float4 tb[NI];
@@ -369,15 +371,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const int col = min(colw + 16 * i, C - 4), ridx = (col % P.rot_C) >> 1;
+                    int col = min(colw + 16 * i, C - 4);
+                    if (rpad > 0) col = (col / rpad) * rlen + min(col % rpad, rlen - 4);
+                    const int ridx = (col % P.rot_C) >> 1;
                     const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx);
                     tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
                 }
             }
-            transpose_round(rr, vv[rr]);
+            transpose_round(rr, v[rr]);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                float4 x = vv[rr][i];
+                float4 x = v[rr][i];
                 if (rot) {
                     // x cos + swap(x) sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
                     const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
@@ -387,25 +391,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     x.w = __fadd_rn(__fmul_rn(x3, tb[i].y), __fmul_rn(x2, tb[i].w));
                 }
                 x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-                vv[rr][i] = x;
+                if (mode == PG_PLANES && P.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                v[rr][i] = x;
             }
             __builtin_amdgcn_sched_barrier(0);                   // keep the stores below behind the loads of the next round
         }
+        if (mode == PG_F32) {
+            float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (grow[rr] >= rows) continue;
+            for (int rr = 0; rr < 2; ++rr) {
+                if (grow[rr] >= rows) continue;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int col = colw + 16 * i;
-                if (col < C && ABL != 7) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = vv[rr][i];
+                for (int i = 0; i < NI; ++i) {
+                    const int col = colw + 16 * i;
+                    if (col < C && ABL != 7) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                }
             }
+            PG_STAMP(6);
+            return;
         }
-        PG_STAMP(6);
-        return;
+    } else {
+        transpose_round(0, v[0]);
+        transpose_round(1, v[1]);
     }
-    float4 v[2][NI];
-    transpose_round(0, v[0]);
-    transpose_round(1, v[1]);
     PG_STAMP(4);
 
     if (mode == PG_LN) {
@@ -486,14 +494,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-    } else if (P.relu) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                v[rr][i].x = fmaxf(v[rr][i].x, 0.f); v[rr][i].y = fmaxf(v[rr][i].y, 0.f);
-                v[rr][i].z = fmaxf(v[rr][i].z, 0.f); v[rr][i].w = fmaxf(v[rr][i].w, 0.f);
-            }
     }
     PG_STAMP(5);
     if (!P.pimg) return;
@@ -506,11 +506,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int rowc = min(grow[rr], rows - 1);
         float bound;
         if (mode == PG_LN) bound = (P.bnd_res ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
-        else bound = fmaxf(P.bnd0[rowc], nc1 > 0 ? P.bnd1[rowc] : 0.f) * P.W.wnorm[nb];
-        if (P.pbnd && rok && nb == 0 && wn == 0 && q == 0) P.pbnd[grow[rr]] = bound;
+        else {
+            // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
+            // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
+            const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + rowc / P.grp_rows] : fmaxf(P.bnd0[rowc], nc1 > 0 ? P.bnd1[rowc] : 0.f);
+            bound = bin * P.W.wnorm[nb] * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+        }
+        const bool per_blk = P.pimg_blk_stride != 0;
+        if (P.pbnd && rok && (nb == 0 || per_blk) && wn == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
         const float sc = pow2i(scale_exp(bound));
         const int rl = wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;
-        char* const rowp = P.pimg + (((size_t)rb * P.p_nct + P.p_kc0 + nb * (C >> 4) + wn * (BNW >> 4)) * 128 + rl) * 64;
+        char* const rowp = P.pimg + (size_t)nb * P.pimg_blk_stride +
+                           (((size_t)rb * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + wn * (BNW >> 4)) * 128 + rl) * 64;
         const unsigned uh = (unsigned)(((q >> 1) ^ swz) << 4), ul = (unsigned)(((2 + (q >> 1)) ^ swz) << 4);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -533,13 +540,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---------------------------------------------------------------------------------------------------------------------
 // weights: per output column c the scale 2^s_c and the L1 norm; then the image
 // ---------------------------------------------------------------------------------------------------------------------
+// (olen, opad): the image's row c' is row (c' / opad) olen + c' % opad of the block (zero where c' % opad >= olen): output
+// columns padded per head (108 -> 112) so that the attention kernel's operands start every head at a k-chunk; olen = opad = C: identity
+__device__ __forceinline__ int pg_src_row(int c, int C, int olen, int opad, int rows_src) {
+    if (c >= C) return -1;
+    const int r = (c / opad) * olen + c % opad;
+    return (c % opad < olen && r < rows_src) ? r : -1;
+}
 __global__ __launch_bounds__(256) void pg_wscale_kernel(const float* __restrict__ W, int nblk, int C, int K, int BN, float* __restrict__ cinv,
-                                                        float* __restrict__ wnorm) {
+                                                        float* __restrict__ wnorm, int olen, int opad, int rows_src) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= nblk * BN) return;
     const int nb = idx / BN, c = idx % BN;
-    if (c >= C) { if (lane == 0) cinv[idx] = 1.f; return; }
-    const float* wr = W + (size_t)(nb * C + c) * K;
+    const int sr = pg_src_row(c, C, olen, opad, rows_src);
+    if (sr < 0) { if (lane == 0) cinv[idx] = 1.f; return; }
+    const float* wr = W + (size_t)(nb * rows_src + sr) * K;
     float mx = 0.f, l1 = 0.f;
     for (int k = lane; k < K; k += 64) { const float a = fabsf(wr[k]); mx = fmaxf(mx, a); l1 += a; }
     mx = wave_max(mx);
@@ -551,19 +566,21 @@ __global__ __launch_bounds__(256) void pg_wscale_kernel(const float* __restrict_
     }
 }
 __global__ __launch_bounds__(256) void pg_pack_kernel(const float* __restrict__ W, int nblk, int C, int K, int BN, int nct, int piece_len,
-                                                      int piece_pad, const float* __restrict__ cinv, char* __restrict__ img) {
+                                                      int piece_pad, const float* __restrict__ cinv, char* __restrict__ img, int olen, int opad,
+                                                      int rows_src) {
     const size_t n = (size_t)nblk * nct * BN * 2, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int half = (int)(idx & 1);
     size_t rest = idx >> 1;
     const int c = (int)(rest % BN); rest /= BN;
     const int kc = (int)(rest % nct), nb = (int)(rest / nct);
-    const float sc = c < C ? 1.0f / cinv[nb * BN + c] : 0.f;          // (a power of two: exact)
+    const int sr = c < BN ? pg_src_row(c, C, olen, opad, rows_src) : -1;
+    const float sc = sr >= 0 ? 1.0f / cinv[nb * BN + c] : 0.f;       // (a power of two: exact)
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int kp = kc * 16 + half * 8 + e, piece = kp / piece_pad, off = kp % piece_pad, k = piece * piece_len + off;
-        x[e] = (c < C && off < piece_len && k < K) ? W[(size_t)(nb * C + c) * K + k] * sc : 0.f;
+        x[e] = (sr >= 0 && off < piece_len && k < K) ? W[(size_t)(nb * rows_src + sr) * K + k] * sc : 0.f;
     }
     uint4 hi, lo;
     split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y); split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const float* __restrict__ 
 
 // fp32 rows -> plane image, bound = max |row| (one wave per row; K <= 1024)
 __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ x, int ldx, int rows, int K, char* __restrict__ img,
-                                                              float* __restrict__ bnd) {
+                                                              float* __restrict__ bnd, const float* __restrict__ bnd_in) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int ng = K >> 3, nct = K >> 4;                              // 8-wide groups
@@ -592,6 +609,7 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
         }
     }
     mx = wave_max(mx);
+    if (bnd_in) mx = bnd_in[row];                                     // the caller's bound (must be >= the row's maximum)
     if (lane == 0) bnd[row] = mx;
     const float sc = pow2i(scale_exp(mx));
     const int rb = row >> 7, r = row & 127, swz = (r >> 2) & 3;
@@ -730,17 +748,20 @@ int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, in
     PgW v;
     pgemm_weight_view(buf, C, nblk, nct, &v);
     DR_HIP_CHECK(hipMemsetAsync((void*)v.wnorm, 0, (size_t)nblk * 4, st));
-    hipLaunchKernelGGL(pg_wscale_kernel, dim3((nblk * BN + 3) / 4), dim3(256), 0, st, W, nblk, C, K, BN, (float*)v.cinv, (float*)v.wnorm);
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((nblk * BN + 3) / 4), dim3(256), 0, st, W, nblk, C, K, BN, (float*)v.cinv, (float*)v.wnorm, C, C, C);
     DR_LAUNCH_CHECK();
     const size_t n = (size_t)nblk * nct * BN * 2;
     hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, nblk, C, K, BN, nct, piece_len, piece_pad,
-                       v.cinv, (char*)v.img);
+                       v.cinv, (char*)v.img, C, C, C);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
 
 // one block (C rows of W [C, K]) into block `nb` of a view
-int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& v, int nb, hipStream_t st) {
+int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& v, int nb, hipStream_t st, int out_len,
+                             int out_pad) {
+    // out_len / out_pad > 0: W has (C / out_pad) * out_len rows, spread to C image rows with zero rows in the pads
+    const int olen = out_len > 0 ? out_len : C, opad = out_pad > 0 ? out_pad : C, rows_src = out_len > 0 ? C / opad * olen : C;
     if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
     const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
     if (nct != v.nct) return DR_EINVAL;
@@ -749,19 +770,35 @@ int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int pi
     float* wnorm = (float*)v.wnorm + nb;
     char* img = (char*)v.img + (size_t)nb * nct * pg_bst(C);
     DR_HIP_CHECK(hipMemsetAsync(wnorm, 0, 4, st));
-    hipLaunchKernelGGL(pg_wscale_kernel, dim3((BN + 3) / 4), dim3(256), 0, st, W, 1, C, K, BN, cinv, wnorm);
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((BN + 3) / 4), dim3(256), 0, st, W, 1, C, K, BN, cinv, wnorm, olen, opad, rows_src);
     DR_LAUNCH_CHECK();
     const size_t n = (size_t)nct * BN * 2;
     hipLaunchKernelGGL(pg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, 1, C, K, BN, nct, piece_len, piece_pad,
-                       (const float*)cinv, img);
+                       (const float*)cinv, img, olen, opad, rows_src);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
 
-int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st) {
+// out[g] = max over the rows of group g of bnd[row]; groups of `grp_rows` consecutive rows (one wave per group)
+__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ bnd, int ngroups, int grp_rows, float* __restrict__ out) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= ngroups) return;
+    float m = 0.f;
+    for (int r = lane; r < grp_rows; r += 64) m = fmaxf(m, bnd[(size_t)g * grp_rows + r]);
+    m = wave_max(m);
+    if (lane == 0) out[g] = m;
+}
+int launch_group_max(const float* bnd, int ngroups, int grp_rows, float* out, hipStream_t st) {
+    if (ngroups < 1) return DR_OK;
+    hipLaunchKernelGGL(group_max_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, st, bnd, ngroups, grp_rows, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, float* bnd, hipStream_t st, const float* bnd_in) {
     if (K % 16 || K > 1024 || ldx % 4 || ((uintptr_t)x & 15)) return DR_ENOSUP;
     if (rows < 1) return DR_OK;
-    hipLaunchKernelGGL(planes_from_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, rows, K, img, bnd);
+    hipLaunchKernelGGL(planes_from_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, rows, K, img, bnd, bnd_in);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -798,6 +835,28 @@ size_t dr_plane_image_bytes(int rows, int K) { return (rows > 0 && K > 0 && K % 
 int dr_planes_from_f32(int rows, int K, const float* x, int ldx, void* image, float* bound, void* stream) {
     if (rows < 0 || K <= 0 || !x || !image || !bound || ldx < K) return DR_EINVAL;
     return launch_planes_from_f32(x, ldx, rows, K, (char*)image, bound, (hipStream_t)stream);
+}
+
+int dr_planes_from_f32_bounded(int rows, int K, const float* x, int ldx, const float* bound_in, void* image, float* bound, void* stream) {
+    if (rows < 0 || K <= 0 || !x || !image || !bound || !bound_in || ldx < K) return DR_EINVAL;
+    return launch_planes_from_f32(x, ldx, rows, K, (char*)image, bound, (hipStream_t)stream, bound_in);
+}
+
+int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                        const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                        void* out_image, float* out_bound, void* stream) {
+    if (P < 1 || Lq < 1 || Lk < 1 || H < 1 || d < 4 || d % 4 || !q_image || !k_image || !v_image || !q_bound || !k_bound || !v_bound || !out_image ||
+        !out_bound) return DR_EINVAL;
+    const int dp = (d + 15) / 16 * 16;
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.H = H; a.d = d; a.qmask = q_mask; a.kmask = k_mask;
+    a.nseg = P; a.q0 = 0; a.qstride = Lq; a.Lq = Lq; a.k0 = 0; a.kstride = Lk; a.Lk = Lk;
+    a.scale = 1.0f / sqrtf((float)d);
+    a.pimg[0] = a.pimg[1] = (char*)out_image; a.p_split = 0x7fffffff; a.p_nct = H * dp / 16; a.p_dp = dp; a.pbnd = out_bound;
+    a.qimg[0] = a.qimg[1] = (const char*)q_image; a.kimg[0] = a.kimg[1] = (const char*)k_image; a.vimg[0] = a.vimg[1] = (const char*)v_image;
+    a.qbnd = q_bound; a.kgb = k_bound; a.vgb = v_bound;
+    return launch_attention(a, (hipStream_t)stream);
 }
 
 int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream) {

@@ -102,6 +102,8 @@ SIGNATURES.update({
                                      c_int, c_float, c_void_p]),
     "dr_plane_image_bytes": (c_size_t, [c_int, c_int]),
     "dr_planes_from_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_planes_from_f32_bounded": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_attention_planes": (c_int, [c_int] * 5 + [c_void_p] * 10 + [c_void_p]),
     "dr_planes_to_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dr_plane_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -229,6 +231,43 @@ def planes_from_f32(x):
     bnd = torch.empty(rows, device=x.device)
     check(_lib.dr_planes_from_f32(rows, K, ptr(x), K, ptr(img), ptr(bnd), stream_of(x)))
     return img, bnd
+
+
+def planes_from_f32_bounded(x, bound_in):
+    ensure_init()
+    x = x.contiguous()
+    rows, K = x.shape
+    img = torch.zeros(_lib.dr_plane_image_bytes(rows, K), dtype=torch.uint8, device=x.device)
+    bnd = torch.empty(rows, device=x.device)
+    check(_lib.dr_planes_from_f32_bounded(rows, K, ptr(x), K, ptr(bound_in.contiguous()), ptr(img), ptr(bnd), stream_of(x)))
+    return img, bnd
+
+
+def attention_planes(q, k, v, H, q_mask=None, k_mask=None):
+    """q [P,Lq,C], k, v [P,Lk,C] float32 (rotary already applied) -> softmax(q k^T / sqrt(d)) v per head, [P,Lq,C], through the
+    plane-image attention kernel (images built here: head-padded columns, one k / v bound per segment)."""
+    ensure_init()
+    P, Lq, C = q.shape
+    Lk = k.shape[1]
+    d = C // H
+    dp = (d + 15) // 16 * 16
+
+    def pad(x):
+        y = torch.zeros(x.shape[0] * x.shape[1], H * dp, device=x.device)
+        xr = x.reshape(-1, H, d)
+        y.view(-1, H, dp)[:, :, :d] = xr
+        return y
+    qi, qb = planes_from_f32(pad(q))
+    kb_in = k.abs().amax((1, 2)).repeat_interleave(Lk)
+    vb_in = v.abs().amax((1, 2)).repeat_interleave(Lk)
+    ki, kb = planes_from_f32_bounded(pad(k), kb_in)
+    vi, vb = planes_from_f32_bounded(pad(v), vb_in)
+    oi = torch.zeros(_lib.dr_plane_image_bytes(P * Lq, H * dp), dtype=torch.uint8, device=q.device)
+    ob = torch.zeros(P * Lq, device=q.device)
+    check(_lib.dr_attention_planes(P, Lq, Lk, H, d, ptr(qi), ptr(qb), ptr(ki), ptr(kb), ptr(vi), ptr(vb), ptr(mask_u8(q_mask)), ptr(mask_u8(k_mask)),
+                                   ptr(oi), ptr(ob), stream_of(q)))
+    o = planes_to_f32(oi, ob, P * Lq, H * dp).view(P * Lq, H, dp)[:, :, :d]
+    return o.reshape(P, Lq, C)
 
 
 def planes_to_f32(img, bnd, rows, K):

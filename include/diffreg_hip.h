@@ -134,6 +134,16 @@ int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float
 size_t dr_plane_image_bytes(int rows, int K);
 /* fp32 rows -> image, bound[row] = max |x[row][:]| (the external features entering the first layer) */
 int dr_planes_from_f32(int rows, int K, const float* x, int ldx, void* image, float* bound, void* stream);
+/* the same with the caller's bounds (bound_in[row] >= max |x[row][:]|; e.g. one bound for all the key rows of a pair) */
+int dr_planes_from_f32_bounded(int rows, int K, const float* x, int ldx, const float* bound_in, void* image, float* bound, void* stream);
+/* einsum / mask / softmax / einsum of GeometryAttentionLayer.forward (3D/models/transformero.py:79-85) on plane images: P segments of
+ * Lq queries attending Lk keys (rows p Lq .. / p Lk .. of the images), H heads of d features laid out head-padded (head h at
+ * k = h dp, dp = d rounded up to 16, zeros in the pad; images of H dp columns).  All key rows of a segment must carry ONE k bound
+ * and ONE v bound (read at the segment's first key row).  Three fp16 MFMA products per fp32 product, K / V tiles by LDS-DMA.
+ * out_image: the merge projection's operand (same layout), out_bound [P Lq].  d in {64, 108, 132} (dp 64, 112, 144). */
+int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                        const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                        void* out_image, float* out_bound, void* stream);
 /* image -> fp32 rows (tests) */
 int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream);
 /* weights W [nblk * C, K] (nn.Linear layout; nblk stacked layers of C output columns each, C <= 448, C % 16 == 0) ->

@@ -22,7 +22,7 @@ from diffreg_hip import synth  # noqa: E402
 from oracle import diffreg_oracle as orc  # noqa: E402
 from tests.helpers import T, weights, pair, masks  # noqa: E402
 
-TAU = 2.5e-5
+TAU = 2e-5
 LOOPS = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "n128_s1_mc200"),
          ("3dmatch", 128, 128, 128, 128, 20, 0, 11, "n128_s20_mc0"),
          ("3dmatch", 96, 80, 96, 80, 5, 200, 12, "n96x80_s5_mc200"),

@@ -126,3 +126,32 @@ def test_degenerate_rows_stay_in_their_rows():
     assert float(err.max()) < 3e-6
     assert torch.equal(out[3], torch.zeros(C, device=DEV))
     assert not torch.isfinite(out[200]).all() and not torch.isfinite(out[201]).all()
+
+
+@pytest.mark.parametrize("P,Lq,Lk,H,d", [(1, 32, 32, 1, 108), (2, 128, 64, 4, 108), (3, 200, 256, 4, 108), (2, 96, 80, 4, 132), (2, 64, 160, 4, 64)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_on_plane_images(P, Lq, Lk, H, d, masked):
+    """dr_attention_planes: q | k | v as head-padded plane images with bounds (what the q|k|v GEMM's epilogue writes), softmax(q k^T /
+    sqrt(d)) v per head as a plane image (what the merge GEMM reads) -- against float64 attention (transformero.py:73-84: keys
+    outside k_mask get -inf)."""
+    torch.manual_seed(P * 1000 + Lq + d)
+    C = H * d
+    q = torch.randn(P, Lq, C, device=DEV)
+    k = torch.randn(P, Lk, C, device=DEV)
+    v = torch.randn(P, Lk, C, device=DEV) * 3
+    qm = km = None
+    if masked:
+        qm = torch.ones(P, Lq, dtype=torch.bool, device=DEV)
+        km = torch.ones(P, Lk, dtype=torch.bool, device=DEV)
+        qm[:, Lq - 5:] = False
+        km[:, Lk - 7:] = False
+        km[0, :3] = False
+    o = lib.attention_planes(q, k, v, H, qm, km)
+    qh, kh, vh = (z.double().view(P, -1, H, d).transpose(1, 2) for z in (q, k, v))
+    logit = qh @ kh.transpose(-1, -2) / d ** 0.5
+    if masked:
+        logit = logit.masked_fill(~km[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(logit, -1) @ vh).transpose(1, 2).reshape(P, Lq, C)
+    keep = qm if masked else torch.ones(P, Lq, dtype=torch.bool, device=DEV)
+    assert not torch.isnan(o[keep]).any()
+    assert float((o.double() - ref)[keep].abs().max()) < 1e-5 * float(ref.abs().max())

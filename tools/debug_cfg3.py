@@ -12,7 +12,7 @@ v = synth.VARIANTS[variant]
 g = np.load(os.path.join(ROOT, "tests/golden/4dmatch_loop_n512_s20_mc40_masked.npz"))
 for strict in (False, True):
     eng = DenoiseEngine(weights(variant), variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps,
-                        sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=DEV, strict_f64=strict)
+                        sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=DEV, strict_f64=strict, planes=True)
     _, p = pair(variant, N, M, 62)
     ms = (torch.arange(N)[None] < 470).to(DEV); mt = (torch.arange(M)[None] < 391).to(DEV)
     noise = T(synth.step_noise(N, M, 62, steps))[:, None].to(DEV)
