@@ -1,5 +1,5 @@
 """Collect rocprofv3 PMC counters of one kernel in separate passes (<= 8 SQ counters per pass; FETCH_SIZE / WRITE_SIZE alone)
-and write a JSON summary.   python tools/pmc_collect.py OUT.json KERNEL_SUBSTR -- python3 tools/prog.py
+and write a JSON summary.   python tools/pmc_collect.py OUT.json KERNEL_SUBSTR[,KERNEL_SUBSTR2=OUT2.json,...] -- python3 tools/prog.py
 (run from the repo root ON THE GPU BOX; the profiled program goes after `--` unwrapped)"""
 import csv, glob, json, os, subprocess, sys, tempfile
 
@@ -13,9 +13,9 @@ PASSES = [
 
 
 def main():
-    out, kern = sys.argv[1], sys.argv[2]
+    out, kerns = sys.argv[1], sys.argv[2].split(",")
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    res, dur = {}, []
+    dirs = []
     for ctrs in PASSES:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
@@ -24,6 +24,15 @@ def main():
         if r.returncode != 0:
             print("pass failed:", ctrs, r.stdout[-2000:])
             continue
+        dirs.append(d)
+    for i, k in enumerate(kerns):
+        kern, _, o = k.partition("=")
+        summarise(dirs, kern, o or out, cmd)
+
+
+def summarise(dirs, kern, out, cmd):
+    res, dur = {}, []
+    for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             acc = {}
             for row in csv.DictReader(open(f)):
