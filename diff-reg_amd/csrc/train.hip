@@ -1,0 +1,280 @@
+// train.hip -- forward half of the training branch around the loop's kernels (HBM-bound, one pass each):
+//   match_matrix   match_2_conf_matrix / matrix_gt                  (3D/models/loss.py:316-320, pipeline.py:203-206)
+//   gt_noising     structured noise + q_sample + nan_to_num + min   (pipeline.py:209-214, q_sample :84-95)
+//   focal_loss     compute_correspondence_loss                      (loss.py:273-314)
+//   match_recall   compute_match_recall                             (loss.py:323-345)
+//   motion_l1      L1 motion term of ge_coarse_loss                 (loss.py:108-128)
+// Reductions are two kernels (fixed grid of partials, one finishing workgroup that adds them in index order): results do
+// not depend on the launch's scheduling.
+#include "kernels.h"
+
+namespace dr {
+namespace {
+
+constexpr int TR_BLOCKS = 1024;      // partials of a reduction
+constexpr int TR_THREADS = 256;
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* s) {      // s: [TR_THREADS / 64]
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) s[wave_id()] = v;
+    __syncthreads();
+    T r = s[0];
+    for (int k = 1; k < TR_THREADS / 64; ++k) r += s[k];
+    return r;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_matrix_kernel(int K, long long NM, int N, int M, int P, const long long* __restrict__ m,
+                                                           float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const long long b = m[3 * k], i = m[3 * k + 1], j = m[3 * k + 2];
+    if (b < 0 || b >= P || i < 0 || i >= N || j < 0 || j >= M) return;      // (the reference would raise)
+    out[b * NM + i * M + j] = 1.0f;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------
+// noise = ((|r| % 1) * (|r| / r)) * 1.5 in float32 (r = 0 gives 0 * nan = nan -> 0 by nan_to_num); x = sa * gt + sb * noise in
+// float64 (a float64 [1,1,1] tensor times a float32 matrix promotes; separate multiply and add, no contraction)
+__device__ __forceinline__ double noised_value(float g, float r, double sa, double sb) {
+    const float a = fabsf(r);
+    const float frac = a - floorf(a);                     // fmod(a, 1) for a >= 0: exact
+    const float sgn = __fdiv_rn(a, r);                    // +-1, nan at r = 0
+    const float n = __fmul_rn(__fmul_rn(frac, sgn), 1.5f);
+    double x = __dadd_rn(__dmul_rn(sa, (double)g), __dmul_rn(sb, (double)n));
+    if (x != x) x = 0.0;                                  // nan_to_num(nan = 0); +-inf cannot occur (|noise| < 1.5)
+    return x;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void gt_noising_min_kernel(long long n, const float* __restrict__ gt, const float* __restrict__ r,
+                                                                    double sa, double sb, double* __restrict__ out, double* __restrict__ part) {
+    __shared__ double s[TR_THREADS / 64];
+    double m = INFINITY;
+    for (long long e = (long long)blockIdx.x * TR_THREADS + threadIdx.x; e < n; e += (long long)TR_BLOCKS * TR_THREADS) {
+        const double x = noised_value(gt[e], r[e], sa, sb);
+        out[e] = x;
+        m = fmin(m, x);
+    }
+    m = wave_min(m);
+    if (lane_id() == 0) s[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < TR_THREADS / 64; ++k) m = fmin(m, s[k]);
+        part[blockIdx.x] = fmin(m, s[0]);
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void gt_noising_shift_kernel(long long n, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double s[TR_THREADS / 64];
+    double m = INFINITY;
+    for (int k = threadIdx.x; k < TR_BLOCKS; k += TR_THREADS) m = fmin(m, part[k]);
+    m = wave_min(m);
+    if (lane_id() == 0) s[wave_id()] = m;
+    __syncthreads();
+    m = s[0];
+    for (int k = 1; k < TR_THREADS / 64; ++k) m = fmin(m, s[k]);
+    for (long long e = (long long)blockIdx.x * TR_THREADS + threadIdx.x; e < n; e += (long long)TR_BLOCKS * TR_THREADS) out[e] = out[e] - m;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------
+// focal terms in float32 in the reference's operation order ((-alpha * pow) * log), summed in float64
+struct FocalArgs {
+    const float* conf; const float* gt; const float* weight; long long n; float alpha, gamma, pos_w, neg_w; int dual_softmax;
+    double* part;      // [TR_BLOCKS][4]: sum pos, n pos, sum neg, n neg
+    float* loss;
+};
+
+__device__ __forceinline__ float powg(float x, float g) { return g == 2.0f ? x * x : (g == 1.0f ? x : powf(x, g)); }
+
+__global__ __launch_bounds__(TR_THREADS) void focal_partial_kernel(FocalArgs A) {
+    __shared__ double s[TR_THREADS / 64];
+    double sp = 0, np = 0, sn = 0, nn = 0;
+    for (long long e = (long long)blockIdx.x * TR_THREADS + threadIdx.x; e < A.n; e += (long long)TR_BLOCKS * TR_THREADS) {
+        const float g = A.gt[e];
+        const float c = fminf(fmaxf(A.conf[e], 1e-6f), 1.0f - 1e-6f);
+        if (g == 1.0f) {
+            float l = __fmul_rn(__fmul_rn(-A.alpha, powg(1.0f - c, A.gamma)), logf(c));
+            if (A.dual_softmax && A.weight) l = __fmul_rn(l, A.weight[e]);
+            sp += (double)l; np += 1.0;
+        } else if (g == 0.0f && !A.dual_softmax) {
+            const float l = __fmul_rn(__fmul_rn(-A.alpha, powg(c, A.gamma)), logf(1.0f - c));
+            sn += (double)l; nn += 1.0;
+        } else if (g == 0.0f) {
+            nn += 1.0;
+        }
+    }
+    sp = block_sum(sp, s); np = block_sum(np, s); sn = block_sum(sn, s); nn = block_sum(nn, s);
+    if (threadIdx.x == 0) {
+        double* p = A.part + 4 * blockIdx.x;
+        p[0] = sp; p[1] = np; p[2] = sn; p[3] = nn;
+    }
+}
+
+__global__ __launch_bounds__(64) void focal_final_kernel(FocalArgs A) {
+    if (threadIdx.x != 0) return;
+    double sp = 0, np = 0, sn = 0, nn = 0;
+    for (int k = 0; k < TR_BLOCKS; ++k) { sp += A.part[4 * k]; np += A.part[4 * k + 1]; sn += A.part[4 * k + 2]; nn += A.part[4 * k + 3]; }
+    // corner cases (loss.py:287-297): no positive (negative) entry -> entry [0,0,0] stands in with weight 0: the term is 0 x finite.
+    // dual_softmax without any negative entry: weight[0,0,0] = 0 (:294) zeroes the weighted term of entry 0, which IS positive
+    if (A.dual_softmax && A.weight && nn == 0 && A.n > 0 && A.gt[0] == 1.0f) {
+        const float c = fminf(fmaxf(A.conf[0], 1e-6f), 1.0f - 1e-6f);
+        sp -= (double)__fmul_rn(__fmul_rn(__fmul_rn(-A.alpha, powg(1.0f - c, A.gamma)), logf(c)), A.weight[0]);
+    }
+    const float mp = np > 0 ? (float)(sp / np) : 0.0f;
+    const float mn = nn > 0 ? (float)(sn / nn) : 0.0f;
+    const float pw = np > 0 ? A.pos_w : 0.0f, nw = nn > 0 ? A.neg_w : 0.0f;
+    *A.loss = A.dual_softmax ? __fmul_rn(pw, mp) : __fadd_rn(__fmul_rn(pw, mp), __fmul_rn(nw, mn));
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mark_pred_kernel(int K, long long NM, int N, int M, int P, const long long* __restrict__ m,
+                                                        uint8_t* __restrict__ mark) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const long long b = m[3 * k], i = m[3 * k + 1], j = m[3 * k + 2];
+    if (b < 0 || b >= P || i < 0 || i >= N || j < 0 || j >= M) return;
+    mark[b * NM + i * M + j] = 1;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void recall_partial_kernel(long long n, const float* __restrict__ gt, const uint8_t* __restrict__ mark,
+                                                                    double* __restrict__ part) {
+    __shared__ double s[TR_THREADS / 64];
+    double tp = 0, ng = 0;
+    for (long long e = (long long)blockIdx.x * TR_THREADS + threadIdx.x; e < n; e += (long long)TR_BLOCKS * TR_THREADS) {
+        const float g = gt[e];
+        // true_positive = (pred == gt) * gt  (loss.py:339): gt where the two agree
+        if ((mark[e] ? 1.0f : 0.0f) == g) tp += (double)g;
+        ng += (double)g;
+    }
+    tp = block_sum(tp, s); ng = block_sum(ng, s);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = tp; part[2 * blockIdx.x + 1] = ng; }
+}
+
+__global__ __launch_bounds__(64) void recall_final_kernel(const double* __restrict__ part, int K, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double tp = 0, ng = 0;
+    for (int k = 0; k < TR_BLOCKS; ++k) { tp += part[2 * k]; ng += part[2 * k + 1]; }
+    out[0] = (float)tp / (float)ng;                       // recall (nan without any ground-truth entry, like the reference)
+    out[1] = (float)tp / (float)(K > 1 ? K : 1);          // precision
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------
+// e1[b][i] = sum_c |(R_p s + t_p - s) - (R_g (s + flow) + t_g - s)|_c over the rows inside the overlap mask; mean over those rows
+struct MotionArgs {
+    const float* s; const float* flow; const float* Rp; const float* tp; const float* Rg; const float* tg; const uint8_t* mask; int P, N;
+    double* part;      // [TR_BLOCKS][2]
+    float* loss;
+};
+
+__global__ __launch_bounds__(TR_THREADS) void motion_partial_kernel(MotionArgs A) {
+    __shared__ double s[TR_THREADS / 64];
+    double se = 0, cnt = 0;
+    const long long n = (long long)A.P * A.N;
+    for (long long e = (long long)blockIdx.x * TR_THREADS + threadIdx.x; e < n; e += (long long)TR_BLOCKS * TR_THREADS) {
+        if (!A.mask[e]) continue;
+        const int b = (int)(e / A.N);
+        const float x = A.s[3 * e], y = A.s[3 * e + 1], z = A.s[3 * e + 2];
+        float dx = x, dy = y, dz = z;
+        if (A.flow) { dx += A.flow[3 * e]; dy += A.flow[3 * e + 1]; dz += A.flow[3 * e + 2]; }
+        const float* Rp = A.Rp + 9 * b; const float* Rg = A.Rg + 9 * b;
+        float e1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float wp = (Rp[3 * c] * x + Rp[3 * c + 1] * y + Rp[3 * c + 2] * z) + A.tp[3 * b + c];
+            const float wg = (Rg[3 * c] * dx + Rg[3 * c + 1] * dy + Rg[3 * c + 2] * dz) + A.tg[3 * b + c];
+            const float sc = c == 0 ? x : (c == 1 ? y : z);
+            e1 += fabsf((wp - sc) - (wg - sc));
+        }
+        se += (double)e1; cnt += 1.0;
+    }
+    se = block_sum(se, s); cnt = block_sum(cnt, s);
+    if (threadIdx.x == 0) { A.part[2 * blockIdx.x] = se; A.part[2 * blockIdx.x + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(64) void motion_final_kernel(MotionArgs A) {
+    if (threadIdx.x != 0) return;
+    double se = 0, cnt = 0;
+    for (int k = 0; k < TR_BLOCKS; ++k) { se += A.part[2 * k]; cnt += A.part[2 * k + 1]; }
+    *A.loss = (float)(se / cnt);                          // mean of an empty selection is nan in the reference too
+}
+
+}  // namespace
+}  // namespace dr
+
+extern "C" {
+
+size_t dr_train_workspace_bytes(int P, int N, int M) {
+    if (P < 0 || N < 0 || M < 0) return 0;
+    return (size_t)dr::TR_BLOCKS * 4 * sizeof(double) + (((size_t)P * N * M + 255) & ~(size_t)255);
+}
+
+int dr_match_matrix_f32(int P, int N, int M, int K, const int64_t* matches, float* out, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || K < 0 || !out || (K > 0 && !matches)) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DR_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)P * N * M * sizeof(float), st));
+    if (K == 0 || P == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::match_matrix_kernel, dim3((K + 255) / 256), dim3(256), 0, st, K, (long long)N * M, N, M, P, (const long long*)matches, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int dr_gt_noising_f64(int P, int N, int M, const float* matrix_gt, const float* randn, double sqrt_ac, double sqrt_one_minus_ac, double* out,
+                      void* workspace, void* stream) {
+    if (P < 1 || N < 1 || M < 1 || !matrix_gt || !randn || !out || !workspace) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)P * N * M;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(dr::gt_noising_min_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, n, matrix_gt, randn, sqrt_ac, sqrt_one_minus_ac, out, part);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::gt_noising_shift_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, n, part, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int dr_focal_loss_f32(int P, int N, int M, const float* conf, const float* conf_gt, const float* weight, float alpha, float gamma, float pos_w,
+                      float neg_w, int match_type, float* loss, void* workspace, void* stream) {
+    if (P < 1 || N < 1 || M < 1 || !conf || !conf_gt || !loss || !workspace || (match_type != DR_MATCH_SINKHORN && match_type != DR_MATCH_DUAL_SOFTMAX))
+        return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dr::FocalArgs A{conf, conf_gt, weight, (long long)P * N * M, alpha, gamma, pos_w, neg_w, match_type == DR_MATCH_DUAL_SOFTMAX, (double*)workspace, loss};
+    hipLaunchKernelGGL(dr::focal_partial_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, A);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::focal_final_kernel, dim3(1), dim3(64), 0, st, A);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int dr_match_recall_f32(int P, int N, int M, const float* conf_gt, int K, const int64_t* match_pred, float* recall_precision, void* workspace,
+                        void* stream) {
+    if (P < 1 || N < 1 || M < 1 || K < 0 || !conf_gt || !recall_precision || !workspace || (K > 0 && !match_pred)) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    uint8_t* mark = (uint8_t*)workspace + (size_t)dr::TR_BLOCKS * 4 * sizeof(double);
+    const long long n = (long long)P * N * M;
+    DR_HIP_CHECK(hipMemsetAsync(mark, 0, (size_t)n, st));
+    if (K > 0) {
+        hipLaunchKernelGGL(dr::mark_pred_kernel, dim3((K + 255) / 256), dim3(256), 0, st, K, (long long)N * M, N, M, P, (const long long*)match_pred, mark);
+        DR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(dr::recall_partial_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, n, conf_gt, mark, part);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::recall_final_kernel, dim3(1), dim3(64), 0, st, part, K, recall_precision);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
+                     const float* t_gt, const uint8_t* overlap_mask, float* loss, void* workspace, void* stream) {
+    if (P < 1 || N < 1 || !s_pcd || !R_pred || !t_pred || !R_gt || !t_gt || !overlap_mask || !loss || !workspace) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dr::MotionArgs A{s_pcd, flow, R_pred, t_pred, R_gt, t_gt, overlap_mask, P, N, (double*)workspace, loss};
+    hipLaunchKernelGGL(dr::motion_partial_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, A);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::motion_final_kernel, dim3(1), dim3(64), 0, st, A);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}  // extern "C"

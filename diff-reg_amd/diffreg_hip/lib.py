@@ -129,6 +129,13 @@ SIGNATURES.update({
     "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
+    "dr_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_match_matrix_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_gt_noising_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "dr_focal_loss_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    "dr_match_recall_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_motion_l1_f32": (c_int, [c_int, c_int] + [c_void_p] * 10),
     "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -322,6 +329,74 @@ def scatter_rows(src, src_index, dst_index, dst):
     assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[-1] == src.shape[-1]
     check(_lib.dr_scatter_rows_f32(si.numel(), src.shape[-1], ptr(src), ptr(si), ptr(di), ptr(dst), stream_of(src)))
     return dst
+
+
+# ---- forward half of the training branch (csrc/train.hip) -------------------------------------------------------------------------
+MATCH_SINKHORN, MATCH_DUAL_SOFTMAX = 0, 1
+
+
+def _train_ws(P, N, M, dev):
+    return torch.empty(_lib.dr_train_workspace_bytes(P, N, M), dtype=torch.uint8, device=dev)
+
+
+def match_matrix(matches, P, N, M):
+    """rows (b, i, j) of matches [K,3] int64 -> [P,N,M] float32 with 1 at the rows (match_2_conf_matrix, loss.py:316-320)"""
+    ensure_init()
+    matches = matches.to(torch.int64).contiguous()
+    out = torch.empty(P, N, M, device=matches.device)
+    check(_lib.dr_match_matrix_f32(P, N, M, matches.shape[0], ptr(matches), ptr(out), stream_of(out)))
+    return out
+
+
+def gt_noising(matrix_gt, randn, sqrt_ac, sqrt_one_minus_ac):
+    """pipeline.py:209-214 -> matrix_gt_disturbed [P,N,M] float64"""
+    ensure_init()
+    matrix_gt, randn = matrix_gt.contiguous().float(), randn.contiguous().float()
+    P, N, M = matrix_gt.shape
+    out = torch.empty(P, N, M, dtype=torch.float64, device=matrix_gt.device)
+    ws = _train_ws(P, N, M, out.device)
+    check(_lib.dr_gt_noising_f64(P, N, M, ptr(matrix_gt), ptr(randn), float(sqrt_ac), float(sqrt_one_minus_ac), ptr(out), ptr(ws), stream_of(out)))
+    return out
+
+
+def focal_loss(conf, conf_gt, weight=None, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0, match_type="sinkhorn"):
+    """compute_correspondence_loss (loss.py:273-314) -> 0-d float32 tensor"""
+    ensure_init()
+    conf, conf_gt = conf.contiguous().float(), conf_gt.contiguous().float()
+    weight = weight.contiguous().float() if weight is not None else None
+    P, N, M = conf.shape
+    loss = torch.empty((), device=conf.device)
+    ws = _train_ws(P, N, M, conf.device)
+    mt = {"sinkhorn": MATCH_SINKHORN, "dual_softmax": MATCH_DUAL_SOFTMAX}[match_type]
+    check(_lib.dr_focal_loss_f32(P, N, M, ptr(conf), ptr(conf_gt), ptr(weight), alpha, gamma, pos_w, neg_w, mt, ptr(loss), ptr(ws), stream_of(conf)))
+    return loss
+
+
+def match_recall(conf_gt, match_pred):
+    """compute_match_recall (loss.py:323-345) -> (recall, precision) 0-d float32 tensors"""
+    ensure_init()
+    conf_gt = conf_gt.contiguous().float()
+    match_pred = match_pred.to(torch.int64).contiguous()
+    P, N, M = conf_gt.shape
+    out = torch.empty(2, device=conf_gt.device)
+    ws = _train_ws(P, N, M, conf_gt.device)
+    check(_lib.dr_match_recall_f32(P, N, M, ptr(conf_gt), match_pred.shape[0], ptr(match_pred), ptr(out), ptr(ws), stream_of(conf_gt)))
+    return out[0], out[1]
+
+
+def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
+    """the L1 motion term of ge_coarse_loss (loss.py:108-128) -> 0-d float32 tensor"""
+    ensure_init()
+    P, N, _ = s_pcd.shape
+    f = lambda x: x.contiguous().float()
+    s_pcd, R_pred, t_pred, R_gt, t_gt = f(s_pcd), f(R_pred), f(t_pred.reshape(P, 3)), f(R_gt), f(t_gt.reshape(P, 3))
+    flow = f(flow) if flow is not None else None
+    loss = torch.empty((), device=s_pcd.device)
+    ws = _train_ws(P, N, 1, s_pcd.device)
+    om = mask_u8(overlap_mask)
+    check(_lib.dr_motion_l1_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(loss),
+                                ptr(ws), stream_of(s_pcd)))
+    return loss
 
 
 def mutual_match(conf, thr=0.0, mutual=True, cap=None, want_mask=False):

@@ -107,6 +107,37 @@ def make_weights(C, seed=7, n_layers=6, head_gain=1.0, dtype=np.float32):
     return w
 
 
+def make_weights_coarse(C, seed=17, head_gain=1.0, dtype=np.float32):
+    """Weights of the NON-denoising branch of the training forward (row f3; 3D/models/pipeline.py:142-147): coarse_transformer with
+    layer_types [self, cross, positioning, self, cross] (layers.2 = [Matching, SoftProcrustesLayer]) and coarse_matching, in the
+    reference's state-dict layout.  Same distributions as make_weights."""
+    w = {}
+    st = 0
+
+    def lin(out_f, in_f, gain=1.0):
+        nonlocal st
+        st += 1
+        a = gain * math.sqrt(3.0 / in_f)
+        return hash_uniform(seed, st, (out_f, in_f), -a, a).astype(dtype)
+
+    for l in (0, 1, 3, 4):
+        p = "coarse_transformer.layers.%d." % l
+        w[p + "q_proj.weight"] = lin(C, C)
+        w[p + "k_proj.weight"] = lin(C, C)
+        w[p + "v_proj.weight"] = lin(C, C)
+        w[p + "merge.weight"] = lin(C, C)
+        w[p + "mlp.0.weight"] = lin(2 * C, 2 * C)
+        w[p + "mlp.2.weight"] = lin(C, 2 * C)
+        for nm, base, amp in (("norm1.weight", 1.0, 0.1), ("norm1.bias", 0.0, 0.05), ("norm2.weight", 1.0, 0.1), ("norm2.bias", 0.0, 0.05)):
+            st += 1
+            w[p + nm] = (base + amp * hash_uniform(seed, st, (C,))).astype(dtype)
+    for p in ("coarse_transformer.layers.2.0.", "coarse_matching."):
+        w[p + "src_proj.weight"] = lin(C, C, head_gain)
+        w[p + "tgt_proj.weight"] = lin(C, C)
+        w[p + "bin_score"] = np.asarray(1.0, dtype=dtype)
+    return w
+
+
 def _rodrigues(axis, theta):
     axis = axis / np.linalg.norm(axis)
     K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])

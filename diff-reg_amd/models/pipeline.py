@@ -5,7 +5,9 @@ matching matrix -> conf_matrix_pred / match_pred / (R, t).
 The evaluation branch (`not self.training and not eval_flag`) runs entirely in libdiffreg_hip through
 diffreg_hip.engine.DenoiseEngine (one HIP-graph replay per forward).  The KPFCN backbone (SURVEY section 8
 row f1) is `models.backbone.KPFCN` of this overlay (HIP ops, the reference's state-dict layout), or whatever is
-injected with `backbone=`.  The training branch (row f3) is not built.
+injected with `backbone=`.  The training branch (row f3) computes its FORWARD values on the device (no autograd graph:
+`self.training` gives conf_matrix_pred / coarse_match_pred / (R, t) of the non-denoising branch and conf_matrix_gt_hat of the
+denoising branch on the noised ground-truth matrix, for models.loss.MatchMotionLoss); backward kernels are not built.
 """
 import math
 
@@ -131,7 +133,7 @@ class Pipeline(nn.Module):
         data.update({"s_pcd": s_pcd, "t_pcd": t_pcd})
         if self.timers: self.timers.toc("coarse_preprocess")
         if self.training:
-            raise NotImplementedError("the training branch (pipeline.py:182-216) is outside the accelerated path")
+            return self._training_forward(data, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask)
         if eval_flag:
             return data
         P, N, _ = src_feats.shape
@@ -171,6 +173,44 @@ class Pipeline(nn.Module):
             R, t = out["R_final"], out["t_final"]
         data.update({"R_s2t_pred": R, "t_s2t_pred": t})
         return data
+
+    def _training_forward(self, data, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask):
+        """the `if self.training:` block of pipeline.py:182-216, values only: both transformers, both matching heads and the two
+        Procrustes fits run on the HIP kernels of the loop; the GT-matrix noising (q_sample on the structured noise, nan_to_num,
+        batch-wide minimum) is dr_gt_noising_f64.  data['coarse_matches'] = per pair [2, K] index tensors, as the collate gives."""
+        from diffreg_hip import lib
+        src_backbone, tgt_backbone = src_feats, tgt_feats
+        dev = src_feats.device
+        P, N, _ = src_feats.shape
+        M = tgt_feats.shape[1]
+        src_feats, tgt_feats, src_pe, tgt_pe = self.coarse_transformer(src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask, data)
+        conf, match_pred = self.coarse_matching(src_feats, tgt_feats, src_pe, tgt_pe, src_mask, tgt_mask, data, pe_type=self.pe_type)
+        data.update({"conf_matrix_pred": conf, "coarse_match_pred": match_pred})
+        R, t, _, _, _, _ = self.soft_procrustes(conf, s_pcd, t_pcd, src_mask, tgt_mask)
+        data.update({"R_s2t_pred": R, "t_s2t_pred": t})
+        ts = data["ts"] if "ts" in data else torch.randint(0, self.num_timesteps, (1,), device=dev).long()          # pipeline.py:202
+        rows = [torch.cat([torch.full((1, m.shape[1]), b, dtype=torch.int64, device=m.device), m.to(torch.int64)], 0).t()
+                for b, m in enumerate(data["coarse_matches"])]
+        matrix_gt = lib.match_matrix(torch.cat(rows, 0).to(dev), P, N, M)
+        random_number = data["randn"] if "randn" in data else torch.randn(P, N, M, device=dev)                    # pipeline.py:209
+        ac = self.alphas_cumprod[int(ts.reshape(-1)[0])]
+        noised = lib.gt_noising(matrix_gt, random_number, float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac)))
+        data["matrix_gt_disturbed"] = noised
+        src_w, tgt_w = self.get_warped_from_noising_matching(s_pcd, t_pcd, src_mask, tgt_mask, noised.clone())
+        s_n, t_n, src_pe, tgt_pe = self.denoising_transformer(src_backbone, tgt_backbone, src_w, tgt_w, src_mask, tgt_mask, data)
+        hat, match_hat = self.denoising_coarse_matching(s_n, t_n, src_pe, tgt_pe, src_mask, tgt_mask, data, pe_type=self.pe_type)
+        data.update({"conf_matrix_gt_hat": hat, "coarse_match_gt_hat": match_hat})
+        return data
+
+    def get_warped_from_noising_matching(self, s_pcd, t_pcd, src_mask, tgt_mask, matrix_gt_disturbed):
+        """pipeline.py:293-309: mask (in place), Sinkhorn in the matrix's dtype, Procrustes on float32(conf), the warped source"""
+        matrix_gt_disturbed.masked_fill_(~(src_mask[..., None] * tgt_mask[:, None]).bool(), float("-inf"))
+        Z = log_optimal_transport(matrix_gt_disturbed, self.denoising_coarse_matching.bin_score, self.denoising_coarse_matching.skh_iters,
+                                  src_mask, tgt_mask)
+        conf = Z.exp()[:, :-1, :-1].contiguous().type(torch.float32)
+        R, t, R_forwd, t_forwd, condition, solution_mask = self.denoising_soft_procrustes(conf, s_pcd, t_pcd, src_mask, tgt_mask)
+        src_w = (torch.matmul(R_forwd.type(torch.float32), s_pcd.transpose(1, 2)) + t_forwd.type(torch.float32)).transpose(1, 2)
+        return src_w, t_pcd.type(torch.float32)
 
     def predict_noise_from_start(self, x_t, t, x0):
         return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \

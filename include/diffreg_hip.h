@@ -501,6 +501,43 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
                          double* x_final, int64_t* matches, int32_t* match_count, float* img_out, float* pcd_out,
                          const dr_loop_trace* trace, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Forward half of the training branch: the pieces of Pipeline.forward's
+ * `if self.training:` block (3D/models/pipeline.py:182-216) and of MatchMotionLoss.ge_coarse_loss
+ * (3D/models/loss.py:80-170) that are not already kernels of the loop.  Values only: no backward.
+ * `workspace`: dr_train_workspace_bytes(P, N, M) bytes, any content.
+ */
+#define DR_MATCH_SINKHORN 0
+#define DR_MATCH_DUAL_SOFTMAX 1
+size_t dr_train_workspace_bytes(int P, int N, int M);
+
+/* match_2_conf_matrix (loss.py:316-320) and matrix_gt (pipeline.py:203-206): out [P,N,M] = 0, then 1 at the rows (b, i, j) of
+ * matches [K,3] int64 (duplicates set the same entry; rows outside the matrix are skipped -- the reference raises) */
+int dr_match_matrix_f32(int P, int N, int M, int K, const int64_t* matches, float* out, void* stream);
+
+/* pipeline.py:209-214: noise = (|r| % 1) * (|r| / r) * 1.5 of randn [P,N,M] (float32 arithmetic), q_sample(x_start = matrix_gt, t,
+ * noise) = sqrt(ac_t) matrix_gt + sqrt(1 - ac_t) noise in float64 (pipeline.py:84-95: the schedule is float64 and promotes),
+ * nan_to_num(nan = 0), minus the minimum over the WHOLE [P,N,M] tensor (not per pair).  Bit-exact against the reference. */
+int dr_gt_noising_f64(int P, int N, int M, const float* matrix_gt, const float* randn, double sqrt_ac, double sqrt_one_minus_ac, double* out,
+                      void* workspace, void* stream);
+
+/* MatchMotionLoss.compute_correspondence_loss (loss.py:273-314): focal loss of conf [P,N,M] against conf_gt (entries 1 / 0) ->
+ * *loss (device float).  DR_MATCH_SINKHORN: pos_w mean_pos(-alpha (1-c)^gamma log c) + neg_w mean_neg(-alpha c^gamma log(1-c));
+ * DR_MATCH_DUAL_SOFTMAX: pos_w mean_pos(... weight).  c clamped to [1e-6, 1-1e-6]; a class without entries contributes 0 (the
+ * reference's stand-in entry with weight 0).  Terms in float32 in the reference's operation order, summed in float64. */
+int dr_focal_loss_f32(int P, int N, int M, const float* conf, const float* conf_gt, const float* weight, float alpha, float gamma, float pos_w,
+                      float neg_w, int match_type, float* loss, void* workspace, void* stream);
+
+/* MatchMotionLoss.compute_match_recall (loss.py:323-345): match_pred [K,3] int64 rows (b, i, j) -> recall_precision[0] = TP / sum(conf_gt),
+ * [1] = TP / max(K, 1), TP = ground-truth entries among the (distinct) predicted ones */
+int dr_match_recall_f32(int P, int N, int M, const float* conf_gt, int K, const int64_t* match_pred, float* recall_precision, void* workspace,
+                        void* stream);
+
+/* the L1 motion term (loss.py:108-128): mean over the rows with overlap_mask [P,N] set of |(R_pred s + t_pred) - (R_gt (s + flow) + t_gt)|_1;
+ * s_pcd [P,N,3], flow [P,N,3] or NULL (3DMatch), R [P,3,3], t [P,3] float32 */
+int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
+                     const float* t_gt, const uint8_t* overlap_mask, float* loss, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

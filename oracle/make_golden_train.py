@@ -1,0 +1,160 @@
+"""Mint golden vectors for the forward half of the training branch by RUNNING THE REFERENCE
+(build container only; needs /root/reference).
+
+    python oracle/make_golden_train.py          # writes tests/golden/train_forward.npz
+
+What runs: the reference's own Pipeline.forward with `model.train()` (3D/models/pipeline.py:182-216: coarse transformer with its
+positioning layer, coarse matching, soft Procrustes, GT-matrix noising through q_sample, denoising transformer + matching on
+the warped source) and the reference's MatchMotionLoss.forward on the dict it returns (3D/models/loss.py:73-170), plus
+MatchMotionLoss.compute_correspondence_loss / compute_match_recall alone on corner cases.  Shims: the ones of
+oracle/make_golden.py (open3d / easydict / tensorboardX / cv2 / nibabel mocks, attribute dict, stub backbone); torch.randint and
+torch.randn are replaced by injected values for the two draws of the branch (the time step, the noise matrix).
+Inputs and weights come from diffreg_hip.synth (integer hash): only reference OUTPUTS are stored.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden", "train_forward.npz")
+TREE = "/root/reference/Diff-Reg-3dmatch"
+sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
+sys.path.insert(0, ROOT)
+
+# (tag, B, N, M, seed of pair 0, time step, max_condition_num)
+# seeds: chosen so that none of the three Procrustes fits of a case has equal K-th and (K+1)-th confidences (asserted below).  Exact ties
+# are common in these matrices (a target column nobody matches gets the same Sinkhorn mass from every row that sits in its dustbin), and
+# torch.topk leaves the choice among equal values to the implementation -- the reference's own CPU and CUDA runs differ there.
+CASES = [("b1", 1, 96, 80, 50, 137, 200.0), ("b2", 2, 64, 64, 60, 640, 200.0)]
+LOSS_CFG = dict(focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0, neg_weight=1.0, motion_loss_type="L1", motion_weight=0.0, match_weight=1,
+                match_type="sinkhorn", positioning_type="procrustes", confidence_threshold_metric=0.05, mutual_nearest=False,
+                inlier_thr=0.1, fmr_thr=0.05, registration_threshold=0.2, dataset="3dmatch")
+
+
+def main():
+    import torch
+    from oracle.make_golden import ref_config, to_attr, HEAD_GAIN
+    sys.modules["open3d"] = MagicMock()
+    for m in ("easydict", "tensorboardX", "nibabel", "nibabel.quaternions", "cv2"):
+        sys.modules.setdefault(m, MagicMock())
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    os.chdir(TREE)
+    sys.path.insert(0, TREE)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from diffreg_hip import synth
+    from models.pipeline import Pipeline
+    from models.loss import MatchMotionLoss
+    from configs.models import architectures
+    from models.procrustes import SoftProcrustesLayer
+    real_proc = SoftProcrustesLayer.forward
+
+    def tie_checked(self, conf_matrix, src_pcd, tgt_pcd, src_mask, tgt_mask):
+        K = max(conf_matrix.shape[1:])
+        for b in range(conf_matrix.shape[0]):
+            w = torch.topk(conf_matrix[b].reshape(-1), K + 1)[0]
+            assert w[K - 1] != w[K], "tie at the K-th confidence: pick another seed"
+        return real_proc(self, conf_matrix, src_pcd, tgt_pcd, src_mask, tgt_mask)
+    SoftProcrustesLayer.forward = tie_checked
+
+    v = synth.VARIANTS["3dmatch"]
+    C = v["C"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Wnp = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN))
+    Wnp.update(synth.make_weights_coarse(C, seed=17, head_gain=HEAD_GAIN))
+
+    class StubBackbone(torch.nn.Module):
+        feats = None
+
+        def forward(self, data, phase="coarse"):
+            return self.feats
+
+    real_randn, real_randint = torch.randn, torch.randint
+    out = {}
+    for tag, B, N, M, seed, ts, mc in CASES:
+        cfg = ref_config("3dmatch", 20, mc)
+        cfg.kpfcn_config["architecture"] = architectures["3dmatch"]
+        model = Pipeline(cfg)
+        model.backbone = StubBackbone()
+        sd = model.state_dict()
+        for k, a in Wnp.items():
+            assert k in sd, k
+            sd[k] = T(a)
+        missing = [k for k in sd if k not in Wnp and not k.startswith("backbone") and "alphas_cumprod" not in k]
+        assert not missing, missing[:5]
+        model.load_state_dict(sd)
+        model.train()
+        prs = [synth.make_pair(N, M, C, seed=seed + b) for b in range(B)]
+        feats = torch.cat([T(p["src_feats"]) for p in prs] + [T(p["tgt_feats"]) for p in prs], 0)
+        pts = torch.cat([T(p["s_pcd"]) for p in prs] + [T(p["t_pcd"]) for p in prs], 0)
+        model.backbone.feats = feats
+        data = {"points": [None, None, pts, None], "src_mask": torch.ones(B, N, dtype=torch.bool), "tgt_mask": torch.ones(B, M, dtype=torch.bool),
+                "src_ind_coarse_split": torch.arange(B * N), "tgt_ind_coarse_split": torch.arange(B * M),
+                "src_ind_coarse": torch.arange(B * N), "tgt_ind_coarse": torch.arange(B * N, B * (N + M)),
+                "coarse_matches": [T(p["gt_matches"]).t().contiguous() for p in prs],
+                "batched_rot": torch.stack([T(p["R_gt"]).float() for p in prs]),
+                "batched_trn": torch.stack([T(p["t_gt"]).float().view(3, 1) for p in prs])}
+        randn = T(synth.hash_normal(seed, 900, (B, N, M)).astype(np.float32))
+        randn[0, 0, 0] = 0.0                                   # the 0 / 0 = nan -> 0 entry of nan_to_num
+        captured = {}
+        orig = model.get_warped_from_noising_matching
+
+        def spy(s_pcd, t_pcd, src_mask, tgt_mask, matrix_gt_disturbed):
+            captured["noised"] = matrix_gt_disturbed.detach().clone()
+            r = orig(s_pcd, t_pcd, src_mask, tgt_mask, matrix_gt_disturbed)
+            captured["src_warped"] = r[0].detach().clone()
+            return r
+        model.get_warped_from_noising_matching = spy
+        torch.randn = lambda *a, **k: randn.clone()
+        torch.randint = lambda *a, **k: torch.tensor([ts])
+        try:
+            with torch.no_grad():
+                res = model(data)
+        finally:
+            torch.randn, torch.randint = real_randn, real_randint
+        assert captured["noised"].dtype == torch.float64
+        rec = dict(ts=np.int64(ts), noised=captured["noised"].numpy(), src_warped=captured["src_warped"].numpy(),
+                   conf_matrix_pred=res["conf_matrix_pred"].numpy(), coarse_match_pred=res["coarse_match_pred"].numpy(),
+                   R_s2t_pred=res["R_s2t_pred"].numpy(), t_s2t_pred=res["t_s2t_pred"].numpy(),
+                   conf_matrix_gt_hat=res["conf_matrix_gt_hat"].numpy(), coarse_match_gt_hat=res["coarse_match_gt_hat"].numpy())
+        for mot_w in (0.0, 1.0):
+            crit = MatchMotionLoss(dict(LOSS_CFG, motion_weight=mot_w))
+            info = crit(res)
+            for k, val in info.items():
+                rec["loss_mot%d_%s" % (int(mot_w), k)] = np.asarray(float(val), dtype=np.float64)
+        for k, a in rec.items():
+            out[tag + "_" + k] = a
+        print(tag, "noised", rec["noised"].dtype, "min %.3f max %.3f" % (rec["noised"].min(), rec["noised"].max()), "conf_pred", res["conf_matrix_pred"].dtype,
+              {k: float(a) for k, a in rec.items() if k.startswith("loss_")})
+
+    # ---- compute_correspondence_loss / compute_match_recall alone, corner cases included (loss.py:273-345)
+    P, N, M = 2, 40, 56
+    conf = T(synth.hash_u01(5, 1, P * N * M).reshape(P, N, M).astype(np.float32))
+    conf[0, 0, :4] = T(np.array([0.0, 1.0, 1e-7, 1 - 1e-8], dtype=np.float32))          # both clamps
+    gt = torch.zeros(P, N, M)
+    gi = torch.from_numpy(synth.hash_u01(5, 2, 60)).mul(P * N * M).long()
+    gt.view(-1)[gi] = 1.0
+    weight = T(synth.hash_u01(5, 3, P * N * M).reshape(P, N, M).astype(np.float32))
+    for mt in ("sinkhorn", "dual_softmax"):
+        for gamma, alpha, pw, nw in ((2.0, 0.25, 1.0, 1.0), (1.5, 0.4, 0.7, 2.0)):
+            crit = MatchMotionLoss(dict(LOSS_CFG, match_type=mt, focal_gamma=gamma, focal_alpha=alpha, pos_weight=pw, neg_weight=nw))
+            nm = "focal_%s_g%s" % (mt, str(gamma).replace(".", "p"))
+            out[nm] = np.float64(float(crit.compute_correspondence_loss(conf.clone(), gt.clone(), weight=weight.clone())))
+            out[nm + "_nopos"] = np.float64(float(crit.compute_correspondence_loss(conf.clone(), torch.zeros_like(gt), weight=weight.clone())))
+            out[nm + "_noneg"] = np.float64(float(crit.compute_correspondence_loss(conf.clone(), torch.ones_like(gt), weight=weight.clone())))
+    pred = torch.stack([gi[:40] // (N * M), (gi[:40] // M) % N, gi[:40] % M], 1)           # 40 true entries ...
+    extra = torch.tensor([[0, 1, 1], [1, 2, 3], [1, 2, 3], [0, 39, 55]])                    # ... and 4 more (one repeated)
+    pred = torch.cat([pred, extra], 0)
+    r, p = MatchMotionLoss.compute_match_recall(gt, pred)
+    out["recall"], out["precision"] = np.float64(float(r)), np.float64(float(p))
+    out["recall_pred"] = pred.numpy()
+    out["focal_gt_index"] = gi.numpy()
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -98,3 +98,41 @@ def guarded(shape, dtype, device, fill=None):
         torch.cuda.synchronize()
         assert bool((raw[:GUARD] == 0xA5).all()) and bool((raw[GUARD + nbytes:] == 0xA5).all()), "guard band damaged"
     return t, check
+
+
+# ------------------------------------------------------------------------------------------------
+# forward half of the training branch; oracle/make_golden_train.py mints its vectors on exactly these inputs
+# ------------------------------------------------------------------------------------------------
+TRAIN_CASES = {"b1": (1, 96, 80, 50, 137, 200.0), "b2": (2, 64, 64, 60, 640, 200.0)}      # B, N, M, seed, time step, max_condition_num
+
+
+def train_weights():
+    C = synth.VARIANTS["3dmatch"]["C"]
+    w = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN))
+    w.update(synth.make_weights_coarse(C, seed=17, head_gain=HEAD_GAIN))
+    return {k: T(v) for k, v in w.items()}
+
+
+def train_case(tag):
+    B, N, M, seed, ts, mc = TRAIN_CASES[tag]
+    C = synth.VARIANTS["3dmatch"]["C"]
+    prs = [synth.make_pair(N, M, C, seed=seed + b) for b in range(B)]
+    randn = T(synth.hash_normal(seed, 900, (B, N, M)).astype(np.float32))
+    randn[0, 0, 0] = 0.0
+    st = lambda k: torch.stack([T(p[k]) for p in prs])
+    return dict(B=B, N=N, M=M, ts=ts, mc=mc, f_s=st("src_feats"), f_t=st("tgt_feats"), p_s=st("s_pcd"), p_t=st("t_pcd"), randn=randn,
+                matches=[T(p["gt_matches"]).t().contiguous() for p in prs],
+                R_gt=torch.stack([T(p["R_gt"]).float() for p in prs]), t_gt=torch.stack([T(p["t_gt"]).float().view(3, 1) for p in prs]),
+                src_mask=torch.ones(B, N, dtype=torch.bool), tgt_mask=torch.ones(B, M, dtype=torch.bool))
+
+
+def focal_case():
+    """inputs of the stand-alone compute_correspondence_loss / compute_match_recall vectors"""
+    P, N, M = 2, 40, 56
+    conf = T(synth.hash_u01(5, 1, P * N * M).reshape(P, N, M).astype(np.float32))
+    conf[0, 0, :4] = T(np.array([0.0, 1.0, 1e-7, 1 - 1e-8], dtype=np.float32))
+    gt = torch.zeros(P, N, M)
+    gi = torch.from_numpy(synth.hash_u01(5, 2, 60)).mul(P * N * M).long()
+    gt.view(-1)[gi] = 1.0
+    weight = T(synth.hash_u01(5, 3, P * N * M).reshape(P, N, M).astype(np.float32))
+    return conf, gt, weight, gi

@@ -1,0 +1,144 @@
+"""Forward half of the training branch on the device: dr_match_matrix_f32, dr_gt_noising_f64, dr_focal_loss_f32,
+dr_match_recall_f32, dr_motion_l1_f32 and the overlay's Pipeline.forward under model.train() + models.loss.MatchMotionLoss -- against
+the reference-minted vectors (tests/golden/train_forward.npz, oracle/make_golden_train.py) and oracle/train_oracle.py.  Needs a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffreg_hip import lib, synth
+from oracle import train_oracle as tro
+from tests.helpers import TRAIN_CASES, focal_case, guarded, train_case, train_weights
+from tests.test_models_api_gpu import StubBackbone, ref_like_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_forward.npz"))
+LOSS_CFG = dict(focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0, neg_weight=1.0, motion_loss_type="L1", motion_weight=0.0, match_weight=1,
+                match_type="sinkhorn", positioning_type="procrustes", confidence_threshold_metric=0.05, mutual_nearest=False,
+                inlier_thr=0.1, fmr_thr=0.05, registration_threshold=0.2, dataset="3dmatch")
+
+
+def rows_of(matches):
+    return torch.cat([torch.cat([torch.full((1, m.shape[1]), b, dtype=torch.int64), m], 0).t() for b, m in enumerate(matches)], 0)
+
+
+@pytest.mark.parametrize("tag", list(TRAIN_CASES))
+def test_gt_noising_bit_exact_against_reference(tag):
+    c = train_case(tag)
+    B, N, M = c["B"], c["N"], c["M"]
+    gt = lib.match_matrix(rows_of(c["matches"]).to(DEV), B, N, M)
+    assert torch.equal(gt.cpu(), tro.match_matrix(c["matches"], B, N, M))
+    ac = tro.orc.diffusion_schedule()[0][c["ts"]]
+    out, chk = guarded((B, N, M), torch.float64, DEV, fill=float("nan"))
+    ws = torch.empty(lib.raw().dr_train_workspace_bytes(B, N, M), dtype=torch.uint8, device=DEV)
+    lib.check(lib.raw().dr_gt_noising_f64(B, N, M, lib.ptr(gt), lib.ptr(c["randn"].to(DEV)), float(ac.sqrt()), float((1.0 - ac).sqrt()), lib.ptr(out),
+                                          lib.ptr(ws), None))
+    torch.cuda.synchronize()
+    chk()
+    assert np.array_equal(out.cpu().numpy(), G[tag + "_noised"])
+
+
+def test_gt_noising_large_and_duplicates():
+    """a matrix larger than one sweep of the reduction grid; repeated match rows set their entry once"""
+    P, N, M = 3, 300, 333
+    g = torch.Generator().manual_seed(2)
+    r = torch.randn(P, N, M, generator=g)
+    r[1, 5, 7] = 0.0
+    m = [torch.randint(0, 300, (2, 200), generator=g) for _ in range(P)]
+    m[0][:, 10] = m[0][:, 3]
+    gt = lib.match_matrix(rows_of(m).to(DEV), P, N, M)
+    assert torch.equal(gt.cpu(), tro.match_matrix(m, P, N, M))
+    ac = tro.orc.diffusion_schedule()[0][500]
+    out = lib.gt_noising(gt, r.to(DEV), float(ac.sqrt()), float((1.0 - ac).sqrt()))
+    assert torch.equal(out.cpu(), tro.gt_noising(gt.cpu(), r, 500))
+
+
+@pytest.mark.parametrize("mt", ["sinkhorn", "dual_softmax"])
+@pytest.mark.parametrize("gamma,alpha,pw,nw", [(2.0, 0.25, 1.0, 1.0), (1.5, 0.4, 0.7, 2.0)])
+def test_focal_loss_against_reference(mt, gamma, alpha, pw, nw):
+    conf, gt, weight, _ = focal_case()
+    nm = "focal_%s_g%s" % (mt, str(gamma).replace(".", "p"))
+    for suffix, g in (("", gt), ("_nopos", torch.zeros_like(gt)), ("_noneg", torch.ones_like(gt))):
+        got = float(lib.focal_loss(conf.to(DEV), g.to(DEV), weight.to(DEV), alpha, gamma, pw, nw, mt))
+        want = float(G[nm + suffix])
+        assert abs(got - want) <= 2e-6 * max(1e-3, abs(want)), (nm + suffix, got, want)
+
+
+def test_match_recall_against_reference():
+    _, gt, _, _ = focal_case()
+    r, p = lib.match_recall(gt.to(DEV), torch.from_numpy(G["recall_pred"]).to(DEV))
+    assert float(r) == float(G["recall"]) and float(p) == float(G["precision"])
+    r0, p0 = lib.match_recall(gt.to(DEV), torch.zeros(0, 3, dtype=torch.int64, device=DEV))
+    assert float(r0) == 0.0 and float(p0) == 0.0
+
+
+def test_motion_l1_against_oracle():
+    P, N = 3, 500
+    g = torch.Generator().manual_seed(7)
+    s = torch.rand(P, N, 3, generator=g) * 3
+    flow = torch.randn(P, N, 3, generator=g) * 0.05
+    Rp = torch.linalg.qr(torch.randn(P, 3, 3, generator=g))[0]
+    Rg = torch.linalg.qr(torch.randn(P, 3, 3, generator=g))[0]
+    tp, tg = torch.randn(P, 3, 1, generator=g), torch.randn(P, 3, 1, generator=g)
+    ov = torch.rand(P, N, generator=g) > 0.4
+    for f in (None, flow):
+        got = float(lib.motion_l1(s.to(DEV), Rp.to(DEV), tp.to(DEV), Rg.to(DEV), tg.to(DEV), ov.to(DEV), None if f is None else f.to(DEV)))
+        want = float(tro.motion_l1(s, Rp, tp, Rg, tg, ov, f))
+        assert abs(got - want) <= 2e-6 * abs(want)
+
+
+@pytest.mark.parametrize("tag", list(TRAIN_CASES))
+def test_training_forward_and_loss_against_reference(tag):
+    """models.pipeline.Pipeline under .train() + models.loss.MatchMotionLoss, with the time step and the noise draw injected: every
+    output the reference's branch leaves in `data`, and every entry of the reference's loss_info"""
+    from models.loss import MatchMotionLoss
+    from models.pipeline import Pipeline
+    c = train_case(tag)
+    B, N, M = c["B"], c["N"], c["M"]
+    model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
+    sd = model.state_dict()
+    for k, a in train_weights().items():
+        assert k in sd, k
+        sd[k] = a
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    feats = torch.cat([c["f_s"].reshape(B * N, -1), c["f_t"].reshape(B * M, -1)], 0)
+    pts = torch.cat([c["p_s"].reshape(B * N, 3), c["p_t"].reshape(B * M, 3)], 0)
+    data = {"points": [None, None, pts.to(DEV), None], "_feats": feats.to(DEV), "src_mask": c["src_mask"].to(DEV), "tgt_mask": c["tgt_mask"].to(DEV),
+            "src_ind_coarse_split": torch.arange(B * N, device=DEV), "tgt_ind_coarse_split": torch.arange(B * M, device=DEV),
+            "src_ind_coarse": torch.arange(B * N, device=DEV), "tgt_ind_coarse": torch.arange(B * N, B * (N + M), device=DEV),
+            "coarse_matches": [m.to(DEV) for m in c["matches"]], "batched_rot": c["R_gt"].to(DEV), "batched_trn": c["t_gt"].to(DEV),
+            "ts": torch.tensor([c["ts"]], device=DEV), "randn": c["randn"].to(DEV)}
+    res = model(data)
+    assert res["matrix_gt_disturbed"].dtype == torch.float64
+    assert np.array_equal(res["matrix_gt_disturbed"].cpu().numpy(), G[tag + "_noised"])
+    assert np.abs(res["R_s2t_pred"].cpu().numpy() - G[tag + "_R_s2t_pred"]).max() < 1e-4
+    assert np.abs(res["t_s2t_pred"].cpu().numpy() - G[tag + "_t_s2t_pred"]).max() < 1e-4
+    # the two conf matrices: plain 1e-4 against the reference, except where the reference's own float32 value is > 2e-5 from the float64
+    # evaluation of the branch (the rule of tests/test_loop_gpu.py::assert_matrix_parity, applied on the spot)
+    from tests.test_loop_gpu import assert_matrix_parity
+    W64 = {k: a.double() for k, a in train_weights().items()}
+    o64 = tro.training_forward(W64, synth.VARIANTS["3dmatch"], c["f_s"].double(), c["f_t"].double(), c["p_s"], c["p_t"], c["src_mask"], c["tgt_mask"],
+                               c["matches"], c["randn"], c["ts"], c["mc"])
+    for k in ("conf_matrix_pred", "conf_matrix_gt_hat"):
+        assert res[k].dtype == torch.float32
+        assert_matrix_parity(res[k].cpu().numpy(), G[tag + "_" + k], o64[k].numpy(), tag + " " + k)
+    # The match lists are mutual-maximum read-outs: rows that put all their mass on one unmatched target column get the SAME confidence
+    # there up to the last bit (exp(log mu) after the row normalisation), so which of them is "the" column maximum is decided by
+    # float32 rounding -- the reference lists the exact ties of its own arithmetic.  Every row that differs must be such a near-tie
+    # (within 3e-4 of its row and column maximum in the reference's matrix: the ill-conditioned entries of assert_matrix_parity); recall / precision are compared on the reference's list.
+    for k, ck in (("coarse_match_pred", "conf_matrix_pred"), ("coarse_match_gt_hat", "conf_matrix_gt_hat")):
+        got = set(map(tuple, res[k].cpu().numpy().tolist()))
+        want = set(map(tuple, G[tag + "_" + k].tolist()))
+        conf = G[tag + "_" + ck]
+        for (b, i, j) in got ^ want:
+            assert conf[b, i, j] > 0.2 - 3e-4 and conf[b, i, j] >= conf[b, i].max() - 3e-4 and conf[b, i, j] >= conf[b, :, j].max() - 3e-4, (k, b, i, j)
+        assert len(got & want) >= 0.6 * len(want)
+    res_ref_list = dict(res, coarse_match_pred=torch.from_numpy(G[tag + "_coarse_match_pred"]).to(DEV))
+    for mot_w in (0.0, 1.0):
+        info = MatchMotionLoss(dict(LOSS_CFG, motion_weight=mot_w))(res_ref_list)
+        for k, val in info.items():
+            want = float(G[tag + "_loss_mot%d_%s" % (int(mot_w), k)])
+            assert abs(float(val) - want) <= 1e-4 * max(1.0, abs(want)), (k, float(val), want)
