@@ -96,3 +96,84 @@ def test_cfg5_1024x2048_10_steps():
     dc = (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs()
     assert (dc > 1e-4).double().mean().item() <= 1e-3, dc.max().item()
     assert float(dc[valid].max()) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the overlay for an unmodified EXP/model.py (diffreg_hip/overlay2d3d.py).  MATR2D3D itself cannot be imported on the GPU box (no
+# /root/reference there; it needs vision3d, open3d, depth_anything), so the test drives the overlay with a host that makes the SAME
+# calls in the same order as the loop of MATR2D3D.forward (EXP/model.py:637-694) -- three sub-calls per step, then the DDIM update,
+# the final Sinkhorn and the top-1 union -- written here from the oracle's pieces.
+# ---------------------------------------------------------------------------------------------------------------------------------
+class _Bag(torch.nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def forward(self, *a, **k):
+        raise AssertionError("the original sub-module must not run in eval mode once the overlay is installed")
+
+
+class _Host2D3D(torch.nn.Module):
+    def __init__(self, W, steps, mc):
+        super().__init__()
+        self._W = W
+        self.sampling_timesteps = steps
+        self.denoising_transformer = _Bag()
+        self.denoising_coarse_matching = _Bag(skh_iters=3, bin_score=W["denoising_coarse_matching.bin_score"])
+        self.denoising_soft_procrustes = _Bag(sample_rate=1.0, max_condition_num=mc)
+
+    def state_dict(self, *a, **k):
+        return dict(self._W)
+
+    def get_warped_from_noising_matching3D3D(self, *a):
+        raise AssertionError("replaced by the overlay")
+
+    def forward(self, q, src_mask, tgt_mask, tgt_mask_da, x_T):
+        ac, sra, srm1 = (t.to(x_T.device) for t in orc.diffusion_schedule())
+        x = x_T.clone()
+        for t, tn in orc.time_pairs(self.sampling_timesteps):
+            warped, _, R_forwd, t_forwd = self.get_warped_from_noising_matching3D3D(q("s_pcd"), q("t_pcd_da"), src_mask, tgt_mask_da, x)
+            f_img, f_pcd = self.denoising_transformer(q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), warped)
+            x_start, _, _, _ = self.denoising_coarse_matching(f_pcd, f_img, src_mask, tgt_mask, True)
+            eps = (sra[t].view(1, 1, 1) * x - x_start) / srm1[t].view(1, 1, 1)
+            sigma, c, sqrt_an = orc.ddim_coefficients(ac, t, tn)
+            x = x_start * sqrt_an + c * eps
+        x = x.masked_fill(~(src_mask[..., None] * tgt_mask[:, None]).bool(), float("-inf"))
+        from diffreg_hip import lib
+        conf = lib.sinkhorn(x, self.denoising_coarse_matching.bin_score.to(x.device), 3, src_mask, tgt_mask, strict=True)
+        return dict(conf_matrix_pred=conf, x_final=x)
+
+
+@pytest.mark.parametrize("N,M,nv,mv,mv_da,steps,mc,seed,tag", [(96, 160, 90, 150, 141, 3, 200, 31, "n96x160_s3_masked"),
+                                                                 (128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")])
+def test_overlay_for_unmodified_model(golden, N, M, nv, mv, mv_da, steps, mc, seed, tag):
+    from diffreg_hip.overlay2d3d import accelerate
+    g = golden("2d3d_loop_" + tag)
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W = {k: T(a).to(DEV) for k, a in Wn.items()}
+    pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
+    q = lambda k: T(pr[k])[None].to(DEV)
+    ms, mt = masks(N, M, nv, mv)
+    mt_da = torch.arange(M)[None] < mv_da
+    host = _Host2D3D(W, steps, mc).eval()
+    ov = accelerate(host)
+    out = host(q, ms.to(DEV), mt.to(DEV), mt_da.to(DEV), q("x_T"))
+    conf = out["conf_matrix_pred"][0].cpu().numpy()
+    assert out["conf_matrix_pred"].dtype == torch.float64
+    assert (np.abs(conf - g["conf"]) > 1e-4).mean() <= 1e-3
+    # ... and it is the engine's own result: same x_start sequence, the host's DDIM arithmetic on top
+    from diffreg_hip.engine import DenoiseEngine2D3D
+    eng = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=DEV)
+    ref = eng.run(q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"), q("x_T"), (ms.to(DEV), mt.to(DEV), mt_da.to(DEV)))
+    fin = torch.isfinite(ref["x_final"])
+    assert torch.equal(fin, torch.isfinite(out["x_final"]) | ~torch.isfinite(ref["x_final"]) & fin)
+    both = fin & torch.isfinite(out["x_final"])
+    assert (ref["x_final"][both] - out["x_final"][both]).abs().max().item() < 1e-9
+    assert (ref["conf_matrix_pred"] - out["conf_matrix_pred"]).abs().max().item() < 1e-6      # (the engine's final Sinkhorn runs float32 arithmetic)
+    # a second forward starts a new loop (the step counter wrapped), and .remove() restores the call sites
+    out2 = host(q, ms.to(DEV), mt.to(DEV), mt_da.to(DEV), q("x_T"))
+    assert torch.equal(out2["conf_matrix_pred"], out["conf_matrix_pred"])
+    ov.remove()
+    with pytest.raises(AssertionError):
+        host(q, ms.to(DEV), mt.to(DEV), mt_da.to(DEV), q("x_T"))
