@@ -1,4 +1,5 @@
 // api.hip -- version / error reporting of the C ABI.
+#include <stdlib.h>
 #include "kernels.h"
 #include <vector>
 #include <stdio.h>
@@ -8,6 +9,14 @@ namespace dr {
 static thread_local char g_hip_err[512] = "";
 void set_hip_error(hipError_t e, const char* where) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+}
+
+static bool g_env_knobs = false;
+void enable_env_knobs(bool on) { g_env_knobs = on; }
+int env_knob(const char* name, int def) {
+    if (!g_env_knobs) return def;
+    const char* e = getenv(name);
+    return e ? atoi(e) : def;
 }
 
 bool g_prof_on = false;

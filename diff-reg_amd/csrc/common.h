@@ -10,6 +10,10 @@ namespace dr {
 constexpr int WAVE = 64;
 
 void set_hip_error(hipError_t e, const char* where);
+// Tuning / diagnostic overrides from the environment (tools/): read ONLY after dr_debug_enable_env(1) -- the product path never
+// enables it, so a stray DR_* variable in a deployment's environment cannot change which kernels run.
+int env_knob(const char* name, int def);
+void enable_env_knobs(bool on);
 
 #define DR_HIP_CHECK(expr)                                   \
     do {                                                     \

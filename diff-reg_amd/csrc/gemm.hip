@@ -906,7 +906,7 @@ __global__ void pack_weights_f16_kernel(const float* __restrict__ W, char* __res
 static int g_f16x2 = -1;         // -1 = environment (DR_GEMM_F16X2, default ON); set BEFORE the weights are packed
 void gemm_force_f16x2(int on) { g_f16x2 = on; }
 bool gemm_f16x2() {
-    static const int v = [] { const char* e = getenv("DR_GEMM_F16X2"); return e ? atoi(e) : 1; }();
+    static const int v = env_knob("DR_GEMM_F16X2", 1);
     return (g_f16x2 >= 0 ? g_f16x2 : v) != 0;
 }
 
@@ -1244,7 +1244,7 @@ static int launch_wide2(const GemmBatch& g, hipStream_t st) {
     double flops = 0;
     for (int i = 0; i < g.n; ++i) flops += 2.0 * g.p[i].rows * g.p[i].ncols * g.p[i].K;
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
-    static const int no_amax = [] { const char* e = getenv("DR_GEMM_NO_AMAX"); return e ? atoi(e) : 0; }();   // diagnostics: sweep always
+    static const int no_amax = env_knob("DR_GEMM_NO_AMAX", 0);   // diagnostics: sweep always
     if (no_amax) {
         GemmBatch h = g;
         for (int i = 0; i < h.n; ++i) { if (no_amax & 1) { h.p[i].amax = nullptr; h.p[i].amax2 = nullptr; } if (no_amax & 2) h.p[i].omax = nullptr; }
@@ -1388,7 +1388,7 @@ void gemm_force_config(int c) { g_force_cfg = c; }
 static int g_wide_min = -1;      // tests: force the threshold (-1 = environment / default)
 void gemm_force_wide_min(int n) { g_wide_min = n; }
 int gemm_wide_min_tiles() {
-    static const int v = [] { const char* e = getenv("DR_GEMM_WIDE_MIN"); return e ? atoi(e) : 128; }();
+    static const int v = env_knob("DR_GEMM_WIDE_MIN", 128);
     return g_wide_min >= 0 ? g_wide_min : v;
 }
 
@@ -1422,7 +1422,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
     // 8-13 % faster (tools/gemm_split.py); inside the loop, where the engine keeps two batches in flight on two
     // streams, its 160 KB of LDS keeps the other stream's kernels off the CU and the 4-wave form wins by 2 %
     // (bench.py, DR_GEMM_WIDE8_MAX sweep) -- so it is opt-in.
-    static const int wide8_max = [] { const char* e = getenv("DR_GEMM_WIDE8_MAX"); return e ? atoi(e) : 0; }();
+    static const int wide8_max = env_knob("DR_GEMM_WIDE8_MAX", 0);
     // (weights packed in the two-plane fp16 mode can only be read by the two-plane kernel: whatever the tile count)
     // (and only deep reductions: below K = 128 the 2^-22 representation error is not hidden by the accumulation's own
     //  rounding -- those launches stay on the f32-input MFMA kernels, which read the fp32 weights)
@@ -1438,11 +1438,11 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         maxK = g.p[i].K > maxK ? g.p[i].K : maxK;
         n32 += (long)((g.p[i].rows + 31) / 32) * ((g.p[i].ncols + 31) / 32) * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
     }
-    static const int direct_max = [] { const char* e = getenv("DR_GEMM_DIRECT_MAX"); return e ? atoi(e) : 1024; }();
+    static const int direct_max = env_knob("DR_GEMM_DIRECT_MAX", 1024);
     if (g_force_cfg < 0 && n32 <= direct_max && maxK <= 16 * 8 * 7) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
-    static const int env_cfg = [] { const char* e = getenv("DR_GEMM_CFG"); return e ? atoi(e) : -1; }();   // tools/: tile experiments
+    static const int env_cfg = env_knob("DR_GEMM_CFG", -1);   // tools/: tile experiments
     if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
     if (g_force_cfg >= 0) cfg = g_force_cfg;
     for (int i = 0; i < g.n; ++i)

@@ -172,8 +172,8 @@ struct PlanesWs {
     static size_t img_bytes(int PN, int PM, int K) { return plane_image_bytes(PN, K) + plane_image_bytes(PM, K); }
     static void carve(Carver& c, PlanesWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const int C = cfg.C, PN = P * N, PM = P * M, T = PN + PM;
-        static const int min_rows = [] { const char* e = getenv("DR_PLANES_MIN_ROWS"); return e ? atoi(e) : 8192; }();
-        static const int enabled = [] { const char* e = getenv("DR_PLANES"); return e ? atoi(e) : 1; }();
+        static const int min_rows = env_knob("DR_PLANES_MIN_ROWS", 8192);
+        static const int enabled = env_knob("DR_PLANES", 1);
         w.on = enabled && Prepack::supported(cfg) && T >= min_rows;
         if (cfg.flags & DR_LOOP_PLANES_FORCE) w.on = Prepack::supported(cfg);
         if (cfg.flags & DR_LOOP_PLANES_OFF) w.on = false;
@@ -680,6 +680,7 @@ int dr_init(void) {
 }
 
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
+void dr_debug_enable_env(int on) { enable_env_knobs(on != 0); }
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
 void dr_debug_gemm_wide_min(int tiles) { gemm_force_wide_min(tiles); }
 void dr_debug_gemm_f16x2(int on) { gemm_force_f16x2(on); }

@@ -698,8 +698,8 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
-    static const bool dbg = [] { const char* e = getenv("DR_PG_STAMPS"); return e && atoi(e) != 0; }();
-    static const int abl = [] { const char* e = getenv("DR_PG_ABL"); return e ? atoi(e) : 0; }();
+    static const bool dbg = env_knob("DR_PG_STAMPS", 0) != 0;
+    static const int abl = env_knob("DR_PG_ABL", 0);
     const int mode = g.p[0].mode;
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch

@@ -121,6 +121,7 @@ SIGNATURES.update({
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
+    "dr_debug_enable_env": (None, [c_int]),
     "dr_debug_gemm_config": (None, [c_int]),
     "dr_debug_gemm_wide_min": (None, [c_int]),
     "dr_debug_gemm_f16x2": (None, [c_int]),
@@ -182,6 +183,9 @@ def ensure_init():
     """kernel attributes (dynamic LDS) -- needs a GPU, so it runs lazily before the first launch."""
     global _INIT_DONE
     if not _INIT_DONE:
+        # tools/ only: the library ignores the DR_* tuning variables unless this one explicit switch is set
+        if os.environ.get("DR_DIAGNOSTICS") == "1":
+            _lib.dr_debug_enable_env(1)
         check(_lib.dr_init())
         _INIT_DONE = True
 

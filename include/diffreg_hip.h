@@ -237,7 +237,14 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
                       double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
 
-/* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
+/* ---- diagnostics (tools/ and the kernel-forcing test fixtures; NOT part of the drop-in boundary) ------------------------------
+ * The library reads no environment variable unless dr_debug_enable_env(1) was called first (before the first launch: values
+ * are cached on first use): the DR_* tuning variables of tools/ (DR_PG_STAMPS, DR_PG_ABL, DR_GEMM_*, DR_ATTN_*, DR_PLANES*,
+ * DR_SK_PERSIST_GRID) cannot change which kernels a deployment runs.  Per-call choices of the product path are arguments:
+ * dr_loop_config.flags (DR_LOOP_PLANES_FORCE / _OFF, DR_LOOP_STRICT_F64, DR_LOOP_RAGGED), DR_SK_* flags.  The dr_debug_* setters below
+ * are process-wide and meant for single-threaded tools and tests only. */
+void dr_debug_enable_env(int on);
+/* force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_gemm_config(int c);
 /* launches with at least this many 128 x 224 tiles use the packed split-operand GEMM (default 128; -1 restores it).
  * Set it BEFORE sizing a loop workspace: it decides whether the loop packs its weights. */
@@ -247,9 +254,9 @@ void dr_debug_gemm_wide_min(int tiles);
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
 int dr_debug_gemm_stamps(long long* h_out256);
-int dr_debug_pgemm_stamps(long long* h_out128);   /* with DR_PG_STAMPS=1: phase stamps of workgroup 0 of the last plane GEMM */
+int dr_debug_pgemm_stamps(long long* h_out128);   /* with dr_debug_enable_env(1) and DR_PG_STAMPS=1: phase stamps of workgroup 0 of the last plane GEMM */
 /* packed GEMMs: 1 = two-plane fp16 operand split with exact power-of-two row / column scaling (three MFMA products per
- * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = environment DR_GEMM_F16X2 (default 1).
+ * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = default (1; DR_GEMM_F16X2 under dr_debug_enable_env).
  * Set before weights are packed: an image is only readable in the mode it was packed in. */
 void dr_debug_gemm_f16x2(int on);
 /* attention: use the 128-query (flash) kernel from this many workgroups on; -1 = default rule (256) */

@@ -1,6 +1,7 @@
 """timing of the 3-block F32 launch under the DR_PG_ABL ablations (DR_PG_STAMPS=1 builds)"""
 import os, sys
 os.environ["DR_PG_STAMPS"] = "1"
+os.environ["DR_DIAGNOSTICS"] = "1"     # the library reads DR_* variables only under this switch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
 import torch

@@ -1,6 +1,7 @@
 """DR_PG_STAMPS=1 python tools/pgemm_stamps.py : phase stamps (us) of workgroup 0 of the plane GEMM launches"""
 import os, sys, ctypes
 os.environ["DR_PG_STAMPS"] = "1"
+os.environ["DR_DIAGNOSTICS"] = "1"     # the library reads DR_* variables only under this switch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
 import torch
