@@ -315,6 +315,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wn == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
     PG_STAMP(2);
+    if (ABL == 9) return;                                        // (diagnostics: the kernel without its epilogue -- timing only, no output)
     __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
     PG_STAMP(3);
 
@@ -669,7 +670,7 @@ static int configure_mode(bool with_dbg) {
 #define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM))
     PG_ATTR(false, 0);
     if constexpr (TNW == 7) {
-        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); }
+        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); PG_ATTR(true, 9); }
     }
 #undef PG_ATTR
     return DR_OK;
@@ -714,6 +715,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         case 5: PG_LAUNCH(7, 4, MODE, true, 5); break;             \
         case 6: PG_LAUNCH(7, 4, MODE, true, 6); break;             \
         case 7: PG_LAUNCH(7, 4, MODE, true, 7); break;             \
+        case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
         default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
     }
     if (bn == G9::BN) {

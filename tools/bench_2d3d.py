@@ -33,4 +33,15 @@ if os.environ.get("CPU", "1") == "1":
     orc.denoise_loop_2d3d(W, synth.VARIANTS["2d3d"], q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"),
                           ms, mt, mt, q("x_T"), steps, mc)
     res["cpu_oracle_s_per_pair_16_threads"] = time.perf_counter() - t0
+from diffreg_hip import lib
+lib.prof_enable(True)
+eng.run(*args)
+prof = lib.prof_collect()
+lib.prof_enable(False)
+tot = sum(v[1] for v in prof.values())
+res["kernel_families"] = {k: {"launches": v[0], "ms": v[1], "share": v[1] / tot} for k, v in prof.items() if v[0]}
+dom = max(prof, key=lambda k: prof[k][1])
+c, ms_, work = prof[dom]
+res["dominant_family"] = {"family": dom, "avg_us_per_launch": ms_ / c * 1e3, "achieved": work / (ms_ * 1e-3) / (1e9 if dom in ("sinkhorn", "state", "position_code", "layernorm") else 1e12),
+                          "unit": "GB/s" if dom in ("sinkhorn", "state", "position_code", "layernorm") else "TFLOP/s"}
 print(json.dumps(res))
