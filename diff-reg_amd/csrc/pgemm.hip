@@ -716,7 +716,6 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         case 6: PG_LAUNCH(7, 4, MODE, true, 6); break;             \
         case 7: PG_LAUNCH(7, 4, MODE, true, 7); break;             \
         case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
-        case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
         default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
     }
     if (bn == G9::BN) {
