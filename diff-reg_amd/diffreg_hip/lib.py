@@ -130,6 +130,10 @@ SIGNATURES.update({
     "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
+    "dr_patch_similarity_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    "dr_unique_pairs_workspace_bytes": (c_size_t, [c_int]),
+    "dr_unique_pairs_i64": (c_int, [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dr_corr_gather_f32": (c_int, [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_int] + [c_void_p] * 14),
     "dr_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_match_matrix_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_gt_noising_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p]),
@@ -766,6 +770,51 @@ def batch_mutual_topk_select(score_mat, k, row_masks=None, col_masks=None, large
     if two_d:
         return idx[:, 1], idx[:, 2], sc
     return idx[:, 0], idx[:, 1], idx[:, 2], sc
+
+
+def patch_similarity(img_feats, img_knn_indices, pcd_feats, pcd_knn_indices):
+    """[P,Ki,Kc] similarity of the image / point patches of P node correspondences (EXP/model.py:726-738); an index equal to
+    pcd_feats.shape[0] addresses the zero row the reference appends"""
+    ensure_init()
+    img_feats, pcd_feats = img_feats.contiguous().float(), pcd_feats.contiguous().float()
+    ii, pj = img_knn_indices.to(torch.int64).contiguous(), pcd_knn_indices.to(torch.int64).contiguous()
+    P, Ki = ii.shape
+    Kc = pj.shape[1]
+    out = torch.empty(P, Ki, Kc, device=img_feats.device)
+    check(_lib.dr_patch_similarity_f32(P, Ki, Kc, img_feats.shape[1], ptr(img_feats), ptr(ii), ptr(pcd_feats), ptr(pj), pcd_feats.shape[0], ptr(out),
+                                       stream_of(out)))
+    return out
+
+
+def unique_pairs(first, second, multiplier):
+    """sorted distinct first * multiplier + second (torch.unique of EXP/model.py:760-761) -> (keys [n] int64, count [1] int32) without a host sync"""
+    ensure_init()
+    a, b = first.to(torch.int64).contiguous(), second.to(torch.int64).contiguous()
+    n = a.numel()
+    keys = torch.empty(max(n, 1), dtype=torch.int64, device=a.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=a.device)
+    wsb = _lib.dr_unique_pairs_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    check(_lib.dr_unique_pairs_i64(n, ptr(a), ptr(b), int(multiplier), ptr(keys), ptr(cnt), ptr(ws), wsb, stream_of(a)))
+    return keys, cnt
+
+
+def corr_gather(keys, count, num_points_f, img_points_f, img_pixels_f, pcd_points_f, pcd_pixels_f, img_feats_f, pcd_feats_f):
+    """EXP/model.py:761-774 -> dict with the reference's output names (one host read of the count to size the views)"""
+    ensure_init()
+    f = lambda x, w: x.contiguous().float().view(-1, w)
+    ip, ix, pp, px = f(img_points_f, 3), f(img_pixels_f, 2), f(pcd_points_f, 3), f(pcd_pixels_f, 2)
+    fi, fp = img_feats_f.contiguous().float(), pcd_feats_f.contiguous().float()
+    cap = keys.numel()
+    dev = keys.device
+    o = dict(img_corr_indices=torch.empty(cap, dtype=torch.int64, device=dev), pcd_corr_indices=torch.empty(cap, dtype=torch.int64, device=dev),
+             img_corr_points=torch.empty(cap, 3, device=dev), img_corr_pixels=torch.empty(cap, 2, device=dev),
+             pcd_corr_points=torch.empty(cap, 3, device=dev), pcd_corr_pixels=torch.empty(cap, 2, device=dev), corr_scores=torch.empty(cap, device=dev))
+    check(_lib.dr_corr_gather_f32(cap, ptr(count), ptr(keys), int(num_points_f), fi.shape[1], ptr(ip), ptr(ix), ptr(pp), ptr(px), ptr(fi), ptr(fp),
+                                  ptr(o["img_corr_indices"]), ptr(o["pcd_corr_indices"]), ptr(o["img_corr_points"]), ptr(o["img_corr_pixels"]),
+                                  ptr(o["pcd_corr_points"]), ptr(o["pcd_corr_pixels"]), ptr(o["corr_scores"]), stream_of(keys)))
+    n = int(count.item())
+    return {k: v[:n] for k, v in o.items()}
 
 
 PROF_KINDS = ("gemm", "attention", "layernorm", "position_code", "sinkhorn", "procrustes", "state", "gemm_split")

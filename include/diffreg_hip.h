@@ -457,6 +457,27 @@ int dr_mutual_topk_select_f32(int B, int N, int M, const float* score, int k, in
                               int mutual, const uint8_t* row_masks, const uint8_t* col_masks, int64_t* out_idx, float* out_score,
                               long long capacity, int32_t* total, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The rest of the patch-correspondence block behind the 2D-3D loop (EXP/model.py:707-780), around dr_mutual_topk_select_f32:
+ *
+ * dr_patch_similarity_f32: for every node correspondence b the similarity of its image patch and its point patch (model.py:726-738):
+ *   out[b][i][j] = 0.5 (<img_feats[img_knn_indices[b][i]], pcd_feats[pcd_knn_indices[b][j]]> + 1)
+ *   = index_select (vision3d/ops/index_select.py:4-33) of both sides + pairwise_cosine_similarity(normalized = True)
+ *   (vision3d/ops/cosine_similarity.py:34-66).  img_feats [*, C], pcd_feats [pcd_rows, C] float32; an index == pcd_rows is the zero row the
+ *   reference appends (model.py:707); img_knn_indices [P, Ki], pcd_knn_indices [P, Kc] int64, Kc <= 128; out [P, Ki, Kc].
+ * dr_unique_pairs_i64: the duplicate removal of model.py:759-763: sorted distinct values of first[i] * multiplier + second[i] (torch.unique),
+ *   unique_keys [n], count[0] = how many.  workspace: dr_unique_pairs_workspace_bytes(n).
+ * dr_corr_gather_f32: model.py:761-774 for the first count[0] keys: img / pcd indices = key / num_points_f, key % num_points_f, the gathered
+ *   points [.,3] / pixels [.,2] of both sides and corr_scores = <img_feats_f[i], pcd_feats_f[j]>; `capacity` = rows of the outputs. */
+int dr_patch_similarity_f32(int P, int Ki, int Kc, int C, const float* img_feats, const int64_t* img_knn_indices, const float* pcd_feats,
+                            const int64_t* pcd_knn_indices, long long pcd_rows, float* out, void* stream);
+size_t dr_unique_pairs_workspace_bytes(int n);
+int dr_unique_pairs_i64(int n, const int64_t* first, const int64_t* second, long long multiplier, int64_t* unique_keys, int32_t* count,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int dr_corr_gather_f32(int capacity, const int32_t* count, const int64_t* unique_keys, long long num_points_f, int C, const float* img_points_f,
+                       const float* img_pixels_f, const float* pcd_points_f, const float* pcd_pixels_f, const float* img_feats_f, const float* pcd_feats_f,
+                       int64_t* img_corr_indices, int64_t* pcd_corr_indices, float* img_corr_points, float* img_corr_pixels, float* pcd_corr_points,
+                       float* pcd_corr_pixels, float* corr_scores, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
  * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)

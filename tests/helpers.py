@@ -136,3 +136,48 @@ def focal_case():
     gt.view(-1)[gi] = 1.0
     weight = T(synth.hash_u01(5, 3, P * N * M).reshape(P, N, M).astype(np.float32))
     return conf, gt, weight, gi
+
+
+# ------------------------------------------------------------------------------------------------
+# the patch-correspondence block behind the 2D-3D loop (row f4); oracle/make_golden_fine2d3d.py mints its vectors on exactly these inputs
+# ------------------------------------------------------------------------------------------------
+def fine2d3d_case(seed=5, C=128, n_img=48 * 64, n_pcd=3000, levels=((12, 16, 20), (6, 8, 80)), n_pcd_nodes=96, Kc=128, n_corr=150):
+    """Two image levels of (h_c x w_c nodes, Ki pixels per patch), n_pcd_nodes point patches of Kc points (ragged: masks), n_corr node
+    correspondences spread over the levels.  Fine features are unit vectors; a share of the points copies the feature of a pixel (+ noise)
+    so that similarities beyond the 0.75 threshold exist."""
+    u = lambda s, shape: synth.hash_normal(seed, s, shape)
+    fi = u(1, (n_img, C)); fi /= np.linalg.norm(fi, axis=1, keepdims=True)
+    fp = u(2, (n_pcd, C))
+    twin = (synth.hash_u01(seed, 3, n_pcd) * n_img).astype(np.int64)                       # the pixel a point resembles
+    has = synth.hash_u01(seed, 4, n_pcd) < 0.5
+    fp[has] = fi[twin[has]] + 0.05 * fp[has]
+    fp /= np.linalg.norm(fp, axis=1, keepdims=True)
+    all_knn, totals, lev, tot = [], [], [], 0
+    for li, (h, w, Ki) in enumerate(levels):
+        nn_ = h * w
+        all_knn.append(T((synth.hash_u01(seed, 10 + li, nn_ * Ki).reshape(nn_, Ki) * n_img).astype(np.int64)))
+        totals.append(tot); tot += nn_
+        lev.append(np.full(nn_, li, dtype=np.int64))
+    pk = (synth.hash_u01(seed, 20, n_pcd_nodes * Kc).reshape(n_pcd_nodes, Kc) * n_pcd).astype(np.int64)
+    # every point patch contains the twins of some pixels of image patches, so that real matches fall inside corresponding patches
+    sizes = (synth.hash_u01(seed, 21, n_pcd_nodes) * (Kc - 40)).astype(np.int64) + 40
+    pm = np.arange(Kc)[None, :] < sizes[:, None]
+    pk[~pm] = n_pcd                                                                        # padded entries address the zero row
+    img_nodes = (synth.hash_u01(seed, 30, n_corr) * tot).astype(np.int64)
+    pcd_nodes = (synth.hash_u01(seed, 31, n_corr) * n_pcd_nodes).astype(np.int64)
+    # plant matches: for correspondence c, make the first 12 valid points of its point patch twins of pixels of its image patch
+    fp_t = fp.copy()
+    lev_all = np.concatenate(lev)
+    for c in range(n_corr):
+        li = int(lev_all[img_nodes[c]]); loc = int(img_nodes[c] - totals[li])
+        pix = all_knn[li][loc].numpy()
+        for q in range(12):
+            pt = pk[pcd_nodes[c], q]
+            if pt < n_pcd:
+                v = fi[pix[(7 * q + c) % len(pix)]] + 0.03 * u(40 + c % 7, (C,))
+                fp_t[pt] = v / np.linalg.norm(v)
+    return dict(img_node_corr_indices=T(img_nodes), pcd_node_corr_indices=T(pcd_nodes), img_node_levels=T(lev_all), all_img_total_nodes=totals,
+                all_img_node_knn_indices=all_knn, pcd_node_knn_indices=T(pk), pcd_node_knn_masks=T(pm), img_feats_f=T(fi.astype(np.float32)),
+                pcd_feats_f=T(fp_t.astype(np.float32)), img_points_f=T(u(50, (n_img, 3)).astype(np.float32)),
+                img_pixels_f=T(u(51, (n_img, 2)).astype(np.float32)), pcd_points_f=T(u(52, (n_pcd, 3)).astype(np.float32)),
+                pcd_pixels_f=T(u(53, (n_pcd, 2)).astype(np.float32)))
