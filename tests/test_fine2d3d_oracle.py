@@ -12,7 +12,6 @@ G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 
 
 def test_block_matches_reference_ops():
-    torch.set_num_threads(4)
     tr = []
     o = fo.extract_patch_correspondences(trace=tr, **fine2d3d_case())
     for t in tr:

@@ -65,7 +65,6 @@ def test_training_forward_matches_reference():
     tag = "b1"
     c = train_case(tag)
     v = synth.VARIANTS["3dmatch"]
-    torch.set_num_threads(8)
     o = tro.training_forward(train_weights(), v, c["f_s"], c["f_t"], c["p_s"], c["p_t"], c["src_mask"], c["tgt_mask"], c["matches"], c["randn"],
                              c["ts"], c["mc"])
     assert np.array_equal(o["noised"].numpy(), G[tag + "_noised"])
