@@ -57,14 +57,14 @@ def make_inputs(variant, P, N, M, seed0, device, seeds=None):
     return prs, dict(f_s=st("src_feats"), f_t=st("tgt_feats"), p_s=st("s_pcd"), p_t=st("t_pcd"), x_T=st("x_T"))
 
 
-def make_engine(variant, steps, mc, device):
+def make_engine(variant, steps, mc, device, strict_f64=False):
     from diffreg_hip import synth
     from diffreg_hip.engine import DenoiseEngine
     v = synth.VARIANTS[variant]
     W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
     return W, DenoiseEngine(W, variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps,
                             sk_iters=v["skh_iters"], sample_rate=v["sample_rate"], max_condition_num=mc,
-                            n_layers=v["n_layers"], device=device)
+                            n_layers=v["n_layers"], device=device, strict_f64=strict_f64)
 
 
 def sinkhorn_microbench(device, B=4096, N=256, M=256, reps=20):
@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFREG_BENCH_STREAMS", "2")),
                     help="the pairs of a pass are split into this many batches, one captured graph each, replayed "
                          "concurrently on separate HIP streams")
+    ap.add_argument("--strict-f64", action="store_true",
+                    help="run the Sinkhorn calls on the fp64 state in fp64 arithmetic like the reference (DR_LOOP_STRICT_F64); the default "
+                         "computes them in fp32 from the fp64 state (stated in config.state)")
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--max-condition-num", type=float, default=200.0)
@@ -252,7 +255,7 @@ def main():
     if stub:
         eng = W = None
     else:
-        W, eng = make_engine(variant, S, args.max_condition_num, dev)
+        W, eng = make_engine(variant, S, args.max_condition_num, dev, strict_f64=args.strict_f64)
         for gi, pg in enumerate(per):
             prs_g, ig = make_inputs(variant, pg, N, M, 0, dev, seeds=[5000 + i for i in pair_ids[off:off + pg]])
             off += pg
@@ -334,7 +337,7 @@ def main():
         "config": {"workload": "cfg2: 3DMatch N=M=%d, C=432, %d denoise steps, max_condition_num=%g (warp active), "
                                "%d independent B=1 pairs per pass per GPU as %d concurrent batch(es), one HIP-graph replay each on its own stream" % (N, S, args.max_condition_num, max(int(p) for p in per_rank_pairs), nstreams),
                    "pairs_per_pass_per_gpu": P, "streams": nstreams, "denoise_steps": S, "N": N, "M": M, "graph": use_graph,
-                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic fp32", "gemm_path": "plane images (csrc/pgemm.hip), weights packed once per engine",
+                   "state": "fp64 (quirk Q2), Sinkhorn arithmetic " + ("fp64 (DR_LOOP_STRICT_F64)" if args.strict_f64 else "fp32"), "gemm_path": "plane images (csrc/pgemm.hip), weights packed once per engine",
                    "gemm_arithmetic": "fp32 in / fp32 out; each product as %s, fp32 accumulate (error vs fp64 = that of an fp32 GEMM)" % SPLIT_TEXT, "parallelism": "pairs sharded over %d GPU(s)" % world},
         "conf_checksum": float(checksum.item()),
         "metric_gather": dict(gathered, collective="all_reduce(SUM) of [sum IR, sum FMR, sum RR, n_pairs, sum t] (float64)",
