@@ -402,6 +402,11 @@ def main():
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
                 roof["effective_clock_GHz_pmc"] = tj.get("derived", {}).get("effective_clock_GHz")
                 roof["avg_us_per_launch_pmc_run"] = tj.get("avg_us_per_launch_profiled")
+                if roof["traffic"] and tj.get("avg_us_per_launch_profiled"):
+                    # the family's average HBM rate over its own launches: the layer is 125 FLOP per byte, below the balance
+                    # point of this ceiling and ~5 TB/s of achievable HBM bandwidth -- the second roof this kernel family sits under
+                    roof["hbm_avg_GBps_pmc"] = roof["traffic"] / tj["avg_us_per_launch_profiled"] / 1e3
+                    roof["flop_per_hbm_byte"] = (work / c) / roof["traffic"]
             roof["avg_us_per_launch"] = ms_ / c * 1e3
             roof["work_per_launch"] = work / c
             roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "
