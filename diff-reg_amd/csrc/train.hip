@@ -278,3 +278,234 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
 }
 
 }  // extern "C"
+
+// ===============================================================================================================================
+// Backward of the matching head's loss (first backward kernels of row f3): d loss / d conf of the focal loss and the backward of
+// log_optimal_transport + exp + slice (3D/models/matching.py:61-93, 207-216) -> d loss / d scores, d loss / d bin_score.
+//
+// Forward (per pair, extended matrix Z = [[scores, a], [a, a]], i <= N, j <= M):  u^0 = v^0 = 0,
+//     u^t_i = log mu_i - LSE_j(Z_ij + v^{t-1}_j),   v^t_j = log nu_j - LSE_i(Z_ij + u^t_i),   t = 1 .. T,
+//     conf_ij = exp(Z_ij + u^T_i + v^T_j - norm),  i < N, j < M.
+// Backward with D_ij = conf_ij dL/dconf_ij and the transport plans Pv^t_ij = exp(Z_ij + u^t_i + v^t_j - log nu_j),
+// Pu^t_ij = exp(Z_ij + v^{t-1}_j + u^t_i - log mu_i):
+//     vb^T_j = sum_i D_ij,   ub^T_i = sum_j D_ij - sum_j vb^T_j Pv^T_ij,
+//     vb^{t-1}_j = - sum_i ub^t_i Pu^t_ij,   ub^{t-1}_i = - sum_j vb^{t-1}_j Pv^{t-1}_ij,
+//     dL/dZ_ij = D_ij - sum_t (vb^t_j Pv^t_ij + ub^t_i Pu^t_ij);   dL/da = sum over the dustbin row and column of dL/dZ.
+// One workgroup per pair; every step is one sweep over the matrix: row quantities by one wave per row (lanes over the columns, DPP
+// reduction), column quantities by one thread per column (rows in order, coalesced): no atomics, results do not depend on scheduling.
+// The 2 T + 2 T vectors live in the workspace (L2-resident); float32 arithmetic like the training forward.
+// ===============================================================================================================================
+namespace dr {
+namespace {
+
+struct SkBwdArgs {
+    const float* scores; const uint8_t* sm; const uint8_t* tm; const float* alpha; const float* gconf; float* gscores; float* galpha; float* ws;
+    int N, M, iters;
+};
+
+__device__ __forceinline__ float zval(const float* __restrict__ Z, int i, int j, int N, int M, float a) {
+    return (i < N && j < M) ? Z[(size_t)i * M + j] : a;
+}
+
+__global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
+    const int N = A.N, M = A.M, T = A.iters, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = 16;
+    const int pair = blockIdx.x;
+    const float* __restrict__ Z = A.scores + (size_t)pair * N * M;
+    const float* __restrict__ G = A.gconf + (size_t)pair * N * M;
+    const float a = *A.alpha;
+    __shared__ int s_cnt[2];
+    __shared__ float s_red[16];
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        for (int i = t; i < N; i += 1024) c0 += A.sm ? (A.sm[(size_t)pair * N + i] != 0) : 1;
+        for (int j = t; j < M; j += 1024) c1 += A.tm ? (A.tm[(size_t)pair * M + j] != 0) : 1;
+        if (c0) atomicAdd(&s_cnt[0], c0);
+        if (c1) atomicAdd(&s_cnt[1], c1);
+    }
+    __syncthreads();
+    const int ms = s_cnt[0], ns = s_cnt[1];
+    const float norm = -logf((float)(ms + ns));
+    const float lmuN = logf((float)ns) + norm, lnuM = logf((float)ms) + norm;
+    // workspace vectors of this pair: u[T][N+1], v[T+1][M+1] (v[0] = 0), ub[T][N+1], vb[T][M+1]
+    const int R = N + 1, Cn = M + 1;
+    float* U = A.ws + (size_t)pair * ((size_t)2 * T * R + (size_t)(2 * T + 1) * Cn);
+    float* V = U + (size_t)T * R;
+    float* UB = V + (size_t)(T + 1) * Cn;
+    float* VB = UB + (size_t)T * R;
+    for (int j = t; j < Cn; j += 1024) V[j] = 0.f;
+    __syncthreads();
+    auto lmu = [&](int i) { return i < N ? norm : lmuN; };
+    auto lnu = [&](int j) { return j < M ? norm : lnuM; };
+
+    // ---- forward, keeping every u^t, v^t
+    for (int it = 1; it <= T; ++it) {
+        const float* vp = V + (size_t)(it - 1) * Cn;
+        float* un = U + (size_t)(it - 1) * R;
+        for (int i = w; i < R; i += NW) {                        // u^t: one wave per row, online log-sum-exp over the columns
+            float mx = -INFINITY, s = 0.f;
+            for (int j = lane; j < Cn; j += 64) {
+                const float x = zval(Z, i, j, N, M, a) + vp[j];
+                if (x > mx) { s = s * expf(mx - x) + 1.f; mx = x; } else if (x > -INFINITY) s += expf(x - mx);
+            }
+            const float gm = wave_max(mx);
+            s = (mx > -INFINITY) ? s * expf(mx - gm) : 0.f;
+            s = wave_sum(s);
+            if (lane == 0) un[i] = lmu(i) - (gm + logf(s));
+        }
+        __threadfence_block();
+        __syncthreads();
+        float* vn = V + (size_t)it * Cn;
+        for (int j = t; j < Cn; j += 1024) {                     // v^t: one thread per column, rows in order
+            float mx = -INFINITY, s = 0.f;
+            for (int i = 0; i < R; ++i) {
+                const float x = zval(Z, i, j, N, M, a) + un[i];
+                if (x > mx) { s = s * expf(mx - x) + 1.f; mx = x; } else if (x > -INFINITY) s += expf(x - mx);
+            }
+            vn[j] = lnu(j) - (mx + logf(s));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ---- backward vectors
+    const float* uT = U + (size_t)(T - 1) * R;
+    const float* vT = V + (size_t)T * Cn;
+    {   // vb^T_j = sum_i D_ij  (D = 0 on the dustbin row / column)
+        float* vb = VB + (size_t)(T - 1) * Cn;
+        for (int j = t; j < Cn; j += 1024) {
+            float s = 0.f;
+            if (j < M)
+                for (int i = 0; i < N; ++i) {
+                    const float z = Z[(size_t)i * M + j];
+                    if (z > -INFINITY) s += expf(z + uT[i] + vT[j] - norm) * G[(size_t)i * M + j];
+                }
+            vb[j] = s;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int it = T; it >= 1; --it) {
+        const float* u = U + (size_t)(it - 1) * R;
+        const float* v = V + (size_t)it * Cn;
+        const float* vprev = V + (size_t)(it - 1) * Cn;
+        const float* vb = VB + (size_t)(it - 1) * Cn;
+        float* ub = UB + (size_t)(it - 1) * R;
+        for (int i = w; i < R; i += NW) {                        // ub^t_i = [t == T] sum_j D_ij - sum_j vb^t_j Pv^t_ij
+            float s = 0.f;
+            for (int j = lane; j < Cn; j += 64) {
+                const float z = zval(Z, i, j, N, M, a);
+                if (z > -INFINITY) {
+                    s -= vb[j] * expf(z + u[i] + v[j] - lnu(j));
+                    if (it == T && i < N && j < M) s += expf(z + u[i] + v[j] - norm) * G[(size_t)i * M + j];
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) ub[i] = s;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (it > 1) {                                            // vb^{t-1}_j = - sum_i ub^t_i Pu^t_ij
+            float* vbp = VB + (size_t)(it - 2) * Cn;
+            for (int j = t; j < Cn; j += 1024) {
+                float s = 0.f;
+                for (int i = 0; i < R; ++i) {
+                    const float z = zval(Z, i, j, N, M, a);
+                    if (z > -INFINITY) s -= ub[i] * expf(z + vprev[j] + u[i] - lmu(i));
+                }
+                vbp[j] = s;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    // ---- dL/dZ in one sweep; the dustbin entries go to dL/dalpha (wave partials in fixed order)
+    float ga = 0.f;
+    for (int i = w; i < R; i += NW) {
+        for (int j = lane; j < Cn; j += 64) {
+            const float z = zval(Z, i, j, N, M, a);
+            float g = 0.f;
+            if (z > -INFINITY) {
+                if (i < N && j < M) g = expf(z + uT[i] + vT[j] - norm) * G[(size_t)i * M + j];
+                for (int it = 1; it <= T; ++it) {
+                    const float ui = U[(size_t)(it - 1) * R + i];
+                    g -= VB[(size_t)(it - 1) * Cn + j] * expf(z + ui + V[(size_t)it * Cn + j] - lnu(j));
+                    g -= UB[(size_t)(it - 1) * R + i] * expf(z + V[(size_t)(it - 1) * Cn + j] + ui - lmu(i));
+                }
+            }
+            if (i < N && j < M) A.gscores[((size_t)pair * N + i) * M + j] = g;
+            else ga += g;
+        }
+    }
+    ga = wave_sum(ga);
+    if (lane == 0) s_red[w] = ga;
+    __syncthreads();
+    if (t == 0) {
+        float s = 0.f;
+        for (int k = 0; k < NW; ++k) s += s_red[k];
+        A.galpha[pair] = s;
+    }
+}
+
+// d loss / d conf of compute_correspondence_loss (sinkhorn form): the clamp passes no gradient outside [1e-6, 1 - 1e-6]
+__global__ __launch_bounds__(256) void focal_backward_kernel(long long n, const float* __restrict__ conf, const float* __restrict__ gt,
+                                                             const double* __restrict__ part, float alpha, float gamma, float pos_w, float neg_w,
+                                                             float* __restrict__ gconf) {
+    __shared__ float s_inv[2];
+    if (threadIdx.x == 0) {
+        double np = 0, nn = 0;
+        for (int k = 0; k < TR_BLOCKS; ++k) { np += part[4 * k + 1]; nn += part[4 * k + 3]; }
+        s_inv[0] = np > 0 ? pos_w / (float)np : 0.f;
+        s_inv[1] = nn > 0 ? neg_w / (float)nn : 0.f;
+    }
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float c = conf[e], g = gt[e];
+    float d = 0.f;
+    if (c >= 1e-6f && c <= 1.0f - 1e-6f) {
+        if (g == 1.0f) d = -alpha * (-gamma * powg(1.0f - c, gamma - 1.0f) * logf(c) + powg(1.0f - c, gamma) / c) * s_inv[0];
+        else if (g == 0.0f) d = -alpha * (gamma * powg(c, gamma - 1.0f) * logf(1.0f - c) - powg(c, gamma) / (1.0f - c)) * s_inv[1];
+    }
+    gconf[e] = d;
+}
+
+}  // namespace
+}  // namespace dr
+
+extern "C" {
+
+size_t dr_sinkhorn_backward_workspace_bytes(int P, int N, int M, int iters) {
+    if (P < 0 || N < 1 || M < 1 || iters < 1) return 0;
+    return (size_t)P * ((size_t)2 * iters * (N + 1) + (size_t)(2 * iters + 1) * (M + 1)) * sizeof(float);
+}
+
+int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
+                             int iters, const float* grad_conf, float* grad_scores, float* grad_bin_score, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || iters < 1 || !scores || !bin_score || !grad_conf || !grad_scores || !grad_bin_score || !workspace) return DR_EINVAL;
+    if ((src_mask == nullptr) != (tgt_mask == nullptr)) return DR_EINVAL;
+    if (workspace_bytes < dr_sinkhorn_backward_workspace_bytes(P, N, M, iters)) return DR_EWORKSPACE;
+    if (P == 0) return DR_OK;
+    dr::SkBwdArgs A{scores, src_mask, tgt_mask, bin_score, grad_conf, grad_scores, grad_bin_score, (float*)workspace, N, M, iters};
+    hipLaunchKernelGGL(dr::sk_backward_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+int dr_focal_loss_backward_f32(int P, int N, int M, const float* conf, const float* conf_gt, float alpha, float gamma, float pos_w, float neg_w,
+                               float* grad_conf, void* workspace, void* stream) {
+    if (P < 1 || N < 1 || M < 1 || !conf || !conf_gt || !grad_conf || !workspace) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)P * N * M;
+    float dummy_unused = 0.f; (void)dummy_unused;
+    dr::FocalArgs A{conf, conf_gt, nullptr, n, alpha, gamma, pos_w, neg_w, 0, (double*)workspace, nullptr};
+    hipLaunchKernelGGL(dr::focal_partial_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, A);        // class counts
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::focal_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, conf, conf_gt, (const double*)workspace, alpha,
+                       gamma, pos_w, neg_w, grad_conf);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}  // extern "C"

@@ -141,6 +141,10 @@ SIGNATURES.update({
                                   c_void_p]),
     "dr_match_recall_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_motion_l1_f32": (c_int, [c_int, c_int] + [c_void_p] * 10),
+    "dr_focal_loss_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "dr_sinkhorn_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dr_sinkhorn_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_size_t, c_void_p]),
     "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -405,6 +409,33 @@ def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
     check(_lib.dr_motion_l1_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(loss),
                                 ptr(ws), stream_of(s_pcd)))
     return loss
+
+
+def focal_loss_backward(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0):
+    """d loss / d conf of the sinkhorn-form focal loss (loss.py:311-314) -> [P,N,M] float32"""
+    ensure_init()
+    conf, conf_gt = conf.contiguous().float(), conf_gt.contiguous().float()
+    P, N, M = conf.shape
+    g = torch.empty_like(conf)
+    ws = _train_ws(P, N, M, conf.device)
+    check(_lib.dr_focal_loss_backward_f32(P, N, M, ptr(conf), ptr(conf_gt), alpha, gamma, pos_w, neg_w, ptr(g), ptr(ws), stream_of(conf)))
+    return g
+
+
+def sinkhorn_backward(scores, bin_score, iters, src_mask, tgt_mask, grad_conf):
+    """backward of conf = exp(log_optimal_transport(scores, bin_score, iters, masks))[:, :-1, :-1] -> (grad_scores [P,N,M], grad_bin_score 0-d)"""
+    ensure_init()
+    scores, grad_conf = scores.contiguous().float(), grad_conf.contiguous().float()
+    P, N, M = scores.shape
+    gs = torch.empty_like(scores)
+    ga = torch.empty(P, device=scores.device)
+    wsb = _lib.dr_sinkhorn_backward_workspace_bytes(P, N, M, int(iters))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=scores.device)
+    sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    bs = torch.as_tensor(bin_score).detach().reshape(1).float().to(scores.device).contiguous()
+    check(_lib.dr_sinkhorn_backward_f32(P, N, M, ptr(scores), ptr(sm), ptr(tm), ptr(bs), int(iters), ptr(grad_conf), ptr(gs), ptr(ga), ptr(ws), wsb,
+                                        stream_of(scores)))
+    return gs, ga.sum()
 
 
 def mutual_match(conf, thr=0.0, mutual=True, cap=None, want_mask=False):

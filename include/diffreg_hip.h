@@ -566,6 +566,20 @@ int dr_match_recall_f32(int P, int N, int M, const float* conf_gt, int K, const 
 int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
                      const float* t_gt, const uint8_t* overlap_mask, float* loss, void* workspace, void* stream);
 
+/* First backward kernels of the training branch: the matching head's loss.
+ * dr_focal_loss_backward_f32: d loss / d conf of compute_correspondence_loss in its sinkhorn form (loss.py:311-314; torch.clamp passes no
+ *   gradient outside [1e-6, 1 - 1e-6]); workspace: dr_train_workspace_bytes(P, N, M).
+ * dr_sinkhorn_backward_f32: backward of log_optimal_transport + exp + [:, :-1, :-1] (matching.py:61-93, 207-216): scores [P,N,M] as the forward
+ *   saw them (masked entries -inf), the masks (both or none), bin_score, iters, grad_conf = d loss / d conf [P,N,M] ->
+ *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32; every
+ *   reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
+int dr_focal_loss_backward_f32(int P, int N, int M, const float* conf, const float* conf_gt, float alpha, float gamma, float pos_w, float neg_w,
+                               float* grad_conf, void* workspace, void* stream);
+size_t dr_sinkhorn_backward_workspace_bytes(int P, int N, int M, int iters);
+int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
+                             int iters, const float* grad_conf, float* grad_scores, float* grad_bin_score, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,29 @@ def main():
     out["recall"], out["precision"] = np.float64(float(r)), np.float64(float(p))
     out["recall_pred"] = pred.numpy()
     out["focal_gt_index"] = gi.numpy()
+    # ---- backward of the matching head's loss: autograd through the reference's own log_optimal_transport (models/matching.py:61-93),
+    #      exp + slice (:213-214) and compute_correspondence_loss (models/loss.py:273-314)
+    from models.matching import log_optimal_transport
+    from tests.helpers import train_backward_case
+    bw = {}
+    for tag in ("full", "masked", "big"):
+        sc, gt_b, sm, tm = train_backward_case(tag)
+        sc = sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf")).requires_grad_(True)
+        alpha = torch.tensor(1.0, requires_grad=True)
+        with torch.enable_grad():
+            Z = log_optimal_transport(sc, alpha, 3, sm, tm)
+            conf = Z.exp()[:, :-1, :-1].contiguous()
+            conf.retain_grad()
+            crit = MatchMotionLoss(dict(LOSS_CFG))
+            loss = crit.compute_correspondence_loss(conf, gt_b.clone())
+            loss.backward()
+        bw[tag + "_loss"] = np.float64(float(loss))
+        bw[tag + "_conf"] = conf.detach().numpy()
+        bw[tag + "_grad_conf"] = conf.grad.numpy()
+        bw[tag + "_grad_scores"] = sc.grad.numpy()
+        bw[tag + "_grad_bin_score"] = np.float64(float(alpha.grad))
+        print("backward", tag, "loss %.6f" % float(loss), "|grad_scores| max %.3e" % float(sc.grad.abs().max()), "grad_bin_score %.6e" % float(alpha.grad))
+    np.savez_compressed(OUT.replace("train_forward", "train_backward"), **bw)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

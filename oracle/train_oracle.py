@@ -108,3 +108,53 @@ def training_forward(W, cfg, f_s, f_t, p_s, p_t, mask_s, mask_t, matches, randn,
     d_s, d_t, qe_s, qe_t = orc.denoiser(W, cfg, f_s, f_t, warped, p_t.float(), mask_s, mask_t)
     hat = orc.match_head(W, cfg, d_s, d_t, qe_s, qe_t, mask_s, mask_t)
     return dict(conf_matrix_pred=conf, R_s2t_pred=R, t_s2t_pred=tt, noised=noised, src_warped=warped, conf_matrix_gt_hat=hat)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# backward of the matching head's loss, written out (the golden vectors are torch autograd through the reference's own functions)
+# ------------------------------------------------------------------------------------------------------------------------------
+def focal_loss_backward(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0):
+    """d loss / d conf of 3D/models/loss.py:311-314 (clamp :299 passes no gradient outside its range)"""
+    pos, neg = conf_gt == 1, conf_gt == 0
+    npos, nneg = pos.sum().clamp(min=1), neg.sum().clamp(min=1)
+    pw = pos_w if pos.any() else 0.0
+    nw = neg_w if neg.any() else 0.0
+    c = conf
+    live = (c >= 1e-6) & (c <= 1 - 1e-6)
+    dpos = -alpha * (-gamma * (1 - c) ** (gamma - 1) * c.log() + (1 - c) ** gamma / c) * (pw / npos)
+    dneg = -alpha * (gamma * c ** (gamma - 1) * (1 - c).log() - c ** gamma / (1 - c)) * (nw / nneg)
+    g = torch.where(pos, dpos, torch.where(neg, dneg, torch.zeros_like(c)))
+    return torch.where(live, g, torch.zeros_like(c))
+
+
+def sinkhorn_backward(scores, alpha, iters, src_mask, tgt_mask, grad_conf):
+    """backward of conf = exp(log_optimal_transport(scores, alpha, iters, masks))[:, :-1, :-1] (3D/models/matching.py:61-93, 213-214) by the
+    adjoint recurrences of the iteration (csrc/train.hip states them): -> grad_scores [B,N,M], grad_alpha (0-d)"""
+    B, N, M = scores.shape
+    dt = scores.dtype
+    a = torch.as_tensor(alpha).to(dt)
+    rows, cols = src_mask.sum(1, keepdim=True), tgt_mask.sum(1, keepdim=True)
+    Z = torch.full((B, N + 1, M + 1), 0.0, dtype=dt)
+    Z[:, :N, :M] = scores
+    Z[:, :N, M] = a
+    Z[:, N, :] = a
+    norm = -(rows + cols).log().to(dt)
+    log_mu = torch.cat([norm.expand(B, N), cols.log().to(dt) + norm], 1)
+    log_nu = torch.cat([norm.expand(B, M), rows.log().to(dt) + norm], 1)
+    us, vs = [], [torch.zeros_like(log_nu)]
+    for _ in range(iters):
+        us.append(log_mu - torch.logsumexp(Z + vs[-1][:, None, :], dim=2))
+        vs.append(log_nu - torch.logsumexp(Z + us[-1][:, :, None], dim=1))
+    D = torch.zeros_like(Z)
+    D[:, :N, :M] = (Z[:, :N, :M] + us[-1][:, :N, None] + vs[-1][:, None, :M] - norm[:, :, None]).exp() * grad_conf
+    gZ = D.clone()
+    vb = D.sum(1)
+    for t in range(iters, 0, -1):
+        Pv = (Z + us[t - 1][:, :, None] + vs[t][:, None, :] - log_nu[:, None, :]).exp()
+        ub = (D.sum(2) if t == iters else 0) - (vb[:, None, :] * Pv).sum(2)
+        gZ = gZ - vb[:, None, :] * Pv
+        Pu = (Z + vs[t - 1][:, None, :] + us[t - 1][:, :, None] - log_mu[:, :, None]).exp()
+        gZ = gZ - ub[:, :, None] * Pu
+        vb = -(ub[:, :, None] * Pu).sum(1)
+    g_alpha = gZ[:, N, :].sum() + gZ[:, :N, M].sum()
+    return gZ[:, :N, :M].contiguous(), g_alpha

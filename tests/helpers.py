@@ -181,3 +181,17 @@ def fine2d3d_case(seed=5, C=128, n_img=48 * 64, n_pcd=3000, levels=((12, 16, 20)
                 pcd_feats_f=T(fp_t.astype(np.float32)), img_points_f=T(u(50, (n_img, 3)).astype(np.float32)),
                 img_pixels_f=T(u(51, (n_img, 2)).astype(np.float32)), pcd_points_f=T(u(52, (n_pcd, 3)).astype(np.float32)),
                 pcd_pixels_f=T(u(53, (n_pcd, 2)).astype(np.float32)))
+
+
+def train_backward_case(tag):
+    """inputs of the matching-head backward vectors (oracle/make_golden_train.py, section "backward")"""
+    P, N, M, nv, mv, seed = {"full": (2, 64, 48, 64, 48, 3), "masked": (2, 96, 80, 70, 61, 4), "big": (1, 256, 256, 256, 256, 5)}[tag]
+    sc = T((3.0 * synth.hash_normal(seed, 700, (P, N, M))).astype(np.float32))
+    gt = torch.zeros(P, N, M)
+    k = min(nv, mv) // 2
+    for b in range(P):
+        i = T((synth.hash_u01(seed, 710 + b, k) * nv).astype(np.int64)); j = T((synth.hash_u01(seed, 720 + b, k) * mv).astype(np.int64))
+        gt[b, i, j] = 1.0
+        sc[b, i, j] += 6.0
+    sm, tm = torch.arange(N)[None].expand(P, N) < nv, torch.arange(M)[None].expand(P, M) < mv
+    return sc, gt, sm, tm

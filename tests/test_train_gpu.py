@@ -142,3 +142,46 @@ def test_training_forward_and_loss_against_reference(tag):
         for k, val in info.items():
             want = float(G[tag + "_loss_mot%d_%s" % (int(mot_w), k)])
             assert abs(float(val) - want) <= 1e-4 * max(1.0, abs(want)), (k, float(val), want)
+
+
+GB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_backward.npz"))
+
+
+@pytest.mark.parametrize("tag", ["full", "masked", "big"])
+def test_matching_head_backward_against_reference_autograd(tag):
+    """dr_focal_loss_backward_f32 and dr_sinkhorn_backward_f32 against torch autograd through the reference's own log_optimal_transport,
+    exp + slice and compute_correspondence_loss (tests/golden/train_backward.npz)"""
+    from tests.helpers import train_backward_case
+    sc, gt, sm, tm = train_backward_case(tag)
+    sc = sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf"))
+    conf = torch.from_numpy(GB[tag + "_conf"]).to(DEV)
+    gconf = lib.focal_loss_backward(conf, gt.to(DEV))
+    ref_gc = GB[tag + "_grad_conf"]
+    assert np.abs(gconf.cpu().numpy() - ref_gc).max() <= 2e-6 * np.abs(ref_gc).max()
+    gs, ga = lib.sinkhorn_backward(sc.to(DEV), torch.tensor(1.0), 3, sm.to(DEV), tm.to(DEV), torch.from_numpy(ref_gc).to(DEV))
+    ref = GB[tag + "_grad_scores"]
+    assert not torch.isnan(gs).any()
+    assert np.abs(gs.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), np.abs(gs.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert float((gs[~(sm[:, :, None] & tm[:, None, :]).to(DEV)]).abs().max() if tag == "masked" else 0.0) == 0.0
+    assert abs(float(ga) - float(GB[tag + "_grad_bin_score"])) <= 1e-4 * abs(float(GB[tag + "_grad_bin_score"])) + 1e-7
+    # the chain the trainer would run: conf from the forward kernel, its loss gradient, back to the scores -- against the same vectors
+    conf_hip = lib.sinkhorn(sc.to(DEV), torch.tensor(1.0, device=DEV), 3, sm.to(DEV), tm.to(DEV))
+    gs2, _ = lib.sinkhorn_backward(sc.to(DEV), torch.tensor(1.0), 3, sm.to(DEV), tm.to(DEV), lib.focal_loss_backward(conf_hip, gt.to(DEV)))
+    assert np.abs(gs2.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tag", ["full", "masked"])
+def test_autograd_wrappers(tag):
+    """loss.backward() through diffreg_hip.autograd: the same gradients as autograd through the reference's functions"""
+    from diffreg_hip.autograd import focal_loss, sinkhorn_conf
+    from tests.helpers import train_backward_case
+    sc, gt, sm, tm = train_backward_case(tag)
+    sc = sc.to(DEV).requires_grad_(True)
+    alpha = torch.tensor(1.0, device=DEV, requires_grad=True)
+    conf = sinkhorn_conf(sc, alpha, 3, sm.to(DEV), tm.to(DEV))
+    loss = focal_loss(conf, gt.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(GB[tag + "_loss"])) <= 1e-5 * float(GB[tag + "_loss"])
+    ref = GB[tag + "_grad_scores"]
+    assert np.abs(sc.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert abs(float(alpha.grad) - float(GB[tag + "_grad_bin_score"])) <= 2e-4 * abs(float(GB[tag + "_grad_bin_score"])) + 1e-7

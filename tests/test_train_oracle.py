@@ -73,3 +73,21 @@ def test_training_forward_matches_reference():
     for k in ("conf_matrix_pred", "conf_matrix_gt_hat"):
         d = np.abs(o[k].numpy() - G[tag + "_" + k])
         assert d.max() < 2e-3 and (d > 1e-4).mean() < 1e-3, (k, d.max())       # (host BLAS, sharp entries: as tests/test_oracle_golden.py)
+
+
+GB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_backward.npz"))
+
+
+@pytest.mark.parametrize("tag", ["full", "masked", "big"])
+def test_matching_head_backward_against_reference_autograd(tag):
+    """the written-out adjoint recurrences against torch autograd through the reference's own log_optimal_transport and focal loss"""
+    from tests.helpers import train_backward_case
+    sc, gt, sm, tm = train_backward_case(tag)
+    sc = sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf"))
+    conf = torch.from_numpy(GB[tag + "_conf"])
+    gconf = tro.focal_loss_backward(conf, gt)
+    assert np.abs(gconf.numpy() - GB[tag + "_grad_conf"]).max() <= 1e-6 * np.abs(GB[tag + "_grad_conf"]).max()
+    gs, ga = tro.sinkhorn_backward(sc.double(), 1.0, 3, sm, tm, torch.from_numpy(GB[tag + "_grad_conf"]).double())
+    ref = GB[tag + "_grad_scores"]
+    assert np.abs(gs.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert abs(float(ga) - float(GB[tag + "_grad_bin_score"])) <= 2e-5 * abs(float(GB[tag + "_grad_bin_score"])) + 1e-8
