@@ -64,17 +64,21 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int TNW_, int NST_>
+// WMN = waves along the rows: 4 -> 128-row workgroups of 512 threads; 2 -> 64-row workgroups of 256 threads (same wave tile, same ring
+// depth): twice the workgroups for launches that would leave CUs idle (fewer 128-row workgroups than CUs: small batches, BASELINE cfg3's 8 pairs)
+template <int TNW_, int NST_, int WMN_ = 4>
 struct PgGeom {
-    static constexpr int TNW = TNW_, NST = NST_;
-    static constexpr int BM = 128, BNW = 32 * TNW, BN = 2 * BNW;
+    static constexpr int TNW = TNW_, NST = NST_, WMN = WMN_;
+    static constexpr int BM = 32 * WMN, BNW = 32 * TNW, BN = 2 * BNW, NTHR = 128 * WMN;
     static constexpr int A_ST = BM * 64, B_ST = BN * 64, STAGE = A_ST + B_ST;
+    static constexpr int A_IMG = 128 * 64;                  // bytes between two k-chunks of a 128-row block in an A image
+    static constexpr int NA = A_ST / 1024;                  // DMA instructions of the A part of a stage (8 / 4)
     static constexpr int NB = B_ST / 1024;                  // DMA instructions of the weight part of a stage (28)
     static constexpr int NFULL = NB / 8, REM = NB % 8;      // every wave issues 1 (A) + NFULL, waves < REM one more
     static constexpr int RING = NST * STAGE;
     static constexpr int NI = BNW / 16;                     // float4 pieces of a row a lane holds after the transposition (14)
     static constexpr int EP_S = (BNW - 48 + 63) / 64 * 64 + 48;   // row stride of the transposition, = 48 mod 64 floats: conflict-free float4 reads
-    static constexpr int EP_BYTES = 8 * 16 * EP_S * 4;
+    static constexpr int EP_BYTES = 2 * WMN * 16 * EP_S * 4;
     static constexpr int WORK = RING > EP_BYTES ? RING : EP_BYTES;
     static constexpr int SMEM = WORK + 6 * 128 * 4 + 2 * BN * 4;   // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta [2][BN]
     static constexpr int MID = (TNW - 1) / 2 - 1 < 0 ? 0 : (TNW - 1) / 2 - 1;   // the barrier sits after this tile (2 of 7)
@@ -88,31 +92,32 @@ __device__ long long g_pg_stamps[128];
 // cycle stamps (s_memtime) inside stage 10 of waves 0 and 4 of workgroup 0: slots 64 + 16 grp + i
 #define PG_CSTAMP(i) do { if (DBG && s == 10 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 255) == 0) g_pg_stamps[64 + 16 * GRP + (i)] = clock64(); } while (0)
 
-template <int TNW, int NST, int MODE, bool DBG = false, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgemm_kernel(PgBatch G) {
-    using GG = PgGeom<TNW, NST>;
-    constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S;
+template <int TNW, int NST, int MODE, bool DBG = false, int ABL = 0, int WMN = 4>
+__global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN / 2, WMN / 2))) void pgemm_kernel(PgBatch G) {
+    using GG = PgGeom<TNW, NST, WMN>;
+    constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S, BM = GG::BM, NTHR = GG::NTHR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
 
     const PgProblem& P = G.p[blockIdx.y];
     const int rows = P.rows, C = P.C, nblk = P.nblk, nc0 = P.nc0, nc1 = P.A1 ? P.nc1 : 0, nst = nc0 + nc1;
-    const int rbs = (rows + 127) >> 7;
+    const int rbs = (rows + BM - 1) / BM;                       // BM-row blocks; block rb = rows rb BM .. of the 128-row image block rb BM / 128
     // workgroup id -> (row block, column block), XCD-aware: ids are dealt round-robin to the 8 XCDs, so the column blocks of a
     // row block get ids 8 apart: they share an L2 and the A rows cross the fabric once
     const int grp = blockIdx.x / (8 * nblk), rem = blockIdx.x % (8 * nblk);
     const int rb = grp * 8 + (rem & 7), nb = rem >> 3;
     if (rb >= rbs) return;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w & 3, wn = w >> 2;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w % WMN, wn = w / WMN;
+    const int rb128 = (rb * BM) >> 7, sub = (rb * BM) & 127;      // image block and first row inside it (0 / 64)
 
     float* const s_fac = reinterpret_cast<float*>(lds + GG::WORK);   // 2^(s1 - s0) of the rows (two-segment A operand)
     float* const s_rinv = s_fac + 128;                               // 2^-s of the rows (last segment)
     float* const s_sum = s_rinv + 128;                               // [2][128] LayerNorm partial sums of the two column waves
     float* const s_sq = s_sum + 256;                                 // [2][128] partial squares
-    if (t < 128) {
-        const int row = min(rb * 128 + t, rows - 1);
+    if (t < BM) {
+        const int row = min(rb * BM + t, rows - 1);
         const int e0 = scale_exp(P.bnd0[row]);
         int e1 = e0;
         if (nc1 > 0) e1 = scale_exp(P.bnd1[row]);
@@ -149,42 +154,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // both groups issue stage s + 2 in the second burst and wait for everything at the next barrier.
         constexpr bool EARLY = GRP == 0 && NST >= 4;
         constexpr int AHEAD = EARLY ? NST - 2 : NST - 1;             // stages in flight beyond the current one after the prologue
-        constexpr int WB_CNT = (GG::NB + 8) / 2 - 8;                 // weight instructions of group 1
+        constexpr int WB_CNT = (GG::NB + GG::NA) / 2 - GG::NA;       // weight instructions of group 1
         constexpr int NW0 = GG::NB - WB_CNT;                         // weight instructions of group 0
-        constexpr int NPIECE = GRP ? 2 + (WB_CNT + 3) / 4 : (NW0 + 3) / 4;
-        constexpr int NFULLP = GRP ? 2 + WB_CNT / 4 : NW0 / 4;       // pieces every wave of the group issues
-        static_assert(2 * NPIECE <= 3 * (TNW - TNW / 2), "the DMA pieces of a stage must fit the gaps of the second burst");
-        constexpr int REMP = GRP ? WB_CNT % 4 : NW0 % 4;             // waves (local index) < REMP issue one more
-        const int wl = w & 3;
+        constexpr int NPIECE = GRP ? 2 + (WB_CNT + WMN - 1) / WMN : (NW0 + WMN - 1) / WMN;
+        constexpr int NFULLP = GRP ? 2 + WB_CNT / WMN : NW0 / WMN;   // pieces every wave of the group issues
+        constexpr int PSTEP = (2 * NPIECE <= 3 * (TNW - TNW / 2)) ? 2 : 1;   // gaps between two pieces issued in the second burst
+        static_assert(PSTEP * NPIECE <= 3 * (TNW - TNW / 2), "the DMA pieces of a stage must fit the gaps of the second burst");
+        static_assert(NPIECE <= 3 * (TNW / 2), "... and those of the early group the gaps of the first");
+        constexpr int REMP = GRP ? WB_CNT % WMN : NW0 % WMN;         // waves (local index) < REMP issue one more
+        const int wl = w % WMN;
         // DMA pieces of this wave (1 KB instructions; `ins` = index inside the A block / the weight block of a stage):
         //   group 1: A instructions 2 wl, 2 wl + 1, then weight instructions st0 .. (WB_CNT dealt 3, 3, 2, 2)
         //   group 0: weight instructions st0 .. (the other NB - WB_CNT dealt 5, 5, 4, 4)
         // issued in the SGPR-base + VGPR-offset + immediate form: per piece an s_mov to M0 and the load, nothing else
-        const int st0 = GRP ? wl * (WB_CNT / 4) + min(wl, WB_CNT % 4) : WB_CNT + wl * (NW0 / 4) + min(wl, NW0 % 4);
-        const unsigned voffW = lane * 16 + st0 * 1024, voffW4 = voffW + 4096, voffA = lane * 16 + 2 * wl * 1024;
-        const char* ga = P.A0 + (size_t)rb * nc0 * A_ST;             // A block of stage ti (wave-uniform)
+        const int st0 = GRP ? wl * (WB_CNT / WMN) + min(wl, WB_CNT % WMN) : WB_CNT + wl * (NW0 / WMN) + min(wl, NW0 % WMN);
+        const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * wl * 1024;
+        const char* ga = P.A0 + (size_t)rb128 * nc0 * GG::A_IMG + sub * 64;   // A block of stage ti (wave-uniform)
         const char* gb = P.W.img + (size_t)nb * nst * GG::B_ST;      // weight block of stage ti
-        const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * A_ST : nullptr;
+        const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb128 * nc1 * GG::A_IMG + sub * 64 : nullptr;
         int ti = 0;                                                  // next stage this wave issues
         // (the instruction's immediate offset is added to the global address AND to the LDS address M0 + 16 lane)
 #define PG_DMA(ldsaddr, voff, gbase, imm)                                                                  \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(ldsaddr), "v"(voff), "s"(gbase), "i"(imm) : "memory")
         auto dma_piece = [&](int p, unsigned dstb) __attribute__((always_inline)) {   // dstb = LDS address of the slot of stage ti
             const unsigned m0w = dstb + A_ST + st0 * 1024;
-            if (GRP) {
-                if (p < 2) { if (ABL != 6) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024); }
-                else if (ABL == 5) {}
-                else if (p - 2 < WB_CNT / 4 || wl < WB_CNT % 4) PG_DMA(m0w, voffW, gb, (p - 2) * 1024);
-            } else if (ABL == 5) {
-            } else {
-                if (p < 4) { if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w, voffW, gb, (p & 3) * 1024); }
-                else if (p < NW0 / 4 || wl < NW0 % 4) PG_DMA(m0w + 4096, voffW4, gb, ((p - 4) & 3) * 1024);
-            }
+            // weight piece pw of a wave: the immediate reaches 3 KB, every 4 pieces move the register base by 4 KB
+            const int pw = GRP ? p - 2 : p;
+            const unsigned hop = (unsigned)(pw >> 2) * 4096;
+            if (GRP && p < 2) { if (ABL != 6) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024); }
+            else if (ABL == 5) {}
+            else if (pw < (GRP ? WB_CNT : NW0) / WMN || wl < (GRP ? WB_CNT : NW0) % WMN) PG_DMA(m0w + hop, voffW + hop, gb, (pw & 3) * 1024);
         };
         auto dma_advance = [&]() __attribute__((always_inline)) {
             ++ti;
             gb += GG::B_ST;
-            ga = (ti == nc0) ? ga1 : ga + A_ST;
+            ga = (ti == nc0) ? ga1 : ga + GG::A_IMG;
         };
 
         // One stage = two MFMA bursts with no wait inside: tiles 0 .. NT1 - 1 (fragment set X), then tiles NT1 .. TNW - 1 (set Y).
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 // ---- DMA pieces: group 0 in burst 1 (stage s + NST - 2), group 1 in burst 2 (stage s + NST - 1)
-                constexpr int MF = EARLY ? 0 : M1 + 1, STEP = EARLY ? 1 : 2;
+                constexpr int MF = EARLY ? 0 : (PSTEP == 2 ? M1 + 1 : M1), STEP = EARLY ? 1 : PSTEP;
                 if (m >= MF && m < MF + STEP * NPIECE && (m - MF) % STEP == 0) {
                     if (do_issue && ABL != 1) dma_piece((m - MF) / STEP, dstb);
                     if ((m - MF) / STEP == NPIECE - 1 && do_issue) dma_advance();
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
     int grow[2];
-    grow[0] = rb * 128 + wm * 32 + lr;
+    grow[0] = rb * BM + wm * 32 + lr;
     grow[1] = grow[0] + 16;
     constexpr int mode = MODE;                                  // (one instantiation per epilogue: each gets its own register allocation)
 
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // nn.LayerNorm over the C columns of the block (biased variance, eps inside the sqrt; transformero.py:88-94)
         float* const s_gam = s_sq + 256;                         // gamma | beta of the block, staged once per workgroup
         float* const s_bet = s_gam + BN;
-        for (int c = t; c < BN; c += 512) {
+        for (int c = t; c < BN; c += NTHR) {
             s_gam[c] = c < C ? P.gamma[c] : 0.f;
             s_bet[c] = c < C ? P.beta[c] : 0.f;
         }
@@ -516,9 +520,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool per_blk = P.pimg_blk_stride != 0;
         if (P.pbnd && rok && (nb == 0 || per_blk) && wn == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
         const float sc = pow2i(scale_exp(bound));
-        const int rl = wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;
+        const int rl = sub + wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;       // row inside the 128-row image block
         char* const rowp = P.pimg + (size_t)nb * P.pimg_blk_stride +
-                           (((size_t)rb * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + wn * (BNW >> 4)) * 128 + rl) * 64;
+                           (((size_t)rb128 * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + wn * (BNW >> 4)) * 128 + rl) * 64;
         const unsigned uh = (unsigned)(((q >> 1) ^ swz) << 4), ul = (unsigned)(((2 + (q >> 1)) ^ swz) << 4);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -657,6 +661,8 @@ __global__ __launch_bounds__(256) void ln_bound_kernel(const float* __restrict__
 
 using G7 = PgGeom<7, 4>;     // column blocks of up to 448 (3DMatch: C = 432; 2D-3D: 256), 4-slot ring
 using G9 = PgGeom<9, 3>;     // column blocks of up to 576 (4DMatch: C = 528), 3-slot ring (the stage is 44 KB)
+using G7H = PgGeom<7, 4, 2>; // the same with 64-row workgroups (4 waves): launches that would leave CUs idle
+using G9H = PgGeom<9, 3, 2>;
 
 }  // namespace
 
@@ -682,6 +688,10 @@ int pgemm_configure() {
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>(false);
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_PLANES>(false);
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_LN>(false);
+#define PG_ATTR_H(TNW, NST, MODE, GH) if (rc == DR_OK) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::SMEM))
+    PG_ATTR_H(7, 4, PG_F32, G7H); PG_ATTR_H(7, 4, PG_PLANES, G7H); PG_ATTR_H(7, 4, PG_LN, G7H);
+    PG_ATTR_H(9, 3, PG_F32, G9H); PG_ATTR_H(9, 3, PG_PLANES, G9H); PG_ATTR_H(9, 3, PG_LN, G9H);
+#undef PG_ATTR_H
     return rc;
 }
 
@@ -690,11 +700,18 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     int maxt = 0;
     double flops = 0;
     const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G7::BN ? G7::NST : G9::NST;
+    // 64-row workgroups when the launch would not give every CU a 128-row one (DR_PG_HALF under dr_debug_enable_env: 0 never, 2 always)
+    static const int half_env = env_knob("DR_PG_HALF", 1);
+    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    long wg128 = 0;
+    for (int i = 0; i < g.n; ++i) wg128 += (long)((g.p[i].rows + 127) / 128) * g.p[i].nblk;
+    const bool half = half_env == 2 || (half_env == 1 && wg128 < n_cu);
+    const int bm = half ? 64 : 128;
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
         if (!pgemm_shape_ok(p.C) || pgemm_bn(p.C) != bn || p.rows < 1 || p.nblk < 1 || p.nc0 < 1 || p.nc0 + (p.A1 ? p.nc1 : 0) < nst_min) return DR_ENOSUP;
         if (p.W.nct != p.nc0 + (p.A1 ? p.nc1 : 0)) return DR_EINVAL;
-        const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk;
+        const int tl = ((p.rows + bm - 1) / bm + 7) / 8 * 8 * p.nblk;
         maxt = tl > maxt ? tl : maxt;
         flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
@@ -704,7 +721,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     const int mode = g.p[0].mode;
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
-    const dim3 grid(maxt, g.n), blk(512);
+    const dim3 grid(maxt, g.n), blk(half ? 256 : 512);
 #define PG_LAUNCH(TNW, NST, MODE, DBGF, ABLV) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>), grid, blk, (PgGeom<TNW, NST>::SMEM), st, g)
 #define PG_LAUNCH_DBG(MODE)                                        \
     switch (abl) {                                                 \
@@ -718,7 +735,15 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
         default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
     }
-    if (bn == G9::BN) {
+    if (half && !dbg) {
+#define PG_LAUNCH_H(TNW, NST, MODE, GH) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, MODE, false, 0, 2>), grid, blk, (GH::SMEM), st, g)
+        if (bn == G9::BN) {
+            if (mode == PG_F32) PG_LAUNCH_H(9, 3, PG_F32, G9H); else if (mode == PG_PLANES) PG_LAUNCH_H(9, 3, PG_PLANES, G9H); else PG_LAUNCH_H(9, 3, PG_LN, G9H);
+        } else {
+            if (mode == PG_F32) PG_LAUNCH_H(7, 4, PG_F32, G7H); else if (mode == PG_PLANES) PG_LAUNCH_H(7, 4, PG_PLANES, G7H); else PG_LAUNCH_H(7, 4, PG_LN, G7H);
+        }
+#undef PG_LAUNCH_H
+    } else if (bn == G9::BN) {
         if (mode == PG_F32) PG_LAUNCH(9, 3, PG_F32, false, 0);
         else if (mode == PG_PLANES) PG_LAUNCH(9, 3, PG_PLANES, false, 0);
         else PG_LAUNCH(9, 3, PG_LN, false, 0);
