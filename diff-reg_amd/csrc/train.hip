@@ -509,3 +509,32 @@ int dr_focal_loss_backward_f32(int P, int N, int M, const float* conf, const flo
 }
 
 }  // extern "C"
+
+// embed_rotary (3D/models/position_encoding.py:25-35) and its transpose: out = R(+-theta) x * scale, cos / sin [rows, C/2]
+namespace dr {
+namespace {
+__global__ __launch_bounds__(256) void rotary_kernel(long long n2, int halfC, const float* __restrict__ x, const float* __restrict__ cs,
+                                                     const float* __restrict__ sn, float sign, float scale, float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;      // pair index: row * C/2 + k
+    if (e >= n2) return;
+    const float2 v = reinterpret_cast<const float2*>(x)[e];
+    const float c = cs[e], s = sign * sn[e];
+    float2 o;
+    o.x = __fadd_rn(__fmul_rn(v.x, c), __fmul_rn(-v.y, s)) * scale;
+    o.y = __fadd_rn(__fmul_rn(v.y, c), __fmul_rn(v.x, s)) * scale;
+    reinterpret_cast<float2*>(out)[e] = o;
+    (void)halfC;
+}
+}  // namespace
+}  // namespace dr
+
+extern "C" int dr_rotary_f32(int rows, int C, const float* x, const float* cos_t, const float* sin_t, int inverse, float scale, float* out,
+                             void* stream) {
+    if (rows < 0 || C < 2 || (C & 1) || !x || !cos_t || !sin_t || !out) return DR_EINVAL;
+    if (rows == 0) return DR_OK;
+    const long long n2 = (long long)rows * (C / 2);
+    hipLaunchKernelGGL(dr::rotary_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n2, C / 2, x, cos_t, sin_t,
+                       inverse ? -1.0f : 1.0f, scale, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}

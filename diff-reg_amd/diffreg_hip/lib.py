@@ -141,6 +141,7 @@ SIGNATURES.update({
                                   c_void_p]),
     "dr_match_recall_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_motion_l1_f32": (c_int, [c_int, c_int] + [c_void_p] * 10),
+    "dr_rotary_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "dr_focal_loss_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "dr_sinkhorn_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_sinkhorn_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -409,6 +410,16 @@ def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
     check(_lib.dr_motion_l1_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(loss),
                                 ptr(ws), stream_of(s_pcd)))
     return loss
+
+
+def rotary(x, cos_t, sin_t, inverse=False, scale=1.0):
+    """embed_rotary on rows [rows, C] with half tables [rows, C/2] (inverse = its transpose)"""
+    ensure_init()
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    rows, C = x.reshape(-1, x.shape[-1]).shape
+    check(_lib.dr_rotary_f32(rows, C, ptr(x), ptr(cos_t.contiguous()), ptr(sin_t.contiguous()), 1 if inverse else 0, float(scale), ptr(out), stream_of(x)))
+    return out
 
 
 def focal_loss_backward(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0):

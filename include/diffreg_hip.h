@@ -573,6 +573,9 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
  *   saw them (masked entries -inf), the masks (both or none), bin_score, iters, grad_conf = d loss / d conf [P,N,M] ->
  *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32; every
  *   reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
+/* embed_rotary (position_encoding.py:25-35) on contiguous rows [rows, C]: out = R(theta) x * scale with cos / sin [rows, C/2]; inverse != 0:
+ * R(-theta), the transpose = the backward of the embedding */
+int dr_rotary_f32(int rows, int C, const float* x, const float* cos_t, const float* sin_t, int inverse, float scale, float* out, void* stream);
 int dr_focal_loss_backward_f32(int P, int N, int M, const float* conf, const float* conf_gt, float alpha, float gamma, float pos_w, float neg_w,
                                float* grad_conf, void* workspace, void* stream);
 size_t dr_sinkhorn_backward_workspace_bytes(int P, int N, int M, int iters);

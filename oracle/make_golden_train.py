@@ -174,6 +174,34 @@ def main():
         bw[tag + "_grad_scores"] = sc.grad.numpy()
         bw[tag + "_grad_bin_score"] = np.float64(float(alpha.grad))
         print("backward", tag, "loss %.6f" % float(loss), "|grad_scores| max %.3e" % float(sc.grad.abs().max()), "grad_bin_score %.6e" % float(alpha.grad))
+    # ---- the whole matching head: autograd through the reference's Matching.forward (models/matching.py:164-216, sinkhorn, rotary code) and the
+    #      focal loss, down to the features, the shared projection weight (quirk Q1) and bin_score
+    from models.matching import Matching
+    from models.position_encoding import VolumetricPositionEncoding
+    cfgm = ref_config("3dmatch", 20, 200.0)
+    head = Matching(cfgm.coarse_matching)
+    head.load_state_dict({k[len("coarse_matching."):]: T(a) for k, a in Wnp.items() if k.startswith("coarse_matching.")})
+    pe_mod = VolumetricPositionEncoding(cfgm.coarse_transformer)
+    c1 = None
+    from tests.helpers import train_case
+    c1 = train_case("b2")
+    fs = (c1["f_s"] * 0.2).clone().requires_grad_(True)
+    ft = (c1["f_t"] * 0.2).clone().requires_grad_(True)
+    smk = torch.arange(c1["N"])[None].expand(c1["B"], -1) < 57
+    tmk = torch.arange(c1["M"])[None].expand(c1["B"], -1) < 60
+    with torch.enable_grad():
+        conf_h, _ = head(fs, ft, pe_mod(c1["p_s"]), pe_mod(c1["p_t"]), smk, tmk, {}, pe_type="rotary")
+        gt_h = torch.zeros_like(conf_h)
+        for b_, m_ in enumerate(c1["matches"]):
+            keep = (m_[0] < 57) & (m_[1] < 60)
+            gt_h[b_][m_[0][keep], m_[1][keep]] = 1
+        loss_h = MatchMotionLoss(dict(LOSS_CFG)).compute_correspondence_loss(conf_h, gt_h)
+        loss_h.backward()
+    bw.update(head_loss=np.float64(float(loss_h)), head_conf=conf_h.detach().numpy(), head_gt=gt_h.numpy(), head_grad_src=fs.grad.numpy(),
+              head_grad_tgt=ft.grad.numpy(), head_grad_weight=head.src_proj.weight.grad.numpy(), head_grad_bin_score=np.float64(float(head.bin_score.grad)))
+    assert head.tgt_proj.weight.grad is None                     # (allocated, never used: quirk Q1)
+    print("backward head loss %.6f |g_src| %.3e |g_W| %.3e g_bin %.3e" % (float(loss_h), float(fs.grad.abs().max()), float(head.src_proj.weight.grad.abs().max()),
+                                                                         float(head.bin_score.grad)))
     np.savez_compressed(OUT.replace("train_forward", "train_backward"), **bw)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

@@ -185,3 +185,30 @@ def test_autograd_wrappers(tag):
     ref = GB[tag + "_grad_scores"]
     assert np.abs(sc.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
     assert abs(float(alpha.grad) - float(GB[tag + "_grad_bin_score"])) <= 2e-4 * abs(float(GB[tag + "_grad_bin_score"])) + 1e-7
+
+
+def test_matching_head_backward_to_features_and_weights():
+    """diffreg_hip.autograd.matching_head (Matching.forward, sinkhorn + rotary code) + focal_loss: loss.backward() against torch autograd through
+    the reference's own Matching.forward (tests/golden/train_backward.npz: head_*), masks included"""
+    from diffreg_hip.autograd import focal_loss, matching_head
+    from models.position_encoding import VolumetricPositionEncoding
+    c = train_case("b2")
+    cfg = ref_like_config("3dmatch", 20, 200.0)
+    pe_mod = VolumetricPositionEncoding(cfg.coarse_transformer)
+    W = train_weights()
+    w = W["coarse_matching.src_proj.weight"].to(DEV).requires_grad_(True)
+    bs = W["coarse_matching.bin_score"].to(DEV).requires_grad_(True)
+    fs = (c["f_s"] * 0.2).to(DEV).requires_grad_(True)
+    ft = (c["f_t"] * 0.2).to(DEV).requires_grad_(True)
+    sm = (torch.arange(c["N"])[None].expand(c["B"], -1) < 57).to(DEV)
+    tm = (torch.arange(c["M"])[None].expand(c["B"], -1) < 60).to(DEV)
+    conf = matching_head(fs, ft, w, bs, pe_mod(c["p_s"].to(DEV)), pe_mod(c["p_t"].to(DEV)), sm, tm, 3)
+    assert np.abs(conf.detach().cpu().numpy() - GB["head_conf"]).max() < 1e-4
+    loss = focal_loss(conf, torch.from_numpy(GB["head_gt"]).to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(GB["head_loss"])) <= 1e-4 * float(GB["head_loss"]) + 1e-7
+    for got, key in ((fs.grad, "head_grad_src"), (ft.grad, "head_grad_tgt"), (w.grad, "head_grad_weight")):
+        ref = GB[key]
+        err = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= 2e-3, (key, err)
+    assert abs(float(bs.grad) - float(GB["head_grad_bin_score"])) <= 2e-3 * abs(float(GB["head_grad_bin_score"]))
