@@ -538,3 +538,157 @@ extern "C" int dr_rotary_f32(int rows, int C, const float* x, const float* cos_t
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
+
+// ===============================================================================================================================
+// Pieces of the GeometryAttentionLayer backward (3D/models/transformero.py:43-96) that are not GEMMs: LayerNorm forward with saved
+// statistics + backward, the masked row softmax of the explicit attention matrix + its backward, ReLU backward.  The GEMMs of the
+// backward run on dr_linear_f32; diffreg_hip/autograd.py composes them.  One wave per row; parameter gradients of LayerNorm through a
+// fixed grid of partials (bit-reproducible).
+// ===============================================================================================================================
+namespace dr {
+namespace {
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                     float eps, float* __restrict__ y, float* __restrict__ stats) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (xr[c] - mean) * rstd * g[c] + b[c];
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+constexpr int LNB_BLOCKS = 256;
+// gx = rstd (g gy - mean_c(g gy) - xhat mean_c(g gy xhat));  partial sums of gy xhat and gy over this block's rows
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ stats,
+                                                     const float* __restrict__ gy, float* __restrict__ gx, float* __restrict__ part) {
+    extern __shared__ float sp[];                      // [4 waves][2][C]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* pg = sp + (size_t)w * 2 * C;
+    float* pb = pg + C;
+    for (int c = lane; c < C; c += 64) { pg[c] = 0.f; pb[c] = 0.f; }
+    for (int row = blockIdx.x * 4 + w; row < rows; row += LNB_BLOCKS * 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float* xr = x + (size_t)row * C;
+        const float* gr = gy + (size_t)row * C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, d = gr[c] * g[c];
+            s1 += d; s2 = fmaf(d, xh, s2);
+            pg[c] = fmaf(gr[c], xh, pg[c]); pb[c] += gr[c];
+        }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mean) * rstd;
+            gx[(size_t)row * C + c] = rstd * (gr[c] * g[c] - s1 - xh * s2);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const float v = sp[c] + sp[2 * C + c] + sp[4 * C + c] + sp[6 * C + c];
+        part[(size_t)blockIdx.x * 2 * C + c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(int C, const float* __restrict__ part, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s = 0.f;
+    for (int k = 0; k < LNB_BLOCKS; ++k) s += part[(size_t)k * 2 * C + c];
+    if (c < C) ggamma[c] = s; else gbeta[c - C] = s;
+}
+
+// P[r][:] = softmax(scale s[r][:]) over the keys; rows r = ((b H + h) L + l); a key j of batch b is masked (-inf) when q_mask[b][l] && !k_mask[b][j]
+__global__ __launch_bounds__(256) void softmax_rows_kernel(int rows, int cols, int L, int H, const float* __restrict__ s, float scale,
+                                                           const uint8_t* __restrict__ qm, const uint8_t* __restrict__ km, float* __restrict__ P) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int l = row % L, b = row / (L * H);
+    const bool qv = qm ? qm[(size_t)b * L + l] != 0 : true;
+    const float* sr = s + (size_t)row * cols;
+    float mx = -INFINITY;
+    for (int j = lane; j < cols; j += 64) {
+        const bool dead = km && qv && !km[(size_t)b * cols + j];
+        if (!dead) mx = fmaxf(mx, sr[j] * scale);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < cols; j += 64) {
+        const bool dead = km && qv && !km[(size_t)b * cols + j];
+        if (!dead) sum += expf(sr[j] * scale - mx);
+    }
+    sum = wave_sum(sum);
+    for (int j = lane; j < cols; j += 64) {
+        const bool dead = km && qv && !km[(size_t)b * cols + j];
+        P[(size_t)row * cols + j] = dead ? 0.f : expf(sr[j] * scale - mx) / sum;
+    }
+}
+// dS = scale P (dP - sum_j dP_j P_j)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int rows, int cols, const float* __restrict__ P, const float* __restrict__ dP, float scale,
+                                                          float* __restrict__ dS) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = P + (size_t)row * cols;
+    const float* d = dP + (size_t)row * cols;
+    float s = 0.f;
+    for (int j = lane; j < cols; j += 64) s = fmaf(p[j], d[j], s);
+    s = wave_sum(s);
+    for (int j = lane; j < cols; j += 64) dS[(size_t)row * cols + j] = scale * p[j] * (d[j] - s);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(long long n, const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) gx[e] = y[e] > 0.f ? gy[e] : 0.f;
+}
+
+}  // namespace
+}  // namespace dr
+
+extern "C" {
+
+int dr_layernorm_f32(int rows, int C, const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean_rstd, void* stream) {
+    if (rows < 0 || C < 1 || !x || !gamma || !beta || !y || !mean_rstd) return DR_EINVAL;
+    if (rows == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, C, x, gamma, beta, eps, y, mean_rstd);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+size_t dr_layernorm_backward_workspace_bytes(int C) { return C > 0 ? (size_t)dr::LNB_BLOCKS * 2 * C * sizeof(float) : 0; }
+int dr_layernorm_backward_f32(int rows, int C, const float* x, const float* gamma, const float* mean_rstd, const float* grad_y, float* grad_x,
+                              float* grad_gamma, float* grad_beta, void* workspace, void* stream) {
+    if (rows < 1 || C < 1 || C > 4096 || !x || !gamma || !mean_rstd || !grad_y || !grad_x || !grad_gamma || !grad_beta || !workspace) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dr::ln_bwd_kernel, dim3(dr::LNB_BLOCKS), dim3(256), (size_t)8 * C * sizeof(float), st, rows, C, x, gamma, mean_rstd, grad_y, grad_x,
+                       (float*)workspace);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::ln_bwd_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, C, (const float*)workspace, grad_gamma, grad_beta);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int dr_softmax_rows_f32(int B, int H, int L, int S, const float* scores, float scale, const uint8_t* q_mask, const uint8_t* k_mask, float* P, void* stream) {
+    if (B < 0 || H < 1 || L < 1 || S < 1 || !scores || !P || ((q_mask == nullptr) != (k_mask == nullptr))) return DR_EINVAL;
+    const int rows = B * H * L;
+    if (rows == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, S, L, H, scores, scale, q_mask, k_mask, P);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int dr_softmax_backward_f32(int rows, int cols, const float* P, const float* grad_P, float scale, float* grad_scores, void* stream) {
+    if (rows < 0 || cols < 1 || !P || !grad_P || !grad_scores) return DR_EINVAL;
+    if (rows == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, cols, P, grad_P, scale, grad_scores);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float* grad_x, void* stream) {
+    if (n < 0 || !y || !grad_y || !grad_x) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    hipLaunchKernelGGL(dr::relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, y, grad_y, grad_x);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
+}  // extern "C"

@@ -87,6 +87,113 @@ class _MatchingHead(torch.autograd.Function):
         return g_src, g_tgt, g_W, ga.reshape(bin_score.shape).to(bin_score.dtype), None, None, None, None, None, None, None
 
 
+def _mm(a, b):
+    """a [R,K] @ b[N,K]^T on dr_linear_f32 (K padded to a multiple of 4: the kernel's vector width)"""
+    a, b = a.contiguous(), b.contiguous()
+    pad = (-a.shape[1]) % 4
+    if pad:
+        a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
+    return lib.linear(a, b)
+
+
+_LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight", "norm1.weight", "norm1.bias",
+               "norm2.weight", "norm2.bias")
+
+
+class _GeometryAttentionLayer(torch.autograd.Function):
+    """GeometryAttentionLayer.forward (3D/models/transformero.py:43-96, rotary code) with the attention matrix made explicit, and its backward:
+    LayerNorm / softmax / ReLU / rotary backward kernels (csrc/train.hip) + every product on dr_linear_f32.  A first, unfused backward: it
+    keeps [B,H,L,S] matrices in memory and loops over (batch, head) for the per-head products."""
+
+    @staticmethod
+    def forward(ctx, x, source, cx, sx, cy, sy, x_mask, source_mask, H, Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2):
+        B, L, C = x.shape
+        S = source.shape[1]
+        d = C // H
+        det = lambda t: t.detach().float().contiguous()
+        x2, s2 = det(x).reshape(B * L, C), det(source).reshape(B * S, C)
+        Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2 = map(det, (Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2))
+        qw = lib.linear(x2, Wq, epilogue=2, cos=cx, sin=sx, rot_C=C)
+        kw = lib.linear(s2, Wk, epilogue=2, cos=cy, sin=sy, rot_C=C)
+        vw = lib.linear(s2, Wv)
+        heads = lambda t, n: t.view(B, n, H, d).permute(0, 2, 1, 3).contiguous()
+        q4, k4, v4 = heads(qw, L), heads(kw, S), heads(vw, S)
+        scores = torch.stack([torch.stack([_mm(q4[b, h], k4[b, h]) for h in range(H)]) for b in range(B)])
+        scale = 1.0 / d ** 0.5
+        P = lib.softmax_rows(scores, scale, x_mask, source_mask)
+        o4 = torch.stack([torch.stack([_mm(P[b, h], v4[b, h].t()) for h in range(H)]) for b in range(B)])       # [B,H,L,d]
+        o2 = o4.permute(0, 2, 1, 3).reshape(B * L, C).contiguous()
+        m_pre = lib.linear(o2, Wm)
+        m, st1 = lib.layernorm(m_pre, g1, b1)
+        cat = torch.cat([x2, m], 1)
+        h = lib.linear(cat, W0, epilogue=1)
+        f_pre = lib.linear(h, W2)
+        f, st2 = lib.layernorm(f_pre, g2, b2)
+        ctx.save_for_backward(x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2)
+        ctx.dims = (B, L, S, C, H, d, scale)
+        return (x2 + f).view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, ge):
+        (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2) = ctx.saved_tensors
+        B, L, S, C, H, d, scale = ctx.dims
+        tr = lambda t: t.transpose(-1, -2).contiguous()
+        ge = ge.contiguous().float().reshape(B * L, C)
+        g_fpre, gg2, gb2 = lib.layernorm_backward(f_pre, g2, st2, ge)
+        g_h = lib.relu_backward(h, _mm(g_fpre, tr(W2)))
+        gW2 = _mm(tr(g_fpre), tr(h))
+        g_cat = _mm(g_h, tr(W0))
+        gW0 = _mm(tr(g_h), tr(cat))
+        g_x = ge + g_cat[:, :C]
+        g_mpre, gg1, gb1 = lib.layernorm_backward(m_pre, g1, st1, g_cat[:, C:].contiguous())
+        g_o2 = _mm(g_mpre, tr(Wm))
+        gWm = _mm(tr(g_mpre), tr(o2))
+        g_o4 = g_o2.view(B, L, H, d).permute(0, 2, 1, 3).contiguous()
+        dV = torch.stack([torch.stack([_mm(tr(P[b, hh]), tr(g_o4[b, hh])) for hh in range(H)]) for b in range(B)])        # [B,H,S,d]
+        dP = torch.stack([torch.stack([_mm(g_o4[b, hh], v4[b, hh]) for hh in range(H)]) for b in range(B)])              # [B,H,L,S]
+        dS = lib.softmax_backward(P, dP, scale)
+        dQ = torch.stack([torch.stack([_mm(dS[b, hh], tr(k4[b, hh])) for hh in range(H)]) for b in range(B)])            # [B,H,L,d]
+        dK = torch.stack([torch.stack([_mm(tr(dS[b, hh]), tr(q4[b, hh])) for hh in range(H)]) for b in range(B)])        # [B,H,S,d]
+        merge = lambda t, n: t.permute(0, 2, 1, 3).reshape(B * n, C).contiguous()
+        g_qpre = lib.rotary(merge(dQ, L), cx, sx, inverse=True)
+        g_kpre = lib.rotary(merge(dK, S), cy, sy, inverse=True)
+        g_vw = merge(dV, S)
+        g_x = g_x + _mm(g_qpre, tr(Wq))
+        g_s = _mm(g_kpre, tr(Wk)) + _mm(g_vw, tr(Wv))
+        gWq, gWk, gWv = _mm(tr(g_qpre), tr(x2)), _mm(tr(g_kpre), tr(s2)), _mm(tr(g_vw), tr(s2))
+        return (g_x.view(B, L, C), g_s.view(B, S, C), None, None, None, None, None, None, None, gWq, gWk, gWv, gWm, gW0, gW2, gg1, gb1, gg2, gb2)
+
+
+def geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask=None, source_mask=None):
+    """differentiable GeometryAttentionLayer.forward for a `models.transformero.GeometryAttentionLayer` module (its parameters receive gradients)"""
+    from models.position_encoding import half_tables
+    cx, sx = half_tables(x_pe)
+    cy, sy = half_tables(source_pe)
+    p = dict(layer.named_parameters())
+    return _GeometryAttentionLayer.apply(x, source, cx, sx, cy, sy, x_mask, source_mask, layer.nhead, *[p[k] for k in _LAYER_KEYS])
+
+
+def denoising_branch(pipeline, src_feats, tgt_feats, src_pcd_wrapped, tgt_pcd_wrapped, src_mask, tgt_mask):
+    """The denoising half of the training forward, differentiable (3D/models/pipeline.py:209-212): denoising_transformer (six self / cross
+    GeometryAttentionLayers on the position code of the warped source) + denoising_coarse_matching -> conf_matrix_gt_hat.  Gradients reach every
+    parameter of the two modules and the backbone features; the warped points (from the noised ground-truth matrix: no parameters) are constants,
+    exactly as in the reference's graph."""
+    tr = pipeline.denoising_transformer
+    src_pe, tgt_pe = tr.positional_encoding(src_pcd_wrapped), tr.positional_encoding(tgt_pcd_wrapped)
+    s, t = src_feats, tgt_feats
+    for layer, name in zip(tr.layers, tr.layer_types):
+        if name == "self":
+            s = geometry_attention_layer(layer, s, s, src_pe, src_pe, src_mask, src_mask)
+            t = geometry_attention_layer(layer, t, t, tgt_pe, tgt_pe, tgt_mask, tgt_mask)
+        elif name == "cross":
+            s = geometry_attention_layer(layer, s, t, src_pe, tgt_pe, src_mask, tgt_mask)
+            t = geometry_attention_layer(layer, t, s, tgt_pe, src_pe, tgt_mask, src_mask)          # the updated src (quirk Q11)
+        else:
+            raise NotImplementedError("positioning layers (Procrustes inside the transformer) have no backward")
+    m = pipeline.denoising_coarse_matching
+    return matching_head(s, t, m.src_proj.weight, m.bin_score, src_pe, tgt_pe, src_mask, tgt_mask, m.skh_iters)
+
+
 def matching_head(src_feats, tgt_feats, weight, bin_score, src_pe, tgt_pe, src_mask, tgt_mask, iters):
     """differentiable Matching.forward (sinkhorn, rotary): src_pe / tgt_pe = the position codes [B,N,C,2] of VolumetricPositionEncoding"""
     from models.position_encoding import half_tables

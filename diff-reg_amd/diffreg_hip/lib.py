@@ -141,6 +141,12 @@ SIGNATURES.update({
                                   c_void_p]),
     "dr_match_recall_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_motion_l1_f32": (c_int, [c_int, c_int] + [c_void_p] * 10),
+    "dr_layernorm_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "dr_layernorm_backward_workspace_bytes": (c_size_t, [c_int]),
+    "dr_layernorm_backward_f32": (c_int, [c_int, c_int] + [c_void_p] * 9),
+    "dr_softmax_rows_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_softmax_backward_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "dr_relu_backward_f32": (c_int, [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_rotary_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "dr_focal_loss_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "dr_sinkhorn_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -410,6 +416,55 @@ def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
     check(_lib.dr_motion_l1_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(loss),
                                 ptr(ws), stream_of(s_pcd)))
     return loss
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    """nn.LayerNorm over the last dim -> (y, mean_rstd [rows,2])"""
+    ensure_init()
+    x = x.contiguous().float()
+    rows, C = x.reshape(-1, x.shape[-1]).shape
+    y = torch.empty_like(x)
+    st = torch.empty(rows, 2, device=x.device)
+    check(_lib.dr_layernorm_f32(rows, C, ptr(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, ptr(y), ptr(st), stream_of(x)))
+    return y, st
+
+
+def layernorm_backward(x, gamma, mean_rstd, grad_y):
+    ensure_init()
+    x, grad_y = x.contiguous().float(), grad_y.contiguous().float()
+    rows, C = x.reshape(-1, x.shape[-1]).shape
+    gx = torch.empty_like(x)
+    gg, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    ws = torch.empty(_lib.dr_layernorm_backward_workspace_bytes(C), dtype=torch.uint8, device=x.device)
+    check(_lib.dr_layernorm_backward_f32(rows, C, ptr(x), ptr(gamma.contiguous()), ptr(mean_rstd), ptr(grad_y), ptr(gx), ptr(gg), ptr(gb), ptr(ws), stream_of(x)))
+    return gx, gg, gb
+
+
+def softmax_rows(scores, scale, q_mask=None, k_mask=None):
+    """scores [B,H,L,S] -> softmax over S of scale * scores with the layer's key mask"""
+    ensure_init()
+    scores = scores.contiguous().float()
+    B, H, L, S = scores.shape
+    P = torch.empty_like(scores)
+    qm, km = mask_u8(q_mask), mask_u8(k_mask)
+    check(_lib.dr_softmax_rows_f32(B, H, L, S, ptr(scores), float(scale), ptr(qm), ptr(km), ptr(P), stream_of(scores)))
+    return P
+
+
+def softmax_backward(P, grad_P, scale):
+    ensure_init()
+    P, grad_P = P.contiguous(), grad_P.contiguous().float()
+    out = torch.empty_like(P)
+    check(_lib.dr_softmax_backward_f32(P.numel() // P.shape[-1], P.shape[-1], ptr(P), ptr(grad_P), float(scale), ptr(out), stream_of(P)))
+    return out
+
+
+def relu_backward(y, grad_y):
+    ensure_init()
+    y, grad_y = y.contiguous(), grad_y.contiguous().float()
+    out = torch.empty_like(y)
+    check(_lib.dr_relu_backward_f32(y.numel(), ptr(y), ptr(grad_y), ptr(out), stream_of(y)))
+    return out
 
 
 def rotary(x, cos_t, sin_t, inverse=False, scale=1.0):

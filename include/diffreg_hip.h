@@ -573,6 +573,19 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
  *   saw them (masked entries -inf), the masks (both or none), bin_score, iters, grad_conf = d loss / d conf [P,N,M] ->
  *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32; every
  *   reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
+/* The non-GEMM pieces of the GeometryAttentionLayer backward (transformero.py:43-96; composed with dr_linear_f32 by diffreg_hip/autograd.py):
+ * nn.LayerNorm forward with saved statistics (mean_rstd [rows,2]) and its backward (grad_x, grad_gamma, grad_beta; workspace:
+ * dr_layernorm_backward_workspace_bytes(C)); the masked softmax of an explicit attention matrix scores [B,H,L,S] over S (a key j is -inf
+ * for a valid query: q_mask[b][l] && !k_mask[b][j], transformero.py:78-79; then / sqrt(d) = `scale`) and its backward
+ * dS = scale P (dP - sum_j dP_j P_j); ReLU backward. */
+int dr_layernorm_f32(int rows, int C, const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean_rstd, void* stream);
+size_t dr_layernorm_backward_workspace_bytes(int C);
+int dr_layernorm_backward_f32(int rows, int C, const float* x, const float* gamma, const float* mean_rstd, const float* grad_y, float* grad_x,
+                              float* grad_gamma, float* grad_beta, void* workspace, void* stream);
+int dr_softmax_rows_f32(int B, int H, int L, int S, const float* scores, float scale, const uint8_t* q_mask, const uint8_t* k_mask, float* P, void* stream);
+int dr_softmax_backward_f32(int rows, int cols, const float* P, const float* grad_P, float scale, float* grad_scores, void* stream);
+int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float* grad_x, void* stream);
+
 /* embed_rotary (position_encoding.py:25-35) on contiguous rows [rows, C]: out = R(theta) x * scale with cos / sin [rows, C/2]; inverse != 0:
  * R(-theta), the transpose = the backward of the embedding */
 int dr_rotary_f32(int rows, int C, const float* x, const float* cos_t, const float* sin_t, int inverse, float scale, float* out, void* stream);

@@ -202,6 +202,52 @@ def main():
     assert head.tgt_proj.weight.grad is None                     # (allocated, never used: quirk Q1)
     print("backward head loss %.6f |g_src| %.3e |g_W| %.3e g_bin %.3e" % (float(loss_h), float(fs.grad.abs().max()), float(head.src_proj.weight.grad.abs().max()),
                                                                          float(head.bin_score.grad)))
+    # ---- one GeometryAttentionLayer (models/transformero.py:43-96): autograd through the reference's module, cross attention with masks
+    from models.transformero import GeometryAttentionLayer
+    lay = GeometryAttentionLayer(cfgm.coarse_transformer)
+    pre = "denoising_transformer.layers.1."
+    lay.load_state_dict({k[len(pre):]: T(a) for k, a in Wnp.items() if k.startswith(pre)})
+    pr = synth.make_pair(64, 48, C, seed=3)
+    xs = (T(pr["src_feats"])[None] * 0.5).clone().requires_grad_(True)
+    ys = (T(pr["tgt_feats"])[None] * 0.5).clone().requires_grad_(True)
+    pxs, pys = pe_mod(T(pr["s_pcd"])[None]), pe_mod(T(pr["t_pcd"])[None])
+    xm, ym = torch.arange(64)[None] < 50, torch.arange(48)[None] < 41
+    Rw = T(synth.hash_normal(3, 800, (1, 64, C)).astype(np.float32))
+    with torch.enable_grad():
+        e = lay(xs, ys, pxs, pys, xm, ym)
+        (e * Rw).sum().backward()
+    bw.update(layer_out=e.detach().numpy(), layer_grad_x=xs.grad.numpy(), layer_grad_source=ys.grad.numpy())
+    for k, prm in lay.named_parameters():
+        gq = prm.grad
+        bw["layer_grad_" + k] = (gq[::6, ::6] if gq.dim() == 2 else gq).numpy()
+        bw["layer_gradnorm_" + k] = np.float64(float(gq.double().norm()))
+    print("backward layer |e| %.3f |g_x| %.3e |g_src| %.3e" % (float(e.abs().max()), float(xs.grad.abs().max()), float(ys.grad.abs().max())))
+    # ---- the denoising branch of the training loss end to end (pipeline.py:209-212 + loss.py:160-163): reference modules, reference autograd
+    cfg_d = ref_config("3dmatch", 20, 200.0)
+    cfg_d.kpfcn_config["architecture"] = architectures["3dmatch"]
+    pipe = Pipeline(cfg_d)
+    sd = pipe.state_dict()
+    for k, a in Wnp.items():
+        sd[k] = T(a)
+    pipe.load_state_dict(sd)
+    cb = train_case("b1")
+    fs_d = (cb["f_s"] * 0.5).clone().requires_grad_(True)
+    ft_d = (cb["f_t"] * 0.5).clone().requires_grad_(True)
+    warped = T(out["b1_src_warped"])
+    with torch.enable_grad():
+        s_n, t_n, pe_s, pe_t = pipe.denoising_transformer(fs_d, ft_d, warped, cb["p_t"], cb["src_mask"], cb["tgt_mask"], {})
+        hat, _ = pipe.denoising_coarse_matching(s_n, t_n, pe_s, pe_t, cb["src_mask"], cb["tgt_mask"], {}, pe_type="rotary")
+        gt_d = torch.zeros_like(hat)
+        gt_d[0][cb["matches"][0][0], cb["matches"][0][1]] = 1
+        loss_d = MatchMotionLoss(dict(LOSS_CFG)).compute_correspondence_loss(hat, gt_d)
+        loss_d.backward()
+    bw.update(branch_loss=np.float64(float(loss_d)), branch_conf=hat.detach().numpy(), branch_grad_src=fs_d.grad.numpy(), branch_grad_tgt=ft_d.grad.numpy())
+    for k, prm in list(pipe.denoising_transformer.named_parameters()) + [("head." + k2, p2) for k2, p2 in pipe.denoising_coarse_matching.named_parameters()]:
+        if prm.grad is not None:
+            bw["branch_gradnorm_" + k] = np.float64(float(prm.grad.double().norm()))
+    bw["branch_grad_layers.0.q_proj.weight"] = pipe.denoising_transformer.layers[0].q_proj.weight.grad[::6, ::6].numpy()
+    bw["branch_grad_layers.5.mlp.2.weight"] = pipe.denoising_transformer.layers[5].mlp[2].weight.grad[::6, ::6].numpy()
+    print("backward branch loss %.6f |g_src| %.3e" % (float(loss_d), float(fs_d.grad.abs().max())), "params with grad:", sum(1 for k in bw if k.startswith("branch_gradnorm_")))
     np.savez_compressed(OUT.replace("train_forward", "train_backward"), **bw)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

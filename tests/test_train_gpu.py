@@ -212,3 +212,117 @@ def test_matching_head_backward_to_features_and_weights():
         err = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
         assert err <= 2e-3, (key, err)
     assert abs(float(bs.grad) - float(GB["head_grad_bin_score"])) <= 2e-3 * abs(float(GB["head_grad_bin_score"]))
+
+
+def test_layer_pieces_against_torch():
+    """LayerNorm forward / backward, masked row softmax / backward, ReLU backward against torch autograd of the same ops"""
+    g = torch.Generator().manual_seed(11)
+    rows, C = 777, 432
+    x = torch.randn(rows, C, generator=g).to(DEV).requires_grad_(True)
+    gam = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    bet = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(rows, C, generator=g).to(DEV)
+    y_ref = torch.nn.functional.layer_norm(x, (C,), gam, bet, 1e-5)
+    y_ref.backward(gy)
+    y, st = lib.layernorm(x.detach(), gam.detach(), bet.detach())
+    gx, gg, gb = lib.layernorm_backward(x.detach(), gam.detach(), st, gy)
+    assert (y - y_ref).abs().max().item() < 2e-5
+    assert (gx - x.grad).abs().max().item() < 1e-4 * x.grad.abs().max().item()
+    assert (gg - gam.grad).abs().max().item() < 1e-4 * gam.grad.abs().max().item()
+    assert (gb - bet.grad).abs().max().item() < 1e-4 * bet.grad.abs().max().item()
+    B, H, L, S = 2, 4, 50, 70
+    sc = torch.randn(B, H, L, S, generator=g).to(DEV).requires_grad_(True)
+    qm = (torch.arange(L)[None].expand(B, -1) < 44).to(DEV)
+    km = (torch.arange(S)[None].expand(B, -1) < 61).to(DEV)
+    a = sc.masked_fill(qm[:, None, :, None] & ~km[:, None, None, :], float("-inf")) * 0.3
+    P_ref = torch.softmax(a, dim=3)
+    dP = torch.randn(B, H, L, S, generator=g).to(DEV)
+    P_ref.backward(dP)
+    P = lib.softmax_rows(sc.detach(), 0.3, qm, km)
+    assert (P - P_ref).abs().max().item() < 1e-6
+    dS = lib.softmax_backward(P, dP, 0.3)
+    assert (dS - sc.grad).abs().max().item() < 1e-5 * max(1.0, sc.grad.abs().max().item())
+    yv = torch.randn(1000, generator=g).to(DEV)
+    gv = torch.randn(1000, generator=g).to(DEV)
+    assert torch.equal(lib.relu_backward(yv, gv), torch.where(yv > 0, gv, torch.zeros_like(gv)))
+
+
+def test_attention_layer_backward_against_reference_autograd():
+    """diffreg_hip.autograd.geometry_attention_layer on a models.transformero.GeometryAttentionLayer: output = the production forward kernel's
+    (dr_attention_layer_f32) and = the reference's; input and parameter gradients = torch autograd through the reference's module (cross attention,
+    masks; tests/golden/train_backward.npz: layer_*)"""
+    from diffreg_hip.autograd import geometry_attention_layer
+    from models.position_encoding import VolumetricPositionEncoding
+    from models.transformero import GeometryAttentionLayer
+    C = synth.VARIANTS["3dmatch"]["C"]
+    cfg = ref_like_config("3dmatch", 20, 200.0)
+    layer = GeometryAttentionLayer(cfg.coarse_transformer)
+    pre = "denoising_transformer.layers.1."
+    layer.load_state_dict({k[len(pre):]: a for k, a in train_weights().items() if k.startswith(pre)})
+    layer = layer.to(DEV)
+    pe_mod = VolumetricPositionEncoding(cfg.coarse_transformer)
+    from tests.helpers import T
+    pr = synth.make_pair(64, 48, C, seed=3)
+    x = (T(pr["src_feats"])[None] * 0.5).to(DEV).requires_grad_(True)
+    y = (T(pr["tgt_feats"])[None] * 0.5).to(DEV).requires_grad_(True)
+    px, py = pe_mod(T(pr["s_pcd"])[None].to(DEV)), pe_mod(T(pr["t_pcd"])[None].to(DEV))
+    xm, ym = (torch.arange(64)[None] < 50).to(DEV), (torch.arange(48)[None] < 41).to(DEV)
+    e = geometry_attention_layer(layer, x, y, px, py, xm, ym)
+    assert np.abs(e.detach().cpu().numpy() - GB["layer_out"]).max() < 1e-4
+    with torch.no_grad():
+        prod = layer(x.detach(), y.detach(), px, py, xm, ym)
+    assert (prod - e.detach()).abs().max().item() < 1e-4
+    Rw = T(synth.hash_normal(3, 800, (1, 64, C)).astype(np.float32)).to(DEV)
+    (e * Rw).sum().backward()
+    for got, key in ((x.grad, "layer_grad_x"), (y.grad, "layer_grad_source")):
+        ref = GB[key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), key
+    for k, prm in layer.named_parameters():
+        gq, ref = prm.grad, GB["layer_grad_" + k]
+        sub = (gq[::6, ::6] if gq.dim() == 2 else gq).cpu().numpy()
+        assert np.abs(sub - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), k
+        assert abs(float(gq.double().norm()) - float(GB["layer_gradnorm_" + k])) <= 1e-3 * float(GB["layer_gradnorm_" + k]), k
+
+
+def test_denoising_branch_backward_end_to_end():
+    """The denoising half of the training loss, differentiable on the device (diffreg_hip.autograd.denoising_branch + focal_loss): six
+    GeometryAttentionLayers + the matching head, 62 parameter tensors.  Loss, conf, the gradients of the backbone features and the gradient norm
+    of every parameter (+ two weight gradients entry-wise) against torch autograd through the reference's modules."""
+    from diffreg_hip.autograd import denoising_branch, focal_loss
+    from models.pipeline import Pipeline
+    c = train_case("b1")
+    model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
+    sd = model.state_dict()
+    for k, a in train_weights().items():
+        sd[k] = a
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_forward.npz"))
+    fs = (c["f_s"] * 0.5).to(DEV).requires_grad_(True)
+    ft = (c["f_t"] * 0.5).to(DEV).requires_grad_(True)
+    warped = torch.from_numpy(G["b1_src_warped"]).to(DEV)
+    hat = denoising_branch(model, fs, ft, warped, c["p_t"].to(DEV), c["src_mask"].to(DEV), c["tgt_mask"].to(DEV))
+    d = np.abs(hat.detach().cpu().numpy() - GB["branch_conf"])
+    assert (d > 1e-4).mean() <= 1e-3 and d.max() < 2e-3
+    gt = torch.zeros_like(hat)
+    gt[0][c["matches"][0][0].to(DEV), c["matches"][0][1].to(DEV)] = 1
+    loss = focal_loss(hat, gt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(GB["branch_loss"])) <= 2e-3 * float(GB["branch_loss"])
+    for got, key in ((fs.grad, "branch_grad_src"), (ft.grad, "branch_grad_tgt")):
+        ref = GB[key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), (key, np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max())
+    named = list(model.denoising_transformer.named_parameters()) + [("head." + k, p) for k, p in model.denoising_coarse_matching.named_parameters()]
+    checked = 0
+    for k, prm in named:
+        key = "branch_gradnorm_" + k
+        if key in GB.files:
+            assert prm.grad is not None, k
+            ref = float(GB[key])
+            assert abs(float(prm.grad.double().norm()) - ref) <= 2e-2 * ref + 1e-9, (k, float(prm.grad.double().norm()), ref)
+            checked += 1
+    assert checked == 62
+    for key, prm in (("branch_grad_layers.0.q_proj.weight", model.denoising_transformer.layers[0].q_proj.weight),
+                     ("branch_grad_layers.5.mlp.2.weight", model.denoising_transformer.layers[5].mlp[2].weight)):
+        ref = GB[key]
+        assert np.abs(prm.grad[::6, ::6].cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), key
