@@ -692,3 +692,59 @@ int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float
 }
 
 }  // extern "C"
+
+// d loss / d (R_pred, t_pred) of the L1 motion term (loss.py:108-128): e1 = sum_c |(R_p s + t_p)_c - (R_g s' + t_g)_c| averaged over the overlap rows of
+// the whole batch: dL/dR_p[b][c][j] = sum_i sign(d_ic) s_ij / n, dL/dt_p[b][c] = sum_i sign(d_ic) / n.  One workgroup per pair, rows in a fixed order.
+namespace dr {
+namespace {
+__global__ __launch_bounds__(256) void motion_bwd_kernel(MotionArgs A, const double* __restrict__ part, float* __restrict__ gR, float* __restrict__ gt) {
+    __shared__ float s_acc[4][12];
+    __shared__ float s_n;
+    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        double cnt = 0;
+        for (int k = 0; k < TR_BLOCKS; ++k) cnt += part[2 * k + 1];
+        s_n = (float)cnt;
+    }
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    const float* Rp = A.Rp + 9 * b; const float* Rg = A.Rg + 9 * b;
+    for (int i = threadIdx.x; i < A.N; i += 256) {
+        const size_t e = (size_t)b * A.N + i;
+        if (!A.mask[e]) continue;
+        const float x = A.s[3 * e], y = A.s[3 * e + 1], z = A.s[3 * e + 2];
+        float dx = x, dy = y, dz = z;
+        if (A.flow) { dx += A.flow[3 * e]; dy += A.flow[3 * e + 1]; dz += A.flow[3 * e + 2]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float wp = (Rp[3 * c] * x + Rp[3 * c + 1] * y + Rp[3 * c + 2] * z) + A.tp[3 * b + c];
+            const float wg = (Rg[3 * c] * dx + Rg[3 * c + 1] * dy + Rg[3 * c + 2] * dz) + A.tg[3 * b + c];
+            const float sc = c == 0 ? x : (c == 1 ? y : z);
+            const float d = (wp - sc) - (wg - sc);
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            acc[3 * c] += sg * x; acc[3 * c + 1] += sg * y; acc[3 * c + 2] += sg * z; acc[9 + c] += sg;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { const float v = wave_sum(acc[k]); if (lane == 0) s_acc[w][k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+        if (threadIdx.x < 9) gR[9 * b + threadIdx.x] = v / s_n; else gt[3 * b + threadIdx.x - 9] = v / s_n;
+    }
+}
+}  // namespace
+}  // namespace dr
+
+extern "C" int dr_motion_l1_backward_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
+                                         const float* t_gt, const uint8_t* overlap_mask, float* grad_R, float* grad_t, void* workspace, void* stream) {
+    if (P < 1 || N < 1 || !s_pcd || !R_pred || !t_pred || !R_gt || !t_gt || !overlap_mask || !grad_R || !grad_t || !workspace) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dr::MotionArgs A{s_pcd, flow, R_pred, t_pred, R_gt, t_gt, overlap_mask, P, N, (double*)workspace, nullptr};
+    hipLaunchKernelGGL(dr::motion_partial_kernel, dim3(dr::TR_BLOCKS), dim3(dr::TR_THREADS), 0, st, A);       // the number of overlap rows
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::motion_bwd_kernel, dim3(P), dim3(256), 0, st, A, (const double*)workspace, grad_R, grad_t);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}

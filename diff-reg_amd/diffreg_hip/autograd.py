@@ -54,19 +54,21 @@ class _MatchingHead(torch.autograd.Function):
         B, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         sf, tf, W = src_feats.detach().float().contiguous(), tgt_feats.detach().float().contiguous(), weight.detach().float().contiguous()
-        a = lib.linear(sf.reshape(B * N, C), W, epilogue=2, cos=cs, sin=ss, rot_C=C).view(B, N, C) / C ** 0.5
-        b = lib.linear(tf.reshape(B * M, C), W, epilogue=2, cos=ct, sin=st, rot_C=C).view(B, M, C) / C ** 0.5
+        cs, ss, ct, st = (t_.detach().float().contiguous() for t_ in (cs, ss, ct, st))
+        spre, tpre = lib.linear(sf.reshape(B * N, C), W), lib.linear(tf.reshape(B * M, C), W)
+        a = lib.rotary(spre, cs, ss, scale=1.0 / C ** 0.5).view(B, N, C)
+        b = lib.rotary(tpre, ct, st, scale=1.0 / C ** 0.5).view(B, M, C)
         sim = torch.stack([lib.linear(a[i], b[i]) for i in range(B)])
         if src_mask is not None:
             sim = sim.masked_fill(~(src_mask[:, :, None] & tgt_mask[:, None, :]), float("-inf"))
         conf = lib.sinkhorn(sim, bin_score.detach().float().reshape(1), iters, src_mask, tgt_mask)
-        ctx.save_for_backward(sf, tf, W, a, b, sim, bin_score.detach(), cs, ss, ct, st)
+        ctx.save_for_backward(sf, tf, W, a, b, sim, bin_score.detach(), cs, ss, ct, st, spre, tpre)
         ctx.iters, ctx.masks = iters, (src_mask, tgt_mask)
         return conf
 
     @staticmethod
     def backward(ctx, grad_conf):
-        sf, tf, W, a, b, sim, bin_score, cs, ss, ct, st = ctx.saved_tensors
+        sf, tf, W, a, b, sim, bin_score, cs, ss, ct, st, spre, tpre = ctx.saved_tensors
         sm, tm = ctx.masks
         B, N, C = sf.shape
         M = tf.shape[1]
@@ -84,7 +86,8 @@ class _MatchingHead(torch.autograd.Function):
         g_tgt = lib.linear(g_tp, Wt).view(B, M, C)
         pad4 = lambda x: torch.nn.functional.pad(x, (0, (-x.shape[1]) % 4))                            # (the GEMM wants K % 4 == 0)
         g_W = lib.linear(pad4(tr(g_sp)), pad4(tr(sf.reshape(B * N, C)))) + lib.linear(pad4(tr(g_tp)), pad4(tr(tf.reshape(B * M, C))))   # g^T x, both sides
-        return g_src, g_tgt, g_W, ga.reshape(bin_score.shape).to(bin_score.dtype), None, None, None, None, None, None, None
+        gcs = gss = gct = gst = None        # (position codes: constants, as in the reference)
+        return g_src, g_tgt, g_W, ga.reshape(bin_score.shape).to(bin_score.dtype), gcs, gss, gct, gst, None, None, None
 
 
 def _mm(a, b):
@@ -113,8 +116,9 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         det = lambda t: t.detach().float().contiguous()
         x2, s2 = det(x).reshape(B * L, C), det(source).reshape(B * S, C)
         Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2 = map(det, (Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2))
-        qw = lib.linear(x2, Wq, epilogue=2, cos=cx, sin=sx, rot_C=C)
-        kw = lib.linear(s2, Wk, epilogue=2, cos=cy, sin=sy, rot_C=C)
+        cx, sx, cy, sy = map(det, (cx, sx, cy, sy))
+        qpre, kpre = lib.linear(x2, Wq), lib.linear(s2, Wk)
+        qw, kw = lib.rotary(qpre, cx, sx), lib.rotary(kpre, cy, sy)
         vw = lib.linear(s2, Wv)
         heads = lambda t, n: t.view(B, n, H, d).permute(0, 2, 1, 3).contiguous()
         q4, k4, v4 = heads(qw, L), heads(kw, S), heads(vw, S)
@@ -129,13 +133,13 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         h = lib.linear(cat, W0, epilogue=1)
         f_pre = lib.linear(h, W2)
         f, st2 = lib.layernorm(f_pre, g2, b2)
-        ctx.save_for_backward(x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2)
+        ctx.save_for_backward(x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2, qpre, kpre)
         ctx.dims = (B, L, S, C, H, d, scale)
         return (x2 + f).view(B, L, C)
 
     @staticmethod
     def backward(ctx, ge):
-        (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2) = ctx.saved_tensors
+        (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2, qpre, kpre) = ctx.saved_tensors
         B, L, S, C, H, d, scale = ctx.dims
         tr = lambda t: t.transpose(-1, -2).contiguous()
         ge = ge.contiguous().float().reshape(B * L, C)
@@ -155,22 +159,123 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         dQ = torch.stack([torch.stack([_mm(dS[b, hh], tr(k4[b, hh])) for hh in range(H)]) for b in range(B)])            # [B,H,L,d]
         dK = torch.stack([torch.stack([_mm(tr(dS[b, hh]), tr(q4[b, hh])) for hh in range(H)]) for b in range(B)])        # [B,H,S,d]
         merge = lambda t, n: t.permute(0, 2, 1, 3).reshape(B * n, C).contiguous()
-        g_qpre = lib.rotary(merge(dQ, L), cx, sx, inverse=True)
-        g_kpre = lib.rotary(merge(dK, S), cy, sy, inverse=True)
+        g_qw, g_kw = merge(dQ, L), merge(dK, S)
+        g_qpre = lib.rotary(g_qw, cx, sx, inverse=True)
+        g_kpre = lib.rotary(g_kw, cy, sy, inverse=True)
         g_vw = merge(dV, S)
+        gcx = gsx = gcy = gsy = None        # (position codes are constants of the graph: the reference detaches them, position_encoding.py:83-84)
         g_x = g_x + _mm(g_qpre, tr(Wq))
         g_s = _mm(g_kpre, tr(Wk)) + _mm(g_vw, tr(Wv))
         gWq, gWk, gWv = _mm(tr(g_qpre), tr(x2)), _mm(tr(g_kpre), tr(s2)), _mm(tr(g_vw), tr(s2))
-        return (g_x.view(B, L, C), g_s.view(B, S, C), None, None, None, None, None, None, None, gWq, gWk, gWv, gWm, gW0, gW2, gg1, gb1, gg2, gb2)
+        return (g_x.view(B, L, C), g_s.view(B, S, C), gcx, gsx, gcy, gsy, None, None, None, gWq, gWk, gWv, gWm, gW0, gW2, gg1, gb1, gg2, gb2)
+
+
+def _tables(pe):
+    """a position code [B,N,C,2] (VolumetricPositionEncoding.forward) or a (cos, sin) pair of half tables [B*N, C/2] -> the pair"""
+    if isinstance(pe, (tuple, list)):
+        return pe
+    from models.position_encoding import half_tables
+    return half_tables(pe)
 
 
 def geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask=None, source_mask=None):
-    """differentiable GeometryAttentionLayer.forward for a `models.transformero.GeometryAttentionLayer` module (its parameters receive gradients)"""
-    from models.position_encoding import half_tables
-    cx, sx = half_tables(x_pe)
-    cy, sy = half_tables(source_pe)
+    """differentiable GeometryAttentionLayer.forward for a `models.transformero.GeometryAttentionLayer` module (its parameters receive gradients;
+    position codes are constants of the graph, as in the reference: position_encoding.py:83-84 detaches them)"""
+    cx, sx = _tables(x_pe)
+    cy, sy = _tables(source_pe)
     p = dict(layer.named_parameters())
     return _GeometryAttentionLayer.apply(x, source, cx, sx, cy, sy, x_mask, source_mask, layer.nhead, *[p[k] for k in _LAYER_KEYS])
+
+
+class _Procrustes(torch.autograd.Function):
+    """SoftProcrustesLayer.forward (3D/models/procrustes.py:17-93) with its gradient into the confidence matrix.  Forward = dr_procrustes_f32 (top-K
+    selection, weighted Kabsch, fp64 3 x 3 SVD on the device).  Backward: the K selected confidences are the weights of the fit; their gradient is
+    taken through a float64 re-evaluation of the fit on the K gathered pairs with torch.svd on the host -- the reference's own arithmetic and
+    autograd path (`Sxy.cpu().double().svd()`, :35-36) -- and scattered back to the selected entries."""
+
+    @staticmethod
+    def forward(ctx, conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond):
+        R, t, Rf, tf, cond, ok, idx = lib.procrustes(conf.detach().float(), src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond, want_topk=True)
+        ctx.save_for_backward(conf.detach(), src_pcd, tgt_pcd, idx, ok)
+        ctx.mark_non_differentiable(cond, ok)
+        return R, t, Rf, tf, cond, ok
+
+    @staticmethod
+    def backward(ctx, gR, gt, gRf, gtf, _gc, _gk):
+        conf, ps, pt, idx, ok = ctx.saved_tensors
+        B, N, M = conf.shape
+        idx = idx.long()
+        okf = ok.view(B, 1, 1).to(gR.dtype)
+        gR_eff, gt_eff = gR + gRf * okf, gt + gtf * okf                    # R_forwd = R where the condition gate passes, identity elsewhere (:85-90)
+        bi = torch.arange(B, device=conf.device).view(B, 1).expand_as(idx)
+        with torch.enable_grad():
+            w = conf.reshape(B, -1).gather(1, idx).double().cpu().requires_grad_(True)
+            X, Y = ps[bi, idx // M].double().cpu(), pt[bi, idx % M].double().cpu()
+            wn = (w / (w.abs().sum(1, keepdim=True) + 1e-4))[..., None]
+            mx, my = (wn * X).sum(1, keepdim=True), (wn * Y).sum(1, keepdim=True)
+            S = (Y - my).transpose(1, 2) @ (wn * (X - mx))
+            U, D, V = S.svd()
+            fix = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
+            fix[:, 2, 2] = (U.det() * V.det()).detach()
+            Rr = U @ (fix @ V.transpose(1, 2))
+            tr_ = my.transpose(1, 2) - Rr @ mx.transpose(1, 2)
+            gw, = torch.autograd.grad((Rr, tr_), w, (gR_eff.double().cpu(), gt_eff.double().cpu()))
+        g_conf = torch.zeros(B, N * M, device=conf.device)
+        g_conf.scatter_add_(1, idx, gw.float().to(conf.device))
+        return g_conf.view(B, N, M), None, None, None, None, None, None
+
+
+def procrustes_fit(layer, conf, src_pcd, tgt_pcd, src_mask, tgt_mask):
+    """differentiable models.procrustes.SoftProcrustesLayer.forward -> R, t, R_forwd, t_forwd, condition, solution_mask"""
+    return _Procrustes.apply(conf, src_pcd.float().contiguous(), tgt_pcd.float().contiguous(), src_mask, tgt_mask, float(layer.sample_rate),
+                             float(layer.max_condition_num))
+
+
+class _MotionL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow):
+        ctx.save_for_backward(s_pcd, R_pred.detach(), t_pred.detach(), R_gt, t_gt, overlap_mask)
+        ctx.flow = flow
+        return lib.motion_l1(s_pcd, R_pred.detach(), t_pred.detach(), R_gt, t_gt, overlap_mask, flow)
+
+    @staticmethod
+    def backward(ctx, g):
+        s_pcd, Rp, tp, Rg, tg, om = ctx.saved_tensors
+        gR, gt = lib.motion_l1_backward(s_pcd, Rp, tp, Rg, tg, om, ctx.flow)
+        return None, gR * g, gt * g, None, None, None, None
+
+
+def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
+    """differentiable L1 motion term of ge_coarse_loss (3D/models/loss.py:108-128) in (R_pred, t_pred)"""
+    return _MotionL1.apply(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow)
+
+
+def coarse_branch(pipeline, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask):
+    """The non-denoising half of the training forward, differentiable (3D/models/pipeline.py:184-196): coarse_transformer -- self, cross, the
+    positioning layer (its Matching + Procrustes fit re-pose the source for the position code, which the reference DETACHES,
+    position_encoding.py:83-84: a constant of the graph), self, cross -- then coarse_matching and the final soft_procrustes
+    -> (conf_matrix_pred, R_s2t_pred, t_s2t_pred); (R, t) back-propagate into conf_matrix_pred (the L1 motion term of 4DMatch's training)."""
+    tr = pipeline.coarse_transformer
+    pe = tr.positional_encoding
+    with torch.no_grad():
+        src_pe, tgt_pe = pe(s_pcd), pe(t_pcd)
+    s, t = src_feats, tgt_feats
+    for layer, name in zip(tr.layers, tr.layer_types):
+        if name == "self":
+            s = geometry_attention_layer(layer, s, s, src_pe, src_pe, src_mask, src_mask)
+            t = geometry_attention_layer(layer, t, t, tgt_pe, tgt_pe, tgt_mask, tgt_mask)
+        elif name == "cross":
+            s = geometry_attention_layer(layer, s, t, src_pe, tgt_pe, src_mask, tgt_mask)
+            t = geometry_attention_layer(layer, t, s, tgt_pe, src_pe, tgt_mask, src_mask)
+        else:                                                       # positioning (transformero.py:183-203): no gradient leaves it
+            with torch.no_grad():
+                conf, _ = layer[0](s.detach(), t.detach(), src_pe, tgt_pe, src_mask, tgt_mask, {}, pe_type=tr.pe_type)
+                _, _, Rf, tf, _, _ = layer[1](conf, s_pcd, t_pcd, src_mask, tgt_mask)
+                src_pe = pe((torch.matmul(Rf, s_pcd.transpose(1, 2)) + tf).transpose(1, 2))
+    m = pipeline.coarse_matching
+    conf = matching_head(s, t, m.src_proj.weight, m.bin_score, src_pe, tgt_pe, src_mask, tgt_mask, m.skh_iters)
+    R, tt, _, _, _, _ = procrustes_fit(pipeline.soft_procrustes, conf, s_pcd, t_pcd, src_mask, tgt_mask)
+    return conf, R, tt
 
 
 def denoising_branch(pipeline, src_feats, tgt_feats, src_pcd_wrapped, tgt_pcd_wrapped, src_mask, tgt_mask):
@@ -195,10 +300,9 @@ def denoising_branch(pipeline, src_feats, tgt_feats, src_pcd_wrapped, tgt_pcd_wr
 
 
 def matching_head(src_feats, tgt_feats, weight, bin_score, src_pe, tgt_pe, src_mask, tgt_mask, iters):
-    """differentiable Matching.forward (sinkhorn, rotary): src_pe / tgt_pe = the position codes [B,N,C,2] of VolumetricPositionEncoding"""
-    from models.position_encoding import half_tables
-    cs, ss = half_tables(src_pe)
-    ct, st = half_tables(tgt_pe)
+    """differentiable Matching.forward (sinkhorn, rotary): src_pe / tgt_pe = position codes [B,N,C,2] or (cos, sin) half-table pairs"""
+    cs, ss = _tables(src_pe)
+    ct, st = _tables(tgt_pe)
     return _MatchingHead.apply(src_feats, tgt_feats, weight, bin_score, cs, ss, ct, st, src_mask, tgt_mask, int(iters))
 
 

@@ -141,6 +141,7 @@ SIGNATURES.update({
                                   c_void_p]),
     "dr_match_recall_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_motion_l1_f32": (c_int, [c_int, c_int] + [c_void_p] * 10),
+    "dr_motion_l1_backward_f32": (c_int, [c_int, c_int] + [c_void_p] * 11),
     "dr_layernorm_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "dr_layernorm_backward_workspace_bytes": (c_size_t, [c_int]),
     "dr_layernorm_backward_f32": (c_int, [c_int, c_int] + [c_void_p] * 9),
@@ -416,6 +417,21 @@ def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
     check(_lib.dr_motion_l1_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(loss),
                                 ptr(ws), stream_of(s_pcd)))
     return loss
+
+
+def motion_l1_backward(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
+    """d loss / d (R_pred, t_pred) of motion_l1 -> ([P,3,3], [P,3,1])"""
+    ensure_init()
+    P, N, _ = s_pcd.shape
+    f = lambda x: x.contiguous().float()
+    s_pcd, R_pred, t_pred, R_gt, t_gt = f(s_pcd), f(R_pred), f(t_pred.reshape(P, 3)), f(R_gt), f(t_gt.reshape(P, 3))
+    flow = f(flow) if flow is not None else None
+    gR, gt = torch.empty(P, 3, 3, device=s_pcd.device), torch.empty(P, 3, device=s_pcd.device)
+    ws = _train_ws(P, N, 1, s_pcd.device)
+    om = mask_u8(overlap_mask)
+    check(_lib.dr_motion_l1_backward_f32(P, N, ptr(s_pcd), ptr(flow), ptr(R_pred), ptr(t_pred), ptr(R_gt), ptr(t_gt), ptr(om), ptr(gR), ptr(gt), ptr(ws),
+                                         stream_of(s_pcd)))
+    return gR, gt.view(P, 3, 1)
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

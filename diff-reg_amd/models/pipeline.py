@@ -202,6 +202,37 @@ class Pipeline(nn.Module):
         data.update({"conf_matrix_gt_hat": hat, "coarse_match_gt_hat": match_hat})
         return data
 
+    def forward_train(self, data):
+        """The training forward WITH a graph (forward() is value-only): the backbone runs frozen (no backward kernels for KPFCN), everything behind its
+        features -- coarse_transformer, coarse_matching, soft_procrustes, the denoising transformer and matching on the noised ground-truth matrix -- is
+        differentiable on the device (diffreg_hip.autograd).  Writes the keys of pipeline.py:182-216 into `data`; `models.loss.MatchMotionLoss.forward_train`
+        turns them into a loss whose .backward() fills the gradients of every parameter the reference's training updates behind the backbone."""
+        from diffreg_hip import autograd as dag, lib
+        with torch.no_grad():
+            coarse_feats = self.backbone(data, phase="coarse")
+            src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask = self.split_feats(coarse_feats, data)
+        data.update({"s_pcd": s_pcd, "t_pcd": t_pcd})
+        dev = src_feats.device
+        P, N, _ = src_feats.shape
+        M = tgt_feats.shape[1]
+        conf, R, t = dag.coarse_branch(self, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask)
+        with torch.no_grad():
+            match_pred, _, _ = self.coarse_matching.get_match(conf.detach(), self.coarse_matching.confidence_threshold)
+            ts = data["ts"] if "ts" in data else torch.randint(0, self.num_timesteps, (1,), device=dev).long()
+            rows = [torch.cat([torch.full((1, m.shape[1]), b, dtype=torch.int64, device=m.device), m.to(torch.int64)], 0).t()
+                    for b, m in enumerate(data["coarse_matches"])]
+            matrix_gt = lib.match_matrix(torch.cat(rows, 0).to(dev), P, N, M)
+            random_number = data["randn"] if "randn" in data else torch.randn(P, N, M, device=dev)
+            ac = self.alphas_cumprod[int(ts.reshape(-1)[0])]
+            noised = lib.gt_noising(matrix_gt, random_number, float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac)))
+            src_w, tgt_w = self.get_warped_from_noising_matching(s_pcd, t_pcd, src_mask, tgt_mask, noised.clone())
+        hat = dag.denoising_branch(self, src_feats, tgt_feats, src_w, tgt_w, src_mask, tgt_mask)
+        with torch.no_grad():
+            match_hat, _, _ = self.denoising_coarse_matching.get_match(hat.detach(), self.denoising_coarse_matching.confidence_threshold)
+        data.update({"conf_matrix_pred": conf, "coarse_match_pred": match_pred, "R_s2t_pred": R, "t_s2t_pred": t, "matrix_gt_disturbed": noised,
+                     "conf_matrix_gt_hat": hat, "coarse_match_gt_hat": match_hat})
+        return data
+
     def get_warped_from_noising_matching(self, s_pcd, t_pcd, src_mask, tgt_mask, matrix_gt_disturbed):
         """pipeline.py:293-309: mask (in place), Sinkhorn in the matrix's dtype, Procrustes on float32(conf), the warped source"""
         matrix_gt_disturbed.masked_fill_(~(src_mask[..., None] * tgt_mask[:, None]).bool(), float("-inf"))

@@ -573,6 +573,10 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
  *   saw them (masked entries -inf), the masks (both or none), bin_score, iters, grad_conf = d loss / d conf [P,N,M] ->
  *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32; every
  *   reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
+/* d loss / d (R_pred [P,3,3], t_pred [P,3]) of dr_motion_l1_f32 (loss.py:108-128; 4DMatch trains with motion_weight 0.1) */
+int dr_motion_l1_backward_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
+                              const float* t_gt, const uint8_t* overlap_mask, float* grad_R, float* grad_t, void* workspace, void* stream);
+
 /* The non-GEMM pieces of the GeometryAttentionLayer backward (transformero.py:43-96; composed with dr_linear_f32 by diffreg_hip/autograd.py):
  * nn.LayerNorm forward with saved statistics (mean_rstd [rows,2]) and its backward (grad_x, grad_gamma, grad_beta; workspace:
  * dr_layernorm_backward_workspace_bytes(C)); the masked softmax of an explicit attention matrix scores [B,H,L,S] over S (a key j is -inf

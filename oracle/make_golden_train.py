@@ -248,6 +248,33 @@ def main():
     bw["branch_grad_layers.0.q_proj.weight"] = pipe.denoising_transformer.layers[0].q_proj.weight.grad[::6, ::6].numpy()
     bw["branch_grad_layers.5.mlp.2.weight"] = pipe.denoising_transformer.layers[5].mlp[2].weight.grad[::6, ::6].numpy()
     print("backward branch loss %.6f |g_src| %.3e" % (float(loss_d), float(fs_d.grad.abs().max())), "params with grad:", sum(1 for k in bw if k.startswith("branch_gradnorm_")))
+    # ---- the non-denoising branch with the motion term (pipeline.py:184-196 + loss.py:97-128, motion_weight 0.1 as 4DMatch trains): coarse_transformer
+    #      (its position codes are detached by the reference, position_encoding.py:83-84) + coarse_matching + soft_procrustes (host SVD, differentiable)
+    fs_c = (cb["f_s"] * 0.5).clone().requires_grad_(True)
+    ft_c = (cb["f_t"] * 0.5).clone().requires_grad_(True)
+    for prm in pipe.parameters():
+        prm.grad = None
+    ov = torch.zeros(1, cb["N"], dtype=torch.bool)
+    ov[0][cb["matches"][0][0]] = True
+    with torch.enable_grad():
+        a_s, a_t, pe_s2, pe_t2 = pipe.coarse_transformer(fs_c, ft_c, cb["p_s"], cb["p_t"], cb["src_mask"], cb["tgt_mask"], {})
+        conf_c, _ = pipe.coarse_matching(a_s, a_t, pe_s2, pe_t2, cb["src_mask"], cb["tgt_mask"], {}, pe_type="rotary")
+        R_c, t_c, _, _, _, _ = pipe.soft_procrustes(conf_c, cb["p_s"], cb["p_t"], cb["src_mask"], cb["tgt_mask"])
+        focal_c = MatchMotionLoss(dict(LOSS_CFG)).compute_correspondence_loss(conf_c, gt_d)
+        wp = (torch.matmul(R_c, cb["p_s"].transpose(1, 2)) + t_c).transpose(1, 2)                       # loss.py:113-127
+        wg = (torch.matmul(cb["R_gt"], cb["p_s"].transpose(1, 2)) + cb["t_gt"]).transpose(1, 2)
+        l1_c = torch.sum(torch.abs((wp - cb["p_s"]) - (wg - cb["p_s"])), 2)[ov].mean()
+        loss_c = focal_c + 0.1 * l1_c
+        loss_c.backward()
+    bw.update(coarse_loss=np.float64(float(loss_c)), coarse_focal=np.float64(float(focal_c)), coarse_l1=np.float64(float(l1_c)), coarse_conf=conf_c.detach().numpy(),
+              coarse_R=R_c.detach().numpy(), coarse_t=t_c.detach().numpy(), coarse_grad_src=fs_c.grad.numpy(), coarse_grad_tgt=ft_c.grad.numpy())
+    n_c = 0
+    for k, prm in list(pipe.coarse_transformer.named_parameters()) + [("head." + k2, p2) for k2, p2 in pipe.coarse_matching.named_parameters()]:
+        if prm.grad is not None:
+            bw["coarse_gradnorm_" + k] = np.float64(float(prm.grad.double().norm()))
+            n_c += 1
+    assert pipe.coarse_transformer.layers[2][0].src_proj.weight.grad is None        # the positioning layer's Matching gets no gradient (detached code)
+    print("backward coarse loss %.6f (focal %.6f, l1 %.6f) |g_src| %.3e params with grad: %d" % (float(loss_c), float(focal_c), float(l1_c), float(fs_c.grad.abs().max()), n_c))
     np.savez_compressed(OUT.replace("train_forward", "train_backward"), **bw)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

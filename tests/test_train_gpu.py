@@ -326,3 +326,107 @@ def test_denoising_branch_backward_end_to_end():
                      ("branch_grad_layers.5.mlp.2.weight", model.denoising_transformer.layers[5].mlp[2].weight)):
         ref = GB[key]
         assert np.abs(prm.grad[::6, ::6].cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), key
+
+
+def test_motion_l1_backward_against_torch():
+    P, N = 3, 400
+    g = torch.Generator().manual_seed(9)
+    s = (torch.rand(P, N, 3, generator=g) * 3).to(DEV)
+    Rp = torch.linalg.qr(torch.randn(P, 3, 3, generator=g))[0].to(DEV).requires_grad_(True)
+    tp = torch.randn(P, 3, 1, generator=g).to(DEV).requires_grad_(True)
+    Rg, tg = torch.linalg.qr(torch.randn(P, 3, 3, generator=g))[0].to(DEV), torch.randn(P, 3, 1, generator=g).to(DEV)
+    ov = (torch.rand(P, N, generator=g) > 0.4).to(DEV)
+    wp = (Rp @ s.transpose(1, 2) + tp).transpose(1, 2)
+    wg = (Rg @ s.transpose(1, 2) + tg).transpose(1, 2)
+    ((wp - s) - (wg - s)).abs().sum(2)[ov].mean().backward()
+    gR, gt = lib.motion_l1_backward(s, Rp.detach(), tp.detach(), Rg, tg, ov)
+    assert (gR - Rp.grad).abs().max().item() < 1e-5 and (gt - tp.grad).abs().max().item() < 1e-5
+
+
+def test_coarse_branch_backward_with_motion_term():
+    """The non-denoising half of the training loss with the L1 motion term (motion_weight 0.1, as 4DMatch trains): autograd.coarse_branch (four attention
+    layers around the positioning layer, whose position code is a constant of the graph as in the reference, + matching head + differentiable
+    Procrustes fit) + focal_loss + motion_l1.  Against torch autograd through the reference's modules: 42 parameter tensors."""
+    from diffreg_hip.autograd import coarse_branch, focal_loss, motion_l1
+    from models.pipeline import Pipeline
+    c = train_case("b1")
+    model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
+    sd = model.state_dict()
+    for k, a in train_weights().items():
+        sd[k] = a
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    fs = (c["f_s"] * 0.5).to(DEV).requires_grad_(True)
+    ft = (c["f_t"] * 0.5).to(DEV).requires_grad_(True)
+    ps, pt, sm, tm = c["p_s"].to(DEV), c["p_t"].to(DEV), c["src_mask"].to(DEV), c["tgt_mask"].to(DEV)
+    conf, R, t = coarse_branch(model, fs, ft, ps, pt, sm, tm)
+    d = np.abs(conf.detach().cpu().numpy() - GB["coarse_conf"])
+    assert (d > 1e-4).mean() <= 1e-3 and d.max() < 2e-3
+    assert np.abs(R.detach().cpu().numpy() - GB["coarse_R"]).max() < 1e-4 and np.abs(t.detach().cpu().numpy() - GB["coarse_t"]).max() < 1e-4
+    gt = torch.zeros_like(conf)
+    gt[0][c["matches"][0][0].to(DEV), c["matches"][0][1].to(DEV)] = 1
+    ov = torch.zeros(1, c["N"], dtype=torch.bool, device=DEV)
+    ov[0][c["matches"][0][0].to(DEV)] = True
+    focal = focal_loss(conf, gt)
+    l1 = motion_l1(ps, R, t, c["R_gt"].to(DEV), c["t_gt"].to(DEV), ov)
+    loss = focal + 0.1 * l1
+    loss.backward()
+    assert abs(float(focal.detach()) - float(GB["coarse_focal"])) <= 2e-3 * float(GB["coarse_focal"])
+    assert abs(float(l1.detach()) - float(GB["coarse_l1"])) <= 1e-3 * float(GB["coarse_l1"])
+    for got, key in ((fs.grad, "coarse_grad_src"), (ft.grad, "coarse_grad_tgt")):
+        ref = GB[key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), (key, np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max())
+    named = list(model.coarse_transformer.named_parameters()) + [("head." + k, p) for k, p in model.coarse_matching.named_parameters()]
+    checked = 0
+    for k, prm in named:
+        key = "coarse_gradnorm_" + k
+        if key in GB.files:
+            ref = float(GB[key])
+            assert prm.grad is not None and abs(float(prm.grad.double().norm()) - ref) <= 2e-2 * ref + 1e-9, (k, ref)
+            checked += 1
+        else:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k          # the positioning layer's Matching, tgt_proj (quirk Q1)
+    assert checked == 42
+
+
+def test_training_step_on_the_device():
+    """Pipeline.forward_train + MatchMotionLoss.forward_train: the loss equals the value-only path's, .backward() reaches the 104 parameter tensors the
+    reference trains behind the backbone (and only those), and a few SGD steps on them lower the loss."""
+    from models.loss import MatchMotionLoss
+    from models.pipeline import Pipeline
+    c = train_case("b1")
+    B, N, M = c["B"], c["N"], c["M"]
+    model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
+    sd = model.state_dict()
+    for k, a in train_weights().items():
+        sd[k] = a
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    feats = torch.cat([c["f_s"].reshape(B * N, -1), c["f_t"].reshape(B * M, -1)], 0) * 0.5
+    pts = torch.cat([c["p_s"].reshape(B * N, 3), c["p_t"].reshape(B * M, 3)], 0)
+
+    def batch():
+        return {"points": [None, None, pts.to(DEV), None], "_feats": feats.to(DEV), "src_mask": c["src_mask"].to(DEV), "tgt_mask": c["tgt_mask"].to(DEV),
+                "src_ind_coarse_split": torch.arange(B * N, device=DEV), "tgt_ind_coarse_split": torch.arange(B * M, device=DEV),
+                "src_ind_coarse": torch.arange(B * N, device=DEV), "tgt_ind_coarse": torch.arange(B * N, B * (N + M), device=DEV),
+                "coarse_matches": [m.to(DEV) for m in c["matches"]], "batched_rot": c["R_gt"].to(DEV), "batched_trn": c["t_gt"].to(DEV),
+                "ts": torch.tensor([c["ts"]], device=DEV), "randn": c["randn"].to(DEV)}
+    crit = MatchMotionLoss(dict(LOSS_CFG, motion_weight=0.1))
+    with torch.no_grad():
+        ref_info = crit(model(batch()))                       # the value-only path (forward under .train())
+    info = crit.forward_train(model.forward_train(batch()))
+    assert abs(float(info["loss"].detach()) - float(ref_info["loss"])) <= 1e-4 * float(ref_info["loss"])
+    info["loss"].backward()
+    with_grad = [k for k, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0]
+    assert len(with_grad) == 104, len(with_grad)
+    assert not any(k.startswith("coarse_transformer.layers.2.") or k.endswith("tgt_proj.weight") for k in with_grad)
+    params = [p for p in model.parameters() if p.grad is not None]
+    opt = torch.optim.SGD(params, lr=2e-3)
+    losses = [float(info["loss"].detach())]
+    for _ in range(3):
+        opt.step()
+        opt.zero_grad()
+        info = crit.forward_train(model.forward_train(batch()))
+        info["loss"].backward()
+        losses.append(float(info["loss"].detach()))
+    assert losses[-1] < losses[0], losses
