@@ -194,9 +194,13 @@ class _Procrustes(torch.autograd.Function):
     autograd path (`Sxy.cpu().double().svd()`, :35-36) -- and scattered back to the selected entries."""
 
     @staticmethod
-    def forward(ctx, conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond):
-        R, t, Rf, tf, cond, ok, idx = lib.procrustes(conf.detach().float(), src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond, want_topk=True)
+    def forward(ctx, conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond, use_mask_len=False):
+        R, t, Rf, tf, cond, ok, idx = lib.procrustes(conf.detach().float(), src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond,
+                                                     use_mask_len=use_mask_len, want_topk=True)
         ctx.save_for_backward(conf.detach(), src_pcd, tgt_pcd, idx, ok)
+        ctx.entry_max = None
+        if use_mask_len:                 # 4D (models/procrustes.py:61-76): K from the mask sums, weights beyond a pair's own count are zeroed
+            ctx.entry_max = (torch.maximum(src_mask.sum(1), tgt_mask.sum(1)).float() * sample_rate).int().cpu()
         ctx.mark_non_differentiable(cond, ok)
         return R, t, Rf, tf, cond, ok
 
@@ -209,7 +213,10 @@ class _Procrustes(torch.autograd.Function):
         gR_eff, gt_eff = gR + gRf * okf, gt + gtf * okf                    # R_forwd = R where the condition gate passes, identity elsewhere (:85-90)
         bi = torch.arange(B, device=conf.device).view(B, 1).expand_as(idx)
         with torch.enable_grad():
-            w = conf.reshape(B, -1).gather(1, idx).double().cpu().requires_grad_(True)
+            w0 = conf.reshape(B, -1).gather(1, idx).double().cpu().requires_grad_(True)
+            w = w0
+            if ctx.entry_max is not None:
+                w = w0 * (torch.arange(idx.shape[1]).view(1, -1) < ctx.entry_max.view(-1, 1)).double()
             X, Y = ps[bi, idx // M].double().cpu(), pt[bi, idx % M].double().cpu()
             wn = (w / (w.abs().sum(1, keepdim=True) + 1e-4))[..., None]
             mx, my = (wn * X).sum(1, keepdim=True), (wn * Y).sum(1, keepdim=True)
@@ -219,16 +226,16 @@ class _Procrustes(torch.autograd.Function):
             fix[:, 2, 2] = (U.det() * V.det()).detach()
             Rr = U @ (fix @ V.transpose(1, 2))
             tr_ = my.transpose(1, 2) - Rr @ mx.transpose(1, 2)
-            gw, = torch.autograd.grad((Rr, tr_), w, (gR_eff.double().cpu(), gt_eff.double().cpu()))
+            gw, = torch.autograd.grad((Rr, tr_), w0, (gR_eff.double().cpu(), gt_eff.double().cpu()))
         g_conf = torch.zeros(B, N * M, device=conf.device)
         g_conf.scatter_add_(1, idx, gw.float().to(conf.device))
-        return g_conf.view(B, N, M), None, None, None, None, None, None
+        return g_conf.view(B, N, M), None, None, None, None, None, None, None
 
 
 def procrustes_fit(layer, conf, src_pcd, tgt_pcd, src_mask, tgt_mask):
     """differentiable models.procrustes.SoftProcrustesLayer.forward -> R, t, R_forwd, t_forwd, condition, solution_mask"""
     return _Procrustes.apply(conf, src_pcd.float().contiguous(), tgt_pcd.float().contiguous(), src_mask, tgt_mask, float(layer.sample_rate),
-                             float(layer.max_condition_num))
+                             float(layer.max_condition_num), bool(getattr(layer, "use_mask_len", False)))
 
 
 class _MotionL1(torch.autograd.Function):
