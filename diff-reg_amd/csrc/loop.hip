@@ -710,6 +710,19 @@ int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, fl
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int dr_gemm_nt_batched_f32(int nbatch, int rows, int ncols, int K, const float* A, long long stride_a, const float* W, long long stride_w, float* out,
+                           long long stride_o, float scale, void* stream) {
+    if (nbatch < 0 || rows < 0 || ncols <= 0 || K <= 0 || (K & 3) || !A || !W || !out) return DR_EINVAL;
+    if (nbatch == 0 || rows == 0) return DR_OK;
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    GemmProblem& p = g.p[0];
+    p.A = A; p.W = W; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = K; p.ldo = ncols; p.epi = EPI_NONE; p.scale = scale;
+    p.nbatch = nbatch; p.sA = stride_a; p.sW = stride_w; p.sO = stride_o;
+    g.n = 1;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const float* W, const float* bias, float* out, int ldo,
                      int epilogue, float scale, void* stream) {
     if (rows < 0 || ncols <= 0 || K <= 0 || !x || !W || !out || lda < K || ldo < ncols || (epilogue & EPI_ROTARY)) return DR_EINVAL;

@@ -58,7 +58,7 @@ class _MatchingHead(torch.autograd.Function):
         spre, tpre = lib.linear(sf.reshape(B * N, C), W), lib.linear(tf.reshape(B * M, C), W)
         a = lib.rotary(spre, cs, ss, scale=1.0 / C ** 0.5).view(B, N, C)
         b = lib.rotary(tpre, ct, st, scale=1.0 / C ** 0.5).view(B, M, C)
-        sim = torch.stack([lib.linear(a[i], b[i]) for i in range(B)])
+        sim = lib.bmm_nt(a, b)
         if src_mask is not None:
             sim = sim.masked_fill(~(src_mask[:, :, None] & tgt_mask[:, None, :]), float("-inf"))
         conf = lib.sinkhorn(sim, bin_score.detach().float().reshape(1), iters, src_mask, tgt_mask)
@@ -77,8 +77,8 @@ class _MatchingHead(torch.autograd.Function):
             tm = torch.ones(B, M, dtype=torch.bool, device=sf.device)
         gs, ga = lib.sinkhorn_backward(sim, bin_score, ctx.iters, sm, tm, grad_conf)                  # d loss / d sim  [B,N,M]
         tr = lambda x: x.transpose(-1, -2).contiguous()
-        g_a = torch.stack([lib.linear(gs[i], tr(b[i])) for i in range(B)])                            # gs b    [B,N,C]
-        g_b = torch.stack([lib.linear(tr(gs[i]), tr(a[i])) for i in range(B)])                        # gs^T a  [B,M,C]
+        g_a = lib.bmm_nt(gs, tr(b))                                                                   # gs b    [B,N,C]
+        g_b = lib.bmm_nt(tr(gs), tr(a))                                                               # gs^T a  [B,M,C]
         g_sp = lib.rotary(g_a.reshape(B * N, C), cs, ss, inverse=True, scale=1.0 / C ** 0.5)          # back through / sqrt(C) and the rotary code
         g_tp = lib.rotary(g_b.reshape(B * M, C), ct, st, inverse=True, scale=1.0 / C ** 0.5)
         Wt = tr(W)
@@ -106,7 +106,7 @@ _LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight"
 class _GeometryAttentionLayer(torch.autograd.Function):
     """GeometryAttentionLayer.forward (3D/models/transformero.py:43-96, rotary code) with the attention matrix made explicit, and its backward:
     LayerNorm / softmax / ReLU / rotary backward kernels (csrc/train.hip) + every product on dr_linear_f32.  A first, unfused backward: it
-    keeps [B,H,L,S] matrices in memory and loops over (batch, head) for the per-head products."""
+    keeps [B,H,L,S] matrices in memory (the per-head products are strided-batch launches of the library's GEMM)."""
 
     @staticmethod
     def forward(ctx, x, source, cx, sx, cy, sy, x_mask, source_mask, H, Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2):
@@ -122,10 +122,10 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         vw = lib.linear(s2, Wv)
         heads = lambda t, n: t.view(B, n, H, d).permute(0, 2, 1, 3).contiguous()
         q4, k4, v4 = heads(qw, L), heads(kw, S), heads(vw, S)
-        scores = torch.stack([torch.stack([_mm(q4[b, h], k4[b, h]) for h in range(H)]) for b in range(B)])
+        scores = lib.bmm_nt(q4, k4)                                                                              # [B,H,L,S], one launch
         scale = 1.0 / d ** 0.5
         P = lib.softmax_rows(scores, scale, x_mask, source_mask)
-        o4 = torch.stack([torch.stack([_mm(P[b, h], v4[b, h].t()) for h in range(H)]) for b in range(B)])       # [B,H,L,d]
+        o4 = lib.bmm_nt(P, v4.transpose(-1, -2))                                                                 # P V  [B,H,L,d]
         o2 = o4.permute(0, 2, 1, 3).reshape(B * L, C).contiguous()
         m_pre = lib.linear(o2, Wm)
         m, st1 = lib.layernorm(m_pre, g1, b1)
@@ -153,11 +153,11 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         g_o2 = _mm(g_mpre, tr(Wm))
         gWm = _mm(tr(g_mpre), tr(o2))
         g_o4 = g_o2.view(B, L, H, d).permute(0, 2, 1, 3).contiguous()
-        dV = torch.stack([torch.stack([_mm(tr(P[b, hh]), tr(g_o4[b, hh])) for hh in range(H)]) for b in range(B)])        # [B,H,S,d]
-        dP = torch.stack([torch.stack([_mm(g_o4[b, hh], v4[b, hh]) for hh in range(H)]) for b in range(B)])              # [B,H,L,S]
+        dV = lib.bmm_nt(tr(P), tr(g_o4))                                          # P^T dO   [B,H,S,d]
+        dP = lib.bmm_nt(g_o4, v4)                                                 # dO V^T   [B,H,L,S]
         dS = lib.softmax_backward(P, dP, scale)
-        dQ = torch.stack([torch.stack([_mm(dS[b, hh], tr(k4[b, hh])) for hh in range(H)]) for b in range(B)])            # [B,H,L,d]
-        dK = torch.stack([torch.stack([_mm(tr(dS[b, hh]), tr(q4[b, hh])) for hh in range(H)]) for b in range(B)])        # [B,H,S,d]
+        dQ = lib.bmm_nt(dS, tr(k4))                                               # dS K     [B,H,L,d]
+        dK = lib.bmm_nt(tr(dS), tr(q4))                                           # dS^T Q   [B,H,S,d]
         merge = lambda t, n: t.permute(0, 2, 1, 3).reshape(B * n, C).contiguous()
         g_qw, g_kw = merge(dQ, L), merge(dK, S)
         g_qpre = lib.rotary(g_qw, cx, sx, inverse=True)

@@ -109,6 +109,8 @@ SIGNATURES.update({
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_ln_bound_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_planes_f32": (c_int, [ctypes.POINTER(PlanesLinear), c_void_p]),
+    "dr_gemm_nt_batched_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong,
+                                       c_float, c_void_p]),
     "dr_linear_ex_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dr_kpconv_gather_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_void_p]),
@@ -604,6 +606,22 @@ def linear(x, W, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
     check(_lib.dr_linear_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(out), epilogue, ptr(cos), ptr(sin),
                              rot_C, float(scale), stream_of(x)))
     return out
+
+
+def bmm_nt(a, b, scale=1.0):
+    """a [..., R, K] @ b[..., N, K]^T over the leading (batch) dims, one launch (dr_gemm_nt_batched_f32; K is zero-padded to a multiple of 4)"""
+    ensure_init()
+    lead = a.shape[:-2]
+    R, K = a.shape[-2:]
+    N = b.shape[-2]
+    a, b = a.reshape(-1, R, K).contiguous().float(), b.reshape(-1, N, K).contiguous().float()
+    pad = (-K) % 4
+    if pad:
+        a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
+    nb = a.shape[0]
+    out = torch.empty(nb, R, N, device=a.device)
+    check(_lib.dr_gemm_nt_batched_f32(nb, R, N, K + pad, ptr(a), R * (K + pad), ptr(b), N * (K + pad), ptr(out), R * N, float(scale), stream_of(a)))
+    return out.view(*lead, R, N)
 
 
 def linear_ex(x, W, bias=None, epilogue=0, scale=1.0, K=None):

@@ -172,6 +172,11 @@ typedef struct {
 } dr_planes_linear;
 int dr_linear_planes_f32(const dr_planes_linear* args, void* stream);
 
+/* strided batch of the same product: out[z] [rows, ncols] = A[z] [rows, K] W[z]^T (W[z] [ncols, K]) * scale, z < nbatch, operands contiguous with the
+ * given strides (floats); K % 4 == 0.  The N x M similarity of a batch of pairs (matching.py:190-196); the per-head products of the training backward. */
+int dr_gemm_nt_batched_f32(int nbatch, int rows, int ncols, int K, const float* A, long long stride_a, const float* W, long long stride_w, float* out,
+                           long long stride_o, float scale, void* stream);
+
 /* nn.Linear with a bias and explicit leading dimensions (x [rows, lda], out [rows, ldo]): the 1x1 Conv1d `coarse_out`
  * of the backbone (3D/models/backbone.py:66, 155-156) and its UnaryBlocks (bias = NULL). */
 int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const float* W, const float* bias, float* out,
