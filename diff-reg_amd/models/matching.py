@@ -102,7 +102,7 @@ class Matching(nn.Module):
         data["src_feats"], data["tgt_feats"] = s_rot, t_rot
         a = s_rot / C ** 0.5
         b = t_rot / C ** 0.5
-        sim = torch.stack([lib.linear(a[i], b[i]) for i in range(B)]) if B > 1 else lib.linear(a[0], b[0])[None]
+        sim = lib.bmm_nt(a, b)                                        # one strided-batch launch over the pairs
         conf = lib.sinkhorn(sim, self.bin_score, self.skh_iters, src_mask, tgt_mask, apply_mask=src_mask is not None)
         coarse_match, _, _ = self.get_match(conf, self.confidence_threshold)
         return conf, coarse_match
