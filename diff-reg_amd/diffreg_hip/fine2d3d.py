@@ -46,3 +46,19 @@ def extract_patch_correspondences(img_node_corr_indices, pcd_node_corr_indices, 
     keys, count = lib.unique_pairs(img_corr_indices, pcd_corr_indices, num_points_f)                        # :759-763
     out.update(lib.corr_gather(keys, count, num_points_f, img_points_f, img_pixels_f, pcd_points_f, pcd_pixels_f, img_feats_f, pcd_feats_f))   # :765-774
     return out
+
+
+def registration_with_pnp_ransac(corr_points, corr_pixels, intrinsics, distortion=None, num_iterations=5000, distance_tolerance=8.0, transposed=True,
+                                 seed=0):
+    """vision3d.utils.opencv.registration_with_pnp_ransac (opencv.py:10-63; called by EXP/eval.py:174-182 with 50000 iterations, tolerance 8) on the
+    device: same arguments, returns the estimated 4 x 4 transform (3D -> camera) as a numpy array, or None with fewer than 4 correspondences.
+    Inputs may be numpy arrays (as in the reference) or device tensors.  No lens distortion (the reference passes none)."""
+    import numpy as np
+    if distortion is not None and np.any(np.asarray(distortion) != 0):
+        raise NotImplementedError("lens distortion")
+    dev = corr_points.device if torch.is_tensor(corr_points) and corr_points.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    P = torch.as_tensor(np.asarray(corr_points) if not torch.is_tensor(corr_points) else corr_points).to(dev, torch.float32)
+    px = torch.as_tensor(np.asarray(corr_pixels) if not torch.is_tensor(corr_pixels) else corr_pixels).to(dev, torch.float32)
+    Kc = intrinsics.detach().cpu().numpy() if torch.is_tensor(intrinsics) else np.asarray(intrinsics)
+    r = lib.pnp_ransac(P, px, Kc, num_iterations, distance_tolerance, seed, transposed)
+    return None if r is None else r["transform"].cpu().numpy()

@@ -132,6 +132,9 @@ SIGNATURES.update({
     "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
+    "dr_pnp_ransac_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_pnp_ransac_f64": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_double, ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
     "dr_patch_similarity_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
     "dr_unique_pairs_workspace_bytes": (c_size_t, [c_int]),
     "dr_unique_pairs_i64": (c_int, [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -901,6 +904,24 @@ def batch_mutual_topk_select(score_mat, k, row_masks=None, col_masks=None, large
     if two_d:
         return idx[:, 1], idx[:, 2], sc
     return idx[:, 0], idx[:, 1], idx[:, 2], sc
+
+
+def pnp_ransac(points, pixels, intrinsics, num_iterations=50000, distance_tolerance=8.0, seed=0, transposed=True):
+    """PnP-RANSAC on device tensors -> dict(transform [4,4] float64 device, n_inlier, best_iter) (None with fewer than 4 correspondences)"""
+    ensure_init()
+    n = points.shape[0]
+    if n < 4:
+        return None
+    points, pixels = points.contiguous().float(), pixels.contiguous().float()
+    K = (ctypes.c_double * 9)(*[float(x) for x in torch.as_tensor(intrinsics, dtype=torch.float64).reshape(-1).tolist()])
+    T = torch.empty(4, 4, dtype=torch.float64, device=points.device)
+    ni = torch.zeros(1, dtype=torch.int32, device=points.device)
+    bi = torch.zeros(1, dtype=torch.int32, device=points.device)
+    wsb = _lib.dr_pnp_ransac_workspace_bytes(n, int(num_iterations))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=points.device)
+    check(_lib.dr_pnp_ransac_f64(n, ptr(points), ptr(pixels), 1 if transposed else 0, K, int(num_iterations), float(distance_tolerance), int(seed), ptr(T),
+                                 ptr(ni), ptr(bi), ptr(ws), wsb, stream_of(points)))
+    return dict(transform=T, n_inlier=ni, best_iter=bi)
 
 
 def patch_similarity(img_feats, img_knn_indices, pcd_feats, pcd_knn_indices):

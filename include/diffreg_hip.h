@@ -483,6 +483,17 @@ int dr_corr_gather_f32(int capacity, const int32_t* count, const int64_t* unique
                        int64_t* img_corr_indices, int64_t* pcd_corr_indices, float* img_corr_points, float* img_corr_pixels, float* pcd_corr_points,
                        float* pcd_corr_pixels, float* corr_scores, void* stream);
 
+/* PnP-RANSAC registration of the fine correspondences (EXP/eval.py:174-182 -> vision3d/utils/opencv.py:10-63 = cv2.solvePnPRansac with
+ * iterationsCount = 50000, reprojectionError = 8.0, flags = SOLVEPNP_P3P).  OpenCV is not part of the reference tree: the published algorithm of
+ * that call -- RANSAC over 4-point samples, P3P on three + disambiguation by the fourth, inliers under the reprojection tolerance, refit on the
+ * inliers -- restated in oracle/pnp_oracle.py (every hypothesis is scored; counter-based sampling; Grunert's quartic; Gauss-Newton refit on the
+ * reprojection error).  PARITY UNPINNED against OpenCV, pinned against the oracle.
+ *   points [n,3], pixels [n,2] float32 device ((h, w) rows when transposed != 0, opencv.py:42-43), intrinsics: 9 doubles on the HOST (row-major K),
+ *   transform: 16 doubles (device, row-major 4 x 4, 3D -> camera), n_inlier / best_iter: device ints.  n >= 4. */
+size_t dr_pnp_ransac_workspace_bytes(int n, int iters);
+int dr_pnp_ransac_f64(int n, const float* points, const float* pixels, int transposed, const double* intrinsics_host, int iters, double distance_tolerance,
+                      uint64_t seed, double* transform, int32_t* n_inlier, int32_t* best_iter, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 2D-3D variant (Diff-Reg-2d3d): the reverse sampling of MATR2D3D.forward
  * (EXP/model.py:637-694, 830-846; EXP = Diff-Reg-2d3d/experiments/2d3dmatr.rgbdv2.stage4.level3.stage1)

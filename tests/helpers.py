@@ -195,3 +195,20 @@ def train_backward_case(tag):
         sc[b, i, j] += 6.0
     sm, tm = torch.arange(N)[None].expand(P, N) < nv, torch.arange(M)[None].expand(P, M) < mv
     return sc, gt, sm, tm
+
+
+# ------------------------------------------------------------------------------------------------
+# PnP-RANSAC scenes (row f4): 3D points in front of a camera, their pixels (h, w) with noise, a share of outliers
+# ------------------------------------------------------------------------------------------------
+def pnp_scene(seed, n=400, outliers=0.4, noise=0.7):
+    u = lambda s, shape: synth.hash_normal(seed, s, shape)
+    K = np.array([[585.0, 0.0, 320.0], [0.0, 585.0, 240.0], [0.0, 0.0, 1.0]])
+    R = synth._rodrigues(u(1, (3,)), 0.5 * float(synth.hash_u01(seed, 2, 1)[0]) + 0.1)
+    t = 0.3 * u(3, (3,))
+    X = (synth.hash_u01(seed, 4, n * 3).reshape(n, 3) * 2 - 1) * np.array([1.2, 0.9, 0.8]) + np.array([0.0, 0.0, 3.0])
+    Y = X @ R.T + t
+    uv = np.stack([K[0, 0] * Y[:, 0] / Y[:, 2] + K[0, 2], K[1, 1] * Y[:, 1] / Y[:, 2] + K[1, 2]], 1) + noise * u(5, (n, 2))
+    bad = synth.hash_u01(seed, 6, n) < outliers
+    uv[bad] = synth.hash_u01(seed, 7, n * 2).reshape(n, 2)[bad] * np.array([640.0, 480.0])
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return X.astype(np.float32), uv[:, ::-1].astype(np.float32).copy(), K, T, ~bad       # pixels as (h, w) rows, like the reference's
