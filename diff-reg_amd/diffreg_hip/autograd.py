@@ -221,7 +221,8 @@ class _Procrustes(torch.autograd.Function):
             wn = (w / (w.abs().sum(1, keepdim=True) + 1e-4))[..., None]
             mx, my = (wn * X).sum(1, keepdim=True), (wn * Y).sum(1, keepdim=True)
             S = (Y - my).transpose(1, 2) @ (wn * (X - mx))
-            U, D, V = S.svd()
+            U, D, Vh = torch.linalg.svd(S)
+            V = Vh.transpose(1, 2)
             fix = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
             fix[:, 2, 2] = (U.det() * V.det()).detach()
             Rr = U @ (fix @ V.transpose(1, 2))
