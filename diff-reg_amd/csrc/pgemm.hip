@@ -371,7 +371,10 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             float4 tb[NI];
-            if (rot) {
+            if (rot && ABL == 10) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) tb[i] = make_float4(1.f, 1.f, 0.f, 0.f);
+            } else if (rot) {
                 const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;
                 const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
 #pragma unroll
@@ -434,7 +437,10 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         // registers, round 1 is parked in the wave's transposition region (free now).
         const float* __restrict__ res = P.resid;
         float4 r0[NI];
-        if (res) {
+        if (res && ABL == 12) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { r0[i] = make_float4(0.f, 0.f, 0.f, 0.f); *reinterpret_cast<float4*>(ep + lr * EP_S + 16 * i + 4 * q) = r0[i]; }
+        } else if (res) {
             const float* rp1 = res + (size_t)min(grow[1], rows - 1) * P.ldr;
             const float* rp0 = res + (size_t)min(grow[0], rows - 1) * P.ldr;
 #pragma unroll
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
                     v[rr][i] = y;
-                    if (P.out && rok) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
+                    if (P.out && rok && ABL != 13) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
                 }
             }
         }
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     if (!P.pimg) return;
 
     // ---- plane image of the result.  Piece i of lane q is columns 16 i + 4 q .. + 3 of chunk (wn BNW / 16 + i): the lanes
-    // q and q ^ 1 hold the two halves of one 16-byte unit; for even i the even lane stores the unit, for odd i the odd one.
+    // q and q ^ 1 hold the two halves of one hi unit and of one lo unit (16 bytes each); the even lane stores the hi unit, the odd one the lo unit.
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const bool rok = grow[rr] < rows;
@@ -530,12 +536,14 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             unsigned h0, l0, h1, l1;
             split2(v[rr][i].x * sc, v[rr][i].y * sc, h0, l0);
             split2(v[rr][i].z * sc, v[rr][i].w * sc, h1, l1);
-            const unsigned ph0 = dpp_xor1(h0), ph1 = dpp_xor1(h1), pl0 = dpp_xor1(l0), pl1 = dpp_xor1(l1);
-            if ((((i ^ q) & 1) == 0) && rok) {
-                const uint4 H = (q & 1) ? make_uint4(ph0, ph1, h0, h1) : make_uint4(h0, h1, ph0, ph1);
-                const uint4 L = (q & 1) ? make_uint4(pl0, pl1, l0, l1) : make_uint4(l0, l1, pl0, pl1);
-                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + uh) = H;
-                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + ul) = L;
+            // ONE 16-byte store per lane: the even lane of a pair writes the hi unit (its 4 columns, then the partner's), the odd lane the lo
+            // unit -- every lane stores, a wave instruction covers 16 rows x 64 contiguous bytes (two stores by half the lanes before:
+            // 39 of the family's 108 ms per pass were these stores, DR_PG_ABL=11)
+            const bool odd = q & 1;
+            const unsigned r0_ = dpp_xor1(odd ? h0 : l0), r1_ = dpp_xor1(odd ? h1 : l1);      // what the partner stores of mine <-> what I store of the partner's
+            if (rok && ABL != 11) {
+                const uint4 U = odd ? make_uint4(r0_, r1_, l0, l1) : make_uint4(h0, h1, r0_, r1_);
+                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)) = U;
             }
         }
     }
@@ -676,7 +684,7 @@ static int configure_mode(bool with_dbg) {
 #define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM))
     PG_ATTR(false, 0);
     if constexpr (TNW == 7) {
-        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); PG_ATTR(true, 9); }
+        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); PG_ATTR(true, 9); PG_ATTR(true, 10); PG_ATTR(true, 11); PG_ATTR(true, 12); PG_ATTR(true, 13); }
     }
 #undef PG_ATTR
     return DR_OK;
@@ -733,6 +741,10 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         case 6: PG_LAUNCH(7, 4, MODE, true, 6); break;             \
         case 7: PG_LAUNCH(7, 4, MODE, true, 7); break;             \
         case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
+        case 10: PG_LAUNCH(7, 4, MODE, true, 10); break;           \
+        case 11: PG_LAUNCH(7, 4, MODE, true, 11); break;           \
+        case 12: PG_LAUNCH(7, 4, MODE, true, 12); break;           \
+        case 13: PG_LAUNCH(7, 4, MODE, true, 13); break;           \
         default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
     }
     if (half && !dbg) {
