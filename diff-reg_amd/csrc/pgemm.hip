@@ -542,8 +542,9 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             const bool odd = q & 1;
             const unsigned r0_ = dpp_xor1(odd ? h0 : l0), r1_ = dpp_xor1(odd ? h1 : l1);      // what the partner stores of mine <-> what I store of the partner's
             if (rok && ABL != 11) {
-                const uint4 U = odd ? make_uint4(r0_, r1_, l0, l1) : make_uint4(h0, h1, r0_, r1_);
-                *reinterpret_cast<uint4*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)) = U;
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v U = odd ? u32x4v{r0_, r1_, l0, l1} : u32x4v{h0, h1, r0_, r1_};
+                __builtin_nontemporal_store(U, reinterpret_cast<u32x4v*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)));
             }
         }
     }
