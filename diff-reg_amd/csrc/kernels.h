@@ -117,7 +117,7 @@ int launch_fourier3d(const float* xyz, int P, int rows_per_pair, const float* R,
 int launch_fourier2d(const float* pix, int rows, int L, float* emb, int ldo, hipStream_t st);
 // rotary tables of warped points: p' = R p + t (R,t per pair, nullable), cos/sin [rows, C/2]
 int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
-                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st);
+                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st, float* cs_pairs = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // top-K weighted Procrustes (procrustes.hip)

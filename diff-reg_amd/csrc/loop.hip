@@ -166,6 +166,7 @@ struct PlanesWs {
     char *qkv_img, *kvc_img;                 // q | k | v images (three images of H dp columns, back to back); cached k | v of layer 1
     float *qkv_bnd, *kvc_bnd;                // [3][T] / [2][T]
     float* grp_x;                            // [2 P] bound of x per key group (src groups, then tgt groups)
+    float* csT;                              // [T][C/2][2] the rotary tables interleaved (cos, sin)
     size_t qkv_stride;                       // bytes from the q image to the k image (= to the next: v)
     size_t side_C, side_att, side_hid;      // byte offset of the tgt part inside an image of K = C / H dp / 2C
     void* own_pack;                         // packed weights inside the workspace (used when the caller passed none)
@@ -189,6 +190,7 @@ struct PlanesWs {
         w.qkv_img = c.take<char>(3 * w.qkv_stride); w.qkv_bnd = c.take<float>(3 * (size_t)T);
         w.kvc_img = c.take<char>(2 * w.qkv_stride); w.kvc_bnd = c.take<float>(2 * (size_t)T);
         w.grp_x = c.take<float>(2 * (size_t)P);
+        w.csT = c.take<float>((size_t)T * C);
         w.own_pack = c.take<char>(Prepack::carve(nullptr, cfg, nullptr));
     }
 };
@@ -339,6 +341,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.W = pgw_blocks(L.qkv, b0, C); p.nblk = nblk; p.rows = nrows(side); p.C = Cq; p.k_alg = C; p.mode = PG_PLANES;
         p.rot_mask = rotm; p.rot_C = C; p.rot_piece_len = d; p.rot_piece_pad = dp; p.scale = 1.f;
         p.cosT = X.cosT + (size_t)r0(side) * halfC; p.sinT = X.sinT + (size_t)r0(side) * halfC;
+        p.csT = X.pw->csT + (size_t)r0(side) * halfC * 2;
         p.pimg = at(img, pw.side_att, side); p.p_nct = nq; p.pbnd = bnd + r0(side);
         p.pimg_blk_stride = (long long)pw.qkv_stride; p.pbnd_blk_stride = T;
         p.grp_bnd = pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_TGT ? X.P : 0; p.grp_rows = side == SIDE_TGT ? X.M : X.N;
@@ -518,6 +521,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
             p.W = ws.pp->head; p.nblk = 1; p.rows = side == SIDE_TGT ? PM : PN; p.C = C; p.mode = PG_F32;
             p.out = ws.proj + (size_t)r0 * C; p.ldo = C; p.blk_stride = 0; p.rot_mask = 1; p.rot_C = C; p.scale = 1.0f / sqrtf((float)C);
             p.cosT = ws.cosT + (size_t)r0 * (C / 2); p.sinT = ws.sinT + (size_t)r0 * (C / 2);
+            p.csT = ws.pl.csT + (size_t)r0 * C;
         }
         int rc = launch_pgemm(g, st);
         if (rc) return rc;
@@ -602,10 +606,11 @@ static int fill_pe(const dr_loop_config& cfg, const dr_loop_weights& w, int P, i
     int rc = DR_OK;
     if (do_src)
         rc = launch_vol_pe(s_pcd, P * N, N, Rf, tf, cfg.C, cfg.origin[0], cfg.origin[1], cfg.origin[2], cfg.voxel, w.pe_freq,
-                           ws.cosT, ws.sinT, st);
+                           ws.cosT, ws.sinT, st, ws.pl.on ? ws.pl.csT : nullptr);
     if (rc == DR_OK && do_tgt)
         rc = launch_vol_pe(t_pcd, P * M, M, nullptr, nullptr, cfg.C, cfg.origin[0], cfg.origin[1], cfg.origin[2], cfg.voxel,
-                           w.pe_freq, ws.cosT + (size_t)P * N * halfC, ws.sinT + (size_t)P * N * halfC, st);
+                           w.pe_freq, ws.cosT + (size_t)P * N * halfC, ws.sinT + (size_t)P * N * halfC, st,
+                           ws.pl.on ? ws.pl.csT + (size_t)P * N * halfC * 2 : nullptr);
     return rc;
 }
 

@@ -41,6 +41,7 @@ struct PgProblem {
     // PG_F32: out[row][nb * blk_stride + col] = rot(acc) * scale     (PG_LN: optional fp32 copy of the result, nb = 0)
     float* out; int ldo; int blk_stride;
     const float* cosT; const float* sinT; int rot_mask; int rot_C; float scale;
+    const float* csT;                   // optional: the same tables interleaved [rows][C/2][cos, sin] (one 16-byte load per rotated float4)
     int rot_piece_len, rot_piece_pad;   // head-padded output columns (pack out_len / out_pad): table index of column c' (0: identity)
     // PG_PLANES / PG_LN: plane image of the output, column block nb -> chunks p_kc0 + nb * (C / 16) ..
     char* pimg; int p_nct; int p_kc0; float* pbnd;

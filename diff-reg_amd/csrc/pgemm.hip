@@ -377,13 +377,19 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             } else if (rot) {
                 const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;
                 const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
+                const float* pp = P.csT ? P.csT + (size_t)min(grow[rr], rows - 1) * halfC * 2 : nullptr;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     int col = min(colw + 16 * i, C - 4);
                     if (rpad > 0) col = (col / rpad) * rlen + min(col % rpad, rlen - 4);
                     const int ridx = (col % P.rot_C) >> 1;
-                    const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx);
-                    tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
+                    if (pp) {
+                        const float4 cs = *reinterpret_cast<const float4*>(pp + 2 * ridx);        // (cos_k, sin_k, cos_k+1, sin_k+1)
+                        tb[i] = make_float4(cs.x, cs.z, cs.y, cs.w);
+                    } else {
+                        const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx);
+                        tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
+                    }
                 }
             }
             transpose_round(rr, v[rr]);

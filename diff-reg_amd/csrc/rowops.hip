@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void vol_pe_kernel(const float* __restrict__ x
                                                      const float* __restrict__ R, const float* __restrict__ tv, int C,
                                                      float ox, float oy, float oz, float voxel,
                                                      const float* __restrict__ freq, float* __restrict__ cosT,
-                                                     float* __restrict__ sinT, float* __restrict__ warped) {
+                                                     float* __restrict__ sinT, float* __restrict__ warped, float2* __restrict__ cs_pairs) {
     const int nf = C / 6, half = C / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * half) return;
@@ -259,18 +259,20 @@ __global__ __launch_bounds__(256) void vol_pe_kernel(const float* __restrict__ x
     const float o = a == 0 ? ox : (a == 1 ? oy : oz);
     const float vox = __fdiv_rn(__fsub_rn(p, o), voxel);
     const float ang = __fmul_rn(vox, freq[k]);
-    cosT[idx] = cosf(ang);
-    sinT[idx] = sinf(ang);
+    const float cv = cosf(ang), sv = sinf(ang);
+    cosT[idx] = cv;
+    sinT[idx] = sv;
+    if (cs_pairs) cs_pairs[idx] = make_float2(cv, sv);      // the same tables interleaved (cos_k, sin_k): one 16-byte load per rotated float4 in the plane GEMM's epilogue
 }
 
 int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R, const float* t, int C, float ox,
-                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st) {
+                  float oy, float oz, float voxel, const float* freq, float* cosT, float* sinT, hipStream_t st, float* cs_pairs) {
     if (C % 6) return DR_ENOSUP;
     const int total = rows * (C / 2);
     if (total <= 0) return DR_OK;
     ProfScope ps(PK_PE, (double)total * 8.0, st);
     hipLaunchKernelGGL(vol_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, st, xyz, rows, rows_per_pair, R, t, C, ox,
-                       oy, oz, voxel, freq, cosT, sinT, (float*)nullptr);
+                       oy, oz, voxel, freq, cosT, sinT, (float*)nullptr, reinterpret_cast<float2*>(cs_pairs));
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
