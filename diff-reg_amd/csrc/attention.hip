@@ -62,7 +62,15 @@ __device__ __forceinline__ void attn_store_planes(const AttnArgs& A, const float
     }
 }
 
-template <int DG, int NDT>
+// key mask of one 32-key tile as bits (bit j = key k0 + j is kept): ONE byte load per lane, issued before the tile's MFMAs, and a
+// ballot after them.  (Sixteen dependent byte loads per lane inside the softmax, each behind its own branch, were the critical path
+// of every kernel below: ~10 of the 20 us of a single-pair launch.)
+__device__ __forceinline__ unsigned char attn_mask_byte(const AttnArgs& A, int kbase, int k0, int Lk, int l31) {
+    return A.kmask ? (unsigned char)A.kmask[kbase + min(k0 + l31, Lk - 1)] : (unsigned char)1;
+}
+__device__ __forceinline__ unsigned attn_mask_bits(unsigned char b) { return (unsigned)__ballot(b != 0); }
+
+template <int DG, int NDT, int NWV = 4>
 struct AttnGeom {
     static constexpr int DP = DG * 8;            // padded head dim for the QK^T k-loop
     static constexpr int QS = DP + 4;            // LDS row stride of the Q / K tiles
@@ -72,16 +80,17 @@ struct AttnGeom {
     static constexpr int m1 = 32 * QS + NDT * 32;         // last row may be read NDT*32 wide
     static constexpr int m2 = m1 > NDT * 32 * 32 ? m1 : NDT * 32 * 32;
     static constexpr int WBUF = (m2 + 15) / 16 * 16;      // floats per wave buffer
-    static constexpr int SMEM_FLOATS = 32 * QS + 4 * WBUF + 256;
+    static constexpr int SMEM_FLOATS = 32 * QS + NWV * WBUF + 64 * NWV;   // NWV waves deal the key tiles (8 for the single-pair
+                                                                          // launches: a wave's chain is one or two key tiles long)
 };
 
-template <int DG, int NDT>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
-    using G = AttnGeom<DG, NDT>;
+template <int DG, int NDT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attention_kernel(AttnArgs A) {
+    using G = AttnGeom<DG, NDT, NWV>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* wbuf = smem + 32 * G::QS + (threadIdx.x >> 6) * G::WBUF;
-    float* s_ml = smem + 32 * G::QS + 4 * G::WBUF;      // [4][32] m, [4][32] l
+    float* s_ml = smem + 32 * G::QS + NWV * G::WBUF;    // [NWV][32] m, [NWV][32] l
 
     // ---- which segment / head / query tile ---------------------------------------------------
     int seg = blockIdx.z, qbase, kbase, Lq, Lk;
@@ -94,19 +103,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     const int qt = blockIdx.x;
     if (qt * 32 >= Lq) return;
     const int head = blockIdx.y, d = A.d;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, l31 = lane & 31;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5, l31 = lane & 31;
     const int nv4 = d >> 2;                       // float4 per row (d % 4 == 0)
-
-    // ---- stage the Q tile (zero padded) ---------------------------------------------------------
-    for (int s = t; s < 32 * (G::DP / 4); s += 256) {
-        const int r = s / (G::DP / 4), c4 = s % (G::DP / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int qr = qt * 32 + r;
-        if (qr < Lq && c4 < nv4)
-            v = *reinterpret_cast<const float4*>(A.q + (size_t)(qbase + qr) * A.ldq + head * d + 4 * c4);
-        *reinterpret_cast<float4*>(Qs + r * G::QS + 4 * c4) = v;
-    }
-    __syncthreads();
 
     const int my_q = qt * 32 + l31;
     const bool q_valid = my_q < Lq && (!A.qmask || A.qmask[qbase + my_q]);
@@ -122,42 +120,61 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
     const float sc2 = A.scale * 1.4426950408889634f;
     // tile staging: lane owns DG float4 slots of the [32][DP/4] image; slot s = lane + 64 j -> row s / (DP/4)
     float4 kreg[DG], vreg[DG];
-    // per-slot descriptor, computed once: row r (bits 0-7), LDS float offset (bits 8-23), column-valid (bit 31);
-    // global column offset = head*d + 4*min(c4, nv4-1)
-    unsigned sdesc[DG];
-    int scol[DG];
-#pragma unroll
-    for (int j = 0; j < DG; ++j) {
-        const int sl = lane + 64 * j;
-        const int r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
-        sdesc[j] = (unsigned)r | ((unsigned)(r * G::QS + 4 * c4) << 8) | (c4 < nv4 ? 0x80000000u : 0u);
-        scol[j] = head * d + 4 * min(c4, nv4 - 1);
-    }
+    // slot s = lane + 64 j -> row s / (DP/4), float4 column s % (DP/4); global column offset = head*d + 4*min(c4, nv4-1).  (Recomputed
+    // at each use: a table of them is 2 DG registers, which the 8-wave form -- 256 registers per wave -- does not have.)
     auto load_tile = [&](const float* base, int ld, int kt, float4 (&reg)[DG]) {
         const int lim = Lk - 1 - kt * 32;                         // last valid row of this tile
-        const float* tb = base + (size_t)(kbase + kt * 32) * ld;
+        const float* tb = base + (size_t)(kbase + kt * 32) * ld + head * d;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                              // (opaque: the slot arithmetic is redone here, not kept live between tiles)
 #pragma unroll
         for (int j = 0; j < DG; ++j) {
-            const int r = (int)(sdesc[j] & 0xFFu);
-            reg[j] = *reinterpret_cast<const float4*>(tb + min(r, lim) * ld + scol[j]);
+            const int sl = ln + 64 * j, r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
+            const unsigned off = (unsigned)(min(r, lim) * ld + 4 * min(c4, nv4 - 1));      // uniform base + 32-bit lane offset
+            reg[j] = *reinterpret_cast<const float4*>(tb + off);
         }
     };
     // zeroing of padding rows / columns happens at store time (touching the data earlier would wait for the load)
     auto store_tile_k = [&](const float4 (&reg)[DG], int kt) {
         const int lim = Lk - 1 - kt * 32;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int j = 0; j < DG; ++j) {
-            const bool ok = (int)(sdesc[j] & 0xFFu) <= lim && (sdesc[j] >> 31);
+            const int sl = ln + 64 * j, r = sl / (G::DP / 4), c4 = sl % (G::DP / 4);
+            const bool ok = r <= lim && c4 < nv4;
             const float4 v = reg[j];
-            *reinterpret_cast<float4*>(wbuf + ((sdesc[j] >> 8) & 0xFFFFu)) =
+            *reinterpret_cast<float4*>(wbuf + r * G::QS + 4 * c4) =
                 make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
     if (w < nkt) load_tile(A.k, A.ldk, w, kreg);
-    for (int kt = w; kt < nkt; kt += 4) {
+    // ---- stage the Q tile (zero padded): every load of it is in flight together, behind the first K tile's ---------------------
+    {
+        constexpr int NQ = (32 * (G::DP / 4) + 64 * NWV - 1) / (64 * NWV);
+        float4 qv[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int sq = t + 64 * NWV * i, r = sq / (G::DP / 4), c4 = sq % (G::DP / 4), qr = qt * 32 + r;
+            qv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sq < 32 * (G::DP / 4) && qr < Lq && c4 < nv4)
+                qv[i] = *reinterpret_cast<const float4*>(A.q + (size_t)(qbase + qr) * A.ldq + head * d + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int sq = t + 64 * NWV * i, r = sq / (G::DP / 4), c4 = sq % (G::DP / 4);
+            if (sq < 32 * (G::DP / 4)) *reinterpret_cast<float4*>(Qs + r * G::QS + 4 * c4) = qv[i];
+        }
+    }
+    __syncthreads();
+    // (the 8-wave form is launched for key ranges of at most 8 tiles: one tile per wave, no next tile to prefetch)
+    const int kt_end = NWV == 8 ? min(nkt, w + 1) : nkt;
+    for (int kt = w; kt < kt_end; kt += NWV) {
         // ---- K tile -> LDS; V tile of the same keys starts loading -------------------------------------
+        const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
         wave_lds_fence();
         store_tile_k(kreg, kt);
+        __builtin_amdgcn_sched_barrier(0);                       // (the V loads after the K stores: the two staging sets never live together)
         load_tile(A.v, A.ldv, kt, vreg);
         wave_lds_fence();
         // ---- S^T = K Q^T ----------------------------------------------------------------------------
@@ -166,7 +183,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         const float* kp = wbuf + l31 * G::QS + 4 * h;
         const float* qp = Qs + l31 * G::QS + 4 * h;
-#pragma unroll
+        constexpr int UG = (NWV == 8 && DG % 2 == 0) ? DG / 2 : DG;   // (8 waves = 256 registers per wave: bound the fragment preloading)
+#pragma unroll UG
         for (int g = 0; g < DG; ++g) {
             const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
             const float4 b = *reinterpret_cast<const float4*>(qp + 8 * g);
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
             sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, sc, 0, 0, 0);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----
+        const unsigned kbits = attn_mask_bits(mbyte) >> (4 * h);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -183,8 +202,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
             float s = sc[r];
             // transformero.py:82: fill where the query is valid and the key is not; keys beyond the
             // segment exist only as tile padding
-            bool drop = kk >= Lk;
-            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
             s = drop ? -INFINITY : s * sc2;                     // log2-domain logits: 2^(s*scale*log2 e)
             sc[r] = s;
             mx = fmaxf(mx, s);
@@ -214,13 +232,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
         // ---- V tile -> LDS (same buffer); the K tile of this wave's next keys starts loading -------------
         wave_lds_fence();
         store_tile_k(vreg, kt);
-        if (kt + 4 < nkt) load_tile(A.k, A.ldk, kt + 4, kreg);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NWV != 8 && kt + NWV < nkt) load_tile(A.k, A.ldk, kt + NWV, kreg);
         wave_lds_fence();
         // ---- O^T += V^T P^T : step r contracts keys (r&3)+8(r>>2) (h = 0 lanes) and +4 (h = 1 lanes) ----
         // MFMA row l31 of tile i is feature NDT*l31 + i (any bijection works: output rows are only labels), so the
         // NDT operands of a step are NDT consecutive floats of one V row: one vector LDS read per step
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+          if (NWV == 8) __builtin_amdgcn_sched_barrier(0);          // (bounds the fragment preloading of the 8-wave form)
+#pragma unroll
+          for (int r = r0; r < r0 + 4; ++r) {
             const float* vp = wbuf + ((r & 3) + 8 * (r >> 2) + 4 * h) * G::QS + NDT * l31;
             float vv[NDT];
             if (NDT == 4) {
@@ -235,10 +257,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
             }
 #pragma unroll
             for (int i = 0; i < NDT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i], sc[r], acc[i], 0, 0, 0);
+          }
         }
     }
 
-    // ---- merge the 4 waves: out = sum_w e^{m_w - m*} O_w / sum_w e^{m_w - m*} l_w ---------------------
+    // ---- merge the NWV waves: out = sum_w e^{m_w - m*} O_w / sum_w e^{m_w - m*} l_w ---------------------
     // per-wave O tile image: [dcol][q ^ (dcol & 31)] (conflict-free for the lane = q writes and the lane = dcol reads)
     wave_lds_fence();
 #pragma unroll
@@ -250,23 +273,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs A) {
         }
     if (h == 0) {
         s_ml[w * 32 + l31] = m_run;
-        s_ml[128 + w * 32 + l31] = l_run;
+        s_ml[NWV * 32 + w * 32 + l31] = l_run;
     }
     __syncthreads();
     const float* W0 = smem + 32 * G::QS;
-    for (int idx = t; idx < 32 * d; idx += 256) {
+    for (int idx = t; idx < 32 * d; idx += 64 * NWV) {
         const int q = idx / d, c = idx % d;
         if (qt * 32 + q >= Lq) continue;
         float ms = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ms = fmaxf(ms, s_ml[k * 32 + q]);
+        for (int k = 0; k < NWV; ++k) ms = fmaxf(ms, s_ml[k * 32 + q]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NWV; ++k) {
             const float mk = s_ml[k * 32 + q];
             const float e = (mk == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mk - ms);
             num = fmaf(e, W0[k * G::WBUF + c * 32 + (q ^ (c & 31))], num);
-            den = fmaf(e, s_ml[128 + k * 32 + q], den);
+            den = fmaf(e, s_ml[NWV * 32 + k * 32 + q], den);
         }
         A.out[(size_t)(qbase + qt * 32 + q) * A.ldo + head * d + c] = num / den;
     }
@@ -372,6 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) load_tiles(kt + 1);
+        const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
         const float* Kt = smem + (kt & 1) * 2 * G::TILE;
         const float* Vt = Kt + G::TILE;
         // ---- S^T = K Q^T ----------------------------------------------------------------------------
@@ -389,13 +413,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, sc, 0, 0, 0);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----
+        const unsigned kbits = attn_mask_bits(mbyte) >> (4 * h);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float s = sc[r];
-            bool drop = kk >= Lk;                                // transformero.py:82
-            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
             s = drop ? -INFINITY : s * sc2;
             sc[r] = s;
             mx = fmaxf(mx, s);
@@ -633,6 +657,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = kt + 1 < nkt;
         if (more) load_k(kt + 1);
+        const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
         // ---- S^T = K Q^T ----------------------------------------------------------------------------------
         f32x16 sc;
 #pragma unroll
@@ -663,13 +688,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             load_v(kt + 1);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile) ----------
+        const unsigned kbits = attn_mask_bits(mbyte) >> (4 * h);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float s = sc[r];
-            bool drop = kk >= Lk;                                // transformero.py:82
-            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
             s = drop ? -INFINITY : s * sc2;
             sc[r] = s;
             mx = fmaxf(mx, s);
@@ -875,6 +900,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // own DMA instructions of tile kt have landed ...
         __syncthreads();                                         // ... and everybody's; everybody is done with the other buffer
         if (kt + 1 < nkt) stage(kt + 1, b ^ 1);
+        const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
         const char* kb = lds + b * G::BUF + l31 * 64;
         const char* vb = lds + b * G::BUF + G::KIMG;
         // ---- S^T = K Q^T
@@ -891,13 +917,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_h, sc, 0, 0, 0);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile)
+        const unsigned kbits = attn_mask_bits(mbyte) >> (4 * h);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float s = sc[r];
-            bool drop = kk >= Lk;                                // transformero.py:82
-            if (!drop && q_valid && A.kmask) drop = !A.kmask[kbase + kk];
+            const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
             s = drop ? -INFINITY : s * sfac;
             sc[r] = s;
             mx = fmaxf(mx, s);
@@ -970,6 +996,9 @@ static int configure_attn() {
     using G = AttnGeom<DG, NDT>;
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(G::SMEM_FLOATS * sizeof(float))));
+    if constexpr (AttnGeom<DG, NDT, 8>::SMEM_FLOATS * sizeof(float) <= 160 * 1024)
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<DG, NDT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(AttnGeom<DG, NDT, 8>::SMEM_FLOATS * sizeof(float))));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_kernel<DG, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(FlashGeom<DG, NDT>::SMEM_FLOATS * sizeof(float))));
     constexpr int KS = (DG * 8 + 15) / 16;
@@ -1033,6 +1062,18 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((attention_flash_kernel<DG, NDT>), fgrid, dim3(256), flds, st, a);
         DR_LAUNCH_CHECK();
         return DR_OK;
+    }
+    // few workgroups (a single pair: 8 query tiles x heads x sides) and a long key range: 8 waves deal the key tiles, a wave's chain
+    // of dependent MFMAs (120 of 64 cycles per key tile at d = 108) is then half as long
+    constexpr size_t lds8 = (size_t)AttnGeom<DG, NDT, 8>::SMEM_FLOATS * sizeof(float);
+    if constexpr (lds8 <= 160 * 1024) {
+        static const int w8_env = env_knob("DR_ATTN_W8_MAX", 256);
+        const int maxLk = a.nseg2 > 0 && a.Lkb > a.Lk ? a.Lkb : a.Lk;
+        if ((int)(grid.x * grid.y * grid.z) <= w8_env && maxLk > 4 * 32 && maxLk <= 8 * 32) {
+            hipLaunchKernelGGL((attention_kernel<DG, NDT, 8>), grid, dim3(512), lds8, st, a);
+            DR_LAUNCH_CHECK();
+            return DR_OK;
+        }
     }
     hipLaunchKernelGGL((attention_kernel<DG, NDT>), grid, dim3(256), lds, st, a);
     DR_LAUNCH_CHECK();
