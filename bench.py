@@ -33,6 +33,9 @@ import torch  # noqa: E402
 
 HEAD_GAIN = 24.0
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA
+DEP_LAUNCH_FLOOR_US = 4.7            # the cheapest kernels of the single-pair chain (LayerNorm of 512 rows, casts, an attention launch
+                                     # that returns at once): 4.7-4.9 us each; an empty kernel in an idle chain: 1.53 us
+                                     # (profiles/r02_b1_launch_floor.json, DESIGN section 5 "Single pair")
 PEAK_MFMA_BF16_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
 # the split-operand GEMMs spend several 16-bit MFMA MACs per fp32 MAC: the ceiling of what they execute, in fp32-equivalent
 # FLOP/s.  Default: two fp16 planes, three products (the fp16 and bf16 dense MFMA peaks are the same); DR_GEMM_F16X2=0: three
@@ -364,6 +367,19 @@ def main():
             torch.cuda.synchronize()
             lat = (time.perf_counter() - t1) / 10
             result["single_pair"] = {"ms_per_pair": lat * 1e3, "pairs_per_s": 1.0 / lat}
+            # its own roofline: one pair is ~1 400 DEPENDENT launches, and no kernel of that chain -- not even an attention launch
+            # that returns at once -- takes less than 4.7 us (profiles/r02_b1_launch_floor.json): the chain alone is above the
+            # 5 ms asked for; the FLOP rate beside it shows how far from the arithmetic roof that leaves the pair
+            lib.prof_enable(True)
+            eng.run(inp1["f_s"], inp1["f_t"], inp1["p_s"], inp1["p_t"], inp1["x_T"], graph=False)
+            p1 = lib.prof_collect()
+            lib.prof_enable(False)
+            n1 = sum(v[0] for v in p1.values())
+            fl1 = sum(v[2] for k, v in p1.items() if k in ("gemm", "gemm_split", "attention"))
+            result["single_pair"]["roofline"] = {
+                "bound": "dependent-launch chain", "launches": n1, "launch_floor_us": DEP_LAUNCH_FLOOR_US,
+                "floor_ms": n1 * DEP_LAUNCH_FLOOR_US * 1e-3, "frac": n1 * DEP_LAUNCH_FLOOR_US * 1e-6 / lat,
+                "mfma_TFLOPs": fl1 / lat / 1e12, "mfma_frac_of_f32_peak": fl1 / lat / 1e12 / PEAK_MFMA_F32_TFLOPS}
 
         if not args.no_breakdown:
             # ---- per-kernel-family GPU time of the same pass (eager launches, HIP events on the stream) ---

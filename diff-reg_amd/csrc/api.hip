@@ -38,6 +38,10 @@ void prof_end(int kind, hipStream_t st) {
 }
 }  // namespace dr
 
+namespace dr {
+__global__ void noop_kernel(int* p) { if (p && threadIdx.x == 0 && blockIdx.x == 0) *p = 0; }
+}
+
 extern "C" {
 void dr_prof_enable(int on) { dr::g_prof_on = on != 0; }
 
@@ -56,6 +60,15 @@ int dr_prof_collect(int* calls, double* ms, double* work) {
         g_pool.push_back(r.a);
     }
     g_prof.clear();
+    return DR_OK;
+}
+
+/* diagnostics: n launches of a kernel that does nothing, each dependent on the one before (same stream) -- what a dependent launch
+ * costs on this platform whatever it does: the floor under the single-pair latency (tools/launch_floor.py) */
+int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream) {
+    if (n < 0 || workgroups < 1 || threads < 64 || threads > 1024) return DR_EINVAL;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(dr::noop_kernel, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, (int*)nullptr);
+    DR_LAUNCH_CHECK();
     return DR_OK;
 }
 

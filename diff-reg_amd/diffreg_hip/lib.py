@@ -124,6 +124,7 @@ SIGNATURES.update({
                                [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
     "dr_debug_enable_env": (None, [c_int]),
+    "dr_debug_launch_chain": (c_int, [c_int, c_int, c_int, c_void_p]),
     "dr_debug_gemm_config": (None, [c_int]),
     "dr_debug_gemm_wide_min": (None, [c_int]),
     "dr_debug_gemm_f16x2": (None, [c_int]),

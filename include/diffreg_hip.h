@@ -259,6 +259,7 @@ void dr_debug_gemm_wide_min(int tiles);
  * dr_procrustes_f32 launch (pair 0); synchronises the device. */
 int dr_debug_procrustes_stamps(long long* h_out8);
 int dr_debug_gemm_stamps(long long* h_out256);
+int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream);   /* n dependent launches of an empty kernel (tools/launch_floor.py) */
 int dr_debug_pgemm_stamps(long long* h_out128);   /* with dr_debug_enable_env(1) and DR_PG_STAMPS=1: phase stamps of workgroup 0 of the last plane GEMM */
 /* packed GEMMs: 1 = two-plane fp16 operand split with exact power-of-two row / column scaling (three MFMA products per
  * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = default (1; DR_GEMM_F16X2 under dr_debug_enable_env).
