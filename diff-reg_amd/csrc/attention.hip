@@ -167,9 +167,7 @@ __global__ __launch_bounds__(64 * NWV) void attention_kernel(AttnArgs A) {
         }
     }
     __syncthreads();
-    // (the 8-wave form is launched for key ranges of at most 8 tiles: one tile per wave, no next tile to prefetch)
-    const int kt_end = NWV == 8 ? min(nkt, w + 1) : nkt;
-    for (int kt = w; kt < kt_end; kt += NWV) {
+    for (int kt = w; kt < nkt; kt += NWV) {
         // ---- K tile -> LDS; V tile of the same keys starts loading -------------------------------------
         const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
         wave_lds_fence();
@@ -233,7 +231,7 @@ __global__ __launch_bounds__(64 * NWV) void attention_kernel(AttnArgs A) {
         wave_lds_fence();
         store_tile_k(vreg, kt);
         __builtin_amdgcn_sched_barrier(0);
-        if (NWV != 8 && kt + NWV < nkt) load_tile(A.k, A.ldk, kt + NWV, kreg);
+        if (kt + NWV < nkt) load_tile(A.k, A.ldk, kt + NWV, kreg);
         wave_lds_fence();
         // ---- O^T += V^T P^T : step r contracts keys (r&3)+8(r>>2) (h = 0 lanes) and +4 (h = 1 lanes) ----
         // MFMA row l31 of tile i is feature NDT*l31 + i (any bijection works: output rows are only labels), so the
@@ -1069,7 +1067,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     if constexpr (lds8 <= 160 * 1024) {
         static const int w8_env = env_knob("DR_ATTN_W8_MAX", 256);
         const int maxLk = a.nseg2 > 0 && a.Lkb > a.Lk ? a.Lkb : a.Lk;
-        if ((int)(grid.x * grid.y * grid.z) <= w8_env && maxLk > 4 * 32 && maxLk <= 8 * 32) {
+        if ((int)(grid.x * grid.y * grid.z) <= w8_env && maxLk > 4 * 32) {
             hipLaunchKernelGGL((attention_kernel<DG, NDT, 8>), grid, dim3(512), lds8, st, a);
             DR_LAUNCH_CHECK();
             return DR_OK;

@@ -1438,7 +1438,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         maxK = g.p[i].K > maxK ? g.p[i].K : maxK;
         n32 += (long)((g.p[i].rows + 31) / 32) * ((g.p[i].ncols + 31) / 32) * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
     }
-    static const int direct_max = env_knob("DR_GEMM_DIRECT_MAX", 1024);
+    static const int direct_max = env_knob("DR_GEMM_DIRECT_MAX", 2048);   // (1193 rows x 1296 columns = 1558 tiles: 21 us against 36 us for the LDS-staged tiles)
     if (g_force_cfg < 0 && n32 <= direct_max && maxK <= 16 * 8 * 7) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)

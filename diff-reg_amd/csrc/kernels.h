@@ -146,8 +146,10 @@ struct DdimArgs {
     float sqrt_an;
 };
 // M, sm, tm (optional): minimum over the entries inside both masks only
+// (scratch: pair_min_scratch_bytes(P) bytes whose last 64 P bytes -- the arrival counters -- are zero; enables the multi-workgroup form)
 int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st, int M = 0, const uint8_t* sm = nullptr,
-                    const uint8_t* tm = nullptr);
+                    const uint8_t* tm = nullptr, void* scratch = nullptr);
+size_t pair_min_scratch_bytes(int P);
 int launch_ddim(const DdimArgs& a, int P, hipStream_t st);
 int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st);
 int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t st);

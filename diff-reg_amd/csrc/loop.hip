@@ -618,6 +618,7 @@ struct LoopWs {
     DenoiseWs dw;
     float *feat0, *wconf, *x0, *R, *t, *Rf, *tf, *conf32;
     double *x, *dmin, *cond;
+    void* pmin;                              // pair_min_scratch_bytes(P): slice minima + arrival counters of the multi-workgroup minimum
     int* ok;
     uint8_t* tokmask;
     void* skws;
@@ -635,6 +636,7 @@ struct LoopWs {
         w.x = c.take<double>(NM);
         w.dmin = c.take<double>(P);
         w.cond = c.take<double>(P);
+        w.pmin = (void*)c.take<char>(pair_min_scratch_bytes(P));
         w.R = c.take<float>((size_t)P * 9);
         w.t = c.take<float>((size_t)P * 3);
         w.Rf = c.take<float>((size_t)P * 9);
@@ -933,6 +935,8 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     }
     rc = launch_f32_to_f64(x_T, L.x, NM, st);     // exact widening; step 1 keeps float32 semantics
     if (rc) return rc;
+    if (!v4d && P <= 32)                          // arrival counters of the multi-workgroup minimum (few pairs: stateops.hip)
+        DR_HIP_CHECK(hipMemsetAsync((char*)L.pmin + pair_min_scratch_bytes(P) - 64 * (size_t)P, 0, 64 * (size_t)P, st));
     rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);  // split-operand images of the weights (the caller may have updated them)
     if (rc) return rc;
     Prepack pp;
@@ -952,7 +956,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         // -- x <- x - x.min() (3D only, pipeline.py:239); mask; Sinkhorn; exp; slice; float32 (pipeline.py:293-302)
         const double* shift = nullptr;
         if (!v4d) {
-            rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm);
+            rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm, P <= 32 ? L.pmin : nullptr);
             if (rc) return rc;
             shift = L.dmin;
         }
@@ -1011,7 +1015,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = launch_sigmoid(L.x, conf, NM, st);                       // 4D/models/pipeline.py:192
         if (rc) return rc;
     } else {
-        rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm);  // pipeline.py:264-272
+        rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm, P <= 32 ? L.pmin : nullptr);  // pipeline.py:264-272
         if (rc) return rc;
         rc = sinkhorn_f64(P, N, M, L.x, L.dmin, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict,
                           conf, L.skws, L.skws_bytes, st);

@@ -31,10 +31,60 @@ __global__ __launch_bounds__(1024) void pair_min_kernel(const double* __restrict
     }
 }
 
-int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st, int M, const uint8_t* sm, const uint8_t* tm) {
+// The same minimum with G workgroups per pair (a single pair, or a few large ones: one workgroup per pair is then one CU streaming
+// the whole matrix -- 88 us at 564 x 629): slice minima to `part`, and the workgroup that arrives last at the pair's counter reduces
+// them (minimum is exact: the result does not depend on the order).  `cnt` must be zero on entry and is left zero.
+constexpr int PM_G = 64;
+__global__ __launch_bounds__(256) void pair_min_split_kernel(const double* __restrict__ x, int NM, int M, const uint8_t* __restrict__ sm,
+                                                             const uint8_t* __restrict__ tm, double* __restrict__ part,
+                                                             unsigned* __restrict__ cnt, double* __restrict__ out) {
+    __shared__ double s[4];
+    __shared__ bool last;
+    const int pair = blockIdx.y, G = gridDim.x;
+    const double* p = x + (size_t)pair * NM;
+    const int per = ((NM + G - 1) / G + 255) / 256 * 256, e0 = blockIdx.x * per, e1 = min(NM, e0 + per);
+    double m = INFINITY;
+    if (sm) {
+        const uint8_t* s1 = sm + (size_t)pair * (NM / M);
+        const uint8_t* t1 = tm + (size_t)pair * M;
+        for (int e = e0 + threadIdx.x; e < e1; e += 256)
+            if (s1[e / M] && t1[e % M]) m = fmin(m, p[e]);
+    } else
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) m = fmin(m, p[e]);
+    m = wave_min(m);
+    if (lane_id() == 0) s[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[(size_t)pair * PM_G + blockIdx.x] = fmin(fmin(s[0], s[1]), fmin(s[2], s[3]));
+        __threadfence();                                          // the slice minimum is visible device-wide before the arrival is
+        last = atomicAdd(&cnt[pair], 1u) == (unsigned)(G - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 64) {
+        double r = INFINITY;
+        for (int g = threadIdx.x; g < G; g += 64)
+            r = fmin(r, __hip_atomic_load(&part[(size_t)pair * PM_G + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        r = wave_min(r);
+        if (threadIdx.x == 0) { out[pair] = r; cnt[pair] = 0u; }
+    }
+}
+
+size_t pair_min_scratch_bytes(int P) { return (size_t)(P > 0 ? P : 1) * (PM_G * sizeof(double) + 64); }
+
+int launch_pair_min(const double* x, int P, int NM, double* out, hipStream_t st, int M, const uint8_t* sm, const uint8_t* tm, void* scratch) {
     if (P <= 0) return DR_OK;
     ProfScope ps(PK_STATE, (double)P * NM * 8.0, st);
     if (!(sm && tm && M > 0)) { sm = tm = nullptr; M = 1; }
+    if (scratch && P <= 32 && NM >= 16384) {
+        const int G = min(PM_G, (NM + 4095) / 4096);
+        double* part = (double*)scratch;
+        unsigned* cnt = (unsigned*)((char*)scratch + (size_t)P * PM_G * sizeof(double));
+        hipLaunchKernelGGL(pair_min_split_kernel, dim3(G, P), dim3(256), 0, st, x, NM, M, sm, tm, part, cnt, out);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     hipLaunchKernelGGL(pair_min_kernel, dim3(P), dim3(1024), 0, st, x, NM, M, sm, tm, out);
     DR_LAUNCH_CHECK();
     return DR_OK;

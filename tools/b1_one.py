@@ -7,7 +7,7 @@ from diffreg_hip import synth
 from diffreg_hip.engine import DenoiseEngine
 from tests.helpers import weights, pair
 DEV = "cuda:0"
-variant, N, M, steps, mc = "3dmatch", 256, 256, 20, 200
+variant, N, M, steps, mc = "3dmatch", int(os.environ.get("B1_N", "256")), int(os.environ.get("B1_M", "256")), 20, 200
 v = synth.VARIANTS[variant]
 planes = {"1": True, "0": False}.get(os.environ.get("B1_PLANES", ""), None)
 eng = DenoiseEngine(weights(variant), variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps, sk_iters=v["skh_iters"],
