@@ -211,11 +211,12 @@ def test_attention_layer(variant, golden):
     assert (both[1] - ref2[0]).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split", [0, 1, -1])
 @pytest.mark.parametrize("Lx,Ly", [(200, 130), (128, 129), (33, 300)])
 def test_attention_flash_ragged(Lx, Ly, split):
     """128-query kernel on lengths that are no multiple of its blocks (partial waves, partial key tiles, masks),
-    two pairs per call, against the oracle layer."""
+    two pairs per call, against the oracle layer.  split = -1: the default rule instead, which at these sizes is the 32-query
+    kernel in its 8-wave form (few workgroups, more than four key tiles: one to three tiles per wave, key mask as ballot bits)."""
     from diffreg_hip import lib
     variant = "3dmatch"
     v = synth.VARIANTS[variant]
@@ -233,7 +234,7 @@ def test_attention_flash_ragged(Lx, Ly, split):
     cx = torch.cat([half_tables(*q)[0] for q in pex]).to(DEV); sx = torch.cat([half_tables(*q)[1] for q in pex]).to(DEV)
     cy = torch.cat([half_tables(*q)[0] for q in pey]).to(DEV); sy = torch.cat([half_tables(*q)[1] for q in pey]).to(DEV)
     m2x, m2y = torch.cat([mx, mx]).to(DEV), torch.cat([my, my]).to(DEV)
-    lib.raw().dr_debug_attention_config(1)
+    lib.raw().dr_debug_attention_config(1 if split >= 0 else -1)
     lib.raw().dr_debug_attention_split(split)
     try:
         got = lib.attention_layer(tens, C, H, x2, y2, cx, sx, cy, sy, m2x, m2y).cpu()
