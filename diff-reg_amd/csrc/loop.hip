@@ -490,12 +490,13 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
             const Tok* nxt = bufs[which];
             int rc;
             if (use_cache && l == 0) {
+                // the tgt half of layer 0 is the cache (rows, plane image, bounds): the src half is written beside it, into the cache's
+                // own token buffer -- layer 1 reads both halves there and nothing later writes to it (no copy of the cached half)
+                nxt = &ws.pl.tgt_l0;
                 rc = layer_call_planes(X, w.layers[0], 0, *cur, SIDE_SRC, *cur, SIDE_SRC, *nxt, self_s, nullptr, st);
                 if (rc) return rc;
-                // the tgt half of layer 0 comes from the cache: rows, plane image and bounds
-                DR_HIP_CHECK(hipMemcpyAsync(nxt->f32 + (size_t)PN * C, ws.pl.tgt_l0.f32 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
-                DR_HIP_CHECK(hipMemcpyAsync(nxt->img + ws.pl.side_C, ws.pl.tgt_l0.img + ws.pl.side_C, plane_image_bytes(PM, C), hipMemcpyDeviceToDevice, st));
-                DR_HIP_CHECK(hipMemcpyAsync(nxt->bnd + PN, ws.pl.tgt_l0.bnd + PN, (size_t)PM * 4, hipMemcpyDeviceToDevice, st));
+                cur = nxt;
+                continue;
             } else if (l % 2 == 0) {
                 rc = layer_call_planes(X, w.layers[l], l, *cur, SIDE_BOTH, *cur, SIDE_BOTH, *nxt, self_s, &self_t, st);
                 if (rc) return rc;
@@ -546,12 +547,13 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
         const PackedLayer* pk = ws.pw.on ? &ws.pw.layer[l] : nullptr;
         int rc;
         if (use_cache && l == 0) {
-            // src half only; the tgt half comes from the cache
+            // src half only, written beside the cached tgt half (into the cache's own buffer: nothing later writes to it)
+            nxt = ws.tgt_l0; nmax = ws.m_tgt_l0;
             rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
                             cmax, cmax, nmax);
             if (rc) return rc;
-            DR_HIP_CHECK(hipMemcpyAsync(nxt + (size_t)PN * C, ws.tgt_l0 + (size_t)PN * C, (size_t)PM * C * 4, hipMemcpyDeviceToDevice, st));
-            DR_HIP_CHECK(hipMemcpyAsync(nmax + PN, ws.m_tgt_l0 + PN, (size_t)PM * 4, hipMemcpyDeviceToDevice, st));
+            cur = nxt; cmax = nmax;
+            continue;
         } else if (use_cache && l == 1) {
             rc = layer_call(w.layers[1], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st,
                             ws.kv_l1, nullptr, pk, cmax, cmax, nmax);
