@@ -382,3 +382,23 @@ def test_cfg3_4dmatch_512_batch8_20_steps(golden):
         assert (one["R_forwd"][:, 0].cpu() - Rf_all[:, i]).abs().max().item() < 1e-4, i
         dd = (one["conf_matrix_pred"][0].cpu() - conf_all[i]).abs()
         assert (dd > 1e-4).double().mean().item() <= 1e-3, (i, dd.max().item())
+
+
+@pytest.mark.parametrize("N,M", [(8, 8), (5, 7), (16, 3), (1, 1), (2, 300), (257, 255)])
+def test_loop_tiny_and_odd_shapes(N, M):
+    """Edge sizes against the oracle: tiles far below a wave, a single point per cloud, a thin tile (K = 2: the fit is degenerate and
+    both sides fall back to the identity, procrustes.py:80-85), and one row / column past the 256 x 256 register-resident limit."""
+    variant, steps, mc = "3dmatch", 2, 200
+    v = synth.VARIANTS[variant]
+    W = weights(variant)
+    _, p = pair(variant, N, M, 5)
+    ms, mt = masks(N, M)
+    trace = []
+    ref = orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc, variant=variant, trace=trace)
+    out = engine(variant, steps, mc).run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV), trace=True)
+    assert (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs().max().item() < 1e-4
+    Rref = torch.stack([r["R_forwd"][0] for r in trace])
+    tref = torch.stack([r["t_forwd"][0] for r in trace])
+    assert (out["R_forwd"][:, 0].cpu() - Rref).abs().max().item() < 1e-4
+    assert (out["t_forwd"][:, 0].cpu() - tref).abs().max().item() < 1e-4
+    assert torch.isfinite(out["conf_matrix_pred"]).all()
