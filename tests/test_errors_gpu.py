@@ -1,0 +1,94 @@
+"""The C ABI refuses bad calls with its status codes (include/diffreg_hip.h:27-31) before anything is launched: NULL pointers, sizes the
+build does not take, missing or short workspaces.  Through the raw ctypes table, as a binding in another language would see them."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diff-reg_amd"))
+from tests.helpers import pair, weights
+from tests.test_loop_gpu import engine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OK, EINVAL, ELAUNCH, ENOSUP, EWORKSPACE = 0, -1, -2, -3, -4
+
+
+def test_status_strings():
+    from diffreg_hip import lib
+    r = lib.raw()
+    assert r.dr_strerror(OK).decode() == "ok"
+    for code in (EINVAL, ELAUNCH, ENOSUP, EWORKSPACE):
+        assert r.dr_strerror(code).decode() not in ("ok", "unknown error")
+    assert r.dr_strerror(-99).decode() == "unknown error"
+
+
+def test_sinkhorn_refuses_bad_calls():
+    from diffreg_hip import lib
+    r = lib.raw()
+    s = torch.randn(2, 64, 64, device=DEV)
+    out = torch.empty_like(s)
+    b = torch.ones(1, device=DEV)
+    st = lib.stream_of(s)
+    assert r.dr_sinkhorn_f32(2, 64, 64, None, None, None, lib.ptr(b), 3, 0, lib.ptr(out), None, 0, st) == EINVAL
+    assert r.dr_sinkhorn_f32(2, 64, 64, lib.ptr(s), None, None, lib.ptr(b), 3, 0, None, None, 0, st) == EINVAL
+    assert r.dr_sinkhorn_f32(2, 0, 64, lib.ptr(s), None, None, lib.ptr(b), 3, 0, lib.ptr(out), None, 0, st) == EINVAL
+    # a tile beyond the register-resident size needs the workspace dr_sinkhorn_workspace_bytes reports
+    big = torch.randn(1, 600, 600, device=DEV)
+    need = r.dr_sinkhorn_workspace_bytes(1, 600, 600, 4, 0)
+    assert need > 0
+    assert r.dr_sinkhorn_f32(1, 600, 600, lib.ptr(big), None, None, lib.ptr(b), 3, 0, lib.ptr(torch.empty_like(big)), None, 0, st) == EWORKSPACE
+    ws = torch.empty(need - 256, dtype=torch.uint8, device=DEV)
+    assert r.dr_sinkhorn_f32(1, 600, 600, lib.ptr(big), None, None, lib.ptr(b), 3, 0, lib.ptr(torch.empty_like(big)), lib.ptr(ws), need - 256, st) == EWORKSPACE
+    torch.cuda.synchronize()
+
+
+def test_linear_and_fine_matching_refuse_unsupported_shapes():
+    from diffreg_hip import lib
+    r = lib.raw()
+    x = torch.randn(16, 6, device=DEV); W = torch.randn(8, 6, device=DEV); out = torch.empty(16, 8, device=DEV)
+    st = lib.stream_of(x)
+    assert r.dr_linear_f32(16, 8, 6, lib.ptr(x), lib.ptr(W), lib.ptr(out), 0, None, None, 0, 1.0, st) == ENOSUP      # K % 4 != 0
+    assert r.dr_linear_f32(16, 8, 0, lib.ptr(x), lib.ptr(W), lib.ptr(out), 0, None, None, 0, 1.0, st) == EINVAL
+    assert r.dr_linear_f32(16, 8, 8, lib.ptr(x), lib.ptr(W), lib.ptr(out), 2, None, None, 8, 1.0, st) == EINVAL      # rotary (epilogue flag 2) without tables
+    f = torch.randn(10, 8, device=DEV); idx = torch.zeros(1, 200, dtype=torch.int64, device=DEV)
+    o = torch.empty(1, 4, 200, device=DEV)
+    assert r.dr_patch_similarity_f32(1, 4, 200, 8, lib.ptr(f), lib.ptr(idx), lib.ptr(f), lib.ptr(idx), 10, lib.ptr(o), st) == ENOSUP   # > 128 patch points
+    a = torch.arange(100, dtype=torch.int64, device=DEV)
+    keys = torch.empty(100, dtype=torch.int64, device=DEV); cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(64, dtype=torch.uint8, device=DEV)
+    assert r.dr_unique_pairs_i64(100, lib.ptr(a), lib.ptr(a), 1000, lib.ptr(keys), lib.ptr(cnt), lib.ptr(ws), 64, st) == EWORKSPACE
+    assert r.dr_unique_pairs_i64(100, None, lib.ptr(a), 1000, lib.ptr(keys), lib.ptr(cnt), lib.ptr(ws), 64, st) == EINVAL
+    torch.cuda.synchronize()
+
+
+def test_loop_refuses_bad_calls():
+    from diffreg_hip import lib
+    variant, N, M = "3dmatch", 32, 32
+    eng = engine(variant, 2, 200)
+    b = eng.make_buffers(1, N, M)
+    _, p = pair(variant, N, M, 3)
+    for k, src in (("src_feats", "f_s"), ("tgt_feats", "f_t"), ("s_pcd", "p_s"), ("t_pcd", "p_t"), ("x_T", "x_T")):
+        b[k].copy_(p[src].to(DEV))
+    r = lib.raw()
+
+    def call(**over):
+        a = dict(b, **over)
+        return r.dr_denoise_loop(
+            ctypes.byref(eng.cfg), ctypes.byref(eng.w), a["P"], a["N"], a["M"], lib.ptr(a["src_feats"]), lib.ptr(a["tgt_feats"]),
+            lib.ptr(a["s_pcd"]), lib.ptr(a["t_pcd"]), lib.ptr(a["src_mask"]), lib.ptr(a["tgt_mask"]), lib.ptr(a["x_T"]),
+            lib.ptr(a["noise"]), lib.ptr(a["conf"]), lib.ptr(a["x_final"]), lib.ptr(a["matches"]), lib.ptr(a["match_count"]),
+            lib.ptr(a["R_final"]), lib.ptr(a["t_final"]), None, lib.ptr(a["ws"]), a["ws_bytes"], lib.stream_of(b["conf"]))
+
+    assert call() == OK
+    assert call(src_feats=None) == EINVAL
+    assert call(conf=None) == EINVAL
+    assert call(ws=None) == EWORKSPACE
+    assert call(ws_bytes=b["ws_bytes"] // 2) == EWORKSPACE
+    assert call(src_mask=torch.ones(1, N, dtype=torch.uint8, device=DEV)) == EINVAL          # one mask without the other
+    assert call(matches=None) == EINVAL                                                        # matches without match_count
+    assert call(R_final=None) == EINVAL                                                        # R without t
+    assert call() == OK                                                                        # and the engine is still usable
+    torch.cuda.synchronize()
