@@ -402,3 +402,42 @@ def test_loop_tiny_and_odd_shapes(N, M):
     assert (out["R_forwd"][:, 0].cpu() - Rref).abs().max().item() < 1e-4
     assert (out["t_forwd"][:, 0].cpu() - tref).abs().max().item() < 1e-4
     assert torch.isfinite(out["conf_matrix_pred"]).all()
+
+
+def test_empty_pair_does_not_poison_batch():
+    """4DMatch (masked batches are its normal mode): a pair whose target mask is empty -- the reference's SVD raises on it -- next to a normal
+    pair in one call: the call returns, the empty pair gets the identity, and the normal pair's results are those of its own single run."""
+    variant, N, M, steps, mc = "4dmatch", 64, 64, 2, 40
+    eng = engine(variant, steps, mc)
+    qs = [pair(variant, N, M, s)[1] for s in (5, 6)]
+    cat = lambda k: torch.cat([q[k] for q in qs]).to(DEV)
+    ms, mt = masks(N, M, 50, 41)
+    _, empty = masks(N, M, 50, 0)
+    sm, tm = torch.cat([ms, ms]).to(DEV), torch.cat([mt, empty]).to(DEV)
+    noise = T(synth.step_noise(N, M, 9, steps))[:, None].to(DEV)
+    both = eng.run(cat("f_s"), cat("f_t"), cat("p_s"), cat("p_t"), cat("x_T"), src_mask=sm, tgt_mask=tm, noise=noise.repeat(1, 2, 1, 1))
+    conf2, R2 = both["conf_matrix_pred"].clone(), both["R_final"].clone()
+    q = qs[0]
+    one = eng.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV), src_mask=ms.to(DEV), tgt_mask=mt.to(DEV),
+                  noise=noise)
+    assert torch.isfinite(conf2).all()
+    assert (conf2[0] - one["conf_matrix_pred"][0]).abs().max().item() < 1e-5
+    assert (R2[0] - one["R_final"][0]).abs().max().item() < 1e-5
+    assert (R2[1] - torch.eye(3, device=DEV)).abs().max().item() == 0 and conf2[1].abs().max().item() == 0
+
+
+def test_ragged_batch_with_a_one_point_cloud():
+    """3DMatch, DR_LOOP_RAGGED: a degenerate item (5 x 1) beside a normal one changes nothing for the normal one."""
+    variant, steps, mc = "3dmatch", 2, 200
+    eng = engine(variant, steps, mc)
+    sizes = [(64, 64), (5, 1)]
+    ps = [pair(variant, n, m, 71 + i)[1] for i, (n, m) in enumerate(sizes)]
+    items = [dict(src_feats=q["f_s"][0].to(DEV), tgt_feats=q["f_t"][0].to(DEV), s_pcd=q["p_s"][0].to(DEV), t_pcd=q["p_t"][0].to(DEV),
+                  x_T=q["x_T"][0].to(DEV)) for q in ps]
+    got = eng.run_ragged(items)
+    c0, R0 = got[0]["conf_matrix_pred"].clone(), got[0]["R_final"].clone()
+    q = ps[0]
+    one = eng.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV))
+    assert torch.isfinite(c0).all() and torch.isfinite(got[1]["conf_matrix_pred"]).all()
+    assert (c0 - one["conf_matrix_pred"][0]).abs().max().item() < 2e-6
+    assert (R0 - one["R_final"][0]).abs().max().item() < 1e-5
