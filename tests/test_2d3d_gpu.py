@@ -177,3 +177,23 @@ def test_overlay_for_unmodified_model(golden, N, M, nv, mv, mv_da, steps, mc, se
     ov.remove()
     with pytest.raises(AssertionError):
         host(q, ms.to(DEV), mt.to(DEV), mt_da.to(DEV), q("x_T"))
+
+
+@pytest.mark.parametrize("N,M", [(8, 8), (5, 7), (16, 3), (2, 300), (257, 255)])
+def test_2d3d_tiny_and_odd_shapes(N, M):
+    """Edge sizes of the 2D-3D loop against the oracle: tiles below a wave, a thin tile, one row / column past the register-resident limit."""
+    steps, mc = 2, 200
+    W, eng, q = setup(N, M, 61, steps, mc)
+    ms, mt = masks(N, M)
+    mt_da = torch.ones(1, M, dtype=torch.bool)
+    d = lambda k: q(k).to(DEV)
+    out = eng.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"),
+                  (ms.to(DEV), mt.to(DEV), mt_da.to(DEV)), trace=True)
+    tr = []
+    ref = orc.denoise_loop_2d3d(W, synth.VARIANTS["2d3d"], q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"),
+                                q("t_pcd_da"), ms, mt, mt_da, q("x_T"), steps, mc, trace=tr)
+    for k in range(steps):
+        assert (out["R_forwd"][k, 0].cpu() - tr[k]["R_forwd"][0]).abs().max().item() < 1e-4, k
+        assert (out["t_forwd"][k, 0].cpu() - tr[k]["t_forwd"][0]).abs().max().item() < 1e-4, k
+    dc = (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs()
+    assert float(dc.max()) < 1e-4, float(dc.max())
