@@ -226,3 +226,26 @@ def test_mutual_topk_select_vs_reference_vectors(golden, name):
                                               c["threshold"], c["mutual"])
     want = mo.batch_mutual_topk_select(c["score"][:1], c["k"], None, None, c["largest"], c["threshold"], c["mutual"])
     assert torch.equal(i1.cpu(), want[1]) and torch.equal(j1.cpu(), want[2]) and torch.equal(s1.cpu(), want[3])
+
+
+@pytest.mark.parametrize("counts", [[0, 0, 0], [0, 5, 2], [1, 3, 64]])
+def test_harness_with_no_or_few_matches(counts):
+    """Pairs without matches (or fewer than a RANSAC sample) in a batch: zero inlier ratio / fitness and a finite pose, no launch failure
+    (tester.py divides by max(len, 1); Open3D's RANSAC returns the identity when it cannot sample)."""
+    from diffreg_hip import metrics
+    torch.manual_seed(0)
+    P, N, M, cap = 3, 40, 50, 64
+    s, t = torch.randn(P, N, 3).cuda(), torch.randn(P, M, 3).cuda()
+    R, tr = torch.eye(3)[None].repeat(P, 1, 1).cuda(), torch.zeros(P, 3, 1).cuda()
+    matches = torch.zeros(P, cap, 3, dtype=torch.int64).cuda()
+    for b, k in enumerate(counts):
+        matches[b, :k, 0] = b
+        matches[b, :k, 1] = torch.randint(0, N, (k,)).cuda()
+        matches[b, :k, 2] = torch.randint(0, M, (k,)).cuda()
+    out = metrics.evaluate_pairs(matches, torch.tensor(counts, dtype=torch.int32).cuda(), s, t, R, tr, ransac_iters=2000)
+    torch.cuda.synchronize()
+    for k in ("ir", "fitness", "rot", "trn"):
+        assert torch.isfinite(out[k]).all(), k
+    for b, k in enumerate(counts):
+        if k == 0:
+            assert float(out["ir"][b]) == 0.0 and float(out["fitness"][b]) == 0.0 and int(out["n_inlier"][b]) == 0

@@ -31,3 +31,20 @@ def test_drop_in_at_the_reference_settings():
     # (w, h) pixel order
     est2 = registration_with_pnp_ransac(torch.from_numpy(X).to(DEV), torch.from_numpy(px[:, ::-1].copy()).to(DEV), K, num_iterations=2000, transposed=False)
     assert np.abs(est2[:3, 3] - T[:3, 3]).max() < 1e-2
+
+
+def test_minimal_and_degenerate_inputs():
+    """fewer than 4 correspondences: no model (the wrapper returns None, as cv2.solvePnPRansac fails); exactly 4, and 20 collinear points (every
+    P3P sample degenerate): a finite transform and an inlier count, no launch failure"""
+    K = [[500., 0, 320], [0, 500., 240], [0, 0, 1]]
+    g = torch.Generator().manual_seed(1)
+    for n in (0, 3):
+        assert lib.pnp_ransac(torch.zeros(n, 3, device=DEV), torch.zeros(n, 2, device=DEV), K, num_iterations=64) is None
+    pts = (torch.randn(4, 3, generator=g) + torch.tensor([0, 0, 5.0])).to(DEV)
+    pix = (torch.rand(4, 2, generator=g) * 400).to(DEV)
+    r = lib.pnp_ransac(pts, pix, K, num_iterations=256)
+    assert torch.isfinite(r["transform"]).all() and 0 <= int(r["n_inlier"]) <= 4
+    line = torch.stack([torch.linspace(-1, 1, 20), torch.zeros(20), torch.full((20,), 5.0)], 1).to(DEV)
+    lpix = torch.stack([torch.linspace(100, 500, 20), torch.full((20,), 240.0)], 1).to(DEV)
+    r = lib.pnp_ransac(line, lpix, K, num_iterations=256)
+    assert torch.isfinite(r["transform"]).all() and 0 <= int(r["n_inlier"]) <= 20
