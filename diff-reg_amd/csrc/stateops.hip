@@ -516,6 +516,7 @@ int dr_mutual_topk_select_f32(int B, int N, int M, const float* score, int k, in
                               long long capacity, int32_t* total, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace dr;
     if (B < 0 || N <= 0 || M <= 0 || k < 1 || k > MT_MAX_K || capacity < 0 || !total) return DR_EINVAL;
+    if (k > N || k > M) return DR_EINVAL;                              // torch.topk raises "selected index k out of range" (mutual_topk_select.py:27-28)
     hipStream_t st = (hipStream_t)stream;
     DR_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int32_t), st));
     if (B == 0) return DR_OK;

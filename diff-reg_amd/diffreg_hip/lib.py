@@ -889,6 +889,8 @@ def batch_mutual_topk_select(score_mat, k, row_masks=None, col_masks=None, large
     two_d = score_mat.dim() == 2
     s = (score_mat[None] if two_d else score_mat).to(torch.float32).contiguous()
     B, N, M = s.shape
+    if k > N or k > M:
+        raise RuntimeError("selected index k out of range")      # what torch.topk says in the reference (mutual_topk_select.py:27-28)
     dev = s.device
     cap = B * (min(N, M) if mutual else (N + M)) * k
     idx = torch.empty(max(cap, 1), 3, dtype=torch.int64, device=dev)

@@ -457,7 +457,7 @@ int dr_radius_neighbors_f32(int nq, int ns, int nb, const float* queries, const 
  * behind the 2D-3D loop, EXP/model.py:744-752: k = 2, threshold 0.75, mutual): per batch element the entries among the k best of
  * their row and (mutual) / or of their column, beyond `threshold` when use_threshold (> for largest, < otherwise), inside
  * row_masks [B,N] / col_masks [B,M] (NULL = all).  out_idx int64 [capacity,3] rows (b, i, j) in torch.nonzero order, out_score
- * [capacity]; total[0] = number selected (entries beyond capacity are counted, not written).  k <= 8, N*M <= 262144. */
+ * [capacity]; total[0] = number selected (entries beyond capacity are counted, not written).  k <= min(8, N, M) (DR_EINVAL beyond: torch.topk raises there), N*M <= 262144. */
 size_t dr_mutual_topk_workspace_bytes(int B, int N, int M);
 int dr_mutual_topk_select_f32(int B, int N, int M, const float* score, int k, int largest, int use_threshold, float threshold,
                               int mutual, const uint8_t* row_masks, const uint8_t* col_masks, int64_t* out_idx, float* out_score,

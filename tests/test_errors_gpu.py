@@ -92,3 +92,21 @@ def test_loop_refuses_bad_calls():
     assert call(R_final=None) == EINVAL                                                        # R without t
     assert call() == OK                                                                        # and the engine is still usable
     torch.cuda.synchronize()
+
+
+def test_mutual_topk_refuses_k_beyond_the_matrix():
+    """torch.topk in the reference raises when k exceeds a dimension (mutual_topk_select.py:27-28): same message from the wrapper,
+    DR_EINVAL from the C entry"""
+    from diffreg_hip import lib
+    sc = torch.rand(2, 4, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        lib.batch_mutual_topk_select(sc, 10)
+    r = lib.raw()
+    idx = torch.empty(64, 3, dtype=torch.int64, device=DEV); s = torch.empty(64, device=DEV); tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+    wsb = r.dr_mutual_topk_workspace_bytes(2, 4, 3)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    assert r.dr_mutual_topk_select_f32(2, 4, 3, lib.ptr(sc), 4, 1, 0, 0.0, 1, None, None, lib.ptr(idx), lib.ptr(s), 64, lib.ptr(tot), lib.ptr(ws), wsb,
+                                       lib.stream_of(sc)) == EINVAL
+    assert r.dr_mutual_topk_select_f32(2, 4, 3, lib.ptr(sc), 3, 1, 0, 0.0, 1, None, None, lib.ptr(idx), lib.ptr(s), 64, lib.ptr(tot), lib.ptr(ws), wsb,
+                                       lib.stream_of(sc)) == OK
+    torch.cuda.synchronize()
