@@ -173,7 +173,9 @@ struct PlanesWs {
     static size_t img_bytes(int PN, int PM, int K) { return plane_image_bytes(PN, K) + plane_image_bytes(PM, K); }
     static void carve(Carver& c, PlanesWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const int C = cfg.C, PN = P * N, PM = P * M, T = PN + PM;
-        static const int min_rows = env_knob("DR_PLANES_MIN_ROWS", 8192);
+        // (crossover re-measured with the 64-row plane workgroups, tools/bench_planes_threshold.py: 256-point pairs 24.5 / 37.7 ms on the
+        //  f32 kernels against 31.6 / 31.9 ms on the plane path at 2048 / 4096 token rows; 512-point 4D pairs 60.9 vs 62.0 ms at 4096)
+        static const int min_rows = env_knob("DR_PLANES_MIN_ROWS", 4096);
         static const int enabled = env_knob("DR_PLANES", 1);
         w.on = enabled && Prepack::supported(cfg) && T >= min_rows;
         if (cfg.flags & DR_LOOP_PLANES_FORCE) w.on = Prepack::supported(cfg);

@@ -302,7 +302,7 @@ int dr_mutual_match_f32(int P, int N, int M, const float* conf, float thr, int m
  * Sinkhorn marginals (DR_SK_RAGGED), from x.min(), from the top-K rule (K from the true sizes) and from the read-out. */
 #define DR_LOOP_RAGGED 0x2
 /* The layer GEMMs run on fp16 hi / lo plane images (pgemm, see "Plane images" above) when the configuration allows it
- * (C <= 448, C % 16 == 0) and the call has at least DR_PLANES_MIN_ROWS (environment, default 8192) token rows; these two
+ * (C <= 448, C % 16 == 0) and the call has at least DR_PLANES_MIN_ROWS (environment, default 4096) token rows; these two
  * flags take the decision away from the size rule (tests hold the small golden loops to the reference through both paths) */
 #define DR_LOOP_PLANES_FORCE 0x4
 #define DR_LOOP_PLANES_OFF 0x8
