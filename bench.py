@@ -235,6 +235,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     stub = args.cpu_stub
+    if args.gpus != world:
+        # one process per GPU (the driver launches N ranks with --gpus N; N = 1 runs without a launcher): anything else would
+        # report an aggregate over a rank count the line does not name
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d)\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

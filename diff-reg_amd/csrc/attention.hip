@@ -1030,7 +1030,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     const double flops = 4.0 * a.H * a.d * ((double)a.nseg * a.Lq * a.Lk + (double)a.nseg2 * a.Lqb * a.Lkb);
     ProfScope ps(PK_ATTN, flops, st);
     // the flash form has a quarter of the workgroups: below ~one per CU the 32-query kernel fills the chip better
-    static const int flash_env = env_knob("DR_ATTN_FLASH_MIN", 256);
+    const int flash_env = env_knob("DR_ATTN_FLASH_MIN", 256);
     const int flash_min = g_flash_min >= 0 ? g_flash_min : flash_env;
     dim3 fgrid((maxLq + 127) / 128, a.H, a.nseg + a.nseg2);
     if (a.qimg[0]) {
@@ -1043,7 +1043,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         return DR_OK;
     }
     if (a.pimg[0] || ((int)(fgrid.x * fgrid.y * fgrid.z) >= flash_min && (a.ldo % 4) == 0 && (((uintptr_t)a.out) & 15) == 0)) {
-        static const int split_env = env_knob("DR_ATTN_SPLIT", 1);
+        const int split_env = env_knob("DR_ATTN_SPLIT", 1);
         const int mode = g_attn_split >= 0 ? g_attn_split : split_env;     // 0 f32-input MFMA, 1 split operands
         // d = 132 (4DMatch) needs 288 V staging blocks and 9 k-steps of Q in registers: more than two waves per SIMD
         // allow -> f32 kernel.  (A hybrid with only PV split measured slower than both: 93 vs 84 / 108 us.)
@@ -1065,7 +1065,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // of dependent MFMAs (120 of 64 cycles per key tile at d = 108) is then half as long
     constexpr size_t lds8 = (size_t)AttnGeom<DG, NDT, 8>::SMEM_FLOATS * sizeof(float);
     if constexpr (lds8 <= 160 * 1024) {
-        static const int w8_env = env_knob("DR_ATTN_W8_MAX", 256);
+        const int w8_env = env_knob("DR_ATTN_W8_MAX", 256);
         const int maxLk = a.nseg2 > 0 && a.Lkb > a.Lk ? a.Lkb : a.Lk;
         if ((int)(grid.x * grid.y * grid.z) <= w8_env && maxLk > 4 * 32) {
             hipLaunchKernelGGL((attention_kernel<DG, NDT, 8>), grid, dim3(512), lds8, st, a);

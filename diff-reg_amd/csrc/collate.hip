@@ -163,7 +163,7 @@ static int next_pow2(int n) {
     return p;
 }
 
-static int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hipStream_t st) {
+int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hipStream_t st) {   // (kernels.h: also sorts the keys of fine2d3d.hip)
     const int chunks = (n_pad + BS_CHUNK - 1) / BS_CHUNK;
     hipLaunchKernelGGL(bitonic_local_kernel, dim3(chunks), dim3(1024), 0, st, keys, vals, n_pad, 2, min(n_pad, BS_CHUNK));
     DR_LAUNCH_CHECK();

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
-#include "../../include/diffreg_hip.h"
+#include "../../include/diffreg_hip_debug.h"
 
 namespace dr {
 

@@ -5,11 +5,9 @@
 //   unique_i64         duplicate removal: torch.unique of img_index * num_points_f + pcd_index (model.py:760-763)
 //   corr_gather        the final gathers and corr_scores = <img_feats_f[i], pcd_feats_f[j]> (model.py:766-774)
 // (the selection between them is dr_mutual_topk_select_f32, stateops.hip).  Off the hot path: small, memory- / latency-bound
-// kernels; the sort of unique_i64 is rocPRIM's radix sort (a device library of this platform), everything else is written here.
+// kernels; unique_i64 = the bitonic (key, index) sort of collate.hip + a one-workgroup ordered compaction of the segment heads.
 #include <cstring>
 #include "kernels.h"
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
 
 namespace dr {
 namespace {
@@ -70,10 +68,40 @@ __global__ __launch_bounds__(256) void patch_similarity_kernel(int Ki, int Kc, i
     }
 }
 
-__global__ __launch_bounds__(256) void make_keys_kernel(int n, const long long* __restrict__ a, const long long* __restrict__ b, long long mul,
-                                                        long long* __restrict__ keys) {
+// keys as unsigned 64-bit numbers in the order of the signed ones (sign bit flipped); rows >= n: pad keys that sort last
+constexpr unsigned long long UQ_BIAS = 0x8000000000000000ull;
+__global__ __launch_bounds__(256) void make_keys_kernel(int n, int n_pad, const long long* __restrict__ a, const long long* __restrict__ b,
+                                                        long long mul, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = a[i] * mul + b[i];
+    if (i >= n_pad) return;
+    keys[i] = i < n ? ((unsigned long long)(a[i] * mul + b[i]) ^ UQ_BIAS) : ~0ull;
+    vals[i] = (unsigned)i;
+}
+// the distinct keys of the sorted list in ascending order (torch.unique): ONE workgroup walks the list 1024 entries at a time; an
+// entry is kept when it differs from its predecessor; ranks inside a step = wave ballots + a 16-entry scan (lists of this block
+// are a few thousand entries: latency of one small kernel, no multi-kernel scan)
+__global__ __launch_bounds__(1024) void unique_sorted_kernel(int n, const unsigned long long* __restrict__ sorted, long long* __restrict__ out,
+                                                             int* __restrict__ count) {
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const unsigned long long k = i < n ? sorted[i] : 0ull;
+        const bool head = i < n && (i == 0 || sorted[i - 1] != k);
+        const unsigned long long b = __ballot(head);
+        if (lane == 0) s_w[w] = __popcll(b);
+        __syncthreads();
+        int before = s_base;
+        for (int q = 0; q < w; ++q) before += s_w[q];
+        if (head) out[before + __popcll(b & ((1ull << lane) - 1ull))] = (long long)(k ^ UQ_BIAS);
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int q = 0; q < 16; ++q) tot += s_w[q]; s_base += tot; }
+        __syncthreads();
+    }
+    if (t == 0) *count = s_base;
 }
 
 // one wave per correspondence: indices back from the key, the point / pixel rows, the feature dot product
@@ -114,14 +142,12 @@ int dr_patch_similarity_f32(int P, int Ki, int Kc, int C, const float* img_feats
     return DR_OK;
 }
 
+static int uq_pad(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
 size_t dr_unique_pairs_workspace_bytes(int n) {
     if (n < 1) return 256;
-    size_t sort_b = 0, uniq_b = 0;
-    long long* nul = nullptr;
-    int* cnt = nullptr;
-    if (rocprim::radix_sort_keys(nullptr, sort_b, nul, nul, (size_t)n) != hipSuccess) return 0;
-    if (rocprim::unique(nullptr, uniq_b, nul, nul, cnt, (size_t)n) != hipSuccess) return 0;
-    return 2 * dr::align256((size_t)n * 8) + dr::align256(sort_b > uniq_b ? sort_b : uniq_b);
+    const size_t np = (size_t)uq_pad(n);
+    return dr::align256(np * 8) + dr::align256(np * 4);
 }
 
 int dr_unique_pairs_i64(int n, const int64_t* first, const int64_t* second, long long multiplier, int64_t* unique_keys, int32_t* count,
@@ -130,19 +156,16 @@ int dr_unique_pairs_i64(int n, const int64_t* first, const int64_t* second, long
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { DR_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), st)); return DR_OK; }
     if (workspace_bytes < dr_unique_pairs_workspace_bytes(n)) return DR_EWORKSPACE;
-    long long* keys = (long long*)workspace;
-    long long* sorted = (long long*)((char*)workspace + dr::align256((size_t)n * 8));
-    void* tmp = (char*)workspace + 2 * dr::align256((size_t)n * 8);
-    size_t tmp_b = workspace_bytes - 2 * dr::align256((size_t)n * 8);
-    hipLaunchKernelGGL(dr::make_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, (const long long*)first, (const long long*)second, multiplier, keys);
+    const int n_pad = uq_pad(n);
+    unsigned long long* keys = (unsigned long long*)workspace;
+    unsigned* vals = (unsigned*)((char*)workspace + dr::align256((size_t)n_pad * 8));
+    hipLaunchKernelGGL(dr::make_keys_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, n, n_pad, (const long long*)first, (const long long*)second,
+                       multiplier, keys, vals);
     DR_LAUNCH_CHECK();
-    size_t need = 0;
-    DR_HIP_CHECK(rocprim::radix_sort_keys(nullptr, need, keys, sorted, (size_t)n));
-    if (need > tmp_b) return DR_EWORKSPACE;
-    DR_HIP_CHECK(rocprim::radix_sort_keys(tmp, need, keys, sorted, (size_t)n, 0, 64, st));
-    DR_HIP_CHECK(rocprim::unique(nullptr, need, sorted, (long long*)unique_keys, count, (size_t)n));
-    if (need > tmp_b) return DR_EWORKSPACE;
-    DR_HIP_CHECK(rocprim::unique(tmp, need, sorted, (long long*)unique_keys, count, (size_t)n, rocprim::equal_to<long long>(), st));
+    const int rc = dr::launch_bitonic_sort(keys, vals, n_pad, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dr::unique_sorted_kernel, dim3(1), dim3(1024), 0, st, n, keys, (long long*)unique_keys, count);
+    DR_LAUNCH_CHECK();
     return DR_OK;
 }
 

@@ -28,7 +28,6 @@ struct GemmProblem {
     const float* A;     // [rows, K1] row-major, leading dimension lda
     const float* A2;    // [rows, K - K1] or nullptr
     const float* W;     // [ncols, K] row-major (the nn.Linear weight)
-    const void* Wsplit; // the same weight packed by launch_pack_weights (bf16 x 3 split image) or nullptr
     float* out;         // [rows, ldo]
     const float* cosT;  // rotary tables [rows, C/2] (EPI_ROTARY)
     const float* sinT;
@@ -41,11 +40,6 @@ struct GemmProblem {
     // strided batch (f32-MFMA kernels only): instance z = blockIdx.z uses A + z sA, W + z sW, out + z sO (floats)
     int nbatch;         // 0 or 1 = a single instance
     long long sA, sW, sO;
-    // two-plane fp16 kernel only (ignored elsewhere): max |A[r][:]| per row as `amax_parts` partial maxima
-    // amax[p * amax_stride + r] (nullptr: the kernel sweeps its rows itself), likewise for A2 (one part), and where to put
-    // the maxima of the OUTPUT rows: omax[tile_n * omax_stride + r], one part per 224-column tile (nullptr: not wanted)
-    const float* amax; const float* amax2; float* omax;
-    int amax_parts; long long amax_stride, omax_stride;
 };
 
 struct GemmBatch {
@@ -54,14 +48,8 @@ struct GemmBatch {
 };
 
 int launch_gemm(const GemmBatch& g, hipStream_t st);
-size_t gemm_packed_weight_bytes(int ncols, int K);
-void gemm_force_wide_min(int n);
-int gemm_wide_min_tiles();   // launches with fewer 128 x 224 tiles stay on the f32-MFMA kernels
-int launch_pack_weights(const float* W, int ncols, int K, void* out, hipStream_t st);
 int gemm_configure();
 void gemm_force_config(int c);
-void gemm_force_f16x2(int on);   // experimental two-plane fp16 split (set before the weights are packed); -1 = environment
-int read_gemm_stamps(long long* h_out256);
 
 // ---------------------------------------------------------------------------------------------
 // attention (transformero.py:79-85): segments of queries attending segments of keys
@@ -105,7 +93,6 @@ void attention_force_split(int on);
 // rowmax (optional): max |out[r][:]| per row, for the consumer GEMM's operand scaling
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                      int ldo, int rows, int C, hipStream_t st, float* rowmax = nullptr);
-int launch_rowmax(const float* x, int ldx, int rows, int C, float* rowmax, hipStream_t st);
 // post-LN form: out[r] = LayerNorm(x[r] + res[r]) * g + b   (vision3d AttentionLayer / AttentionOutput)
 int launch_layernorm_postadd(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                              int ldo, int rows, int C, hipStream_t st);
@@ -157,6 +144,9 @@ int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st);
 template <typename T>
 int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st, const uint8_t* sm = nullptr,
                       const uint8_t* tm = nullptr);
+
+// collate.hip: in-place bitonic sort of (key, value) pairs ascending by (key, value); n_pad = a power of two (pad keys ~0ull sort last)
+int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hipStream_t st);
 
 // sinkhorn.hip (internal form of dr_sinkhorn_*: `shift` = per-tile value subtracted first, nullable)
 int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,

@@ -28,12 +28,9 @@ struct Carver {
 // buffers of one attention-layer evaluation over `T` token rows
 struct LayerWs {
     float *qkv, *att, *mrg, *msg, *hid, *g2;
-    float *msg_max, *hid_max;   // row maxima of msg [T] and of hid [tiles][T] (operand scaling of the fp16-split GEMM)
     size_t T;
     static size_t carve(Carver& c, LayerWs& w, size_t T, int C) {
         w.T = T;
-        w.msg_max = c.take<float>(T);
-        w.hid_max = c.take<float>(T * ((2 * C + 223) / 224));
         w.qkv = c.take<float>(T * 3 * C);
         w.att = c.take<float>(T * C);
         w.mrg = c.take<float>(T * C);
@@ -43,50 +40,6 @@ struct LayerWs {
         return c.off;
     }
 };
-
-// split-operand images of one layer's weights (launch_pack_weights), filled once per loop call
-struct PackedLayer {
-    void *q, *k, *v, *merge, *mlp0, *mlp2;
-};
-struct PackedWeights {
-    static constexpr int MAXL = 16;
-    PackedLayer layer[MAXL];
-    void* src_proj;
-    bool on;
-    static void carve(Carver& c, PackedWeights& w, int n_layers, int C, size_t T) {
-        // the largest launch of the loop is the q|k|v projection of all T tokens (3 problems, ceil(C / 224) column tiles):
-        // if even that is below the wide kernel's threshold nothing would read the images
-        const long big = (long)((T + 127) / 128) * ((C + 223) / 224) * 3;
-        w.on = n_layers <= MAXL && C % 8 == 0 && big >= gemm_wide_min_tiles();
-        for (int l = 0; l < n_layers && w.on; ++l) {
-            PackedLayer& L = w.layer[l];
-            L.q = c.take<char>(gemm_packed_weight_bytes(C, C));
-            L.k = c.take<char>(gemm_packed_weight_bytes(C, C));
-            L.v = c.take<char>(gemm_packed_weight_bytes(C, C));
-            L.merge = c.take<char>(gemm_packed_weight_bytes(C, C));
-            L.mlp0 = c.take<char>(gemm_packed_weight_bytes(2 * C, 2 * C));
-            L.mlp2 = c.take<char>(gemm_packed_weight_bytes(C, 2 * C));
-        }
-        w.src_proj = w.on ? c.take<char>(gemm_packed_weight_bytes(C, C)) : nullptr;
-    }
-    int fill(const dr_loop_weights& W, int n_layers, int C, hipStream_t st) const {
-        if (!on) return DR_OK;
-        int rc = DR_OK;
-        for (int l = 0; l < n_layers && rc == DR_OK; ++l) {
-            const dr_layer_weights& w = W.layers[l];
-            const PackedLayer& L = layer[l];
-            rc = launch_pack_weights(w.q_proj, C, C, L.q, st);
-            if (rc == DR_OK) rc = launch_pack_weights(w.k_proj, C, C, L.k, st);
-            if (rc == DR_OK) rc = launch_pack_weights(w.v_proj, C, C, L.v, st);
-            if (rc == DR_OK) rc = launch_pack_weights(w.merge, C, C, L.merge, st);
-            if (rc == DR_OK) rc = launch_pack_weights(w.mlp0, 2 * C, 2 * C, L.mlp0, st);
-            if (rc == DR_OK) rc = launch_pack_weights(w.mlp2, C, 2 * C, L.mlp2, st);
-        }
-        if (rc == DR_OK) rc = launch_pack_weights(W.src_proj, C, C, src_proj, st);
-        return rc;
-    }
-};
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Plane-image path of the layer GEMMs (pgemm.h): every activation that feeds a GEMM lives as an fp16 hi / lo plane image
@@ -175,8 +128,8 @@ struct PlanesWs {
         const int C = cfg.C, PN = P * N, PM = P * M, T = PN + PM;
         // (crossover re-measured with the 64-row plane workgroups, tools/bench_planes_threshold.py: 256-point pairs 24.5 / 37.7 ms on the
         //  f32 kernels against 31.6 / 31.9 ms on the plane path at 2048 / 4096 token rows; 512-point 4D pairs 60.9 vs 62.0 ms at 4096)
-        static const int min_rows = env_knob("DR_PLANES_MIN_ROWS", 4096);
-        static const int enabled = env_knob("DR_PLANES", 1);
+        const int min_rows = env_knob("DR_PLANES_MIN_ROWS", 4096);
+        const int enabled = env_knob("DR_PLANES", 1);
         w.on = enabled && Prepack::supported(cfg) && T >= min_rows;
         if (cfg.flags & DR_LOOP_PLANES_FORCE) w.on = Prepack::supported(cfg);
         if (cfg.flags & DR_LOOP_PLANES_OFF) w.on = false;
@@ -207,38 +160,32 @@ struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k
 static int layer_call(const dr_layer_weights& W, int C, int H, int P, const float* xin, int xr0, int xrows,
                       const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
                       const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
-                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr,
-                      const PackedLayer* pk = nullptr, const float* xmax = nullptr, const float* ymax = nullptr,
-                      float* outmax = nullptr) {
-    // xmax / ymax: max |row| of xin / yin (indexed like their rows) when their producer left them; outmax: where to leave
-    // those of `out`.  Only the fp16-split GEMM reads them (a launch without them sweeps its rows itself).
+                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr) {
     // kv_cached: K|V of the source rows were projected earlier ([tokens, 2C], rotary applied to K): skip them.
     // kv_store : project ONLY K|V of the source rows into this buffer and return (used to fill the cache).
     const int halfC = C / 2, d = C / H;
     GemmBatch g;
     memset(&g, 0, sizeof(g));
-    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot, const void* Wpk,
-                    const float* inmax) {
-        p.amax = inmax ? inmax + r0 : nullptr; p.amax_parts = 1; p.amax_stride = 0;
-        p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.Wsplit = Wpk; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
+    auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot) {
+        p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
         p.rows = rows; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.lda2 = 0; p.ldo = 3 * C;
         p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
         p.cosT = cosT + (size_t)r0 * halfC; p.sinT = sinT + (size_t)r0 * halfC;
     };
     int rc;
     if (kv_store) {
-        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true, pk ? pk->k : nullptr, ymax);
-        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false, pk ? pk->v : nullptr, ymax);
+        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true);
+        proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false);
         g.p[0].out = kv_store + (size_t)yr0 * 2 * C; g.p[0].ldo = 2 * C;
         g.p[1].out = kv_store + (size_t)yr0 * 2 * C + C; g.p[1].ldo = 2 * C;
         g.n = 2;
         return launch_gemm(g, st);
     }
-    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true, pk ? pk->q : nullptr, xmax);
+    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true);
     g.n = 1;
     if (!kv_cached) {
-        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true, pk ? pk->k : nullptr, ymax);
-        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false, pk ? pk->v : nullptr, ymax);
+        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
+        proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
         g.n = 3;
     }
     rc = launch_gemm(g, st);
@@ -261,37 +208,31 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     // message = norm1(merge(o))
     memset(&g, 0, sizeof(g));
     GemmProblem& m = g.p[0];
-    m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.Wsplit = pk ? pk->merge : nullptr; m.out = ws.mrg + (size_t)xr0 * C;
+    m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.out = ws.mrg + (size_t)xr0 * C;
     m.rows = xrows; m.ncols = C; m.K = C; m.K1 = C; m.lda = C; m.ldo = C; m.epi = EPI_NONE; m.scale = 1.f;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
-    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st,
-                          ws.msg_max + xr0);
+    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st);
     if (rc) return rc;
     // message = norm2(mlp(cat[x, message]))
     memset(&g, 0, sizeof(g));
     GemmProblem& h = g.p[0];
-    h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.Wsplit = pk ? pk->mlp0 : nullptr; h.out = ws.hid + (size_t)xr0 * 2 * C;
+    h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.out = ws.hid + (size_t)xr0 * 2 * C;
     h.rows = xrows; h.ncols = 2 * C; h.K = 2 * C; h.K1 = C; h.lda = C; h.lda2 = C; h.ldo = 2 * C; h.epi = EPI_RELU; h.scale = 1.f;
-    if (xmax) { h.amax = xmax + xr0; h.amax_parts = 1; h.amax2 = ws.msg_max + xr0; }
-    h.omax = ws.hid_max + xr0; h.omax_stride = (long long)ws.T;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
     memset(&g, 0, sizeof(g));
     GemmProblem& o = g.p[0];
-    o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.Wsplit = pk ? pk->mlp2 : nullptr; o.out = ws.g2 + (size_t)xr0 * C;
+    o.A = ws.hid + (size_t)xr0 * 2 * C; o.W = W.mlp2; o.out = ws.g2 + (size_t)xr0 * C;
     o.rows = xrows; o.ncols = C; o.K = 2 * C; o.K1 = 2 * C; o.lda = 2 * C; o.ldo = C; o.epi = EPI_NONE; o.scale = 1.f;
-    // (hid's maxima exist only when the launch above ran on the fp16-split kernel: same rows, twice the column tiles, so
-    //  whenever THIS launch is one of its kind, that one was too)
-    o.amax = ws.hid_max + xr0; o.amax_parts = (2 * C + 223) / 224; o.amax_stride = (long long)ws.T;
     g.n = 1;
     rc = launch_gemm(g, st);
     if (rc) return rc;
     // e = x + message
     return launch_layernorm(ws.g2 + (size_t)xr0 * C, C, W.norm2_w, W.norm2_b, xin + (size_t)xr0 * C, C, out + (size_t)xr0 * C, C,
-                            xrows, C, st, outmax ? outmax + xr0 : nullptr);
+                            xrows, C, st);
 }
 
 
@@ -314,7 +255,6 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     const int C = X.C, H = X.H, PN = X.P * X.N, PM = X.P * X.M, halfC = C / 2, d = C / H, nC = C / 16, dp = X.pp->dp;
     const PrepackLayer& L = X.pp->L[l];
     const PlanesWs& pw = *X.pw;
-    const LayerWs& ws = *X.lw;
     auto r0 = [&](int side) { return side == SIDE_TGT ? PN : 0; };
     auto nrows = [&](int side) { return side == SIDE_TGT ? PM : PN; };
     auto at = [&](char* img, size_t side_off, int side) { return img + (side == SIDE_TGT ? side_off : 0); };
@@ -425,25 +365,15 @@ struct DenoiseWs {
     LayerWs lw;
     float *fa, *fb, *cosT, *sinT, *proj, *sim;
     float *tgt_l0, *kv_l1;      // step-invariant: layer-0 output of the tgt rows, layer-1 K|V of those rows
-    float *m_feat0, *m_fa, *m_fb, *m_tgt_l0;   // row maxima of feat0 / fa / fb / tgt_l0 (fp16-split GEMM operand scaling)
-    PackedWeights pw;
     PlanesWs pl;
     const Prepack* pp;          // packed weights of the plane path (set per call)
     static void carve(Carver& c, DenoiseWs& w, const dr_loop_config& cfg, int P, int N, int M) {
-        const int C = cfg.C, n_layers = cfg.n_layers;
+        const int C = cfg.C;
         const size_t T = (size_t)P * (N + M);
         LayerWs::carve(c, w.lw, T, C);
         PlanesWs::carve(c, w.pl, cfg, P, N, M);
-        // The round-1 packed path (per-call bf16 x 3 / fp16 x 2 images + gemm_nt_wide2_kernel with producer-side row maxima) is
-        // retired from the loop: the full-size configs[2] test (8 pairs x 20 steps at 512 x 512) showed it to be
-        // non-deterministic from a few thousand token rows on (run-to-run differences of O(1) in the refined features; the
-        // stand-alone op dr_linear_packed_f32 is unaffected and keeps the kernel).  Large calls run the plane path, which is
-        // bit-identical between a batch and its pairs' own runs; small ones the f32-input MFMA kernels.
-        w.pw.on = false;
-        (void)n_layers;
         w.tgt_l0 = c.take<float>(T * C);
         w.kv_l1 = c.take<float>(T * 2 * C);
-        w.m_feat0 = c.take<float>(T); w.m_fa = c.take<float>(T); w.m_fb = c.take<float>(T); w.m_tgt_l0 = c.take<float>(T);
         w.fa = c.take<float>(T * C);
         w.fb = c.take<float>(T * C);
         w.cosT = c.take<float>(T * (C / 2));
@@ -470,12 +400,11 @@ static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, i
         if (rc || cfg.n_layers < 2) return rc;
         return layer_call_planes(X, w.layers[1], 1, ws.pl.tgt_l0, 0, ws.pl.tgt_l0, SIDE_TGT, ws.pl.tgt_l0, self_t, nullptr, st, nullptr, ws.kv_l1);
     }
-    const PackedLayer* pk0 = ws.pw.on ? &ws.pw.layer[0] : nullptr;
     int rc = layer_call(w.layers[0], C, H, P, feat0, PN, PM, feat0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                        ws.tgt_l0, st, nullptr, nullptr, pk0, ws.m_feat0, ws.m_feat0, ws.m_tgt_l0);
+                        ws.tgt_l0, st);
     if (rc || cfg.n_layers < 2) return rc;
     return layer_call(w.layers[1], C, H, P, nullptr, 0, 0, ws.tgt_l0, PN, PM, ws.cosT, ws.sinT, tokmask, self_t, nullptr, ws.lw,
-                      nullptr, st, nullptr, ws.kv_l1, ws.pw.on ? &ws.pw.layer[1] : nullptr, nullptr, ws.m_tgt_l0);
+                      nullptr, st, nullptr, ws.kv_l1);
 }
 
 static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w, int P, int N, int M, const float* feat0,
@@ -539,45 +468,35 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     }
     const float* cur = feat0;
     float* bufs[2] = {ws.fa, ws.fb};
-    float* mbufs[2] = {ws.m_fa, ws.m_fb};
-    const float* cmax = ws.m_feat0;
     int which = 0;
     const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
     for (int l = 0; l < cfg.n_layers; ++l) {
         float* nxt = bufs[which];
-        float* nmax = mbufs[which];
-        const PackedLayer* pk = ws.pw.on ? &ws.pw.layer[l] : nullptr;
         int rc;
         if (use_cache && l == 0) {
             // src half only, written beside the cached tgt half (into the cache's own buffer: nothing later writes to it)
-            nxt = ws.tgt_l0; nmax = ws.m_tgt_l0;
-            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
-                            cmax, cmax, nmax);
+            nxt = ws.tgt_l0;
+            rc = layer_call(w.layers[0], C, H, P, cur, 0, PN, cur, 0, PN, ws.cosT, ws.sinT, tokmask, self_s, nullptr, ws.lw, nxt, st);
             if (rc) return rc;
-            cur = nxt; cmax = nmax;
+            cur = nxt;
             continue;
         } else if (use_cache && l == 1) {
             rc = layer_call(w.layers[1], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st,
-                            ws.kv_l1, nullptr, pk, cmax, cmax, nmax);
+                            ws.kv_l1);
             if (rc) return rc;
-            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
-                            cmax, nmax, nmax);
+            rc = layer_call(w.layers[1], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
             if (rc) return rc;
         } else if (l % 2 == 0) {
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st, nullptr, nullptr, pk,
-                            cmax, cmax, nmax);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, T, cur, 0, T, ws.cosT, ws.sinT, tokmask, self_s, &self_t, ws.lw, nxt, st);
             if (rc) return rc;
         } else {
             // src attends tgt, then tgt attends the UPDATED src (quirk Q11)
-            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
-                            cmax, cmax, nmax);
+            rc = layer_call(w.layers[l], C, H, P, cur, 0, PN, cur, PN, PM, ws.cosT, ws.sinT, tokmask, cross_s, nullptr, ws.lw, nxt, st);
             if (rc) return rc;
-            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st, nullptr, nullptr, pk,
-                            cmax, nmax, nmax);
+            rc = layer_call(w.layers[l], C, H, P, cur, PN, PM, nxt, 0, PN, ws.cosT, ws.sinT, tokmask, cross_t, nullptr, ws.lw, nxt, st);
             if (rc) return rc;
         }
         cur = nxt;
-        cmax = nmax;
         which ^= 1;
     }
     *final_feats = cur;
@@ -585,8 +504,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
     GemmBatch g;
     memset(&g, 0, sizeof(g));
     GemmProblem& p = g.p[0];
-    p.A = cur; p.W = w.src_proj; p.Wsplit = ws.pw.on ? ws.pw.src_proj : nullptr; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
-    p.amax = cmax; p.amax_parts = 1;
+    p.A = cur; p.W = w.src_proj; p.out = ws.proj; p.rows = T; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.ldo = C;
     p.epi = EPI_ROTARY; p.rot_C = C; p.cosT = ws.cosT; p.sinT = ws.sinT; p.scale = 1.0f / sqrtf((float)C);
     g.n = 1;
     int rc = launch_gemm(g, st);
@@ -693,11 +611,8 @@ int dr_init(void) {
 /* diagnostics for tools/: force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
 void dr_debug_enable_env(int on) { enable_env_knobs(on != 0); }
 void dr_debug_gemm_config(int c) { gemm_force_config(c); }
-void dr_debug_gemm_wide_min(int tiles) { gemm_force_wide_min(tiles); }
-void dr_debug_gemm_f16x2(int on) { gemm_force_f16x2(on); }
 void dr_debug_attention_config(int flash_min_workgroups) { attention_force_flash_min(flash_min_workgroups); }
 void dr_debug_attention_split(int on) { attention_force_split(on); }
-int dr_debug_gemm_stamps(long long* h_out256) { return read_gemm_stamps(h_out256); }
 
 int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const float* R, const float* t, float origin_x,
                   float origin_y, float origin_z, float voxel, const float* freq, float* cos_out, float* sin_out,
@@ -742,26 +657,6 @@ int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const 
     GemmProblem& p = g.p[0];
     p.A = x; p.W = W; p.bias = bias; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = lda; p.ldo = ldo;
     p.epi = epilogue; p.scale = scale;
-    g.n = 1;
-    return launch_gemm(g, (hipStream_t)stream);
-}
-
-size_t dr_packed_weight_bytes(int ncols, int K) { return (ncols > 0 && K > 0) ? gemm_packed_weight_bytes(ncols, K) : 0; }
-
-int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* stream) {
-    if (ncols <= 0 || K <= 0 || !W || !packed || ((uintptr_t)packed & 15)) return DR_EINVAL;
-    return launch_pack_weights(W, ncols, K, packed, (hipStream_t)stream);
-}
-
-int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
-                         int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream) {
-    if (rows < 0 || ncols <= 0 || K <= 0 || !x || !W || !packed || !out) return DR_EINVAL;
-    if ((epilogue & EPI_ROTARY) && (!cos_t || !sin_t || rot_C <= 0 || (rot_C & 1))) return DR_EINVAL;
-    GemmBatch g;
-    memset(&g, 0, sizeof(g));
-    GemmProblem& p = g.p[0];
-    p.A = x; p.W = W; p.Wsplit = packed; p.out = out; p.rows = rows; p.ncols = ncols; p.K = K; p.K1 = K; p.lda = K; p.ldo = ncols;
-    p.epi = epilogue; p.cosT = cos_t; p.sinT = sin_t; p.rot_C = rot_C; p.scale = scale;
     g.n = 1;
     return launch_gemm(g, (hipStream_t)stream);
 }
@@ -881,13 +776,10 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
     const size_t PN = (size_t)P * N, PM = (size_t)P * M;
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
-    { const int rcm = launch_rowmax(L.feat0, C, (int)(PN + PM), C, L.dw.m_feat0, st); if (rcm) return rcm; }
     if (src_mask) {
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
     }
-    rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);
-    if (rc) return rc;
     Prepack pp;
     rc = planes_begin(*cfg, *w, P, N, M, L.dw, pp, st);
     if (rc) return rc;
@@ -932,7 +824,6 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
 
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0 + PN * C, tgt_feats, PM * C * 4, hipMemcpyDeviceToDevice, st));
-    { const int rcm = launch_rowmax(L.feat0, C, (int)(PN + PM), C, L.dw.m_feat0, st); if (rcm) return rcm; }
     if (src_mask) {
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask, src_mask, PN, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(L.tokmask + PN, tgt_mask, PM, hipMemcpyDeviceToDevice, st));
@@ -941,8 +832,6 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     if (rc) return rc;
     if (!v4d && P <= 32)                          // arrival counters of the multi-workgroup minimum (few pairs: stateops.hip)
         DR_HIP_CHECK(hipMemsetAsync((char*)L.pmin + pair_min_scratch_bytes(P) - 64 * (size_t)P, 0, 64 * (size_t)P, st));
-    rc = L.dw.pw.fill(*w, cfg->n_layers, C, st);  // split-operand images of the weights (the caller may have updated them)
-    if (rc) return rc;
     Prepack pp;
     rc = planes_begin(*cfg, *w, P, N, M, L.dw, pp, st);
     if (rc) return rc;

@@ -87,12 +87,7 @@ struct PgGeom {
 #define PG_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
 #define PG_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
 
-__device__ long long g_pg_stamps[128];
-#define PG_STAMP(i) do { if (DBG && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_pg_stamps[i] = wall_clock64(); } while (0)
-// cycle stamps (s_memtime) inside stage 10 of waves 0 and 4 of workgroup 0: slots 64 + 16 grp + i
-#define PG_CSTAMP(i) do { if (DBG && s == 10 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 255) == 0) g_pg_stamps[64 + 16 * GRP + (i)] = clock64(); } while (0)
-
-template <int TNW, int NST, int MODE, bool DBG = false, int ABL = 0, int WMN = 4>
+template <int TNW, int NST, int MODE, int WMN = 4>
 __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN / 2, WMN / 2))) void pgemm_kernel(PgBatch G) {
     using GG = PgGeom<TNW, NST, WMN>;
     constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S, BM = GG::BM, NTHR = GG::NTHR;
@@ -136,7 +131,6 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     u32x4 fa0[2], fa1[2], fx[TNW / 2][2], fy[TNW - TNW / 2][2];
-    PG_STAMP(0);
 
     // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream but keep
     // their DMA issue -- ~100 cycles of the wave's instruction stream per 1 KB instruction, ~500 per stage, as much again as its
@@ -181,8 +175,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             // weight piece pw of a wave: the immediate reaches 3 KB, every 4 pieces move the register base by 4 KB
             const int pw = GRP ? p - 2 : p;
             const unsigned hop = (unsigned)(pw >> 2) * 4096;
-            if (GRP && p < 2) { if (ABL != 6) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024); }
-            else if (ABL == 5) {}
+            if (GRP && p < 2) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024);
             else if (pw < (GRP ? WB_CNT : NW0) / WMN || wl < (GRP ? WB_CNT : NW0) % WMN) PG_DMA(m0w + hop, voffW + hop, gb, (pw & 3) * 1024);
         };
         auto dma_advance = [&]() __attribute__((always_inline)) {
@@ -220,7 +213,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             auto gap = [&](int m) __attribute__((always_inline)) {
                 // ---- fragment reads of the next burst: two per gap, in the first gaps of the burst (the wait that ends the burst
                 // then finds them landed: the last read is >= 4 MFMAs old)
-                if (ABL != 3) {
+                {
                     if (m < NT2) {                                       // set Y: tile NT1 + m
                         PG_READ(fy[m][0], Bh, (NT1 + m) * 2048);
                         PG_READ(fy[m][1], Bl, (NT1 + m) * 2048);
@@ -235,12 +228,11 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 // ---- DMA pieces: group 0 in burst 1 (stage s + NST - 2), group 1 in burst 2 (stage s + NST - 1)
                 constexpr int MF = EARLY ? 0 : (PSTEP == 2 ? M1 + 1 : M1), STEP = EARLY ? 1 : PSTEP;
                 if (m >= MF && m < MF + STEP * NPIECE && (m - MF) % STEP == 0) {
-                    if (do_issue && ABL != 1) dma_piece((m - MF) / STEP, dstb);
+                    if (do_issue) dma_piece((m - MF) / STEP, dstb);
                     if ((m - MF) / STEP == NPIECE - 1 && do_issue) dma_advance();
                 }
                 // ---- the stage's barrier, between the bursts
                 if (m == M1 - 1) {
-                    PG_CSTAMP(1);
                     if (has_next) {
                         // own DMAs of stage s + 1 have landed (those of stage s + 2, issued later, may still fly)
                         if (NST >= 4 && (STEADY || s + 2 < nst)) {
@@ -249,23 +241,17 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                             PG_VMCNT(0);
                         }
                     }
-                    PG_CSTAMP(2);
-                    if (ABL != 2) __builtin_amdgcn_s_barrier();
-                    PG_CSTAMP(3);
+                    __builtin_amdgcn_s_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set Y has arrived (issued during burst 1)
-                    PG_CSTAMP(4);
                 }
             };
             const f16x8 ah = __builtin_bit_cast(f16x8, ac[0]), al = __builtin_bit_cast(f16x8, ac[1]);
 #define PG_MFMA(X, Y, g)                                                        \
-    if (ABL != 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X, Y, acc[j], 0, 0, 0);      \
-    else asm volatile("" ::"v"(X), "v"(Y));                                     \
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X, Y, acc[j], 0, 0, 0);      \
     __builtin_amdgcn_sched_barrier(0);                                          \
     gap(3 * j + g);                                                             \
     __builtin_amdgcn_sched_barrier(0);
-            PG_CSTAMP(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // A fragments and set X of this stage (issued during the previous burst 2)
-            PG_CSTAMP(6);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NT1; ++j) {
@@ -282,7 +268,6 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 PG_MFMA(ah, bh, 2)
             }
 #undef PG_MFMA
-            PG_CSTAMP(5);
         };
 
         // ---- prologue: group 1 puts stages 0 .. NST - 2 in flight, group 0 stages 0 .. NST - 3 (it issues stage s + NST - 2 in
@@ -303,25 +288,19 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             PG_READ(fx[j][0], lds_base + offBh, j * 2048);
             PG_READ(fx[j][1], lds_base + offBl, j * 2048);
         }
-        PG_STAMP(1);
         int s = 0;
         for (; s + 1 < nst - (NST - 1); s += 2) {                    // steady state: every stage issues, has a successor
             stage(s, std::true_type{}, fa0, fa1);
             stage(s + 1, std::true_type{}, fa1, fa0);
-            if (DBG && s < 100) PG_STAMP(8 + (s >> 1));
         }
         for (; s < nst; s += 2) {                                    // tail
             stage(s, std::false_type{}, fa0, fa1);
             if (s + 1 < nst) stage(s + 1, std::false_type{}, fa1, fa0);
-            if (DBG && s < 100) PG_STAMP(8 + (s >> 1));
         }
     };
     if (wn == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
-    PG_STAMP(2);
-    if (ABL == 9) return;                                        // (diagnostics: the kernel without its epilogue -- timing only, no output)
     __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
-    PG_STAMP(3);
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // The MFMA result has a lane's 16 values in 16 different rows.  Each wave transposes its 32 x 224 strip in two rounds of
@@ -371,10 +350,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             float4 tb[NI];
-            if (rot && ABL == 10) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) tb[i] = make_float4(1.f, 1.f, 0.f, 0.f);
-            } else if (rot) {
+            if (rot) {
                 const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;
                 const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
                 const float* pp = P.csT ? P.csT + (size_t)min(grow[rr], rows - 1) * halfC * 2 : nullptr;
@@ -418,17 +394,15 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int col = colw + 16 * i;
-                    if (col < C && ABL != 7) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                    if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
-            PG_STAMP(6);
             return;
         }
     } else {
         transpose_round(0, v[0]);
         transpose_round(1, v[1]);
     }
-    PG_STAMP(4);
 
     if (mode == PG_LN) {
         // nn.LayerNorm over the C columns of the block (biased variance, eps inside the sqrt; transformero.py:88-94)
@@ -443,10 +417,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         // registers, round 1 is parked in the wave's transposition region (free now).
         const float* __restrict__ res = P.resid;
         float4 r0[NI];
-        if (res && ABL == 12) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) { r0[i] = make_float4(0.f, 0.f, 0.f, 0.f); *reinterpret_cast<float4*>(ep + lr * EP_S + 16 * i + 4 * q) = r0[i]; }
-        } else if (res) {
+        if (res) {
             const float* rp1 = res + (size_t)min(grow[1], rows - 1) * P.ldr;
             const float* rp0 = res + (size_t)min(grow[0], rows - 1) * P.ldr;
 #pragma unroll
@@ -507,12 +478,11 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
                     v[rr][i] = y;
-                    if (P.out && rok && ABL != 13) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
+                    if (P.out && rok) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
                 }
             }
         }
     }
-    PG_STAMP(5);
     if (!P.pimg) return;
 
     // ---- plane image of the result.  Piece i of lane q is columns 16 i + 4 q .. + 3 of chunk (wn BNW / 16 + i): the lanes
@@ -521,15 +491,21 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     for (int rr = 0; rr < 2; ++rr) {
         const bool rok = grow[rr] < rows;
         const int rowc = min(grow[rr], rows - 1);
+        const bool per_blk = P.pimg_blk_stride != 0;
         float bound;
         if (mode == PG_LN) bound = (P.bnd_res ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
         else {
             // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
             // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
             const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + rowc / P.grp_rows] : fmaxf(P.bnd0[rowc], nc1 > 0 ? P.bnd1[rowc] : 0.f);
-            bound = bin * P.W.wnorm[nb] * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+            // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
+            // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
+            // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
+            float wn_ = P.W.wnorm[nb];
+            if (!per_blk)
+                for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
+            bound = bin * wn_ * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
         }
-        const bool per_blk = P.pimg_blk_stride != 0;
         if (P.pbnd && rok && (nb == 0 || per_blk) && wn == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
         const float sc = pow2i(scale_exp(bound));
         const int rl = sub + wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;       // row inside the 128-row image block
@@ -544,17 +520,16 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             split2(v[rr][i].z * sc, v[rr][i].w * sc, h1, l1);
             // ONE 16-byte store per lane: the even lane of a pair writes the hi unit (its 4 columns, then the partner's), the odd lane the lo
             // unit -- every lane stores, a wave instruction covers 16 rows x 64 contiguous bytes (two stores by half the lanes before:
-            // 39 of the family's 108 ms per pass were these stores, DR_PG_ABL=11)
+            // 39 of the family's 108 ms per pass were these stores, measured by ablation in round 2)
             const bool odd = q & 1;
             const unsigned r0_ = dpp_xor1(odd ? h0 : l0), r1_ = dpp_xor1(odd ? h1 : l1);      // what the partner stores of mine <-> what I store of the partner's
-            if (rok && ABL != 11) {
+            if (rok) {
                 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
                 const u32x4v U = odd ? u32x4v{r0_, r1_, l0, l1} : u32x4v{h0, h1, r0_, r1_};
                 __builtin_nontemporal_store(U, reinterpret_cast<u32x4v*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)));
             }
         }
     }
-    PG_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -686,28 +661,27 @@ int pgemm_bn(int C) { return C <= G7::BN ? G7::BN : G9::BN; }
 static size_t pg_bst(int C) { return (size_t)pgemm_bn(C) * 64; }
 
 template <int TNW, int NST, int MODE>
-static int configure_mode(bool with_dbg) {
-    using GG = PgGeom<TNW, NST>;
-#define PG_ATTR(DBGF, ABLV) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::SMEM))
-    PG_ATTR(false, 0);
-    if constexpr (TNW == 7) {
-        if (with_dbg) { PG_ATTR(true, 0); PG_ATTR(true, 1); PG_ATTR(true, 2); PG_ATTR(true, 3); PG_ATTR(true, 4); PG_ATTR(true, 5); PG_ATTR(true, 6); PG_ATTR(true, 7); PG_ATTR(true, 9); PG_ATTR(true, 10); PG_ATTR(true, 11); PG_ATTR(true, 12); PG_ATTR(true, 13); }
-    }
-#undef PG_ATTR
+static int configure_mode() {
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 2>::SMEM));
     return DR_OK;
 }
 int pgemm_configure() {
-    int rc = configure_mode<7, 4, PG_F32>(true);
-    if (rc == DR_OK) rc = configure_mode<7, 4, PG_PLANES>(true);
-    if (rc == DR_OK) rc = configure_mode<7, 4, PG_LN>(true);
-    if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>(false);
-    if (rc == DR_OK) rc = configure_mode<9, 3, PG_PLANES>(false);
-    if (rc == DR_OK) rc = configure_mode<9, 3, PG_LN>(false);
-#define PG_ATTR_H(TNW, NST, MODE, GH) if (rc == DR_OK) DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::SMEM))
-    PG_ATTR_H(7, 4, PG_F32, G7H); PG_ATTR_H(7, 4, PG_PLANES, G7H); PG_ATTR_H(7, 4, PG_LN, G7H);
-    PG_ATTR_H(9, 3, PG_F32, G9H); PG_ATTR_H(9, 3, PG_PLANES, G9H); PG_ATTR_H(9, 3, PG_LN, G9H);
-#undef PG_ATTR_H
+    int rc = configure_mode<7, 4, PG_F32>();
+    if (rc == DR_OK) rc = configure_mode<7, 4, PG_PLANES>();
+    if (rc == DR_OK) rc = configure_mode<7, 4, PG_LN>();
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>();
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_PLANES>();
+    if (rc == DR_OK) rc = configure_mode<9, 3, PG_LN>();
     return rc;
+}
+
+template <int TNW, int NST, int WMN>
+static void pg_launch(int mode, dim3 grid, hipStream_t st, const PgBatch& g) {
+    using GG = PgGeom<TNW, NST, WMN>;
+    if (mode == PG_F32) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, PG_F32, WMN>), grid, dim3(GG::NTHR), GG::SMEM, st, g);
+    else if (mode == PG_PLANES) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, PG_PLANES, WMN>), grid, dim3(GG::NTHR), GG::SMEM, st, g);
+    else hipLaunchKernelGGL((pgemm_kernel<TNW, NST, PG_LN, WMN>), grid, dim3(GG::NTHR), GG::SMEM, st, g);
 }
 
 int launch_pgemm(const PgBatch& g, hipStream_t st) {
@@ -716,7 +690,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     double flops = 0;
     const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G7::BN ? G7::NST : G9::NST;
     // 64-row workgroups when the launch would not give every CU a 128-row one (DR_PG_HALF under dr_debug_enable_env: 0 never, 2 always)
-    static const int half_env = env_knob("DR_PG_HALF", 1);
+    const int half_env = env_knob("DR_PG_HALF", 1);
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     long wg128 = 0;
     for (int i = 0; i < g.n; ++i) wg128 += (long)((g.p[i].rows + 127) / 128) * g.p[i].nblk;
@@ -731,46 +705,12 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
-    static const bool dbg = env_knob("DR_PG_STAMPS", 0) != 0;
-    static const int abl = env_knob("DR_PG_ABL", 0);
     const int mode = g.p[0].mode;
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
-    const dim3 grid(maxt, g.n), blk(half ? 256 : 512);
-#define PG_LAUNCH(TNW, NST, MODE, DBGF, ABLV) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, MODE, DBGF, ABLV>), grid, blk, (PgGeom<TNW, NST>::SMEM), st, g)
-#define PG_LAUNCH_DBG(MODE)                                        \
-    switch (abl) {                                                 \
-        case 1: PG_LAUNCH(7, 4, MODE, true, 1); break;             \
-        case 2: PG_LAUNCH(7, 4, MODE, true, 2); break;             \
-        case 3: PG_LAUNCH(7, 4, MODE, true, 3); break;             \
-        case 4: PG_LAUNCH(7, 4, MODE, true, 4); break;             \
-        case 5: PG_LAUNCH(7, 4, MODE, true, 5); break;             \
-        case 6: PG_LAUNCH(7, 4, MODE, true, 6); break;             \
-        case 7: PG_LAUNCH(7, 4, MODE, true, 7); break;             \
-        case 9: PG_LAUNCH(7, 4, MODE, true, 9); break;             \
-        case 10: PG_LAUNCH(7, 4, MODE, true, 10); break;           \
-        case 11: PG_LAUNCH(7, 4, MODE, true, 11); break;           \
-        case 12: PG_LAUNCH(7, 4, MODE, true, 12); break;           \
-        case 13: PG_LAUNCH(7, 4, MODE, true, 13); break;           \
-        default: PG_LAUNCH(7, 4, MODE, true, 0); break;            \
-    }
-    if (half && !dbg) {
-#define PG_LAUNCH_H(TNW, NST, MODE, GH) hipLaunchKernelGGL((pgemm_kernel<TNW, NST, MODE, false, 0, 2>), grid, blk, (GH::SMEM), st, g)
-        if (bn == G9::BN) {
-            if (mode == PG_F32) PG_LAUNCH_H(9, 3, PG_F32, G9H); else if (mode == PG_PLANES) PG_LAUNCH_H(9, 3, PG_PLANES, G9H); else PG_LAUNCH_H(9, 3, PG_LN, G9H);
-        } else {
-            if (mode == PG_F32) PG_LAUNCH_H(7, 4, PG_F32, G7H); else if (mode == PG_PLANES) PG_LAUNCH_H(7, 4, PG_PLANES, G7H); else PG_LAUNCH_H(7, 4, PG_LN, G7H);
-        }
-#undef PG_LAUNCH_H
-    } else if (bn == G9::BN) {
-        if (mode == PG_F32) PG_LAUNCH(9, 3, PG_F32, false, 0);
-        else if (mode == PG_PLANES) PG_LAUNCH(9, 3, PG_PLANES, false, 0);
-        else PG_LAUNCH(9, 3, PG_LN, false, 0);
-    } else if (dbg) {
-        if (mode == PG_F32) { PG_LAUNCH_DBG(PG_F32) } else if (mode == PG_PLANES) { PG_LAUNCH_DBG(PG_PLANES) } else { PG_LAUNCH_DBG(PG_LN) }
-    } else if (mode == PG_F32) PG_LAUNCH(7, 4, PG_F32, false, 0);
-    else if (mode == PG_PLANES) PG_LAUNCH(7, 4, PG_PLANES, false, 0);
-    else PG_LAUNCH(7, 4, PG_LN, false, 0);
+    const dim3 grid(maxt, g.n);
+    if (bn == G9::BN) { if (half) pg_launch<9, 3, 2>(mode, grid, st, g); else pg_launch<9, 3, 4>(mode, grid, st, g); }
+    else { if (half) pg_launch<7, 4, 2>(mode, grid, st, g); else pg_launch<7, 4, 4>(mode, grid, st, g); }
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -869,12 +809,6 @@ int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hi
 using namespace dr;
 
 extern "C" {
-
-/* diagnostics (DR_PG_STAMPS=1): 100 MHz wall-clock stamps of workgroup 0 of the last plane GEMM launch; synchronises */
-int dr_debug_pgemm_stamps(long long* h_out128) {
-    DR_HIP_CHECK(hipMemcpyFromSymbol(h_out128, HIP_SYMBOL(g_pg_stamps), sizeof(long long) * 128));
-    return DR_OK;
-}
 
 size_t dr_plane_image_bytes(int rows, int K) { return (rows > 0 && K > 0 && K % 16 == 0) ? plane_image_bytes((size_t)rows, K) : 0; }
 

@@ -98,23 +98,6 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     if (rowmax) { ymax = wave_max(ymax); if (lane == 0) rowmax[row] = ymax; }
 }
 
-// max |x[r][:]| per row (the external features entering the first layer)
-__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int ldx, int rows, int C, float* __restrict__ rowmax) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    float m = 0.f;
-    for (int c = lane; c < C; c += 64) m = fmaxf(m, fabsf(x[(size_t)row * ldx + c]));
-    m = wave_max(m);
-    if (lane == 0) rowmax[row] = m;
-}
-int launch_rowmax(const float* x, int ldx, int rows, int C, float* rowmax, hipStream_t st) {
-    if (rows <= 0) return DR_OK;
-    hipLaunchKernelGGL(rowmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, rows, C, rowmax);
-    DR_LAUNCH_CHECK();
-    return DR_OK;
-}
-
 template <bool POSTADD>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* g, const float* b, const float* res, int ldres, float* out,
                                  int ldo, int rows, int C, hipStream_t st, float* rowmax) {
@@ -282,22 +265,32 @@ int launch_vol_pe(const float* xyz, int rows, int rows_per_pair, const float* R,
 // split_feats (3D/models/pipeline.py:350-379): dst[dst_index[i]][:] = src[src_index[i]][:] for i < n (rows of C floats;
 // the padded destination is zero-filled by the caller).  One wave per row.
 // ---------------------------------------------------------------------------------------------
+// Indices follow torch's indexed assignment: negative ones wrap once ([-rows, -1]); anything else out of range is SKIPPED and
+// *status (optional) is set to 1 -- never an out-of-bounds access (PyTorch raises there; the host wrapper turns the flag into one).
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ sidx,
-                                                           const long long* __restrict__ didx, float* __restrict__ dst, int n, int C) {
+                                                           const long long* __restrict__ didx, float* __restrict__ dst, int n, int C,
+                                                           long long n_src, long long n_dst, int* __restrict__ status) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
-    const float* s = src + (size_t)sidx[i] * C;
-    float* d = dst + (size_t)didx[i] * C;
+    long long si = sidx[i], di = didx[i];
+    if (si < 0) si += n_src;
+    if (di < 0) di += n_dst;
+    if (si < 0 || si >= n_src || di < 0 || di >= n_dst) {
+        if (status && lane == 0) *status = 1;
+        return;
+    }
+    const float* s = src + (size_t)si * C;
+    float* d = dst + (size_t)di * C;
     for (int c = lane; c < C; c += 64) d[c] = s[c];
 }
 }  // namespace dr
 
-extern "C" int dr_scatter_rows_f32(int n, int C, const float* src, const int64_t* src_index, const int64_t* dst_index, float* dst,
-                                   void* stream) {
-    if (n < 0 || C < 1 || !src || !src_index || !dst_index || !dst) return DR_EINVAL;
+extern "C" int dr_scatter_rows_f32(int n, int C, const float* src, int64_t n_src_rows, const int64_t* src_index, const int64_t* dst_index,
+                                   float* dst, int64_t n_dst_rows, int32_t* status, void* stream) {
+    if (n < 0 || C < 1 || !src || !src_index || !dst_index || !dst || n_src_rows < 0 || n_dst_rows < 0) return DR_EINVAL;
     if (n == 0) return DR_OK;
     hipLaunchKernelGGL(dr::scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, (const long long*)src_index,
-                       (const long long*)dst_index, dst, n, C);
+                       (const long long*)dst_index, dst, n, C, (long long)n_src_rows, (long long)n_dst_rows, status);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

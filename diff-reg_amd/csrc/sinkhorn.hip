@@ -566,7 +566,7 @@ __global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
 // ---------------------------------------------------------------------------------------------
 // workgroups of the persistent form: one per CU; DR_SK_PERSIST_GRID=0 keeps the one-tile-per-workgroup kernel (tools)
 static int sk_persist_grid() {
-    static const int v = env_knob("DR_SK_PERSIST_GRID", 256);
+    const int v = env_knob("DR_SK_PERSIST_GRID", 256);
     return v;
 }
 typedef __attribute__((address_space(3))) void sk_lds_void;

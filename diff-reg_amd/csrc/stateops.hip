@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void mutual_match_kernel(const T* __restrict_
     for (int j = t; j < M; j += 1024) {
         T best = -INFINITY;
         if (mutual)
-            for (int i = 0; i < N; ++i) { const T v = c[(size_t)i * M + j]; best = v > best ? v : best; }
+            for (int i = 0; i < N; ++i) { const T v = c[(size_t)i * M + j]; best = (v > best || v != v) ? v : best; }   // NaN propagates like torch.max
         s_col[j] = best;
     }
     __syncthreads();
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(1024) void mutual_match_kernel(const T* __restrict_
     auto row_max = [&](int i) {
         T best = -INFINITY;
         if (mutual) {
-            for (int j = lane; j < M; j += 64) { const T v = c[(size_t)i * M + j]; best = v > best ? v : best; }
-            for (int m = 32; m >= 1; m >>= 1) { const T o = __shfl_xor(best, m); best = o > best ? o : best; }
+            for (int j = lane; j < M; j += 64) { const T v = c[(size_t)i * M + j]; best = (v > best || v != v) ? v : best; }
+            for (int m = 32; m >= 1; m >>= 1) { const T o = __shfl_xor(best, m); best = (o > best || o != o) ? o : best; }
         }
         return best;
     };

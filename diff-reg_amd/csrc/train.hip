@@ -659,7 +659,7 @@ int dr_layernorm_f32(int rows, int C, const float* x, const float* gamma, const 
 size_t dr_layernorm_backward_workspace_bytes(int C) { return C > 0 ? (size_t)dr::LNB_BLOCKS * 2 * C * sizeof(float) : 0; }
 int dr_layernorm_backward_f32(int rows, int C, const float* x, const float* gamma, const float* mean_rstd, const float* grad_y, float* grad_x,
                               float* grad_gamma, float* grad_beta, void* workspace, void* stream) {
-    if (rows < 1 || C < 1 || C > 4096 || !x || !gamma || !mean_rstd || !grad_y || !grad_x || !grad_gamma || !grad_beta || !workspace) return DR_EINVAL;
+    if (rows < 1 || C < 1 || C > 2048 || !x || !gamma || !mean_rstd || !grad_y || !grad_x || !grad_gamma || !grad_beta || !workspace) return DR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dr::ln_bwd_kernel, dim3(dr::LNB_BLOCKS), dim3(256), (size_t)8 * C * sizeof(float), st, rows, C, x, gamma, mean_rstd, grad_y, grad_x,
                        (float*)workspace);

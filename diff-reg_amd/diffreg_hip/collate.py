@@ -5,7 +5,7 @@ cpp_subsampling / cpp_neighbors on the data-loader's CPU workers -- and the leve
 (`dataloader.py:120-211`) that builds `points / neighbors / pools / upsamples / stack_lengths` for the KPFCN backbone.
 Everything runs on the device through libdiffreg_hip.so (dr_grid_subsample_f32, dr_radius_neighbors_f32); there is no CPU path.
 The reference-shaped helpers synchronise once to cut their result to its data-dependent shape, as the reference's return values
-require; `build_kpfcn_inputs` does so once per level.
+require; `build_kpfcn_inputs` does so once per level of `encoder_levels(architecture)`.
 """
 import torch
 
@@ -40,50 +40,59 @@ def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_
     return out[:, :w]
 
 
+def encoder_levels(architecture):
+    """The encoder half of a KPFCN architecture string list as resolution levels: [(wide_conv, down, wide_down), ...].
+    A level is the run of convolution blocks at one point density; it ends at the block that changes the density (a 'pool' or
+    'strided' block: `down` = True) or where the decoder starts ('upsample' / 'global', or the end of the list).
+    wide_conv: the level's convolutions search the deformable radius -- the case when a block BEFORE the level's last convolution
+    is deformable (the rule of 3D/datasets/dataloader.py:141-146); wide_down: the density-changing block itself is deformable.
+    A level without convolution blocks (two density changes in a row) has wide_conv = None: it gets no neighbour matrix."""
+    levels, convs = [], []
+    for name in architecture:
+        if "global" in name or "upsample" in name:
+            break
+        if "pool" in name or "strided" in name:
+            levels.append((any("deformable" in c for c in convs[:-1]) if convs else None, True, "deformable" in name))
+            convs = []
+        else:
+            convs.append(name)
+    if convs:
+        levels.append((any("deformable" in c for c in convs[:-1]), False, False))
+    return levels
+
+
 def build_kpfcn_inputs(points, lengths, config, neighborhood_limits):
-    """The level loop of collate_fn_3dmatch (dataloader.py:120-211) on device: stacked points [n,3] + lengths [2 B] ->
-    dict(points, neighbors, pools, upsamples, stack_lengths) with the reference's dtypes (float32 / int64 / int32).
+    """KPFCN index arrays on device (what the level loop of collate_fn_3dmatch builds, dataloader.py:120-211): stacked points
+    [n,3] + lengths [2 B] -> dict(points, neighbors, pools, upsamples, stack_lengths) with the reference's dtypes (float32 /
+    int64 / int32).  Per level L of encoder_levels(): cell size dl0 2^L, ball radius dl0 conv_radius 2^L (deform_radius in its
+    place where the level searches wide); neighbours of the level's cloud in itself; when the level ends in a density change, the
+    next cloud = grid subsampling at twice the cell size, `pools` = the next cloud's neighbours in this one, `upsamples` = this
+    cloud's neighbours in the next one at twice the radius.
     config: architecture, first_subsampling_dl, conv_radius, deform_radius (attribute or item access)."""
     get = (lambda k: config[k]) if isinstance(config, dict) else (lambda k: getattr(config, k))
-    arch = get("architecture")
-    r_normal = get("first_subsampling_dl") * get("conv_radius")
+    dl0, k_conv, k_deform = get("first_subsampling_dl"), get("conv_radius"), get("deform_radius")
     dev = points.device
-    batched_points = points.to(torch.float32).contiguous()
-    batched_lengths = lengths.to(device=dev, dtype=torch.int32)
-    empty_i = lambda: torch.zeros((0, 1), dtype=torch.int64, device=dev)
+    cloud = points.to(torch.float32).contiguous()
+    lens = lengths.to(device=dev, dtype=torch.int32)
+    no_index = lambda: torch.zeros((0, 1), dtype=torch.int64, device=dev)
     out = dict(points=[], neighbors=[], pools=[], upsamples=[], stack_lengths=[])
-    layer_blocks, layer = [], 0
-    for block_i, block in enumerate(arch):
-        if "global" in block or "upsample" in block:
-            break
-        if not ("pool" in block or "strided" in block):
-            layer_blocks += [block]
-            if block_i < len(arch) - 1 and not ("upsample" in arch[block_i + 1]):
-                continue
-        if layer_blocks:
-            r = r_normal * get("deform_radius") / get("conv_radius") if any("deformable" in b for b in layer_blocks[:-1]) else r_normal
-            conv_i = batch_neighbors_kpconv(batched_points, batched_points, batched_lengths, batched_lengths, r, neighborhood_limits[layer])
-        else:
-            conv_i = empty_i()
-        if "pool" in block or "strided" in block:
-            dl = 2 * r_normal / get("conv_radius")
-            pool_p, pool_b = batch_grid_subsampling_kpconv(batched_points, batched_lengths, sampleDl=dl)
-            r = r_normal * get("deform_radius") / get("conv_radius") if "deformable" in block else r_normal
-            pool_i = batch_neighbors_kpconv(pool_p, batched_points, pool_b, batched_lengths, r, neighborhood_limits[layer])
-            up_i = batch_neighbors_kpconv(batched_points, pool_p, batched_lengths, pool_b, 2 * r, neighborhood_limits[layer])
-        else:
-            pool_i, up_i = empty_i(), empty_i()
-            pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
-            pool_b = torch.zeros((0,), dtype=torch.int32, device=dev)
-        out["points"].append(batched_points)
-        out["neighbors"].append(conv_i)
-        out["pools"].append(pool_i)
-        out["upsamples"].append(up_i)
-        out["stack_lengths"].append(batched_lengths)
-        batched_points, batched_lengths = pool_p, pool_b
-        r_normal *= 2
-        layer += 1
-        layer_blocks = []
+    for L, (wide_conv, down, wide_down) in enumerate(encoder_levels(get("architecture"))):
+        cell = dl0 * 2 ** L                       # (the reference doubles a running radius: the same float64 values)
+        radius = lambda wide: cell * k_conv * k_deform / k_conv if wide else cell * k_conv
+        limit = neighborhood_limits[L]
+        out["points"].append(cloud)
+        out["stack_lengths"].append(lens)
+        out["neighbors"].append(no_index() if wide_conv is None else batch_neighbors_kpconv(cloud, cloud, lens, lens, radius(wide_conv), limit))
+        if not down:
+            out["pools"].append(no_index())
+            out["upsamples"].append(no_index())
+            cloud, lens = torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+            continue
+        coarse, coarse_lens = batch_grid_subsampling_kpconv(cloud, lens, sampleDl=2 * cell * k_conv / k_conv)
+        r = radius(wide_down)
+        out["pools"].append(batch_neighbors_kpconv(coarse, cloud, coarse_lens, lens, r, limit))
+        out["upsamples"].append(batch_neighbors_kpconv(cloud, coarse, lens, coarse_lens, 2 * r, limit))
+        cloud, lens = coarse, coarse_lens
     return out
 
 

@@ -43,7 +43,11 @@ class DenoiseEngine:
         self.variant, self.C, self.H, self.n_layers = variant, C, H, n_layers
         self.steps = steps
         dev = self.device
-        f = lambda k: state[k].detach().to(device=dev, dtype=torch.float32).contiguous()
+        # A private snapshot of every weight (copy=True: never an alias of a live nn.Parameter): the f32 kernels read these tensors
+        # and the plane path reads images packed from them below, so both GEMM paths always see the same values.  A caller whose
+        # parameters change (optimizer.step(), in-place edits) builds a new engine -- models.pipeline.Pipeline does so by itself
+        # from the parameters' version counters.
+        f = lambda k: state[k].detach().to(device=dev, dtype=torch.float32, copy=True).contiguous()
         self._tensors = []
         self._layers = (lib.LayerWeights * n_layers)()
         for l in range(n_layers):
@@ -74,7 +78,7 @@ class DenoiseEngine:
         self._ws = None
         self._graphs = collections.OrderedDict()
         self._cache_entries = max(1, int(cache_entries))
-        # the weights are immutable for the life of the engine: their plane images are packed once (dr_loop_prepack)
+        # the snapshot above is immutable for the life of the engine: its plane images are packed once (dr_loop_prepack)
         self._packed = None
         nb = lib.raw().dr_loop_prepack_bytes(ctypes.byref(cfg))
         if nb and prepack:

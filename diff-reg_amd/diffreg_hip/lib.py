@@ -96,10 +96,6 @@ SIGNATURES.update({
                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                               c_float, c_void_p]),
-    "dr_packed_weight_bytes": (c_size_t, [c_int, c_int]),
-    "dr_pack_weight_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dr_linear_packed_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                     c_int, c_float, c_void_p]),
     "dr_plane_image_bytes": (c_size_t, [c_int, c_int]),
     "dr_planes_from_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_planes_from_f32_bounded": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -126,11 +122,7 @@ SIGNATURES.update({
     "dr_debug_enable_env": (None, [c_int]),
     "dr_debug_launch_chain": (c_int, [c_int, c_int, c_int, c_void_p]),
     "dr_debug_gemm_config": (None, [c_int]),
-    "dr_debug_gemm_wide_min": (None, [c_int]),
-    "dr_debug_gemm_f16x2": (None, [c_int]),
     "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
-    "dr_debug_gemm_stamps": (c_int, [c_void_p]),
-    "dr_debug_pgemm_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
     "dr_pnp_ransac_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -159,7 +151,7 @@ SIGNATURES.update({
     "dr_sinkhorn_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_sinkhorn_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_size_t, c_void_p]),
-    "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "dr_mutual_match_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -347,14 +339,30 @@ def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, 
     check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
 
 
-def scatter_rows(src, src_index, dst_index, dst):
-    """dst[dst_index[i]] = src[src_index[i]] (rows; split_feats of the reference)"""
+def scatter_rows(src, src_index, dst_index, dst, validate=True, status=None):
+    """dst[dst_index[i]] = src[src_index[i]] (rows; split_feats of the reference).  Index tensors may live on the host (torch
+    indexing accepts that); out-of-range indices raise IndexError like torch's indexed assignment (validate=True reads a 4-byte
+    device flag, i.e. synchronises the stream; validate=False leaves such rows unwritten and the flag unread: pass `status`, a zeroed
+    int32 device tensor, to share one flag between several calls and check it once with scatter_rows_check)."""
     ensure_init()
     src = src.contiguous().float()
-    si, di = src_index.to(torch.int64).contiguous(), dst_index.to(torch.int64).contiguous()
-    assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[-1] == src.shape[-1]
-    check(_lib.dr_scatter_rows_f32(si.numel(), src.shape[-1], ptr(src), ptr(si), ptr(di), ptr(dst), stream_of(src)))
+    si = src_index.to(device=src.device, dtype=torch.int64).contiguous()
+    di = dst_index.to(device=src.device, dtype=torch.int64).contiguous()
+    assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[-1] == src.shape[-1] and dst.device == src.device
+    assert si.numel() == di.numel()
+    C = src.shape[-1]
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=src.device)
+    check(_lib.dr_scatter_rows_f32(si.numel(), C, ptr(src), src.numel() // C, ptr(si), ptr(di), ptr(dst), dst.numel() // C,
+                                   ptr(status), stream_of(src)))
+    if validate and int(status.item()):
+        raise IndexError("scatter_rows: index out of range (src rows %d, dst rows %d)" % (src.numel() // C, dst.numel() // C))
     return dst
+
+
+def scatter_rows_check(status):
+    if int(status.item()):
+        raise IndexError("scatter_rows: index out of range")
 
 
 # ---- forward half of the training branch (csrc/train.hip) -------------------------------------------------------------------------
@@ -681,25 +689,6 @@ def gather_pool(x, inds, first_only=False):
     inds = inds.contiguous()
     check(_lib.dr_gather_pool_f32(n2, H, H, x.shape[1], ptr(x.contiguous()), x.shape[0], ptr(inds), 1 if first_only else 0, ptr(out),
                                   stream_of(x)))
-    return out
-
-
-def pack_weight(W):
-    """bf16 x 3 split image of an nn.Linear weight [ncols, K] for linear(..., packed=...)."""
-    ensure_init()
-    W = W.contiguous()
-    out = torch.empty(_lib.dr_packed_weight_bytes(W.shape[0], W.shape[1]), dtype=torch.uint8, device=W.device)
-    check(_lib.dr_pack_weight_f32(W.shape[0], W.shape[1], ptr(W), ptr(out), stream_of(W)))
-    return out
-
-
-def linear_packed(x, W, packed, epilogue=0, cos=None, sin=None, rot_C=0, scale=1.0):
-    ensure_init()
-    x = x.contiguous()
-    W = W.contiguous()
-    out = torch.empty(x.shape[0], W.shape[0], device=x.device)
-    check(_lib.dr_linear_packed_f32(x.shape[0], W.shape[0], x.shape[1], ptr(x), ptr(W), ptr(packed), ptr(out), epilogue,
-                                    ptr(cos), ptr(sin), rot_C, float(scale), stream_of(x)))
     return out
 
 

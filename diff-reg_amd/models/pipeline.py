@@ -7,7 +7,8 @@ diffreg_hip.engine.DenoiseEngine (one HIP-graph replay per forward).  The KPFCN 
 row f1) is `models.backbone.KPFCN` of this overlay (HIP ops, the reference's state-dict layout), or whatever is
 injected with `backbone=`.  The training branch (row f3) computes its FORWARD values on the device (no autograd graph:
 `self.training` gives conf_matrix_pred / coarse_match_pred / (R, t) of the non-denoising branch and conf_matrix_gt_hat of the
-denoising branch on the noised ground-truth matrix, for models.loss.MatchMotionLoss); backward kernels are not built.
+denoising branch on the noised ground-truth matrix, for models.loss.MatchMotionLoss); `forward_train` is the differentiable form
+(diffreg_hip.autograd: gradients for every parameter behind the backbone; the backbone itself has no backward kernels).
 """
 import math
 
@@ -105,7 +106,21 @@ class Pipeline(nn.Module):
         self._engine = None
         return super().load_state_dict(*a, **k)
 
+    def train(self, mode=True):
+        if mode:
+            self._engine = None          # the weights are about to change: the engine's snapshot (and its packed images) is stale
+        return super().train(mode)
+
+    def _weights_version(self):
+        """(data_ptr, in-place version) of every tensor the engine snapshots: optimizer.step() / copy_() / a re-assigned .data bump it"""
+        return tuple((v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items()
+                     if k.startswith("denoising_transformer.") or k.startswith("denoising_coarse_matching."))
+
     def _get_engine(self, device):
+        ver = self._weights_version()
+        if self._engine is not None and getattr(self, "_engine_version", None) != ver:
+            self._engine = None
+        self._engine_version = ver
         if self._engine is None or self._engine.device != torch.device(device):
             ct = self.config["coarse_transformer"]
             pc = ct["procrustes"]
@@ -260,9 +275,12 @@ class Pipeline(nn.Module):
         tgt_feats = torch.zeros(b_size * tgt_max, C, device=dev)
         src_pcd = torch.zeros(b_size * src_max, 3, device=dev)
         tgt_pcd = torch.zeros(b_size * tgt_max, 3, device=dev)
-        lib.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], src_feats)     # dr_scatter_rows_f32
-        lib.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_feats)
-        lib.scatter_rows(pcd, data["src_ind_coarse"], data["src_ind_coarse_split"], src_pcd)
-        lib.scatter_rows(pcd, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_pcd)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)      # one out-of-range flag for the four scatters, read once
+        kw = dict(validate=False, status=status)
+        lib.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], src_feats, **kw)     # dr_scatter_rows_f32
+        lib.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_feats, **kw)
+        lib.scatter_rows(pcd, data["src_ind_coarse"], data["src_ind_coarse_split"], src_pcd, **kw)
+        lib.scatter_rows(pcd, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_pcd, **kw)
+        lib.scatter_rows_check(status)                              # IndexError where the reference's indexed assignment raises
         return (src_feats.view(b_size, src_max, -1), tgt_feats.view(b_size, tgt_max, -1), src_pcd.view(b_size, src_max, -1),
                 tgt_pcd.view(b_size, tgt_max, -1), src_mask, tgt_mask)

@@ -111,16 +111,6 @@ int dr_vol_pe_f32(int rows, int rows_per_pair, int C, const float* xyz, const fl
 int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, float* out, int epilogue,
                   const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
 
-/* The same nn.Linear with the weight pre-packed for the split-operand MFMA path: W (fp32) is written once as
- * hi + mid + lo bf16 planes (dr_pack_weight_f32 into dr_packed_weight_bytes bytes, 16-byte aligned) and the
- * GEMM accumulates the six significant bf16 x bf16 products in fp32 -- fp32-level accuracy (error vs an fp64
- * product within that of the f32-input MFMA kernel, tests/test_ops_gpu.py) at 2.67x the f32 MFMA rate.
- * Needs K % 8 == 0; W is still passed for shapes the packed kernel does not take. */
-size_t dr_packed_weight_bytes(int ncols, int K);
-int dr_pack_weight_f32(int ncols, int K, const float* W, void* packed, void* stream);
-int dr_linear_packed_f32(int rows, int ncols, int K, const float* x, const float* W, const void* packed, float* out,
-                         int epilogue, const float* cos_t, const float* sin_t, int rot_C, float scale, void* stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Plane images: the layer nn.Linears of the loop with BOTH operands pre-split into fp16 hi / lo planes (the
  * default path of dr_denoise_loop for C <= 448, C % 16 == 0; 3D/models/transformero.py:26-96).
@@ -242,33 +232,8 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
                       double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
 
-/* ---- diagnostics (tools/ and the kernel-forcing test fixtures; NOT part of the drop-in boundary) ------------------------------
- * The library reads no environment variable unless dr_debug_enable_env(1) was called first (before the first launch: values
- * are cached on first use): the DR_* tuning variables of tools/ (DR_PG_STAMPS, DR_PG_ABL, DR_GEMM_*, DR_ATTN_*, DR_PLANES*,
- * DR_SK_PERSIST_GRID) cannot change which kernels a deployment runs.  Per-call choices of the product path are arguments:
- * dr_loop_config.flags (DR_LOOP_PLANES_FORCE / _OFF, DR_LOOP_STRICT_F64, DR_LOOP_RAGGED), DR_SK_* flags.  The dr_debug_* setters below
- * are process-wide and meant for single-threaded tools and tests only. */
-void dr_debug_enable_env(int on);
-/* force the GEMM tile configuration (-1 auto, 0 small, 1 medium, 2 large) */
-void dr_debug_gemm_config(int c);
-/* launches with at least this many 128 x 224 tiles use the packed split-operand GEMM (default 128; -1 restores it).
- * Set it BEFORE sizing a loop workspace: it decides whether the loop packs its weights. */
-void dr_debug_gemm_wide_min(int tiles);
-
-/* diagnostics for tools/: 8 wall-clock stamps (100 MHz ticks) of the phases of the last
- * dr_procrustes_f32 launch (pair 0); synchronises the device. */
-int dr_debug_procrustes_stamps(long long* h_out8);
-int dr_debug_gemm_stamps(long long* h_out256);
-int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream);   /* n dependent launches of an empty kernel (tools/launch_floor.py) */
-int dr_debug_pgemm_stamps(long long* h_out128);   /* with dr_debug_enable_env(1) and DR_PG_STAMPS=1: phase stamps of workgroup 0 of the last plane GEMM */
-/* packed GEMMs: 1 = two-plane fp16 operand split with exact power-of-two row / column scaling (three MFMA products per
- * fp32 MAC; the default), 0 = three-plane bf16 split (six products); -1 = default (1; DR_GEMM_F16X2 under dr_debug_enable_env).
- * Set before weights are packed: an image is only readable in the mode it was packed in. */
-void dr_debug_gemm_f16x2(int on);
-/* attention: use the 128-query (flash) kernel from this many workgroups on; -1 = default rule (256) */
-void dr_debug_attention_config(int flash_min_workgroups);
-/* flash attention arithmetic: 1 = split-operand bf16 MFMA products (default), 0 = f32-input MFMA, -1 = default */
-void dr_debug_attention_split(int on);
+/* Diagnostics (kernel-forcing setters, phase stamps, the environment switch) are NOT part of the drop-in boundary: they are
+ * declared in include/diffreg_hip_debug.h.  The library reads no environment variable unless dr_debug_enable_env(1) was called. */
 
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
  * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */
@@ -276,8 +241,12 @@ int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches,
 int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream);
 
 /* Pipeline.split_feats (3D/models/pipeline.py:350-379): dst[dst_index[i]][:] = src[src_index[i]][:], i < n, rows of C floats
- * (the stacked coarse features / points of the backbone scattered into the zero-padded [B * N_max, C] tensors). */
-int dr_scatter_rows_f32(int n, int C, const float* src, const int64_t* src_index, const int64_t* dst_index, float* dst, void* stream);
+ * (the stacked coarse features / points of the backbone scattered into the zero-padded [B * N_max, C] tensors).
+ * src has n_src_rows rows, dst n_dst_rows.  Indices behave like torch's indexed assignment: values in [-rows, -1] wrap; any other
+ * out-of-range index is skipped (no access) and *status (device int32, optional, zeroed by the caller) is set to 1 -- where
+ * PyTorch raises IndexError; the Python mirror reads the flag and raises. */
+int dr_scatter_rows_f32(int n, int C, const float* src, int64_t n_src_rows, const int64_t* src_index, const int64_t* dst_index, float* dst,
+                        int64_t n_dst_rows, int32_t* status, void* stream);
 
 /* Matching.get_match(conf, thr, mutual) (3D/models/matching.py:126-143; what 4D/lib/tester.py:266 applies to conf_matrix_pred
  * with thr = 0.55, mutual = True): entries > thr that are also their row's and their column's maximum (mutual; ties all count,

@@ -6,11 +6,12 @@ import re
 from tests.conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "diffreg_hip.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "diffreg_hip_debug.h")     # diagnostics: not part of the drop-in boundary
 LIB = os.path.join(ROOT, "diff-reg_amd", "diffreg_hip", "libdiffreg_hip.so")
 
 
-def declared_symbols():
-    txt = open(HEADER).read()
+def declared_symbols(debug=True):
+    txt = open(HEADER).read() + (open(DEBUG_HEADER).read() if debug else "")
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(dr_[a-z0-9_]+)\s*\(", txt)))
 

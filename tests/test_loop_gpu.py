@@ -113,20 +113,16 @@ def assert_matrix_parity(got, ref, f64, what, exempt=None):
         assert exempt.size <= 0.005 * got.size + 40, (what, "too many exempt entries", exempt.size)
 
 
-@pytest.fixture(params=[1, 0], ids=["fp16x2", "bf16x3"])
-def batch_kernels(request):
-    """Force the kernels that large batches select onto the small golden cases -- the 128-query (split-operand) attention; the
-    packed-weight overrides only reach the stand-alone op since the loop's large-batch GEMM path is the plane path
-    (test_loop_matches_reference_plane_path) -- so that the whole loop is held to the reference with them."""
+@pytest.fixture
+def batch_kernels():
+    """Force the 128-query (split-operand) attention that large f32-path batches select onto the small golden cases (the loop's
+    large-batch GEMM path is the plane path: test_loop_matches_reference_plane_path), so that the whole loop is held to the
+    reference with it."""
     from diffreg_hip import lib
     lib.ensure_init()
-    lib.raw().dr_debug_gemm_f16x2(request.param)
-    lib.raw().dr_debug_gemm_wide_min(1)
     lib.raw().dr_debug_attention_config(1)
     yield
-    lib.raw().dr_debug_gemm_wide_min(-1)
     lib.raw().dr_debug_attention_config(-1)
-    lib.raw().dr_debug_gemm_f16x2(-1)
 
 
 @pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", LOOPS)
@@ -441,3 +437,61 @@ def test_ragged_batch_with_a_one_point_cloud():
     assert torch.isfinite(c0).all() and torch.isfinite(got[1]["conf_matrix_pred"]).all()
     assert (c0 - one["conf_matrix_pred"][0]).abs().max().item() < 2e-6
     assert (R0 - one["R_final"][0]).abs().max().item() < 1e-5
+
+
+def _stack_pairs(variant, N, M, seeds):
+    ps = [pair(variant, N, M, s)[1] for s in seeds]
+    cat = lambda k: torch.cat([q[k] for q in ps]).to(DEV)
+    return ps, dict(src_feats=cat("f_s"), tgt_feats=cat("f_t"), s_pcd=cat("p_s"), t_pcd=cat("p_t"), x_T=cat("x_T"))
+
+
+def _hold_to_own_b1_run(eng1, variant, N, M, steps, mc, seed, q, got_conf, got_R, got_t):
+    """pair `seed` of a batch against ITS OWN B = 1 run (the golden-path kernels) under the exemption rule of the module docstring:
+    |batch - b1| <= 1e-4 everywhere except where the float32 oracle itself is > TAU from the float64 evaluation"""
+    one = eng1.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV))
+    _, conf_f64 = f64_evaluation(variant, N, M, N, M, steps, mc, seed)
+    assert_matrix_parity(got_conf.cpu().numpy(), one["conf_matrix_pred"][0].cpu().numpy(), conf_f64, "conf of pair seed %d vs its B = 1 run" % seed)
+    assert (got_R.cpu() - one["R_final"][0].cpu()).abs().max().item() < 1e-4
+    assert (got_t.cpu() - one["t_final"][0].cpu()).abs().max().item() < 1e-4
+
+
+def test_run_streams_is_the_timed_configuration():
+    """what bench.py times -- DenoiseEngine.run_streams with two groups of 128 pairs of 256 x 256, 20
+    steps, warp active, each group a captured graph on its own stream with a private workspace, plane-image kernels -- is
+    bit-reproducible across replays and equal, pair by pair, to the pairs' own B = 1 runs."""
+    variant, N, M, steps, mc, per = "3dmatch", 256, 256, 20, 200, 128
+    eng = engine(variant, steps, mc)
+    seeds = [[7000 + i for i in range(per)], [7000 + per + i for i in range(per)]]
+    built = [_stack_pairs(variant, N, M, s) for s in seeds]
+    groups = [b[1] for b in built]
+    snaps = []
+    for it in range(4):                      # eager, capture + replay, replay, replay
+        outs = eng.run_streams(groups, 2)
+        torch.cuda.synchronize()
+        snaps.append([(o["conf_matrix_pred"].clone(), o["R_final"].clone(), o["t_final"].clone(), o["match_count"].clone()) for o in outs])
+    for s in snaps[1:]:
+        for g0, g1 in zip(snaps[0], s):
+            for a, b in zip(g0, g1):
+                assert torch.equal(a, b)
+    assert not torch.equal(snaps[0][0][0], snaps[0][1][0])          # the two groups are different pairs (no aliasing of buffers)
+    eng1 = engine(variant, steps, mc)
+    for gi, pi in ((0, 0), (0, 77), (1, 5), (1, 127)):
+        conf, R, t, _ = snaps[-1][gi]
+        _hold_to_own_b1_run(eng1, variant, N, M, steps, mc, seeds[gi][pi], built[gi][0][pi], conf[pi], R[pi], t[pi])
+
+
+def test_cfg4_share_8_pairs_is_exactly_the_plane_threshold():
+    """BASELINE configs[3] = 64 pairs over 8 GPUs: a rank's share is 8 pairs of 256 x 256 = 4096 token rows, exactly the row count
+    from which the loop takes the plane-image path (64-row workgroups).  Held to the pairs' own B = 1 runs; 7 pairs (3584 rows)
+    stay on the f32 kernels and must agree as well."""
+    variant, N, M, steps, mc = "3dmatch", 256, 256, 20, 200
+    eng, eng1 = engine(variant, steps, mc), engine(variant, steps, mc)
+    for count in (8, 7):
+        seeds = [7300 + i for i in range(count)]
+        ps, kw = _stack_pairs(variant, N, M, seeds)
+        out = eng.run(kw["src_feats"], kw["tgt_feats"], kw["s_pcd"], kw["t_pcd"], kw["x_T"], graph=False)
+        out2 = eng.run(kw["src_feats"], kw["tgt_feats"], kw["s_pcd"], kw["t_pcd"], kw["x_T"], graph=True)
+        out3 = eng.run(kw["src_feats"], kw["tgt_feats"], kw["s_pcd"], kw["t_pcd"], kw["x_T"], graph=True)
+        assert torch.equal(out["conf_matrix_pred"], out2["conf_matrix_pred"]) and torch.equal(out["conf_matrix_pred"], out3["conf_matrix_pred"])
+        for pi in (0, count - 1):
+            _hold_to_own_b1_run(eng1, variant, N, M, steps, mc, seeds[pi], ps[pi], out["conf_matrix_pred"][pi], out["R_final"][pi], out["t_final"][pi])

@@ -5,7 +5,7 @@ import torch
 
 from diffreg_hip import synth
 from oracle import diffreg_oracle as orc
-from tests.helpers import T, weights, pair, masks, sinkhorn_case
+from tests.helpers import T, weights, pair, masks, sinkhorn_case, guarded
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -200,6 +200,8 @@ def test_get_match_on_device_equals_reference_rule():
         conf = torch.rand(3, 70, 45, generator=g, dtype=dtype)
         conf[0, 5, 7] = conf[0, 5, 9] = 2.0                    # a tie of two row maxima that are also column maxima
         conf[1] = torch.sigmoid(8 * (conf[1] - 0.5))
+        # NaN (the 3D padded-batch quirk Q8 / Q19): torch.max propagates it, so a row / column holding one has no mutual match
+        conf[2, 11, :] = float("nan"); conf[2, 30, 4] = float("nan"); conf[2, 40, 44] = float("nan")
         for thr, mutual in ((0.55, True), (0.0, True), (0.9, False)):
             idx, mc, mask = Matching.get_match(conf.to(DEV), thr, mutual)
             m_ref = conf > thr
@@ -221,6 +223,23 @@ def test_scatter_rows_is_split_feats():
     ref = torch.zeros(64, 432)
     ref[di] = src[si]
     assert torch.equal(dst.cpu(), ref)
+    # ADVICE (round 2): host index tensors are accepted like torch indexing accepts them; negative indices wrap; an out-of-range
+    # index raises IndexError (torch's behaviour) and touches nothing outside the buffers
+    dst2 = torch.zeros(64, 432, device=DEV)
+    lib.scatter_rows(src.to(DEV), si, di, dst2)
+    assert torch.equal(dst2.cpu(), ref)
+    neg_s, neg_d = torch.tensor([-1, 0, -50]), torch.tensor([-64, 5, -1])
+    d4 = torch.zeros(64, 432, device=DEV)
+    lib.scatter_rows(src.to(DEV), neg_s, neg_d, d4)
+    r4 = torch.zeros(64, 432)
+    r4[neg_d] = src[neg_s]
+    assert torch.equal(d4.cpu(), r4)
+    for bad_s, bad_d in (([50], [0]), ([0], [64]), ([-51], [0]), ([0], [-65])):
+        d5, chk = guarded((64, 432), torch.float32, DEV, fill=0.0)
+        with pytest.raises(IndexError):
+            lib.scatter_rows(src.to(DEV), torch.tensor(bad_s), torch.tensor(bad_d), d5)
+        assert not d5.any()
+        chk()
 
 
 def test_engine_cache_is_bounded_and_results_are_copies():

@@ -30,117 +30,6 @@ def test_linear_matches_fp64(rows, ncols, K):
     assert (got_relu.double() - 0.5 * ref.clamp_min(0)).abs().max().item() < 2e-6 * scale * max(1.0, (K / 432) ** 0.5)
 
 
-@pytest.mark.parametrize("cfg", [50, 60, 61, 70])    # bf16 x 3: 4-wave, 8-wave, 8-wave with two k-chunks per barrier; 70: fp16 x 2
-@pytest.mark.parametrize("rows,ncols,K", [(1000, 432, 432), (4096, 432, 864), (777, 864, 864), (130, 224, 16), (129, 228, 440),
-                                           (5, 4, 8), (8192, 432, 432), (3000, 528, 128)])
-def test_gemm_split_accuracy(rows, ncols, K, cfg):
-    """The split-operand GEMMs (packed weights; three bf16 planes and six MFMA products, or two fp16 planes with exact
-    power-of-two row / column scaling and three products; fp32 accumulate) are fp32 GEMMs: the error against an fp64
-    product stays within 1.25x that of the f32-input MFMA kernel accumulating in the same order (one chain over k), below
-    that of torch's own fp32 matmul, and within the absolute bound of test_linear_matches_fp64 -- with every epilogue, on
-    ragged shapes.  (The fp16 kernel is only dispatched for K >= 128: shallower reductions do not hide its 2^-22
-    representation error behind the accumulation's rounding.)"""
-    from diffreg_hip import lib
-    raw = lib.raw()
-    if cfg == 70 and K < 128:
-        pytest.skip("the two-plane fp16 kernel is dispatched for K >= 128 only")
-    raw.dr_debug_gemm_f16x2(1 if cfg == 70 else 0)          # an image is only readable in the mode it was packed in
-    x = (T(synth.hash_normal(5, rows + K, (rows, K))).float() * 3).to(DEV)
-    W = (T(synth.hash_uniform(6, ncols + K, (ncols, K))).float() / K ** 0.5).to(DEV)
-    Wp = lib.pack_weight(W)
-    ref = x.double() @ W.double().T
-    scale = ref.abs().max().item()
-    try:
-        raw.dr_debug_gemm_config(9)             # 64 x 64 tiles: one accumulation chain over k, like the split kernel
-        base = lib.linear(x, W)
-        raw.dr_debug_gemm_config(cfg)
-        got = lib.linear_packed(x, W, Wp)
-        e_base, e_got = (base.double() - ref).abs(), (got.double() - ref).abs()
-        assert e_got.max().item() < 2e-6 * scale * max(1.0, (K / 432) ** 0.5)
-        assert e_got.mean().item() <= 1.25 * e_base.mean().item() + 1e-9
-        assert e_got.mean().item() <= 1.05 * ((x @ W.T).double() - ref).abs().mean().item() + 1e-9
-        for epi in (1, 2, 3):
-            kw = {}
-            if epi & 2:
-                ang = T(synth.hash_uniform(7, rows, (rows, ncols // 2))).float().to(DEV) * 6.28
-                kw = dict(cos=ang.cos().contiguous(), sin=ang.sin().contiguous(), rot_C=ncols)
-            raw.dr_debug_gemm_config(-1)
-            a = lib.linear(x, W, epilogue=epi, scale=0.37, **kw)
-            raw.dr_debug_gemm_config(cfg)
-            b = lib.linear_packed(x, W, Wp, epilogue=epi, scale=0.37, **kw)
-            assert (a - b).abs().max().item() < 4e-6 * scale * max(1.0, (K / 432) ** 0.5), epi
-    finally:
-        raw.dr_debug_gemm_config(-1)
-        raw.dr_debug_gemm_f16x2(-1)
-
-
-@pytest.mark.parametrize("cfg", [50, 70])
-@pytest.mark.parametrize("case", ["rows and columns x 10^[-3,3]", "activations x 1e-6", "activations x 1e+8, weights x 1e-5",
-                                  "one huge element per row"])
-def test_gemm_split_dynamic_range(cfg, case):
-    """Split-operand GEMMs on operands spanning 12 orders of magnitude (rows of x and of W scaled by 10^[-3, 3]; uniformly
-    tiny or huge operands; rows dominated by one element): the error of every output stays within fp32 rounding of ITS OWN
-    row / column scale -- the bf16 split is relative at every magnitude (bf16 has the exponent range of fp32), the fp16 split
-    scales every row of x and of W by an exact power of two into fp16's range first -- like the f32-input MFMA kernel's."""
-    from diffreg_hip import lib
-    raw = lib.raw()
-    rows, ncols, K = 2048, 432, 432
-    g = torch.Generator().manual_seed(5)
-    sx, sw = torch.ones(rows, 1), torch.ones(ncols, 1)
-    if case.startswith("rows"):
-        sx = 10.0 ** (torch.rand(rows, 1, generator=g) * 6 - 3)
-        sw = 10.0 ** (torch.rand(ncols, 1, generator=g) * 6 - 3)
-    elif case.startswith("activations x 1e-6"):
-        sx = sx * 1e-6
-    elif case.startswith("activations x 1e+8"):
-        sx, sw = sx * 1e8, sw * 1e-5
-    x = torch.randn(rows, K, generator=g) * sx
-    W = torch.randn(ncols, K, generator=g) / K ** 0.5 * sw
-    if case.startswith("one huge"):
-        x[torch.arange(rows), torch.randint(0, K, (rows,), generator=g)] = 3.0e4      # 2^15 times the typical entry
-        sx = sx * 3.0e4
-    x, W = x.to(DEV), W.to(DEV)
-    raw.dr_debug_gemm_f16x2(1 if cfg == 70 else 0)
-    Wp = lib.pack_weight(W)
-    ref = x.double() @ W.double().T
-    scale = (sx.double() * sw.double().T).to(DEV)                # magnitude of out[r][c]
-    try:
-        raw.dr_debug_gemm_config(9)
-        e_base = ((lib.linear(x, W).double() - ref).abs() / scale).max().item()
-        raw.dr_debug_gemm_config(cfg)
-        e_split = ((lib.linear_packed(x, W, Wp).double() - ref).abs() / scale).max().item()
-    finally:
-        raw.dr_debug_gemm_config(-1)
-        raw.dr_debug_gemm_f16x2(-1)
-    assert e_split < 1e-5 and e_split <= 2.0 * e_base, (e_split, e_base)
-
-
-def test_gemm_f16_split_degenerate_rows():
-    """rows / columns without a usable maximum get scale 1: all-zero rows of x and of W give exact zeros, a row holding inf or
-    nan gives non-finite outputs in that row only (as an fp32 GEMM would), everything else is unaffected"""
-    from diffreg_hip import lib
-    raw = lib.raw()
-    rows, ncols, K = 1024, 432, 432
-    g = torch.Generator().manual_seed(9)
-    x = torch.randn(rows, K, generator=g)
-    W = torch.randn(ncols, K, generator=g) / K ** 0.5
-    x[5] = 0.0; x[17, 3] = float("inf"); x[40, 100] = float("nan"); W[7] = 0.0
-    x, W = x.to(DEV), W.to(DEV)
-    raw.dr_debug_gemm_f16x2(1)
-    try:
-        Wp = lib.pack_weight(W)
-        raw.dr_debug_gemm_config(70)
-        y = lib.linear_packed(x, W, Wp)
-    finally:
-        raw.dr_debug_gemm_config(-1)
-        raw.dr_debug_gemm_f16x2(-1)
-    assert (y[5] == 0).all() and (y[:, 7][torch.isfinite(y[:, 7])] == 0).all()
-    assert not torch.isfinite(y[17]).any() and not torch.isfinite(y[40]).any()
-    ok = torch.ones(rows, dtype=torch.bool, device=DEV); ok[[17, 40]] = False
-    ref = x[ok].double() @ W.double().T
-    assert torch.isfinite(y[ok]).all() and (y[ok].double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
-
-
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
 def test_vol_pe_and_rotary_linear(variant, golden):
     from diffreg_hip import lib

@@ -155,3 +155,38 @@ def test_attention_on_plane_images(P, Lq, Lk, H, d, masked):
     keep = qm if masked else torch.ones(P, Lq, dtype=torch.bool, device=DEV)
     assert not torch.isnan(o[keep]).any()
     assert float((o.double() - ref)[keep].abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("gain1", [1.0, 1.37, 0.6])
+def test_column_blocks_sharing_one_image_share_one_scale(gain1):
+    """ADVICE (round 2, high): mlp0's two column blocks write ONE hidden image with ONE bound per row.  The scale of a row must
+    be the same in both blocks whatever their weight norms: rows whose bound sweeps across powers of two (bound x wnorm[0] and
+    bound x wnorm[1] on opposite sides of one for many of them), block 1 with a larger / smaller norm than block 0."""
+    rows, C = 2048, 432
+    torch.manual_seed(11)
+    scale = 2.0 ** (torch.linspace(-3, 9, rows, device=DEV))[:, None]           # row bounds from 2^-3 to 2^9, 170 rows per octave
+    x = torch.randn(rows, C, device=DEV) * scale
+    m = torch.randn(rows, C, device=DEV) * scale * 0.3
+    ximg, xb = lib.planes_from_f32(x)
+    mimg, mb = lib.planes_from_f32(m)
+    W1 = torch.randn(2 * C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    W1[C:] *= gain1
+    hid_img, chk_h = image_like(rows, 2 * C)
+    hid_b, chk_hb = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 2, ximg, xb, C, lib.pack_weight_planes(W1, 2, C), lib.PL_PLANES, a1=mimg, b1=mb, k1=C, out_image=hid_img,
+                      out_image_k=2 * C, out_bound=hid_b, relu=True)
+    chk_h(); chk_hb()
+    refh = torch.relu(torch.cat([x.double(), m.double()], 1) @ W1.double().t())
+    got = lib.planes_to_f32(hid_img, hid_b, rows, 2 * C).double()
+    row_err = (got - refh).abs().amax(1) / refh.abs().amax(1)                  # per ROW: a wrong power of two in one block is O(1) here
+    assert float(row_err.max()) < 4e-6, (float(row_err.max()), int(row_err.argmax()))
+    assert bool((hid_b.double() >= refh.abs().amax(1)).all())                   # the stored bound IS an upper bound for both blocks
+    # and the consumer (mlp2 + LayerNorm) reads every row with the right scale
+    W2 = torch.randn(C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    g1, b1 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+    o32, chk_o = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+    lib.linear_planes(rows, C, 1, hid_img, hid_b, 2 * C, lib.pack_weight_planes(W2, 1, C), lib.PL_LN, out=o32, ldo=C, gamma=g1, beta=b1,
+                      lnb=lib.ln_bound(g1, b1))
+    chk_o()
+    refo = torch.nn.functional.layer_norm(refh @ W2.double().t(), (C,), g1.double(), b1.double())
+    assert float(((o32.double() - refo).abs().amax(1) / refo.abs().amax(1)).max()) < 1e-5

@@ -46,15 +46,18 @@ def test_two_ranks_shard_and_gather():
         assert sums == pytest.approx(want) and tmax == 2.0
 
 
-def _run_bench_stub(nproc, extra):
+def _run_bench_stub(nproc, extra, gpus=None, expect_fail=False):
     """bench.py's own multi-rank control path (torchrun environment, barrier, max time over ranks, metric-vector all_reduce)
     under gloo with the CPU stand-in engine (--cpu-stub)"""
     import json
     import subprocess
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--cpu-stub"] + extra
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc if gpus is None else gpus), "--steps", "3",
+           "--warmup", "1", "--cpu-stub"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if expect_fail:
+        return r
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
@@ -84,6 +87,17 @@ def test_bench_rank_path_ragged_shard():
     assert mg["sum_inlier_ratio"] == pytest.approx(sum((i % 10) / 10.0 for i in range(13)))
     assert mg["sum_registration_recall"] == pytest.approx(sum(1.0 for i in range(13) if i % 3 == 0))
     assert d["value"] == pytest.approx(13 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+def test_bench_cfg4_sharding_and_gpus_world_size_mismatch():
+    """BASELINE configs[3]: 64 pairs sharded over the ranks.  Under world size 2 every pair is owned exactly once (32 + 32), and a
+    `--gpus 8` that does not match the launched world size is refused instead of reported as an 8-GPU line."""
+    d = _run_bench_stub(2, ["--total-pairs", "64"])
+    mg = d["metric_gather"]
+    assert d["n_gpus"] == 2 and mg["n_pairs"] == 64 and sum(mg["per_rank_pairs"]) == 64 and mg["per_rank_pairs"] == [32, 32]
+    assert mg["sum_inlier_ratio"] == pytest.approx(sum((i % 10) / 10.0 for i in range(64)))
+    r = _run_bench_stub(2, ["--total-pairs", "64"], gpus=8, expect_fail=True)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_metric_vector_of_evaluate_pairs_shaped_data():
