@@ -473,11 +473,11 @@ __device__ __forceinline__ void sk_fast_tile(sk_f2 (&E)[16][CPL / 2], const floa
         float rs4[4];
         reduce16x4(p, rs4, OpAdd());
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = mu / fmaf(ed4[k], bM, rs4[k]);
+        for (int k = 0; k < 4; ++k) a4[k] = mu * __builtin_amdgcn_rcpf(fmaf(ed4[k], bM, rs4[k]));      // v_rcp_f32 (1 ulp) instead of the ~9-instruction IEEE division
         sk_f2 bs2 = bj[0];
 #pragma unroll
         for (int k = 1; k < H; ++k) bs2 += bj[k];
-        aN = muN / (wave_allsum_dpp(bs2.x + bs2.y) + bM);
+        aN = muN * __builtin_amdgcn_rcpf(wave_allsum_dpp(bs2.x + bs2.y) + bM);
         sk_f2 cp[H];
 #pragma unroll
         for (int k = 0; k < H; ++k) cp[k] = sk_splat(0.f);
@@ -501,12 +501,12 @@ __device__ __forceinline__ void sk_fast_tile(sk_f2 (&E)[16][CPL / 2], const floa
             float c = aN;
 #pragma unroll
             for (int k = 0; k < NW; ++k) c += s_colpart[k][t];
-            s_b[t] = nu / c;
+            s_b[t] = nu * __builtin_amdgcn_rcpf(c);
         } else if (t == M) {
             float c = aN;
 #pragma unroll
             for (int k = 0; k < NW; ++k) c += s_dust[k];
-            s_b[M] = nuM / c;
+            s_b[M] = nuM * __builtin_amdgcn_rcpf(c);
         }
         __syncthreads();
         float bf[CPL];
@@ -557,12 +557,18 @@ __global__ __launch_bounds__(NW * 64) void sk_fast_kernel(SkArgs A) {
 
 // ---------------------------------------------------------------------------------------------
 // persistent form of the fast kernel for big batches of 256 x 256 float tiles (the roofline micro-benchmark's regime):
-// a workgroup holds one tile in 64 VGPRs per thread, so only ONE workgroup fits a CU and nothing overlaps its compute
-// phase (exponentials + 3 iterations) with memory.  Here a workgroup walks over tiles g, g + G, ... and, while it
-// computes tile i, the first 8 of the 16 rows each wave owns in tile i + 1 are fetched by LDS-DMA (global_load_lds_dwordx4:
-// no VGPRs; one wave-instruction = one 1 KB tile row = the image the owning lanes read back with one ds_read_b128) into
-// 128 KB of LDS.  The other 8 rows are loaded into each row's registers right behind the store of that row in the epilogue,
-// so the HBM reads of the next tile run under the drain of the stores.
+// a workgroup holds one tile in 64 VGPRs per thread, so only ONE workgroup fits a CU and a tile's compute phase
+// (exponentials + 3 iterations, ~6 us) can overlap memory traffic only if this workgroup itself keeps traffic in flight.
+// A workgroup walks over tiles g, g + G, ...; EVERY row of the next tile arrives through a 128 KB LDS image (8 rows per wave)
+// by LDS-DMA, in two halves, and every global access of the loop is hand-placed asm with counted waits:
+//   compute(tile i)   ... the wave's rows 0..7 of tile i + 1 land in the image (DMA issued once the raw scores are consumed)
+//   stores rows 0..7 | vmcnt(8): that DMA has landed | image -> registers of rows 0..7 | DMA rows 8..15 of tile i + 1 |
+//   stores rows 8..15 | vmcnt(8): the DMA and the first stores have landed | image -> registers of rows 8..15 | compute(i + 1)
+// vmcnt retires in order, so a wave can only learn that a load has landed after everything it issued before it has: the last 8
+// stores of a tile are issued BEHIND the last loads and drain under the next tile's compute phase together with its prefetch
+// (256 KB of the 512 KB a tile moves), and nothing in the loop is a compiler-placed load (round 2's form re-loaded half the
+// tile into registers behind the stores: hipcc answered with vmcnt(0) in front of the compute phase, which also waited for
+// the just-issued prefetch: the whole 512 KB was exposed, `profiles/r03_sinkhorn_persist_isa_waits.txt`).
 // ---------------------------------------------------------------------------------------------
 // workgroups of the persistent form: one per CU; DR_SK_PERSIST_GRID=0 keeps the one-tile-per-workgroup kernel (tools)
 static int sk_persist_grid() {
@@ -570,9 +576,36 @@ static int sk_persist_grid() {
     return v;
 }
 typedef __attribute__((address_space(3))) void sk_lds_void;
-typedef const __attribute__((address_space(1))) void sk_glb_void;
-constexpr int SKP_PRE = 8;                                        // rows per wave prefetched through LDS
-constexpr size_t SKP_LDS = 16 * 256 * 4 + 1040 + 64 + 16 * SKP_PRE * 1024;    // colpart + b + dust + prefetch image
+typedef unsigned sk_u4 __attribute__((ext_vector_type(4)));
+constexpr int SKP_PRE = 8;                                        // rows per wave in the LDS image
+constexpr size_t SKP_LDS = 16 * 256 * 4 + 1040 + 64 + 16 * SKP_PRE * 1024;    // colpart + b + dust + image
+
+// 1 KB per wave-instruction, SGPR base + VGPR byte offset + immediate (added to the global AND to the LDS address M0 + 16 lane)
+#define SK_DMA(ldsaddr, voff, gbase, imm)                                                                      \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(ldsaddr), "v"(voff), "s"(gbase), "i"(imm) : "memory")
+// (s_nop 1 behind the store: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers --
+//  hipcc's hazard recognizer pads its own stores, it cannot see into an asm block; without it the next row's products, computed into
+//  the same registers, raced the store's data read: run-to-run different tiles)
+#define SK_STORE(voff, data, gbase, imm) \
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(voff), "v"(data), "s"(gbase), "i"(imm) : "memory")
+
+// the wave's 8 image rows -> registers (one block: the results are valid when it ends)
+__device__ __forceinline__ void skp_read_image(unsigned addr, sk_f2 (*E)[2]) {
+    sk_u4 r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+        "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(addr)
+        : "memory");
+    const sk_u4 rr[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        E[r][0].x = __uint_as_float(rr[r].x); E[r][0].y = __uint_as_float(rr[r].y);
+        E[r][1].x = __uint_as_float(rr[r].z); E[r][1].y = __uint_as_float(rr[r].w);
+    }
+}
 
 __global__ __launch_bounds__(1024) void sk_fast_persist_kernel(SkArgs A) {
     constexpr int NW = 16, CPL = 4, RPW = 16, N = 256, M = 256;
@@ -586,37 +619,63 @@ __global__ __launch_bounds__(1024) void sk_fast_persist_kernel(SkArgs A) {
     const unsigned toff = (unsigned)(w * RPW * M + lane * CPL);
     const float alpha = *A.bin_score;
     const float tot = (float)(N + M);
-    char* my_pref = s_pref + w * SKP_PRE * 1024;                 // this wave's 8 rows (wave-uniform base)
+    // this wave's 8 image rows: wave-uniform LDS base (M0 of the DMA) and the lane's read address
+    const unsigned img = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(sk_lds_void*)(s_pref + w * SKP_PRE * 1024));
+    const unsigned img_lane = img + (unsigned)lane * 16;
+    const unsigned voff = toff * 4;                               // byte offset of the lane's float4 in row 0 of the wave
     const float* scores = reinterpret_cast<const float*>(A.scores);
 
     sk_f2 E[RPW][CPL / 2], bj[CPL / 2];
     float a4[4];
     int tile = blockIdx.x;
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) sk_load_row<NtIO<float, CPL>, float, CPL>(scores + (size_t)tile * N * M + toff + r * M, E[r], 0.0);
+    // rows 8 half .. 8 half + 7 of the tile at `base` -> image rows 0 .. 7
+    auto dma_half = [&](const char* base, int half) __attribute__((always_inline)) {
+        const unsigned v0 = voff + half * 8192;
+        SK_DMA(img, v0, base, 0); SK_DMA(img, v0, base, 1024); SK_DMA(img, v0, base, 2048); SK_DMA(img, v0, base, 3072);
+        SK_DMA(img + 4096, v0 + 4096, base, 0); SK_DMA(img + 4096, v0 + 4096, base, 1024);
+        SK_DMA(img + 4096, v0 + 4096, base, 2048); SK_DMA(img + 4096, v0 + 4096, base, 3072);
+    };
+    {   // the first tile takes the same road (no compiler-placed load anywhere in this kernel: hipcc's own vmcnt waits for one
+        // would sit in the loop header and wait for the stores and prefetches in flight there)
+        const char* base0 = reinterpret_cast<const char*>(scores + (size_t)tile * N * M);
+        dma_half(base0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        skp_read_image(img_lane, &E[0]);
+        dma_half(base0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        skp_read_image(img_lane, &E[8]);
+    }
     while (true) {
         const int next = tile + gridDim.x;
         const bool has_next = next < A.B;
-        const float* nsrc = scores + (size_t)(has_next ? next : tile) * N * M + toff;
-        // once the row maxima have consumed the raw scores, every value of this tile is in registers and the prefetch
-        // image is free again
-        sk_fast_tile<NW, CPL>(E, alpha, A.iters, s_colpart, s_b, s_dust, a4, bj, [&] {
-            if (has_next) {
-                for (int r = 0; r < SKP_PRE; ++r)
-                    __builtin_amdgcn_global_load_lds((sk_glb_void*)(reinterpret_cast<const char*>(nsrc) + r * M * 4),
-                                                     (sk_lds_void*)(my_pref + r * 1024), 16, 0, 0);
+        const char* nbase = reinterpret_cast<const char*>(scores + (size_t)(has_next ? next : tile) * N * M);     // wave-uniform
+        // once the row maxima have consumed the raw scores every value of this tile is in registers (and the image was emptied
+        // before the compute phase began): the next tile's first half starts to arrive
+        sk_fast_tile<NW, CPL>(E, alpha, A.iters, s_colpart, s_b, s_dust, a4, bj, [&] { if (has_next) dma_half(nbase, 0); });
+        char* obase = reinterpret_cast<char*>(reinterpret_cast<float*>(A.out) + (size_t)tile * N * M);           // wave-uniform
+        auto store_rows = [&](int r0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = r0; r < r0 + 8; ++r) {
+                const sk_f2 ar = sk_splat(bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot);
+                const sk_f2 lo = E[r][0] * ar * bj[0], hi = E[r][1] * ar * bj[1];
+                const sk_u4 o = {__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(hi.x), __float_as_uint(hi.y)};
+                const unsigned vo = voff + (unsigned)(r >> 2) * 4096;
+                if ((r & 3) == 0) SK_STORE(vo, o, obase, 0);
+                else if ((r & 3) == 1) SK_STORE(vo, o, obase, 1024);
+                else if ((r & 3) == 2) SK_STORE(vo, o, obase, 2048);
+                else SK_STORE(vo, o, obase, 3072);
             }
-        });
-        float* dst = reinterpret_cast<float*>(A.out) + (size_t)tile * N * M + toff;
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            sk_store_row<NtIO<float, CPL>, float, CPL>(dst + r * M, E[r], bcast_lane(a4[r & 3], 16 * (r >> 2)) * tot, bj);
-            if (r >= SKP_PRE && has_next) sk_load_row<NtIO<float, CPL>, float, CPL>(nsrc + r * M, E[r], 0.0);
+        };
+        store_rows(0);
+        if (has_next) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // everything older than the 8 stores above: the first-half DMA has landed
+            skp_read_image(img_lane, &E[0]);
+            dma_half(nbase, 1);
         }
+        store_rows(8);
         if (!has_next) break;
-#pragma unroll
-        for (int r = 0; r < SKP_PRE; ++r)
-            sk_load_row<VecIO<float, CPL>, float, CPL>(reinterpret_cast<const float*>(my_pref + r * 1024) + lane * CPL, E[r], 0.0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // second-half DMA (and the first stores) landed; the last 8 stores still drain
+        skp_read_image(img_lane, &E[8]);
         tile = next;     // (no barrier: s_colpart / s_b are rewritten only behind the next tile's first barrier)
     }
 }

@@ -1,6 +1,6 @@
 """Iteration sweep of the persistent Sinkhorn kernel at the roofline micro-benchmark's shape (4096 tiles of 256 x 256 float32):
 time per launch against the iteration count -> the cost of one row->column dependent chain per tile, i.e. what a deeper overlap
-could still hide.  Writes one JSON object (profiles/r02_sinkhorn_iteration_chain.json)."""
+could still hide.  Writes one JSON object (profiles/r03_sinkhorn_iteration_chain.json)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
@@ -40,4 +40,4 @@ res = dict(shape=[B, N, M], algorithmic_bytes=byts, sweep=rows, torch_copy_same_
                 "with the tile-copy ceilings of profiles/r01_sinkhorn_copy_ceiling.txt (nt loads + nt stores: 347.6 us = 6.18 TB/s).")
 print(json.dumps(res, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/r02_sinkhorn_iteration_chain.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r03_sinkhorn_iteration_chain.json", "w"), indent=1)
