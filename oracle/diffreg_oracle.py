@@ -320,7 +320,8 @@ def fourier_embedding(p, L=10):
 
 
 def linear(x, W, pre):
-    return x @ W[pre + ".weight"].T + W[pre + ".bias"]
+    w = W[pre + ".weight"]              # (x follows the weights' dtype: the float64 evaluation keeps float32 positions / embeddings as inputs)
+    return x.to(w.dtype) @ w.T + W[pre + ".bias"]
 
 
 def transformer_layer_2d3d(W, pre, x, y, H):

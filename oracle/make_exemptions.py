@@ -44,6 +44,23 @@ def f64_eval(variant, N, M, nv, mv, steps, mc, seed):
     return tr[-1]["x0"][0].double().numpy(), o["conf_matrix_pred"][0].double().numpy()
 
 
+LOOPS_2D3D = [(96, 160, 90, 150, 141, 3, 200, 31, "n96x160_s3_masked"), (128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")]
+
+
+def f64_eval_2d3d(N, M, nv, mv, mv_da, steps, mc, seed):
+    """2D-3D loop (oracle) with float64 weights, features and state; point / pixel coordinates stay float32 inputs"""
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W64 = {k: T(a).double() for k, a in Wn.items()}
+    pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
+    q = lambda k: T(pr[k])[None]
+    ms, mt = masks(N, M, nv, mv)
+    mt_da = torch.arange(M)[None] < mv_da
+    tr = []
+    o = orc.denoise_loop_2d3d(W64, synth.VARIANTS["2d3d"], q("img_feats").double(), q("img_dino").double(), q("img_pixels"), q("pcd_feats").double(),
+                              q("s_pcd"), q("t_pcd_da"), ms, mt, mt_da, q("x_T").double(), steps, mc, trace=tr)
+    return tr[-1]["x0"][0].double().numpy(), o["conf_matrix_pred"][0].double().numpy()
+
+
 def main():
     torch.set_num_threads(8)
     out = {"tau": TAU, "rule": "entries listed: |hip - f64| <= max(1e-4, 2 |ref - f64|); all others: |hip - ref| <= 1e-4",
@@ -52,6 +69,20 @@ def main():
         name = "%s_loop_%s" % (variant, tag)
         g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
         x0_f64, conf_f64 = f64_eval(variant, N, M, nv, mv, steps, mc, seed)
+        ent = {}
+        for key, ref, f64 in (("x0_last", g["x0_last"], x0_f64), ("conf", g["conf"], conf_f64)):
+            dev = np.abs(ref.astype(np.float64) - f64)
+            idx = np.nonzero(dev.ravel() > TAU)[0]
+            ent[key] = {"shape": list(ref.shape), "n_exempt": int(idx.size), "fraction": float(idx.size / ref.size),
+                        "max_ref_minus_f64": float(dev.max()),
+                        "index": idx.tolist(), "ref_minus_f64": [float(x) for x in dev.ravel()[idx]],
+                        "f64": [float(x) for x in f64.ravel()[idx]]}
+            print(name, key, "exempt", idx.size, "of", ref.size, "max |ref - f64|", dev.max())
+        out["fixtures"][name] = ent
+    for N, M, nv, mv, mv_da, steps, mc, seed, tag in LOOPS_2D3D:
+        name = "2d3d_loop_" + tag
+        g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        x0_f64, conf_f64 = f64_eval_2d3d(N, M, nv, mv, mv_da, steps, mc, seed)
         ent = {}
         for key, ref, f64 in (("x0_last", g["x0_last"], x0_f64), ("conf", g["conf"], conf_f64)):
             dev = np.abs(ref.astype(np.float64) - f64)

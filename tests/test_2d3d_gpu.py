@@ -1,4 +1,9 @@
-"""2D-3D variant: dr_denoise_loop_2d3d against the reference-minted vectors.  Needs a GPU."""
+"""2D-3D variant: dr_denoise_loop_2d3d against the reference-minted vectors.  Needs a GPU.
+
+Tolerances: plain bounds, |hip - ref| <= 1e-4 on EVERY entry of x_start / conf_matrix_pred / the state and on (R, t) of every step.  The
+exemption lists of the 3D / 4D loop tests are empty here by measurement (oracle/make_exemptions.py lists both 2D-3D fixtures: the
+reference's own float32 run is within 1.4e-5 of the float64 evaluation on every entry -- the 2D-3D head's logits are two orders of
+magnitude smaller than the 3D head's), so no entry is exempt and no percentile is used."""
 import numpy as np
 import pytest
 import torch
@@ -41,11 +46,11 @@ def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, 
     assert np.abs(out["R_forwd"][:, 0].cpu().numpy() - g["R_forwd"]).max() < 1e-4
     assert np.abs(out["t_forwd"][:, 0].cpu().numpy() - g["t_forwd"]).max() < 1e-4
     x0 = out["x0"][:, 0].cpu().numpy()
-    assert (np.abs(x0[-1] - g["x0_last"]) > 1e-4).mean() <= 1e-3
+    assert np.abs(x0[-1] - g["x0_last"]).max() <= 1e-4
     conf = out["conf_matrix_pred"][0].cpu().numpy()
-    assert (np.abs(conf - g["conf"]) > 1e-4).mean() <= 1e-3
+    assert np.abs(conf - g["conf"]).max() <= 1e-4
     rel = np.abs(conf - g["conf"]) / np.maximum(g["conf"], 1e-9)
-    assert np.quantile(rel[g["conf"] > 1e-6], 0.999) < 5e-3
+    assert rel[g["conf"] > 1e-6].max() < 5e-3
     # read-out = top-1 union of the library's own conf (bit-exact index work)
     cnt = int(out["match_count"][0])
     got = set(map(tuple, out["matches_padded"][0, :cnt, 1:].cpu().tolist()))
@@ -84,7 +89,7 @@ def test_cfg5_1024x2048_10_steps():
         assert (out["R_forwd"][k, 0].cpu() - tr[k]["R_forwd"][0]).abs().max().item() < 1e-4, k
         assert (out["t_forwd"][k, 0].cpu() - tr[k]["t_forwd"][0]).abs().max().item() < 1e-4, k
         dx = (out["x0"][k, 0].cpu() - tr[k]["x0"][0]).abs()
-        assert (dx > 1e-4).float().mean().item() <= 1e-3, (k, dx.max().item())
+        assert dx.max().item() <= 1e-4, (k, dx.max().item())
     # the state after 10 steps: entries masked by the warp helper (src_mask x tgt_mask_da, in place: quirk Q8) are not finite
     # in the oracle and here alike, the others agree
     xf, xr = out["x_final"][0].cpu(), ref["x_final"][0].double()
@@ -92,10 +97,9 @@ def test_cfg5_1024x2048_10_steps():
     assert torch.isfinite(xr[valid]).all() and not torch.isfinite(xr[~valid]).any()
     assert torch.equal(torch.isfinite(xf), torch.isfinite(xr))
     dxf = (xf[valid] - xr[valid]).abs()
-    assert (dxf > 1e-4).double().mean().item() <= 1e-3, dxf.max().item()
+    assert dxf.max().item() <= 1e-4, dxf.max().item()
     dc = (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs()
-    assert (dc > 1e-4).double().mean().item() <= 1e-3, dc.max().item()
-    assert float(dc[valid].max()) < 5e-3
+    assert dc.max().item() <= 1e-4, dc.max().item()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,5 @@
-"""Large-tile Sinkhorn (the shapes beyond the register-resident kernel): time per call of the co-resident form against the
-multi-launch grid form (DR_SK_COOP=0 under DR_DIAGNOSTICS=1).  cfg5: 1 x 1024 x 2048 (2D-3D), cfg3: 8 x 512 x 512 (4DMatch), a real
-3DMatch pair: 1 x 564 x 629.  Writes gpurun_out/r03_sinkhorn_large_tiles_{coop,grid}.json."""
+"""Large-tile Sinkhorn (the shapes beyond the register-resident kernel, multi-launch grid form): graph-replayed time per call.
+cfg5: 1 x 1024 x 2048 (2D-3D), cfg3: 8 x 512 x 512 (4DMatch), a real 3DMatch pair: 1 x 564 x 629.  Writes gpurun_out/r03_sinkhorn_large_tiles.json."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
@@ -32,5 +31,4 @@ for (B, N, M) in ((1, 1024, 2048), (8, 512, 512), (1, 564, 629), (4, 1024, 2048)
     res.append(dict(shape=[B, N, M], us_per_call=us, algorithmic_bytes=byts, GBps=byts / us / 1e3, frac_of_8TBps=byts / us / 1e3 / 8000))
     print(res[-1])
 os.makedirs("gpurun_out", exist_ok=True)
-tag = "coop" if os.environ.get("DR_SK_COOP", "1") != "0" else "grid"
-json.dump(res, open("gpurun_out/r03_sinkhorn_large_tiles_%s.json" % tag, "w"), indent=1)
+json.dump(res, open("gpurun_out/r03_sinkhorn_large_tiles.json", "w"), indent=1)
