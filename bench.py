@@ -37,9 +37,7 @@ DEP_LAUNCH_FLOOR_US = 4.7            # the cheapest kernels of the single-pair c
                                      # that returns at once): 4.7-4.9 us each; an empty kernel in an idle chain: 1.53 us
                                      # (profiles/r02_b1_launch_floor.json, DESIGN section 5 "Single pair")
 PEAK_MFMA_BF16_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-# the split-operand GEMMs spend several 16-bit MFMA MACs per fp32 MAC: the ceiling of what they execute, in fp32-equivalent
-# FLOP/s.  Default: two fp16 planes, three products (the fp16 and bf16 dense MFMA peaks are the same); DR_GEMM_F16X2=0: three
-# bf16 planes, six products.
+# the split-operand GEMMs spend three 16-bit MFMA MACs per fp32 MAC: the ceiling of what they execute, in fp32-equivalent FLOP/s.
 # The layer GEMMs (dr::pgemm_kernel, csrc/pgemm.hip) run on fp16 hi / lo plane images of both operands: three fp16 MFMA products per
 # fp32 MAC (the fp16 and bf16 dense MFMA peaks are the same).
 SPLIT_PRODUCTS = 3.0
@@ -47,7 +45,7 @@ PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / SPLIT_PRODUCTS
 SPLIT_KERNEL = "pgemm_kernel"
 SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand planes (rows of both operands scaled by exact powers of two into fp16's range; "
               "planes written by the producing kernels, both operands streamed by LDS-DMA)")
-LOOP_PMC = os.path.join(ROOT, "profiles", "r02_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
+LOOP_PMC = os.path.join(ROOT, "profiles", "r03_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -112,9 +110,9 @@ def sinkhorn_microbench(device, B=4096, N=256, M=256, reps=20):
     torch.cuda.synchronize()
     # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 correction + WRITE_SIZE)
     traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_sinkhorn_persist_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_sinkhorn_persist_pmc_traffic.json")
     if os.path.exists(pmc) and B == 4096 and N == 256 and M == 256:
-        traffic, src = json.load(open(pmc))["hbm_bytes_per_launch"], "profiles/r01_sinkhorn_persist_pmc_traffic.json"
+        traffic, src = json.load(open(pmc))["hbm_bytes_per_launch"], "profiles/r03_sinkhorn_persist_pmc_traffic.json (python3 tools/sk_one.py 4096; tools/pmc_collect.py)"
     return dict(kernel="sk_fast_persist_kernel (>= 512 tiles; sk_fast_kernel<float,float,16,4> below)", bound="hbm",
                 device_copy_same_bytes_GBps=copy_gbps, tiles_per_launch=B, bytes_per_tile=N * M * 8,
                 us_per_launch=ms * 1e3, achieved=byts / ms / 1e6, peak=PEAK_HBM_GBPS, unit="GB/s",
@@ -420,7 +418,7 @@ def main():
                 # `bench.py --breakdown-only` (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; per launch, averaged like `achieved`)
                 tj = json.load(open(LOOP_PMC))
                 roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/r02_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
+                roof["traffic_source"] = "profiles/r03_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
                 roof["effective_clock_GHz_pmc"] = tj.get("derived", {}).get("effective_clock_GHz")
                 roof["avg_us_per_launch_pmc_run"] = tj.get("avg_us_per_launch_profiled")
@@ -433,7 +431,7 @@ def main():
             roof["work_per_launch"] = work / c
             roof["note"] = ("dominant family by GPU time; achieved = algorithmic fp32 FLOPs (2*rows*cols*K per GEMM) / time; "
                             "the kernel computes each fp32 product as " + SPLIT_TEXT + " accumulated in fp32 "
-                            "(fp32-level accuracy, tests/test_ops_gpu.py::test_gemm_split_accuracy)")
+                            "(fp32-level accuracy: tests/test_planes_gpu.py holds every op of the chain to float64 products)")
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
             result["roofline"] = roof
             result["kernel_families"] = fam
