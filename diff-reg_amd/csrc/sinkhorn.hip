@@ -772,7 +772,6 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
         for (int j = lane; j < M; j += WAVE) {
             T e = t_exp<T>(zval(i, j) - m);
             Ew[(size_t)i * M + j] = e;
-            rs += e;
         }
         rs = wave_sum(rs);
         if (lane == 0) {
@@ -1073,6 +1072,302 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
     return DR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Co-resident form for tiles beyond the register-resident path (4DMatch 512 x 512 x 8, 2D-3D 1024 x 2048, real 3DMatch pairs of
+// 500 - 700 superpoints): ONE launch instead of 2 iters + 1.  A wave owns one row of a tile and keeps its exponentials in
+// registers from the load to the store (E never touches memory); a workgroup = 4 rows; the only thing that crosses workgroups is
+// the column sums, once per iteration, through global memory in two hops:
+//   partials  P[g][0..M] of the workgroup's 4 rows (+ the dustbin column)            -> arrive on counter A
+//   slices    workgroup g sums the G partials of ITS slice of columns (fixed order)   -> arrive on counter B
+//   everyone reads the M + 1 column sums.
+// No atomics on data (bit-reproducible); the exchanged floats are written and read past the L1 and the XCD's L2 (sc1), the
+// counters are agent-scope atomics polled by one lane per workgroup, every spin is bounded (a status word reports a timeout
+// instead of hanging the queue).  All workgroups of the launch must be resident: 256-thread workgroups with <= 32 KB of LDS and
+// <= 64 VGPRs fit 4 per CU, the launcher takes this form only for B ceil(N / 4) <= 4 x CUs / SK_COOP_SHARE, so SK_COOP_SHARE
+// concurrent launches of it (the engine's streams) still fit the chip together.
+// ---------------------------------------------------------------------------------------------
+constexpr int SK_COOP_SHARE = 2;
+constexpr unsigned SK_COOP_SPIN = 1u << 22;
+
+// arrival flags instead of a counter: a workgroup announces "my stores of pass p have left" by ONE sc1 store of p to its own word
+// (no read-modify-write: 256 agent-scope adds to one address serialise at the memory side, ~12 us per hop measured), and the first
+// wave of every workgroup polls the whole flag array, 64 words per instruction, until every word has reached p.  Bounded.
+__device__ __forceinline__ void sk_wait_flags(const unsigned* flags, int G, unsigned target, int* status) {
+    const int lane = threadIdx.x & 63;
+    unsigned spins = 0;
+    while (true) {
+        bool ok = true;
+        for (int q = lane; q < G; q += 64) ok = ok && __hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SK_COOP_SPIN) { if (lane == 0) *status = 1; break; }
+    }
+}
+// exchanged data moves as 16-byte accesses that bypass the L1 and the writer's L2 (sc1): two loads per round trip
+__device__ __forceinline__ void sk_ld2_sc1(const float* p0, const float* p1, float4& a, float4& b) {
+    sk_v4f x, y;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x), "=&v"(y) : "v"(p0), "v"(p1) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w);
+}
+__device__ __forceinline__ void sk_st_sc1(float* p, const float4& v) {      // (s_nop: VMEM store data hazard, see SK_STORE)
+    const sk_v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+
+// workspace of the co-resident form per tile: P [G][M4] | cb [M4] | flags A [G64] | flags B [G64] | status      (M4 = M + 1 rounded up to 4)
+__host__ __device__ inline int sk_coop_m4(int M) { return (M + 1 + 3) & ~3; }
+constexpr int SK_COOP_RW = 8;                                     // rows (waves) per workgroup
+__host__ __device__ inline int sk_coop_g(int N) { return (N + SK_COOP_RW - 1) / SK_COOP_RW; }
+__host__ __device__ inline int sk_coop_g64(int N) { return (sk_coop_g(N) + 63) & ~63; }
+__host__ __device__ inline size_t sk_coop_tile_floats(int N, int M) { return (size_t)(sk_coop_g(N) + 1) * sk_coop_m4(M) + 2 * (size_t)sk_coop_g64(N) + 64; }
+
+template <typename T> struct SkLd4;
+template <> struct SkLd4<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { const float4 x = *reinterpret_cast<const float4*>(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+};
+template <> struct SkLd4<double> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
+        const double2 x = *reinterpret_cast<const double2*>(p), y = *reinterpret_cast<const double2*>(p + 2); v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y;
+    }
+};
+template <typename T> struct SkSt4;
+template <> struct SkSt4<float> {
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct SkSt4<double> {
+    static __device__ __forceinline__ void st(double* p, const float (&v)[4]) {
+        *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]); *reinterpret_cast<double2*>(p + 2) = make_double2((double)v[2], (double)v[3]);
+    }
+};
+
+template <typename TIn, typename TOut, int VPL, int RW>
+__global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
+    constexpr int NT = 64 * RW;                                   // RW rows (waves) per workgroup
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int N = A.N, M = A.M, G = (N + RW - 1) / RW, Mp = VPL * 256, M4 = sk_coop_m4(M), NG4 = M4 / 4;
+    float* s_col = reinterpret_cast<float*>(sk_smem);             // [RW][Mp + 4] column partials of the waves; later the M4 column sums
+    float* s_red = s_col + RW * (Mp + 4);                         // [RW][8]
+    __shared__ int s_cnt[2];
+    const int tile = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
+    float* wsb = reinterpret_cast<float*>(A.ws) + (size_t)tile * sk_coop_tile_floats(N, M);
+    float* P = wsb;                                               // [G][M4]
+    float* cb = P + (size_t)G * M4;                               // [M4]
+    unsigned* flagA = reinterpret_cast<unsigned*>(cb + M4);       // [G64] pass whose partials workgroup q has published
+    unsigned* flagB = flagA + sk_coop_g64(N);                     // [G64] ... whose slice of column sums
+    int* status = reinterpret_cast<int*>(flagB + sk_coop_g64(N));
+    const TIn* src = reinterpret_cast<const TIn*>(A.scores) + (size_t)tile * N * M;
+    const uint8_t* sm = A.src_mask ? A.src_mask + (size_t)tile * N : nullptr;
+    const uint8_t* tm = A.tgt_mask ? A.tgt_mask + (size_t)tile * M : nullptr;
+    const bool apply = (A.flags & DR_SK_APPLY_MASK) != 0, ragged = (A.flags & DR_SK_RAGGED) != 0;
+    const float alpha = *A.bin_score;
+
+    // ---- marginals (float32, quirk Q22) from the mask counts
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        if (sm) { for (int i = t; i < N; i += NT) c0 += sm[i] != 0; } else if (t == 0) c0 = N;
+        if (tm) { for (int j = t; j < M; j += NT) c1 += tm[j] != 0; } else if (t == 0) c1 = M;
+        if (c0) atomicAdd(&s_cnt[0], c0);
+        if (c1) atomicAdd(&s_cnt[1], c1);
+    }
+    __syncthreads();
+    const int ms = s_cnt[0], ns = s_cnt[1];
+    const float normf = -logf((float)(ms + ns));
+    const float mu = expf(normf), muN = expf(logf((float)ns) + normf), nu = mu, nuM = expf(logf((float)ms) + normf);
+    const double xmin_d = A.shift ? A.shift[tile] : 0.0;
+
+    // ---- the wave's row: scores -> exponentials in registers.  Lane l owns columns 4 (l + 64 k) + c, k < VPL, c < 4.
+    const int i = RW * g + w;
+    const bool rowok = i < N, rowmasked = rowok && sm && !sm[i];
+    const bool vec_in = (M & 3) == 0 && ((uintptr_t)src % (4 * sizeof(TIn))) == 0;
+    float E[VPL][4];
+    unsigned colmask = 0;                                         // bit 4 k + c: column exists and is not masked (ragged: b = 0 there)
+    float m = alpha;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int jb = 4 * (lane + 64 * k);
+        TIn raw[4] = {0, 0, 0, 0};
+        if (rowok && vec_in && jb < M) SkLd4<TIn>::ld(src + (size_t)i * M + jb, raw);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = jb + c;
+            float v = -INFINITY;
+            if (j < M && rowok) {
+                const TIn r = vec_in ? raw[c] : src[(size_t)i * M + j];
+                v = (float)((double)r - xmin_d);                 // (float inputs: exact; float64 state: shifted in float64 like the other paths)
+                if (apply && (rowmasked || (tm && !tm[j]))) v = -INFINITY;
+            }
+            if (j < M && !(tm && !tm[j])) colmask |= 1u << (4 * k + c);
+            E[k][c] = v;
+            m = fmaxf(m, v);
+        }
+    }
+    m = wave_max(m);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) E[k][c] = __builtin_amdgcn_exp2f((E[k][c] - m) * LOG2E);      // exp(-inf) = 0: masked / absent entries
+    const float ed = rowok ? __builtin_amdgcn_exp2f((alpha - m) * LOG2E) : 0.f;   // the row's dustbin-column entry
+    const bool a_zero = !rowok || (ragged && rowmasked);
+
+    float b[VPL][4];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[k][c] = (!ragged || ((colmask >> (4 * k + c)) & 1)) ? 1.f : 0.f;
+    float bM = 1.f, aN = muN / ((ragged ? (float)ns : (float)M) + 1.f), ai = 0.f;
+    // this workgroup's slice of the column sums: float4 groups [g0, g1)
+    const int gpw = (NG4 + G - 1) / G, g0 = min(NG4, g * gpw), g1 = min(NG4, g0 + gpw);
+    for (int it = 0; it < A.iters; ++it) {
+        // a_i = mu / (sum_j E_ij b_j + ed bM)
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = fmaf(E[k][c], b[k][c], s);
+        s = wave_sum(s);
+        ai = a_zero ? 0.f : mu / (s + ed * bM);
+        // column partials of the 4 rows -> P[g] (the dustbin column rides at index M)
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            float4 cp;
+            cp.x = E[k][0] * ai; cp.y = E[k][1] * ai; cp.z = E[k][2] * ai; cp.w = E[k][3] * ai;
+            *reinterpret_cast<float4*>(s_col + w * (Mp + 4) + 4 * (lane + 64 * k)) = cp;
+        }
+        if (lane == 0) s_col[w * (Mp + 4) + M] = ed * ai;         // (column M is no column of E: its partial there was 0 or absent)
+        __syncthreads();
+        for (int q4 = t; q4 < NG4; q4 += NT) {
+            float4 v = *reinterpret_cast<const float4*>(s_col + 4 * q4);
+#pragma unroll
+            for (int r = 1; r < RW; ++r) {                        // fixed order over the workgroup's rows
+                const float4 u = *reinterpret_cast<const float4*>(s_col + r * (Mp + 4) + 4 * q4);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            sk_st_sc1(P + (size_t)g * M4 + 4 * q4, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // every store of the workgroup has left
+        if (t == 0) __hip_atomic_store(flagA + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), status);
+        __syncthreads();
+        // this workgroup's slice: column sums over the G partials; thread = partial (G <= 256 per pass), two float4 groups per
+        // round trip; lanes are summed by the butterfly, the 4 waves in fixed order: bit-reproducible
+        for (int gq = g0; gq < g1; gq += 2) {
+            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+            for (int q = t; q < G; q += NT) {
+                float4 y0, y1;
+                const float* pq = P + (size_t)q * M4;
+                sk_ld2_sc1(pq + 4 * gq, pq + 4 * min(gq + 1, NG4 - 1), y0, y1);
+                x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+                x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+            }
+            float r8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r8[e] = wave_sum(r8[e]);
+            if (lane == 0)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_red[w * 8 + e] = r8[e];
+            __syncthreads();
+            if (t < 2 && gq + t < g1) {
+                float4 v = *reinterpret_cast<const float4*>(s_red + 4 * t);
+#pragma unroll
+                for (int r = 1; r < RW; ++r) {
+                    const float4 u = *reinterpret_cast<const float4*>(s_red + 8 * r + 4 * t);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                sk_st_sc1(cb + 4 * (gq + t), v);
+            }
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flagB + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) sk_wait_flags(flagB, G, (unsigned)(it + 1), status);
+        __syncthreads();
+        // the M + 1 column sums -> LDS (two float4 groups per thread per round trip), then b_j = nu / (cb_j + a_N), b_M likewise;
+        // a_N of the NEXT pass from the new b
+        for (int q4 = t; q4 < NG4; q4 += 2 * NT) {
+            float4 y0, y1;
+            const int q4b = min(q4 + NT, NG4 - 1);
+            sk_ld2_sc1(cb + 4 * q4, cb + 4 * q4b, y0, y1);
+            *reinterpret_cast<float4*>(s_col + 4 * q4) = y0;
+            if (q4 + NT < NG4) *reinterpret_cast<float4*>(s_col + 4 * q4b) = y1;
+        }
+        __syncthreads();
+        float bs = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int jb = 4 * (lane + 64 * k);
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jb < M4) cs = *reinterpret_cast<const float4*>(s_col + jb);
+            const float cv[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float bj = 0.f;
+                if (jb + c < M && (!ragged || ((colmask >> (4 * k + c)) & 1))) bj = nu / (cv[c] + aN);
+                b[k][c] = bj;
+                bs += bj;
+            }
+        }
+        bM = nuM / (s_col[M] + aN);
+        bs = wave_sum(bs);
+        aN = muN / (bs + bM);
+        __syncthreads();                                          // s_col is rewritten by the next pass
+    }
+    // ---- out_ij = E_ij a_i b_j e^-norm
+    if (!rowok) return;
+    const float S = expf(-normf) * ai;
+    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (size_t)i * M;
+    const bool vec_out = (M & 3) == 0 && ((uintptr_t)A.out % (4 * sizeof(TOut))) == 0;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int jb = 4 * (lane + 64 * k);
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = E[k][c] * S * b[k][c];
+        if (vec_out) { if (jb < M) SkSt4<TOut>::st(dst + jb, o); }
+        else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (jb + c < M) dst[jb + c] = (TOut)o[c];
+    }
+}
+
+static bool coop_path(int B, int N, int M, int flags) {
+    if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return false;
+    if (M > 2048 || !env_knob("DR_SK_COOP", 1)) return false;
+    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    // 512-thread workgroups with 8 (VPL 256 + 4) floats of LDS: 2 per CU by threads, 2 at VPL = 8 by LDS
+    return (long)B * sk_coop_g(N) <= 2L * n_cu / SK_COOP_SHARE;
+}
+
+template <typename TIn, typename TOut>
+static int launch_coop(const SkArgs& a, hipStream_t st) {
+    const int G = sk_coop_g(a.N), vpl = (a.M + 255) / 256;
+    const size_t tf = sk_coop_tile_floats(a.N, a.M);
+    // counters + status of every tile start at zero
+    for (int b = 0; b < a.B; ++b)
+        DR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<float*>(a.ws) + (size_t)b * tf + (size_t)(G + 1) * sk_coop_m4(a.M), 0,
+                                    (2 * (size_t)sk_coop_g64(a.N) + 64) * 4, st));
+    const dim3 grid(G, a.B), blk(64 * SK_COOP_RW);
+#define SK_COOP_CASE(V)                                                                                                      \
+    case V: {                                                                                                                \
+        const size_t lds = ((size_t)SK_COOP_RW * (V * 256 + 4) + 8 * SK_COOP_RW + 8) * sizeof(float);                        \
+        if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_COOP_RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_COOP_RW>), grid, blk, lds, st, a);                               \
+        break;                                                                                                               \
+    }
+    switch (vpl) {
+        SK_COOP_CASE(1) SK_COOP_CASE(2) SK_COOP_CASE(3) SK_COOP_CASE(4) SK_COOP_CASE(5) SK_COOP_CASE(6) SK_COOP_CASE(7) SK_COOP_CASE(8)
+        default: return DR_ENOSUP;
+    }
+#undef SK_COOP_CASE
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
 static int sk_grid_blocks(int B, int N) {
     // enough workgroups for the chip, at least 8 rows (two per wave) per block, at most 128 blocks (the column
     // partials are G x M values per tile)
@@ -1157,6 +1452,7 @@ static bool reg_path(int N, int M, int flags) {
 // (sized for the largest iteration count the library is used with, so that the size does not depend on it)
 static size_t sk_workspace_need(int B, int N, int M, int esz, int flags, int iters) {
     if (!grid_path(N, M, flags)) return (size_t)B * N * M * esz;
+    // (the co-resident form's exchange area, B sk_coop_tile_floats(N, M) floats ~ a quarter of E, fits inside the grid form's workspace)
     const int G = sk_grid_blocks(B, N);
     return (size_t)B * sk_grid_tile_elems<float>(N, M, G, iters > 16 ? iters : 16) * esz;
 }
@@ -1189,6 +1485,10 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
     const size_t need = sk_workspace_need(B, N, M, strict64 ? 8 : 4, flags, iters);
     if (!ws || ws_bytes < need) return DR_EWORKSPACE;
     a.vec_in = a.vec_out = 0;
+    if (coop_path(B, N, M, flags)) {
+        if (out32) return launch_coop<TIn, float>(a, st);
+        return launch_coop<TIn, double>(a, st);
+    }
     if (grid_path(N, M, flags)) {
         if (strict64) {
             if (out32) return launch_grid<TIn, double, float>(a, st);

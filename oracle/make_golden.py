@@ -304,7 +304,7 @@ def run_2d3d():
     ac, sra, srm1 = diffusion_schedule()
     save = lambda name, **kw: np.savez_compressed(os.path.join(OUT, "2d3d_%s.npz" % name), **kw)
 
-    def run(N, M, nv, mv, mv_da, steps, mc, seed, tag):
+    def run(N, M, nv, mv, mv_da, steps, mc, seed, tag, compact=False):
         proc = SoftProcrustesLayer(to_attr(dict(sample_rate=1.0, max_condition_num=mc)))
         pr = synth.make_pair_2d3d(N, M, seed, weights=Wnp)
         g = lambda k: T(pr[k])[None]
@@ -312,7 +312,8 @@ def run_2d3d():
         tgt_mask = torch.arange(M)[None] < mv
         tgt_mask_da = torch.arange(M)[None] < mv_da
         x = g("x_T").clone()
-        rec = dict(x0=[], Rf=[], tf=[], cond=[])
+        rec = dict(x0=[], Rf=[], tf=[], cond=[], gap=[])
+        Ksel = int(max(nv, mv_da) * 1.0)                # top-K of SoftProcrustesLayer (EXP/procrustes.py:61-62, sample_rate 1)
         with torch.no_grad():
             f_img0, f_pcd0 = fus(g("img_feats"), g("img_dino"), g("img_pixels"), g("pcd_feats"), g("s_pcd"))
             c0, _, _, _ = head(f_pcd0, f_img0, src_mask, tgt_mask, True)
@@ -321,6 +322,8 @@ def run_2d3d():
                 Z = log_optimal_transport(x, head.bin_score, head.skh_iters, src_mask, tgt_mask_da)
                 cd = Z.exp()[:, :-1, :-1].contiguous().type(torch.float32)
                 R, tt, Rf, tf, cond, ok = proc(cd, g("s_pcd"), g("t_pcd_da"), src_mask, tgt_mask_da)
+                vk = cd.flatten().topk(Ksel + 1)[0]
+                rec["gap"].append(float((vk[Ksel - 1] - vk[Ksel]) / vk[Ksel - 1]))   # 0 = exact tie at the K-th boundary: torch.topk's pick is implementation-defined
                 warped = (torch.matmul(Rf.type(torch.float32), g("s_pcd").transpose(1, 2)) + tf.type(torch.float32)).transpose(1, 2)
                 f_img, f_pcd = fus(g("img_feats"), g("img_dino"), g("img_pixels"), g("pcd_feats"), warped)
                 x0, _, _, _ = head(f_pcd, f_img, src_mask, tgt_mask, True)
@@ -337,6 +340,18 @@ def run_2d3d():
             conf = Z.exp()[:, :-1, :-1].contiguous()
             i, j, sc = mutual_topk_select(conf.squeeze(0), 1, largest=True, threshold=None, mutual=False)
         x0s = torch.stack(rec["x0"])
+        if compact:
+            # BASELINE configs[4] size: the matrices are 8 / 16 MB -- the fixture keeps every 8th row and column, the row / column sums of
+            # the whole matrices (any wrong entry above the tolerance moves one of each), and the per-step poses
+            c64 = conf[0].double()
+            fin = torch.isfinite(c64)
+            save("loop_" + tag, conf_sub=c64[::8, ::8].numpy(), conf_rowsum=c64.sum(1).numpy(), conf_colsum=c64.sum(0).numpy(),
+                 conf_dtype=str(conf.dtype), conf_all_finite=bool(fin.all()), x0_corner=x0s[:, :16, :16].numpy(),
+                 x0_last_sub=x0s[-1][::8, ::8].numpy(), x0_last_rowsum=x0s[-1].double().sum(1).numpy(), x0_last_colsum=x0s[-1].double().sum(0).numpy(),
+                 x0_sum=x0s.double().sum((1, 2)).numpy(), R_forwd=torch.stack(rec["Rf"]).numpy(), t_forwd=torch.stack(rec["tf"]).numpy(),
+                 cond=torch.stack(rec["cond"]).numpy(), kth_gap_rel=np.asarray(rec["gap"]), match_i=i.numpy(), match_j=j.numpy())
+            print(tag, "conf", conf.dtype, "cond", [float(c) for c in rec["cond"]], "K-th boundary gaps", rec["gap"])
+            return
         save("loop_" + tag, f_img0=f_img0[0].numpy(), f_pcd0=f_pcd0[0].numpy(), conf0=c0[0].numpy(), conf=conf[0].numpy(),
              conf_dtype=str(conf.dtype), x0_corner=x0s[:, :16, :16].numpy(), x0_last=x0s[-1].numpy(),
              x0_sum=x0s.double().sum((1, 2)).numpy(), R_forwd=torch.stack(rec["Rf"]).numpy(), t_forwd=torch.stack(rec["tf"]).numpy(),
@@ -347,6 +362,13 @@ def run_2d3d():
     # (the random-weight fusion module gives fairly flat matrices, whose top-K is unstable over many steps with the
     #  warp active; the long run therefore uses the identity warp, the short masked run exercises the Procrustes feedback)
     run(128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")
+    # BASELINE configs[4] at its stated size (1024 point nodes x 2048 patches, 10 steps, padding masks on both sides and a different
+    # tgt_mask_da): pins the large-tile Sinkhorn / top-K kernels to the reference's own components.  Identity warp (max_condition_num 0),
+    # like the long small run: with these synthetic weights the noised matrix of step 1 is so flat that its K-th and (K+1)-th confidences
+    # are EQUAL in float32 for every seed tried (kth_gap_rel in the fixture; 41 of 41 seeds): with the warp fed back, torch.topk's
+    # implementation-defined pick among equal values would decide the rest of the trajectory.  cond of a tied step is held loosely by the tests.
+    if os.environ.get("MINT_CFG5", "1") == "1":
+        run(1024, 2048, 1000, 2000, 1900, 10, 0, 51, "n1024x2048_s10_mc0_masked", compact=True)
 
 
 HEAD_GAIN_2D3D = 16.0

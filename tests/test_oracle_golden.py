@@ -170,6 +170,44 @@ def test_2d3d_loop_matches_reference(golden, N, M, nv, mv, mv_da, steps, mc, see
     assert len(got ^ want) <= 0.05 * len(want)
 
 
+def cfg5_compact_checks(g, x0_last, conf, R_forwd, t_forwd, cond, atol_x0=1e-4):
+    """the compact cfg5-size fixture (every 8th row / column + row / column sums of the full matrices + per-step poses)"""
+    np.testing.assert_allclose(R_forwd, g["R_forwd"], atol=1e-4)
+    np.testing.assert_allclose(t_forwd, g["t_forwd"], atol=1e-4)
+    np.testing.assert_allclose(x0_last[::8, ::8], g["x0_last_sub"], atol=atol_x0)
+    np.testing.assert_allclose(x0_last.astype(np.float64).sum(1), g["x0_last_rowsum"], atol=2e-4)
+    np.testing.assert_allclose(x0_last.astype(np.float64).sum(0), g["x0_last_colsum"], atol=2e-4)
+    np.testing.assert_allclose(conf[::8, ::8], g["conf_sub"], atol=1e-5, rtol=1e-3)
+    np.testing.assert_allclose(conf.sum(1), g["conf_rowsum"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(conf.sum(0), g["conf_colsum"], atol=1e-5, rtol=1e-4)
+    # cond comes from the top-K selection: compared where the reference's K-th and (K+1)-th confidences are NOT (near-)equal
+    clear = g["kth_gap_rel"] > 3e-6
+    assert clear[0] and clear.sum() >= 1
+    np.testing.assert_allclose(np.asarray(cond)[clear], g["cond"][clear], rtol=2e-3)
+
+
+def test_2d3d_loop_matches_reference_at_cfg5_size(golden):
+    """BASELINE configs[4] size (1024 x 2048, 10 steps, masks, identity warp): the restatement against the reference's own
+    components (oracle/make_golden.py run_2d3d, compact fixture)."""
+    N, M, nv, mv, mv_da, steps, mc, seed = 1024, 2048, 1000, 2000, 1900, 10, 0, 51
+    g = golden("2d3d_loop_n1024x2048_s10_mc0_masked")
+    v = synth.VARIANTS["2d3d"]
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W = {k: T(a) for k, a in Wn.items()}
+    pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
+    q = lambda k: T(pr[k])[None]
+    ms, mt = masks(N, M, nv, mv)
+    mt_da = torch.arange(M)[None] < mv_da
+    trace = []
+    out = orc.denoise_loop_2d3d(W, v, q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"),
+                                ms, mt, mt_da, q("x_T"), steps, mc, trace=trace)
+    assert str(out["conf_matrix_pred"].dtype) == str(g["conf_dtype"])
+    cfg5_compact_checks(g, trace[-1]["x0"][0].numpy(), out["conf_matrix_pred"][0].double().numpy(),
+                        torch.stack([r["R_forwd"][0] for r in trace]).numpy(), torch.stack([r["t_forwd"][0] for r in trace]).numpy(),
+                        [float(r["cond"][0]) for r in trace])
+    np.testing.assert_allclose(torch.stack([r["x0"][0, :16, :16] for r in trace]).numpy(), g["x0_corner"], atol=1e-4)
+
+
 def kpfcn_inputs(golden):
     """synthetic KPFCN batch + hash weights (+ the reference's kernel points from the fixture) as torch tensors"""
     g = golden("kpfcn_coarse")

@@ -1,4 +1,4 @@
-"""Large-tile Sinkhorn (the shapes beyond the register-resident kernel, multi-launch grid form): graph-replayed time per call.
+"""Large-tile Sinkhorn (the shapes beyond the register-resident kernel: co-resident form where it fits, grid form beyond): graph-replayed time per call.
 cfg5: 1 x 1024 x 2048 (2D-3D), cfg3: 8 x 512 x 512 (4DMatch), a real 3DMatch pair: 1 x 564 x 629.  Writes gpurun_out/r03_sinkhorn_large_tiles.json."""
 import json, os, sys
 import torch
