@@ -97,6 +97,10 @@ def assert_matrix_parity(got, ref, f64, what, exempt=None):
     as twice the reference's distance.  `exempt`: flat indices from the committed list (golden fixtures) or None = the same
     rule applied to (ref, f64) on the spot (cases that are not fixtures)."""
     got, ref, f64 = (np.asarray(a, dtype=np.float64).ravel() for a in (got, ref, f64))
+    fin = np.isfinite(ref)
+    if not fin.all():                       # (padded / masked entries that are not finite in the reference: same pattern, no arithmetic on them)
+        assert np.array_equal(np.isfinite(got), fin), (what, "finite pattern differs")
+        got, ref, f64 = np.where(fin, got, 0.0), np.where(fin, ref, 0.0), np.where(fin & np.isfinite(f64), f64, 0.0)
     rule = np.nonzero(np.abs(ref - f64) > TAU)[0]
     if exempt is None:
         exempt = rule
@@ -244,11 +248,15 @@ def test_ragged_batch_equals_single_pairs(variant):
         dd = (got[i]["conf_matrix_pred"] - one["conf_matrix_pred"][0]).abs()
         # (the batch and the single run pick different GEMM tilings, i.e. summation orders: fp32 rounding only.  The 4D
         #  read-out sigmoid(x) does not pass through a final Sinkhorn and keeps the ill-conditioned entries of the loop
-        #  tests' docstring: same bar as there, <= 0.1 % of the entries beyond 1e-4)
+        #  tests' docstring: the exemption rule applied on the spot -- every entry of the batched result within 1e-4 of the pair's own
+        #  run, except where that run itself is more than TAU from the float64 evaluation of the pair, where both must be as close
+        #  to float64 as twice that distance)
         if variant == "3dmatch":
             assert dd.max().item() < 2e-6, (i, dd.max().item())
         else:
-            assert (dd > 1e-4).double().mean().item() <= 1e-3, (i, dd.max().item())
+            _, conf_f64 = f64_evaluation(variant, n, m, n, m, steps, mc, 61 + i)
+            assert_matrix_parity(got[i]["conf_matrix_pred"].cpu().numpy(), one["conf_matrix_pred"][0].cpu().numpy(), conf_f64,
+                                 "ragged batch vs the pair's own run, pair %d" % i)
         assert (got[i]["R_final"] - one["R_final"][0]).abs().max().item() < 1e-4
         assert (got[i]["t_final"] - one["t_final"][0]).abs().max().item() < 1e-4
         if variant == "3dmatch":
@@ -357,8 +365,11 @@ def test_cfg3_4dmatch_512_batch8_20_steps(golden):
     assert np.abs(Rf_all[:, 0].numpy() - g["R_forwd"]).max() < 1e-4
     assert np.abs(tf_all[:, 0].numpy() - g["t_forwd"]).max() < 1e-4
     against_reference("conf", conf_all[0].numpy())
-    dd = (one["x0"][-1, 0].cpu() - x0_last_all[0]).abs()
-    assert (dd > 1e-4).double().mean().item() <= 1e-3 and dd.max().item() < 1e-3, dd.max().item()
+    # batched x_start of pair 0 against its own B = 1 run: plain 1e-4 outside the fixture's committed exemption list
+    dd = (one["x0"][-1, 0].cpu() - x0_last_all[0]).abs().numpy().ravel()
+    plain = np.ones(dd.size, dtype=bool)
+    plain[np.asarray(ex["x0_last"]["index"], dtype=np.int64)] = False
+    assert dd[plain].max() <= 1e-4 and dd.max() < 1e-3, (dd[plain].max(), dd.max())
     # ---- pair 1 against the oracle
     i = 1
     q = prs[i]
@@ -376,8 +387,14 @@ def test_cfg3_4dmatch_512_batch8_20_steps(golden):
         one = eng.run(q["f_s"].to(DEV), q["f_t"].to(DEV), q["p_s"].to(DEV), q["p_t"].to(DEV), q["x_T"].to(DEV), ms[i:i + 1].to(DEV),
                       mt[i:i + 1].to(DEV), noise=noise[:, i:i + 1].to(DEV), trace=True)
         assert (one["R_forwd"][:, 0].cpu() - Rf_all[:, i]).abs().max().item() < 1e-4, i
-        dd = (one["conf_matrix_pred"][0].cpu() - conf_all[i]).abs()
-        assert (dd > 1e-4).double().mean().item() <= 1e-3, (i, dd.max().item())
+        # conf of the batched run against the pair's own run (no percentile): pairs 2..4 under the exemption rule with the pair's float64
+        # evaluation (a 512 x 512 x 20-step float64 oracle run each: the suite's time bounds how many), the others on a plain bound
+        if i <= 4:
+            _, conf_f64 = f64_evaluation(variant, N, M, cases[i][0], cases[i][1], steps, mc, cases[i][2])
+            assert_matrix_parity(conf_all[i].numpy(), one["conf_matrix_pred"][0].cpu().numpy(), conf_f64, "cfg3 pair %d batched vs single" % i)
+        else:
+            dd = (one["conf_matrix_pred"][0].cpu() - conf_all[i]).abs()
+            assert dd[torch.isfinite(dd)].max().item() < 1e-3, (i, dd[torch.isfinite(dd)].max().item())
 
 
 @pytest.mark.parametrize("N,M", [(8, 8), (5, 7), (16, 3), (1, 1), (2, 300), (257, 255)])
