@@ -716,8 +716,14 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       int32_t* solution_mask, int32_t* topk_idx, void* stream) {
     if (P < 0 || N < 1 || M < 1 || !conf || !src_pcd || !tgt_pcd || !R || !t || !R_forwd || !t_forwd || !condition || !solution_mask)
         return DR_EINVAL;
-    return launch_procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, P, N, M, use_mask_len, sample_rate, max_condition_num,
-                             R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream);
+    // tiles beyond 256 x 256 select with the whole chip: their scratch is stream-ordered (nothing cached across calls)
+    const size_t wsb = procrustes_workspace_bytes(P, N, M);
+    void* ws = nullptr;
+    if (wsb) DR_HIP_CHECK(hipMallocAsync(&ws, wsb, (hipStream_t)stream));
+    const int rc = launch_procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, P, N, M, use_mask_len, sample_rate, max_condition_num,
+                                     R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream, ws, wsb);
+    if (ws) DR_HIP_CHECK(hipFreeAsync(ws, (hipStream_t)stream));
+    return rc;
 }
 
 /* diagnostics: wall-clock phase stamps (100 MHz ticks) of the last dr_procrustes launch, pair 0 */

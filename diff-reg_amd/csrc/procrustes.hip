@@ -34,17 +34,22 @@ struct ProcArgs {
     int* topk_idx;            // optional [P, K] flat indices of the selected entries (index order)
     int N, M, K_fixed, use_mask_len;
     float sample_rate, max_cond;
-    // large tiles (N*M > 65536) with a workspace: candidates >= a lower bound of the K-th largest entry, compacted in
-    // index order by proc_compact_kernel into S slices of up to PC_CAP entries (nullptr = none: stream the tile)
-    unsigned* cellmax;        // [P, PC_NCELL] maxima of contiguous cells
-    unsigned* g_ckey;         // [P, S, PC_CAP]
-    int* g_cidx;              // [P, S, PC_CAP]
-    int* g_ccount;            // [P, S] entries >= the bound in the slice (may exceed PC_CAP: overflow)
-    int S, SL, CL;            // slices per tile, elements per slice, elements per cell
+    // large tiles (N*M > 65536) with a workspace: the K selected entries, written in index order by proc_take_kernel
+    // (nullptr = none: the fit kernel streams the tile itself)
+    unsigned* g_ckey;         // [P, PC_CAP]
+    int* g_cidx;              // [P, PC_CAP]
+    int* g_ccount;            // [P] selected entries
+    int S, SL;                // slices per tile, elements per slice (a multiple of 1024)
+    // large tiles, exact chip-wide selection (proc_hist_kernel x 3 + proc_take_kernel): histograms of the keys' three digits
+    unsigned* g_hist;         // [P, 3, PH_BINS]  digit histograms of the keys that match the digits above (atomics on integers)
+    uint2* g_shist;           // [P, S, PH_LAST]  per slice and last digit b: {keys above (digits so far, b), keys equal to it}
 };
 
-constexpr int PC_NCELL = 4096;   // cells per tile: the K-th largest cell maximum bounds the K-th largest entry from below
-constexpr int PC_CAP = 4096;     // candidate capacity of a slice (= the capacity of the final list)
+constexpr int PH_BINS = 4096;    // digits of 12 / 12 / 8 bits (most significant first)
+constexpr int PH_LAST = 256;
+__host__ __device__ constexpr int ph_shift(int pass) { return pass == 0 ? 20 : (pass == 1 ? 8 : 0); }
+__host__ __device__ constexpr unsigned ph_bins(int pass) { return pass == 2 ? (unsigned)PH_LAST : (unsigned)PH_BINS; }
+constexpr int PC_CAP = 4096;     // capacity of a tile's list of selected entries (= PK_MAX)
 
 __device__ __forceinline__ float key_value(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
@@ -140,83 +145,254 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_w, int& total) {
     return base + incl - v;
 }
 
-// ---- large tiles: two multi-workgroup passes in front of the one-workgroup-per-pair kernel ---------------------------
-// (one workgroup streaming a 1024 x 2048 tile three times took 4.7 ms; these read it twice with the whole chip)
-__global__ __launch_bounds__(256) void proc_cellmax_kernel(ProcArgs A) {
-    const int pair = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int NM = A.N * A.M;
-    const float* conf = A.conf + (size_t)pair * NM;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        const int c = (blockIdx.x * 4 + w) * 4 + q;              // 16 cells per workgroup
-        if (c >= PC_NCELL) return;
-        const int e0 = c * A.CL, e1 = min(NM, e0 + A.CL);
-        unsigned m = 0;
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const unsigned k = order_key(conf[e]);
-            m = k > m ? k : m;
-        }
-        m = wave_max(m);
-        if (lane == 0) A.cellmax[(size_t)pair * PC_NCELL + c] = m;  // 0 = empty cell
-    }
-}
-
-__global__ __launch_bounds__(1024) void proc_compact_kernel(ProcArgs A) {
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_pr[2];
-    __shared__ int s_w[16];
-    __shared__ int s_len[2];
-    const int pair = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
-    const int N = A.N, M = A.M, NM = N * M;
-    const float* conf = A.conf + (size_t)pair * NM;
+// ---- large tiles, exact selection with the whole chip (round 3) -------------------------------------------------------------
+// (one workgroup streaming a 1024 x 2048 tile three times took 4.7 ms.)  Rounds 1-2 bounded the K-th largest entry from below with
+// the K-th largest of 4096 cell maxima and compacted the candidates >= that bound for ONE workgroup to select from; that needs the
+// candidates to fit a 4096-entry list, and flat or massively tied matrices (early denoising steps, the synthetic 2D-3D scenes)
+// overflow it: the single workgroup then streamed the whole tile six times (460 us per call at 1024 x 2048).  Exact form: a
+// 3-digit radix select (12 / 12 / 8 bits) whose histograms are built by S slice workgroups per tile (integer atomics:
+// deterministic), every workgroup re-deriving the digits found so far from the completed histograms of the earlier launches.
+// The last pass also leaves, PER
+// SLICE and per value b of the last digit, how many of the slice's keys are above (digits so far, b) and how many equal it; the take
+// pass reads those two numbers of every slice in front of its own at b = the K-th key's last digit, which gives it the position of
+// its first selected entry in the tile's list and the number of ties already handed out (ties go in index order).  It writes exactly
+// the K selected entries, in index order, into one contiguous list per tile: nothing is left for the fit kernel to select.
+__device__ __forceinline__ int proc_topk_count(const ProcArgs& A, int pair, int* s_len) {
+    const int t = threadIdx.x, N = A.N, M = A.M;
     int K = A.K_fixed;
     if (A.use_mask_len) {                                        // same rule as procrustes_kernel (quirk Q17)
         if (t < 2) s_len[t] = 0;
         __syncthreads();
         int c0 = 0, c1 = 0;
-        for (int i = t; i < N; i += 1024) c0 += A.src_mask[(size_t)pair * N + i] != 0;
-        for (int j = t; j < M; j += 1024) c1 += A.tgt_mask[(size_t)pair * M + j] != 0;
+        for (int i = t; i < N; i += blockDim.x) c0 += A.src_mask[(size_t)pair * N + i] != 0;
+        for (int j = t; j < M; j += blockDim.x) c1 += A.tgt_mask[(size_t)pair * M + j] != 0;
         if (c0) atomicAdd(&s_len[0], c0);
         if (c1) atomicAdd(&s_len[1], c1);
         __syncthreads();
         const int mx = s_len[0] > s_len[1] ? s_len[0] : s_len[1];
         K = (int)((float)mx * A.sample_rate);
     }
-    if (K > NM) K = NM;
+    const long NM = (long)N * M;
+    if (K > NM) K = (int)NM;
     if (K > PK_MAX) K = PK_MAX;
-    const int ncell = (NM + A.CL - 1) / A.CL;                    // non-empty cells
-    unsigned L = 0, dummy;
-    if (K >= 1 && K <= ncell) {
-        unsigned cm[4];
+    return K;
+}
+// the bin of a histogram (NB bins, larger bin = larger keys) that holds the `remaining`-th largest key, and the rank inside it;
+// block-wide (1024 threads, h[] = the thread's NB / 1024 bins in descending order: bin NB-1-(t BPT + i)); s_out[0] = bin, s_out[1] = new
+// remaining (bin 0, unchanged rank when the histogram holds fewer than `remaining` keys)
+template <int NB, int BPT>
+__device__ __forceinline__ void ph_find_bin(const unsigned (&h)[BPT], unsigned remaining, int* s_w, unsigned* s_out) {
+    const int t = threadIdx.x;
+    unsigned sum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cm[q] = A.cellmax[(size_t)pair * PC_NCELL + t + 1024 * q];
-        // L = the K-th largest cell maximum (all four digits: with millions of entries a 16-bit bucket admits far more
-        // than the list holds): >= K entries are >= L, typically a small multiple of K
-        radix_select<4>([&](auto&& f) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) f(cm[q], 0);
-        }, (unsigned)K, s_hist, s_pr, L, dummy);
-    }
-    // this slice, thread t owns a contiguous run (so that (thread, element) order is index order)
-    const int s0 = sl * A.SL, s1 = min(NM, s0 + A.SL);
-    const int CH = (A.SL + 1023) / 1024;
-    const int e0 = min(s1, s0 + t * CH), e1 = min(s1, e0 + CH);
-    int c = 0;
-    for (int e = e0; e < e1; ++e) {
-        const unsigned k = order_key(conf[e]);
-        c += (k >= L && k != 0u) ? 1 : 0;
-    }
+    for (int i = 0; i < BPT; ++i) sum += h[i];
+    if (t == 0) { s_out[0] = 0u; s_out[1] = remaining; }
     int total;
-    int off = block_excl_scan(c, s_w, total);
-    unsigned* ck = A.g_ckey + ((size_t)pair * A.S + sl) * PC_CAP;
-    int* ci = A.g_cidx + ((size_t)pair * A.S + sl) * PC_CAP;
-    if (total <= PC_CAP) {
-        for (int e = e0; e < e1; ++e) {
-            const unsigned k = order_key(conf[e]);
-            if (k >= L && k != 0u) { ck[off] = k; ci[off] = e; ++off; }
+    unsigned excl = (unsigned)block_excl_scan((int)sum, s_w, total);
+    if (excl < remaining && excl + sum >= remaining) {
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (excl < remaining && excl + h[i] >= remaining) {
+                s_out[0] = (unsigned)(NB - 1 - (t * BPT + i));
+                s_out[1] = remaining - excl;
+            }
+            excl += h[i];
         }
     }
-    if (t == 0) A.g_ccount[(size_t)pair * A.S + sl] = total;
+    __syncthreads();
+}
+// digits found by the passes before PASS: prefix (key bits above this pass's digit) and the rank still to find.  Every workgroup
+// derives them from the completed histograms of the earlier launches; ALL their bins are fetched before the first scan so that the
+// levels cost one load latency, not one each (a ticketed "last workgroup finds the digit" variant needs an agent-scope release and
+// acquire per workgroup -- an L2 write-back and invalidate each -- and measured 1.5x slower per pass, 5x on 8 tiles).
+template <int PASS>
+__device__ __forceinline__ void ph_levels(const ProcArgs& A, int pair, unsigned K, int* s_w, unsigned* s_out, unsigned& prefix,
+                                          unsigned& remaining) {
+    constexpr int BPT = PH_BINS / 1024;
+    const int t = threadIdx.x;
+    const unsigned* gh = A.g_hist + (size_t)pair * 3 * PH_BINS;
+    unsigned h0[BPT], h1[BPT], h2[1];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+        h0[i] = PASS > 0 ? gh[PH_BINS - 1 - (t * BPT + i)] : 0u;
+        h1[i] = PASS > 1 ? gh[PH_BINS + PH_BINS - 1 - (t * BPT + i)] : 0u;
+    }
+    h2[0] = (PASS > 2 && t < PH_LAST) ? gh[2 * PH_BINS + PH_LAST - 1 - t] : 0u;
+    prefix = 0; remaining = K;
+    if (PASS > 0) {
+        ph_find_bin<PH_BINS, BPT>(h0, remaining, s_w, s_out);
+        prefix |= s_out[0] << ph_shift(0); remaining = s_out[1];
+        __syncthreads();
+    }
+    if (PASS > 1) {
+        ph_find_bin<PH_BINS, BPT>(h1, remaining, s_w, s_out);
+        prefix |= s_out[0] << ph_shift(1); remaining = s_out[1];
+        __syncthreads();
+    }
+    if (PASS > 2) {
+        ph_find_bin<PH_LAST, 1>(h2, remaining, s_w, s_out);
+        prefix |= s_out[0] << ph_shift(2); remaining = s_out[1];
+        __syncthreads();
+    }
+}
+template <int PASS>
+__global__ __launch_bounds__(1024) void proc_hist_kernel(ProcArgs A) {
+    __shared__ unsigned s_h[PH_BINS];
+    __shared__ int s_w[16];
+    __shared__ unsigned s_out[2];
+    __shared__ int s_len[2];
+    __shared__ unsigned s_above;
+    const int pair = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+    const int NM = A.N * A.M;
+    const float* conf = A.conf + (size_t)pair * NM;
+    // sweeps of 1024 entries, 8 at a time in registers; the first 8 loads are issued before the levels are derived (both wait on memory)
+    const int s0 = sl * A.SL, s1 = min(NM, s0 + A.SL);
+    auto load8 = [&](int c, unsigned (&k)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = s0 + (c * 8 + i) * 1024 + t;
+            k[i] = e < s1 ? order_key(conf[e]) : 0u;
+        }
+    };
+    unsigned ka[8], kb[8];
+    load8(0, ka);
+    const int K = proc_topk_count(A, pair, s_len);
+    unsigned prefix, remaining;
+    ph_levels<PASS>(A, pair, (unsigned)K, s_w, s_out, prefix, remaining);
+    constexpr unsigned mask = PASS == 0 ? 0u : (PASS == 1 ? 0xFFF00000u : 0xFFFFFF00u);
+    for (int b = t; b < PH_BINS; b += 1024) s_h[b] = 0u;
+    if (t == 0) s_above = 0u;
+    __syncthreads();
+    constexpr int shift = ph_shift(PASS);
+    constexpr unsigned bmask = ph_bins(PASS) - 1u;
+    // run-length accumulation per thread: flat or heavily tied tiles put every key in one bin (1024 serialised LDS atomics per sweep)
+    unsigned cur = 0xFFFFFFFFu, run = 0, above = 0;
+    auto tally = [&](const unsigned (&kk)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned k = kk[i];
+            if (PASS == 2) above += (k & mask) > prefix ? 1u : 0u;
+            if (k != 0u && (k & mask) == prefix) {
+                const unsigned b = (k >> shift) & bmask;
+                if (b != cur) {
+                    if (run) atomicAdd(&s_h[cur], run);
+                    cur = b; run = 0;
+                }
+                ++run;
+            }
+        }
+    };
+    const int nchunk = (A.SL / 1024 + 7) / 8;
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) load8(c + 1, kb);
+        tally(ka);
+        if (c + 1 < nchunk) {
+            if (c + 2 < nchunk) load8(c + 2, ka);
+            tally(kb);
+        }
+    }
+    if (run) atomicAdd(&s_h[cur], run);
+    if (PASS == 2) {
+        above = wave_sum(above);
+        if ((t & 63) == 0 && above) atomicAdd(&s_above, above);
+    }
+    __syncthreads();
+    unsigned* gh = A.g_hist + ((size_t)pair * 3 + PASS) * PH_BINS;
+    for (int b = t; b < (int)ph_bins(PASS); b += 1024) {
+        const unsigned c = s_h[b];
+        if (c) atomicAdd(&gh[b], c);
+    }
+    if (PASS == 2) {
+        // per slice, per last digit b: {keys of the slice above (prefix, b), keys equal to it}; thread d owns bin PH_LAST-1-d
+        const int bin = PH_LAST - 1 - t;
+        const unsigned c = bin >= 0 ? s_h[bin] : 0u;
+        int total;
+        const unsigned gt = (unsigned)block_excl_scan((int)c, s_w, total) + s_above;
+        if (bin >= 0) A.g_shist[((size_t)pair * A.S + sl) * PH_LAST + bin] = make_uint2(gt, c);
+    }
+}
+// entries of a slice in (wave, sweep, lane) order: wave w owns the contiguous SL/16 entries from s0 + w SL/16 (SL is a multiple of 1024)
+template <bool CACHED>
+__global__ __launch_bounds__(1024) void proc_take_kernel(ProcArgs A) {
+    __shared__ int s_w[16];
+    __shared__ unsigned s_out[2];
+    __shared__ int s_len[2];
+    __shared__ unsigned s_wg[16], s_we[16];
+    const int pair = blockIdx.y, sl = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int NM = A.N * A.M;
+    const float* conf = A.conf + (size_t)pair * NM;
+    const int WL = A.SL >> 4, IT = WL >> 6;                      // entries per wave, sweeps
+    const int base = sl * A.SL + w * WL + lane;
+    unsigned kc[CACHED ? 32 : 1];
+    auto key_at = [&](int it) -> unsigned {
+        const int e = base + it * 64;
+        return e < NM ? order_key(conf[e]) : 0u;
+    };
+    if (CACHED) {                                                 // issued before the levels are derived (both wait on memory)
+#pragma unroll
+        for (int it = 0; it < 32; ++it) kc[it] = it < IT ? key_at(it) : 0u;
+    }
+    const int K = proc_topk_count(A, pair, s_len);
+    unsigned tau, remaining;                                      // the K-th largest key; `remaining` of the entries equal to it are taken
+    ph_levels<3>(A, pair, (unsigned)K, s_w, s_out, tau, remaining);
+    // selected entries (above tau) and ties in the slices in front of this one
+    unsigned gt_before = 0, eq_before = 0;
+    for (int q = lane; q < sl; q += 64) {
+        const uint2 v = A.g_shist[((size_t)pair * A.S + q) * PH_LAST + (tau & (PH_LAST - 1u))];
+        gt_before += v.x; eq_before += v.y;
+    }
+    gt_before = wave_sum(gt_before);
+    eq_before = wave_sum(eq_before);
+    // f(key, sweep) over the wave's entries in order; beyond 32 sweeps the keys are re-read, 8 loads in flight
+    auto sweep_all = [&](auto&& f) {
+        if (CACHED) {
+#pragma unroll
+            for (int it = 0; it < 32; ++it) if (it < IT) f(kc[it], it);
+        } else {
+            for (int c = 0; c < IT; c += 8) {
+                unsigned k8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) k8[i] = c + i < IT ? key_at(c + i) : 0u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (c + i < IT) f(k8[i], c + i);
+            }
+        }
+    };
+    unsigned cg = 0, ce = 0;
+    sweep_all([&](unsigned k, int) { cg += k > tau ? 1u : 0u; ce += (k == tau && k != 0u) ? 1u : 0u; });
+    cg = wave_sum(cg);
+    ce = wave_sum(ce);
+    if (lane == 0) { s_wg[w] = cg; s_we[w] = ce; }
+    __syncthreads();
+    unsigned gtB = gt_before, eqB = eq_before, gtT = 0, eqT = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) { gtB += s_wg[k]; eqB += s_we[k]; }
+        gtT += s_wg[k]; eqT += s_we[k];
+    }
+    const unsigned rem = K > 0 ? remaining : 0u;
+    // position of this wave's first selected entry: everything above tau in front of it + the ties already handed out
+    unsigned pos = gtB + (eqB < rem ? eqB : rem);
+    unsigned* ck = A.g_ckey + (size_t)pair * PC_CAP;
+    int* ci = A.g_cidx + (size_t)pair * PC_CAP;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto place = [&](unsigned k, int it) {
+        const bool eq = k == tau && k != 0u;
+        const unsigned long long beq = __ballot(eq);
+        const bool sel = K > 0 && (k > tau || (eq && eqB + (unsigned)__popcll(beq & lt) < rem));
+        const unsigned long long bsel = __ballot(sel);
+        if (sel) {
+            const unsigned o = pos + (unsigned)__popcll(bsel & lt);
+            if (o < (unsigned)PC_CAP) { ck[o] = k; ci[o] = base + it * 64; }
+        }
+        pos += (unsigned)__popcll(bsel);
+        eqB += (unsigned)__popcll(beq);
+    };
+    sweep_all(place);
+    if (sl == A.S - 1 && t == 0) {
+        const unsigned e_all = eq_before + eqT;
+        A.g_ccount[pair] = K > 0 ? (int)(gt_before + gtT + (e_all < rem ? e_all : rem)) : 0;
+    }
 }
 
 // REG: the tile (N*M <= 65536) is read ONCE and kept as 64 ordered keys per thread.  !REG: every pass
@@ -311,30 +487,16 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     PROC_STAMP(1);
     if (K > 0) {
         // ---- level 1: lower bound L from the per-thread maxima ---------------------------------------------
-        unsigned tmax = 0;
-        for_each([&](unsigned k, int) { tmax = k > tmax ? k : tmax; });
         unsigned L = 0, dummy;
         int ncand = NM;
         if (!REG && A.g_ckey) {
-            // candidates were compacted by proc_compact_kernel: concatenate the slices (index order)
-            int tot = 0;
-            bool over = false;
-            for (int q = 0; q < A.S; ++q) {
-                const int cq = A.g_ccount[(size_t)pair * A.S + q];
-                over = over || cq > PC_CAP;
-                tot += cq;
-            }
-            if (!over && tot <= CAND_MAX && tot >= K) {
+            // the K selected entries were written by proc_take_kernel, in index order
+            const int tot = A.g_ccount[pair];
+            if (tot == K && tot <= CAND_MAX) {
                 ncand = tot;
                 for (int c = t; c < tot; c += 1024) {
-                    int q = 0, base = 0;
-                    for (;; ++q) {
-                        const int cq = A.g_ccount[(size_t)pair * A.S + q];
-                        if (c < base + cq) break;
-                        base += cq;
-                    }
-                    s_ckey[c] = A.g_ckey[((size_t)pair * A.S + q) * PC_CAP + (c - base)];
-                    s_cidx[c] = A.g_cidx[((size_t)pair * A.S + q) * PC_CAP + (c - base)];
+                    s_ckey[c] = A.g_ckey[(size_t)pair * PC_CAP + c];
+                    s_cidx[c] = A.g_cidx[(size_t)pair * PC_CAP + c];
                 }
             }
             __syncthreads();
@@ -342,6 +504,8 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
             // (threads whose slice is empty have tmax = 0 and are not enumerated; K <= #non-empty is
             //  guaranteed when K <= min(NM, 1024) because slices are filled round-robin)
             // two 8-bit digits suffice for a bound: L = the 16-bit bucket of the K-th largest thread maximum
+            unsigned tmax = 0;
+            for_each([&](unsigned k, int) { tmax = k > tmax ? k : tmax; });
             radix_select<2>([&](auto&& f) { f(tmax, 0); }, (unsigned)K, s_hist, s_pr, L, dummy);
             int c = 0;
             for_each([&](unsigned k, int) { c += (k >= L && k != 0u) ? 1 : 0; });
@@ -495,16 +659,24 @@ int read_proc_stamps(long long* h_out) {
     return DR_OK;
 }
 
-static int proc_slices(long NM) {
-    long S = (NM + 16383) / 16384;
-    return (int)(S > 64 ? 64 : S);
+// slices of a large tile: a workgroup of the selection passes each, about 512 of them over the batch (all co-resident: the levels'
+// preamble is paid once, not once per round), at most 256 per tile, of a multiple of 1024 entries (32768 or fewer keep the take pass's
+// keys in registers)
+static int proc_slice_len(int P, long NM) {
+    long S = 512 / (P > 0 ? P : 1);
+    S = S < 1 ? 1 : (S > 256 ? 256 : S);
+    long SL = (NM + S - 1) / S;
+    SL = (SL + 1023) / 1024 * 1024;
+    return (int)(SL < 4096 ? 4096 : SL);
 }
-
+static size_t proc_zeroed_bytes(int P) { return (size_t)P * 3 * PH_BINS * 4; }
 size_t procrustes_workspace_bytes(int P, int N, int M) {
     const long NM = (long)N * M;
     if (P <= 0 || NM <= 65536) return 0;
-    const size_t S = proc_slices(NM);
-    return (size_t)P * (PC_NCELL * 4 + S * PC_CAP * 8 + S * 4) + 256;
+    const long SL = proc_slice_len(P, NM);
+    const size_t S = (size_t)((NM + SL - 1) / SL);
+    // the list (keys, indices), its length, digit histograms, per-slice {above, equal} tables
+    return (size_t)P * (PC_CAP * 8 + S * PH_LAST * 8) + (((size_t)P * 4 + 255) & ~(size_t)255) + proc_zeroed_bytes(P) + 512;
 }
 
 int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_pcd, const uint8_t* src_mask,
@@ -521,24 +693,31 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
     // K = int(int(max(len_s, len_t) * rate))  with float32 arithmetic (procrustes.py:63-65)
     a.K_fixed = (int)((float)(N > M ? N : M) * sample_rate);
     if (a.K_fixed > PK_MAX) return DR_ENOSUP;
-    a.cellmax = nullptr; a.g_ckey = nullptr; a.g_cidx = nullptr; a.g_ccount = nullptr; a.S = a.SL = a.CL = 0;
+    a.g_ckey = nullptr; a.g_cidx = nullptr; a.g_ccount = nullptr; a.g_hist = nullptr; a.g_shist = nullptr; a.S = a.SL = 0;
     ProfScope ps(PK_PROCRUSTES, (double)P * N * M * 4.0, st);
     const long NM = (long)N * M;
     if (NM <= 65536) {
         hipLaunchKernelGGL(procrustes_kernel<true>, dim3(P), dim3(1024), 0, st, a);
     } else {
         if (ws && ws_bytes >= procrustes_workspace_bytes(P, N, M)) {
-            a.S = proc_slices(NM);
-            a.SL = (int)((NM + a.S - 1) / a.S);
-            a.CL = (int)((NM + PC_NCELL - 1) / PC_NCELL);
+            a.SL = proc_slice_len(P, NM);
+            a.S = (int)((NM + a.SL - 1) / a.SL);
             char* w8 = (char*)ws;
-            a.cellmax = (unsigned*)w8; w8 += (size_t)P * PC_NCELL * 4;
-            a.g_ckey = (unsigned*)w8; w8 += (size_t)P * a.S * PC_CAP * 4;
-            a.g_cidx = (int*)w8; w8 += (size_t)P * a.S * PC_CAP * 4;
-            a.g_ccount = (int*)w8;
-            hipLaunchKernelGGL(proc_cellmax_kernel, dim3(PC_NCELL / 16, P), dim3(256), 0, st, a);
+            a.g_ckey = (unsigned*)w8; w8 += (size_t)P * PC_CAP * 4;
+            a.g_cidx = (int*)w8; w8 += (size_t)P * PC_CAP * 4;
+            a.g_ccount = (int*)w8; w8 += ((size_t)P * 4 + 255) & ~(size_t)255;
+            a.g_hist = (unsigned*)w8;
+            DR_HIP_CHECK(hipMemsetAsync(a.g_hist, 0, proc_zeroed_bytes(P), st));
+            w8 += proc_zeroed_bytes(P);
+            a.g_shist = (uint2*)w8;
+            hipLaunchKernelGGL(proc_hist_kernel<0>, dim3(a.S, P), dim3(1024), 0, st, a);
             DR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(proc_compact_kernel, dim3(a.S, P), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL(proc_hist_kernel<1>, dim3(a.S, P), dim3(1024), 0, st, a);
+            DR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(proc_hist_kernel<2>, dim3(a.S, P), dim3(1024), 0, st, a);
+            DR_LAUNCH_CHECK();
+            if (a.SL <= 32768) hipLaunchKernelGGL(proc_take_kernel<true>, dim3(a.S, P), dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL(proc_take_kernel<false>, dim3(a.S, P), dim3(1024), 0, st, a);
             DR_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(procrustes_kernel<false>, dim3(P), dim3(1024), 0, st, a);

@@ -200,6 +200,52 @@ def test_procrustes_thin_tile_more_than_1024_selected():
         np.testing.assert_allclose(t[b].cpu().numpy(), r[1][0].numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize("N,M", [(1024, 2048), (1500, 1500), (300, 700)])
+@pytest.mark.parametrize("kind", ["distinct", "quantised", "flat", "sparse"])
+def test_procrustes_large_tile_exact_selection(N, M, kind):
+    """Tiles beyond 256 x 256 select their K entries with the whole chip (three digit-histogram passes + an ordered take pass,
+    procrustes.hip).  Bit-exact index work: the selected VALUES are torch.topk's (procrustes.py:66), no index twice, and among the
+    entries equal to the K-th value the lowest indices are the ones taken (the rule the one-workgroup kernels follow; torch.topk
+    leaves it implementation-defined).  `quantised` (16 levels) and `flat` overflow any bounded candidate list; `sparse` has fewer
+    non-zero entries than K."""
+    from diffreg_hip import lib
+    P = 2
+    g = torch.Generator().manual_seed(N + M)
+    conf = torch.rand(P, N, M, generator=g)
+    if kind == "quantised":
+        conf = (conf * 16).floor() / 16
+    elif kind == "flat":
+        conf = torch.full((P, N, M), 1.0 / M)
+    elif kind == "sparse":
+        conf = torch.where(conf > 0.9997, conf, torch.zeros(()))
+    ps = torch.rand(P, N, 3, generator=g)
+    pt = torch.rand(P, M, 3, generator=g)
+    sm, tm = torch.ones(P, N, dtype=torch.bool), torch.ones(P, M, dtype=torch.bool)
+    sm[1, N - 37:] = False
+    for use_len in (False, True):
+        R, t, Rf, tf, cond, ok, idx = lib.procrustes(conf.to(DEV), ps.to(DEV), pt.to(DEV), sm.to(DEV), tm.to(DEV), 1.0, 1e9,
+                                                     use_mask_len=use_len, want_topk=True)
+        for b in range(P):
+            K = max(N, M) if not use_len else max(int(sm[b].sum()), int(tm[b].sum()))
+            flat = conf[b].reshape(-1)
+            top = flat.topk(K)[0]
+            got = idx[b, :K].cpu().long()
+            assert got.unique().numel() == K
+            assert flat[got].sort(descending=True)[0].equal(top)
+            kth = top[-1]
+            n_ties = int((top == kth).sum())
+            tie_idx = (flat == kth).nonzero()[:, 0][:n_ties]                     # the lowest indices among the ties
+            assert got[flat[got] == kth].sort()[0].equal(tie_idx)
+            if kind == "flat":
+                continue                                                           # rank-deficient fit: nothing to compare
+            r = orc.procrustes(conf[b:b + 1], ps[b:b + 1], pt[b:b + 1], sm[b:b + 1], tm[b:b + 1], 1.0, 1e9,
+                               variant="4dmatch" if use_len else "3dmatch") \
+                if kind == "distinct" else None
+            if r is not None:
+                np.testing.assert_allclose(R[b].cpu().numpy(), r[0][0].numpy(), atol=1e-4)
+                np.testing.assert_allclose(t[b].cpu().numpy(), r[1][0].numpy(), atol=1e-4)
+
+
 @pytest.mark.parametrize("N,M", [(128, 128), (96, 80), (256, 256), (33, 500)])
 def test_top1_union(N, M):
     from diffreg_hip import lib
