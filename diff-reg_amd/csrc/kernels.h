@@ -141,9 +141,11 @@ int launch_ddim(const DdimArgs& a, int P, hipStream_t st);
 int launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t st);
 int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t st);
 int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st);
+// ws (optional, top1_union_workspace_bytes): arg-maxima with the whole chip (row blocks) instead of one workgroup per pair
+size_t top1_union_workspace_bytes(int P, int N, int M, size_t elt);
 template <typename T>
 int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st, const uint8_t* sm = nullptr,
-                      const uint8_t* tm = nullptr);
+                      const uint8_t* tm = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
 
 // collate.hip: in-place bitonic sort of (key, value) pairs ascending by (key, value); n_pad = a power of two (pad keys ~0ull sort last)
 int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hipStream_t st);

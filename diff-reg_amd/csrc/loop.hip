@@ -729,13 +729,25 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
 /* diagnostics: wall-clock phase stamps (100 MHz ticks) of the last dr_procrustes launch, pair 0 */
 int dr_debug_procrustes_stamps(long long* h_out8) { return read_proc_stamps(h_out8); }
 
+}  // extern "C"
+// stream-ordered scratch for the stand-alone entries (nothing cached across calls)
+template <typename T>
+static int top1_union_scratch(const T* conf, int P, int N, int M, int64_t* matches, int32_t* count, hipStream_t st) {
+    const size_t wsb = top1_union_workspace_bytes(P, N, M, sizeof(T));
+    void* ws = nullptr;
+    if (wsb) DR_HIP_CHECK(hipMallocAsync(&ws, wsb, st));
+    const int rc = launch_top1_union<T>(conf, P, N, M, (long long*)matches, count, st, nullptr, nullptr, ws, wsb);
+    if (ws) DR_HIP_CHECK(hipFreeAsync(ws, st));
+    return rc;
+}
+extern "C" {
 int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream) {
     if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
-    return launch_top1_union<double>(conf, P, N, M, (long long*)matches, count, (hipStream_t)stream);
+    return top1_union_scratch<double>(conf, P, N, M, matches, count, (hipStream_t)stream);
 }
 int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream) {
     if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
-    return launch_top1_union<float>(conf, P, N, M, (long long*)matches, count, (hipStream_t)stream);
+    return top1_union_scratch<float>(conf, P, N, M, matches, count, (hipStream_t)stream);
 }
 
 static int check_cfg(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M) {
@@ -920,7 +932,8 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
                           conf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
         if (matches) {
-            rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st, rsm, rtm);
+            // (the steps' x0 tile is free by now; the row-block arg-maxima need < N M floats)
+            rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st, rsm, rtm, L.x0, NM * 4);
             if (rc) return rc;
         }
     }

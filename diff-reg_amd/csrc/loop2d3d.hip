@@ -239,7 +239,8 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
     rc = sinkhorn_f64(P, N, M, L.x, nullptr, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict, conf,
                       L.skws, L.skws_bytes, st);
     if (rc) return rc;
-    if (matches) rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st);
+    // (the steps' x0 tile is free by now; the row-block arg-maxima need < N M floats)
+    if (matches) rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st, nullptr, nullptr, L.x0, NM * 4);
     return rc;
 }
 

@@ -166,16 +166,76 @@ int launch_sigmoid(const double* in, double* out, size_t n, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // top-1 union: True at (i, argmax_j conf_ij) for every row and (argmax_i conf_ij, j) for every
-// column, listed row-major as [0, i, j] (int64).  One workgroup per pair; the <= N + M hits are
-// bitonic-sorted by flat index in LDS and de-duplicated.  First occurrence wins a tie.
+// column, listed row-major as [0, i, j] (int64).  The <= N + M hits are bitonic-sorted by flat index
+// in LDS and de-duplicated (one workgroup per pair).  First occurrence wins a tie.
+// With a workspace the arg-maxima come from the whole chip: workgroups of T1_ROWS rows leave the row
+// arg-maxima and, per column, the arg-maximum over their rows; the pair's workgroup merges the row
+// blocks in order.  (One workgroup reading a 1024 x 2048 f64 tile twice took 2.0 ms, 12% of the
+// 2D-3D loop; a 256 x 256 tile 144 us.)
 // ---------------------------------------------------------------------------------------------
 constexpr int T1_MAX = 4096;   // N + M <= T1_MAX
+constexpr int T1_ROWS = 16;    // rows per workgroup of the chip-wide pass (one wave per row)
+
+// s_key[0 .. N+M) = flat indices of the hits (0xFFFFFFFF = none): sort, drop duplicates, write [0, i, j] rows and the count
+__device__ __forceinline__ void top1_emit(unsigned* s_key, int* s_w, int N, int M, long long* __restrict__ o, int* __restrict__ cnt) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int n2 = 1;
+    while (n2 < N + M) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // ordered compaction of the distinct keys: thread t owns entries 4t .. 4t+3 (T1_MAX = 4 x 1024)
+    unsigned k4[4];
+    bool keep[4];
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * t + q;
+        k4[q] = i < n2 ? s_key[i] : 0xFFFFFFFFu;
+        const unsigned prev = (i > 0 && i < n2) ? s_key[i - 1] : 0xFFFFFFFFu;
+        keep[q] = k4[q] != 0xFFFFFFFFu && (i == 0 || k4[q] != prev);
+        c += keep[q] ? 1 : 0;
+    }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int v = s_w[k];
+        if (k < w) base += v;
+        tot += v;
+    }
+    int n = base + incl - c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (keep[q]) {
+            o[n * 3] = 0; o[n * 3 + 1] = k4[q] / M; o[n * 3 + 2] = k4[q] % M;
+            ++n;
+        }
+    if (t == 0) *cnt = tot;
+}
 
 template <typename T>
 __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ conf, int N, int M, long long* __restrict__ out,
                                                           int* __restrict__ count, const uint8_t* __restrict__ smask,
                                                           const uint8_t* __restrict__ tmask) {
     __shared__ unsigned s_key[T1_MAX];
+    __shared__ int s_w[16];
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const T* c = conf + (size_t)pair * N * M;
     // masks (nullable): rows / columns outside them do not exist (DR_LOOP_RAGGED)
@@ -210,49 +270,107 @@ __global__ __launch_bounds__(1024) void top1_union_kernel(const T* __restrict__ 
         if (bi >= 0) s_key[N + j] = (unsigned)(bi * M + j);
     }
     __syncthreads();
-    int n2 = 1;
-    while (n2 < N + M) n2 <<= 1;
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < n2; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned a = s_key[i], b = s_key[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    if (t == 0) {
-        int n = 0;
-        unsigned prev = 0xFFFFFFFFu;
-        long long* o = out + (size_t)pair * (N + M) * 3;
-        for (int i = 0; i < N + M; ++i) {
-            const unsigned k = s_key[i];
-            if (k == 0xFFFFFFFFu) break;
-            if (k != prev) {
-                o[n * 3] = 0; o[n * 3 + 1] = k / M; o[n * 3 + 2] = k % M;
-                ++n;
-                prev = k;
-            }
-        }
-        count[pair] = n;
+    top1_emit(s_key, s_w, N, M, out + (size_t)pair * (N + M) * 3, count + pair);
+}
 
+// chip-wide pass: workgroup (rb, pair) owns rows [rb T1_ROWS, ..+T1_ROWS): same comparisons as above, restricted to its rows
+template <typename T>
+__global__ __launch_bounds__(1024) void top1_block_kernel(const T* __restrict__ conf, int N, int M, unsigned* __restrict__ rowkey,
+                                                          T* __restrict__ colval, int* __restrict__ colrow,
+                                                          const uint8_t* __restrict__ smask, const uint8_t* __restrict__ tmask) {
+    const int pair = blockIdx.y, rb = blockIdx.x, NB = gridDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const T* c = conf + (size_t)pair * N * M;
+    const uint8_t* sm = smask ? smask + (size_t)pair * N : nullptr;
+    const uint8_t* tm = tmask ? tmask + (size_t)pair * M : nullptr;
+    const int i0 = rb * T1_ROWS, i1 = min(N, i0 + T1_ROWS);
+    {
+        const int i = i0 + w;
+        if (i < i1) {
+            unsigned key = 0xFFFFFFFFu;
+            if (!(sm && !sm[i])) {
+                T best = -INFINITY; int bj = 0x7fffffff;
+                for (int j = lane; j < M; j += 64) {
+                    if (tm && !tm[j]) continue;
+                    const T v = c[(size_t)i * M + j];
+                    if (v > best || (v == best && j < bj) || bj == 0x7fffffff) { best = v; bj = j; }
+                }
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const T ov = __shfl_xor(best, m); const int oj = __shfl_xor(bj, m);
+                    if (ov > best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+                }
+                key = (unsigned)(i * M + bj);
+            }
+            if (lane == 0) rowkey[(size_t)pair * N + i] = key;
+        }
     }
+    for (int j = t; j < M; j += 1024) {
+        T best = -INFINITY; int bi = -1;
+        if (!(tm && !tm[j])) {
+            T v[T1_ROWS];
+#pragma unroll
+            for (int r = 0; r < T1_ROWS; ++r) v[r] = i0 + r < i1 ? c[(size_t)(i0 + r) * M + j] : (T)0;
+#pragma unroll
+            for (int r = 0; r < T1_ROWS; ++r) {
+                if (i0 + r >= i1 || (sm && !sm[i0 + r])) continue;
+                if (v[r] > best || bi < 0) { best = v[r]; bi = i0 + r; }
+            }
+        }
+        colval[((size_t)pair * NB + rb) * M + j] = best;
+        colrow[((size_t)pair * NB + rb) * M + j] = bi;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void top1_merge_kernel(int N, int M, int NB, const unsigned* __restrict__ rowkey,
+                                                          const T* __restrict__ colval, const int* __restrict__ colrow,
+                                                          long long* __restrict__ out, int* __restrict__ count) {
+    __shared__ unsigned s_key[T1_MAX];
+    __shared__ int s_w[16];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < T1_MAX; i += 1024) s_key[i] = i < N ? rowkey[(size_t)pair * N + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int j = t; j < M; j += 1024) {
+        T best = -INFINITY; int bi = -1;
+        for (int q = 0; q < NB; ++q) {                           // row blocks in order: the first row that attains the maximum wins
+            const T v = colval[((size_t)pair * NB + q) * M + j];
+            const int r = colrow[((size_t)pair * NB + q) * M + j];
+            if (r >= 0 && (v > best || bi < 0)) { best = v; bi = r; }
+        }
+        if (bi >= 0) s_key[N + j] = (unsigned)(bi * M + j);
+    }
+    __syncthreads();
+    top1_emit(s_key, s_w, N, M, out + (size_t)pair * (N + M) * 3, count + pair);
+}
+
+size_t top1_union_workspace_bytes(int P, int N, int M, size_t elt) {
+    if (P <= 0 || N < 2 * T1_ROWS) return 0;                     // a single row block: the one-workgroup kernel is the same work
+    const size_t NB = (size_t)(N + T1_ROWS - 1) / T1_ROWS;
+    return (size_t)P * NB * M * (elt + 4) + (((size_t)P * N * 4 + 15) & ~(size_t)15) + 64;
 }
 
 template <typename T>
 int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* count, hipStream_t st, const uint8_t* sm,
-                      const uint8_t* tm) {
+                      const uint8_t* tm, void* ws, size_t ws_bytes) {
     if (P <= 0) return DR_OK;
     if (N + M > T1_MAX || (long)N * M >= 0xFFFFFFFFL) return DR_ENOSUP;
     if (!(sm && tm)) sm = tm = nullptr;
+    const size_t need = top1_union_workspace_bytes(P, N, M, sizeof(T));
+    if (ws && need && ws_bytes >= need) {
+        const int NB = (N + T1_ROWS - 1) / T1_ROWS;
+        char* w8 = (char*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+        T* colval = (T*)w8; w8 += (size_t)P * NB * M * sizeof(T);
+        int* colrow = (int*)w8; w8 += (size_t)P * NB * M * 4;
+        unsigned* rowkey = (unsigned*)w8;
+        hipLaunchKernelGGL((top1_block_kernel<T>), dim3(NB, P), dim3(1024), 0, st, conf, N, M, rowkey, colval, colrow, sm, tm);
+        DR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((top1_merge_kernel<T>), dim3(P), dim3(1024), 0, st, N, M, NB, rowkey, colval, colrow, out, count);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
     hipLaunchKernelGGL((top1_union_kernel<T>), dim3(P), dim3(1024), 0, st, conf, N, M, out, count, sm, tm);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
-template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
+template int launch_top1_union<float>(const float*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*, void*, size_t);
 // ---------------------------------------------------------------------------------------------
 // Matching.get_match(conf, thr, mutual=True) (3D/models/matching.py:126-143; the read-out the 4DMatch tester applies to
 // conf_matrix_pred, 4D/lib/tester.py:266): entries that are > thr AND equal to their row maximum AND equal to their column
@@ -350,7 +468,7 @@ int dr_mutual_match_f32(int P, int N, int M, const float* conf, float thr, int m
 }
 namespace dr {
 
-template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*);
+template int launch_top1_union<double>(const double*, int, int, int, long long*, int*, hipStream_t, const uint8_t*, const uint8_t*, void*, size_t);
 
 }  // namespace dr
 

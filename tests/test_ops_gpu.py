@@ -246,8 +246,10 @@ def test_procrustes_large_tile_exact_selection(N, M, kind):
                 np.testing.assert_allclose(t[b].cpu().numpy(), r[1][0].numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("N,M", [(128, 128), (96, 80), (256, 256), (33, 500)])
+@pytest.mark.parametrize("N,M", [(128, 128), (96, 80), (256, 256), (33, 500), (20, 100), (1024, 2048), (1500, 1500), (1000, 3)])
 def test_top1_union(N, M):
+    """From 32 rows on the arg-maxima come from row-block workgroups over the whole chip (stateops.hip), below that from one
+    workgroup per pair; both list exactly the reference's set, first occurrence winning ties (`quantised`: 8 levels)."""
     from diffreg_hip import lib
     conf = T(synth.hash_u01(8, N * M, N * M)).reshape(1, N, M)
     ref = orc.top1_union(conf[0])
@@ -255,3 +257,8 @@ def test_top1_union(N, M):
     assert torch.equal(got, ref)
     got32 = lib.top1_union(conf.float().to(DEV))[0].cpu()
     assert torch.equal(got32, orc.top1_union(conf[0].float()))
+    quant = torch.stack([(conf[0] * 8).floor() / 8, conf[0].flip(0)])           # a batch of two different tiles
+    got = lib.top1_union(quant.to(DEV))
+    for b in range(2):
+        ref = orc.top1_union(quant[b])
+        assert torch.equal(got[b].cpu(), ref)
