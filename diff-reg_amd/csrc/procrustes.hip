@@ -464,10 +464,9 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     if (K > PK_MAX) K = PK_MAX;
     __syncthreads();
 
-    double acc[16];
     int n_listed = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    // the sums are zeroed only when the selection is done: 32 live registers less while the 64 keys are
+    double acc[16];
     const float* Xs = A.src_pcd + (size_t)pair * N * 3;
     const float* Ys = A.tgt_pcd + (size_t)pair * M * 3;
     auto take = [&](unsigned k, int e) {
@@ -483,7 +482,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         acc[13] += wv * y2 * x0; acc[14] += wv * y2 * x1; acc[15] += wv * y2 * x2;
         if (A.topk_idx) A.topk_idx[(size_t)pair * K + atomicAdd(&s_nsel, 1)] = e;
     };
-
     PROC_STAMP(1);
     if (K > 0) {
         // ---- level 1: lower bound L from the per-thread maxima ---------------------------------------------
@@ -503,10 +501,12 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         } else if (K <= 1024) {
             // (threads whose slice is empty have tmax = 0 and are not enumerated; K <= #non-empty is
             //  guaranteed when K <= min(NM, 1024) because slices are filled round-robin)
-            // two 8-bit digits suffice for a bound: L = the 16-bit bucket of the K-th largest thread maximum
+            // L = the K-th largest thread maximum, all four digits (round 3: the 16-bit bucket of rounds 1-2 admitted the whole
+            // near-uniform background of the sharp late-step matrices -- K-th falls into it as soon as two large entries share a
+            // thread -- and sent the last four steps of every run to the 60 us dearer exact select below; +1.1 us here)
             unsigned tmax = 0;
             for_each([&](unsigned k, int) { tmax = k > tmax ? k : tmax; });
-            radix_select<2>([&](auto&& f) { f(tmax, 0); }, (unsigned)K, s_hist, s_pr, L, dummy);
+            radix_select<4>([&](auto&& f) { f(tmax, 0); }, (unsigned)K, s_hist, s_pr, L, dummy);
             int c = 0;
             for_each([&](unsigned k, int) { c += (k >= L && k != 0u) ? 1 : 0; });
             int off = block_excl_scan(c, s_w, ncand);
@@ -525,32 +525,74 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         PROC_STAMP(2);
         unsigned tau = 0, remaining = 0;
         if (ncand > CAND_MAX) {
-            // ---- fallback: radix select over the whole tile, then compact the K selected entries ------------
-            // (rare path: streams the tile from memory so that its branchy code is not unrolled 64x)
+            // ---- fallback: exact select over the whole tile, then compact the K selected entries ------------
             auto for_mem = [&](auto&& f) {
                 for (int e = t; e < NM; e += 1024) f(order_key(conf[e]), e);
             };
-            unsigned ftau, frem;
-            radix_select(for_mem, (unsigned)K, s_hist, s_pr, ftau, frem);
+            unsigned ftau = 0, frem;
             int cg = 0, ce = 0;
-            for_mem([&](unsigned k, int) {
-                cg += k > ftau ? 1 : 0;
-                ce += (k == ftau && k != 0u) ? 1 : 0;
-            });
+            if (REG) {
+                // the K-th largest key by bisection on its bits, from the registers: ftau = the largest v with #(key >= v) >= K.
+                // 32 rounds of 64 wave-wide compares, one barrier each, whatever the values
+                // (the digit histograms of radix_select serialise on a few hot LDS bins for exactly the tiles that end up here:
+                // sharp late-step matrices whose K large entries share threads, flat early ones; it cost 75 us)
+                unsigned* s_cnt = s_hist;                         // [2][16] wave counts, double-buffered
+                for (int b = 31; b >= 0; --b) {
+                    const unsigned cand = ftau | (1u << b);
+                    // half of the keys counted by the scalar unit (lane mask -> s_bcnt1 -> s_add: the CU's ONE scalar unit serves all
+                    // 16 waves), half by the vector unit (compare + add-with-carry per lane, one wave sum per round)
+                    unsigned c = 0, cv = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        c += (unsigned)__popcll(__ballot(key[i] >= cand));
+                        cv += key[32 + i] >= cand ? 1u : 0u;
+                        // (left alone the counts sink into the `lane == 0` branch below and the lane masks they need are kept
+                        //  alive through v_writelane spills: pin the running count to a scalar register every 8 keys)
+                        if ((i & 7) == 7) asm volatile("" : "+s"(c));
+                    }
+                    c += wave_sum(cv);
+                    if (lane == 0) s_cnt[(b & 1) * 16 + w] = c;
+                    __syncthreads();
+                    unsigned tot = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) tot += s_cnt[(b & 1) * 16 + k2];
+                    if (tot >= (unsigned)K) ftau = cand;
+                }
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    cg += key[i] > ftau ? 1 : 0;
+                    ce += (key[i] == ftau && key[i] != 0u) ? 1 : 0;
+                }
+            } else {
+                radix_select(for_mem, (unsigned)K, s_hist, s_pr, ftau, frem);
+                for_mem([&](unsigned k, int) {
+                    cg += k > ftau ? 1 : 0;
+                    ce += (k == ftau && k != 0u) ? 1 : 0;
+                });
+            }
             int tg, te;
             int off_g = block_excl_scan(cg, s_w, tg);
             int rank_e = block_excl_scan(ce, s_w, te);
-            for_mem([&](unsigned k, int e) {
-                if (k > ftau) {
-                    s_ckey[off_g] = k; s_cidx[off_g] = e; ++off_g;
-                } else if (k == ftau && k != 0u) {
-                    if (rank_e < (int)frem) { s_ckey[tg + rank_e] = k; s_cidx[tg + rank_e] = e; }
-                    ++rank_e;
+            frem = (unsigned)(K - tg);
+            // (the same element-to-thread assignment as the counts above: the registers' when REG)
+            auto for_own = [&](auto&& f) {
+                if (REG) for_each(f);
+                else for_mem(f);
+            };
+            for_own([&](unsigned k, int e) {
+                if (k >= ftau && k != 0u) {                       // rare (K of the tile's entries) unless the tile is flat
+                    const bool g = k > ftau;
+                    const int pos = g ? off_g : tg + rank_e;
+                    if (g || rank_e < (int)frem) { s_ckey[pos] = k; s_cidx[pos] = e; }
+                    off_g += g ? 1 : 0;                           // (selects: incrementing one of two counters per branch sent both to scratch)
+                    rank_e += g ? 0 : 1;
                 }
             });
             ncand = K;                      // the list now holds exactly the top K: select all of it below
             __syncthreads();
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
         // ---- exact selection among the listed candidates (thread t owns entries t, t+1024, ..) ----------------
         auto for_cand = [&](auto&& f) {
             for (int c = t; c < ncand; c += 1024) f(s_ckey[c], s_cidx[c]);
@@ -572,6 +614,10 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
             }
         });
     }
+    if (K <= 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    }
     PROC_STAMP(4);
     // only the waves that own list entries (entry c belongs to thread c % 1024) hold non-zero sums
     if (w * 64 < n_listed) {
@@ -584,15 +630,18 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         s_red[w][lane] = 0.0;
     }
     __syncthreads();
+    // sum i over the waves by thread i (one thread reading all 256 partial sums at once spilled them to scratch: 6-11 us)
+    if (t < 16) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += s_red[k][t];
+        s_red[0][t] = v;
+    }
+    __syncthreads();
     if (t != 0) return;
     double sum[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double v = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += s_red[k][i];
-        sum[i] = v;
-    }
+    for (int i = 0; i < 16; ++i) sum[i] = s_red[0][i];
     const double inv = 1.0 / (sum[0] + 1e-4);        // eps of batch_weighted_procrustes
     const double sw = sum[0] * inv;                   // sum of normalised weights (w >= 0 here)
     double mx[3] = {sum[1] * inv, sum[2] * inv, sum[3] * inv};

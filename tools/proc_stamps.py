@@ -5,7 +5,7 @@ from diffreg_hip import lib
 N = M = 256
 g = torch.Generator().manual_seed(0)
 x = torch.randn(1, N, M, generator=g) * 3
-x[0, torch.arange(N), torch.randperm(N, generator=g)] += 8
+x[0, torch.arange(N), torch.randperm(N, generator=g)] += float(os.environ.get("PEAK", "8"))
 conf = lib.sinkhorn(x.cuda(), torch.tensor(1.0).cuda(), 3)
 ps, pt = torch.rand(1, N, 3).cuda(), torch.rand(1, M, 3).cuda()
 for rep in range(3):
