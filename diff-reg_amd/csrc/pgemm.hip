@@ -660,9 +660,13 @@ bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G9::BN; }
 int pgemm_bn(int C) { return C <= G7::BN ? G7::BN : G9::BN; }
 static size_t pg_bst(int C) { return (size_t)pgemm_bn(C) * 64; }
 
+// The 576-column geometry exists in the 64-row form only: its 128-row form (8 waves, 256 registers per wave: 144 accumulators + two fragment
+// sets) spilled 198-226 registers and measured 4 % slower than the 64-row form even where it fills the chip (32 pairs of 512 x 512: 147.6
+// against 141.4 ms per call).
 template <int TNW, int NST, int MODE>
 static int configure_mode() {
-    DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM));
+    if constexpr (TNW <= 7)
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 2>::SMEM));
     return DR_OK;
 }
@@ -694,7 +698,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     long wg128 = 0;
     for (int i = 0; i < g.n; ++i) wg128 += (long)((g.p[i].rows + 127) / 128) * g.p[i].nblk;
-    const bool half = half_env == 2 || (half_env == 1 && wg128 < n_cu);
+    const bool half = bn == G9::BN || half_env == 2 || (half_env == 1 && wg128 < n_cu);
     const int bm = half ? 64 : 128;
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
@@ -709,7 +713,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
     const dim3 grid(maxt, g.n);
-    if (bn == G9::BN) { if (half) pg_launch<9, 3, 2>(mode, grid, st, g); else pg_launch<9, 3, 4>(mode, grid, st, g); }
+    if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, g);
     else { if (half) pg_launch<7, 4, 2>(mode, grid, st, g); else pg_launch<7, 4, 4>(mode, grid, st, g); }
     DR_LAUNCH_CHECK();
     return DR_OK;
