@@ -1141,12 +1141,14 @@ template <> struct SkSt4<double> {
     }
 };
 
-template <typename TIn, typename TOut, int VPL, int RW>
+// RPW = rows per wave: 1, or 2 for batches whose tiles would not all be resident with one row per wave (a wave then adds its rows'
+// column partials before they meet the other waves': the sums associate differently, so RPW is part of the result's last bits)
+template <typename TIn, typename TOut, int VPL, int RW, int RPW>
 __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     constexpr int NT = 64 * RW;                                   // RW rows (waves) per workgroup
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     constexpr float LOG2E = 1.4426950408889634f;
-    const int N = A.N, M = A.M, G = (N + RW - 1) / RW, Mp = VPL * 256, M4 = sk_coop_m4(M), NG4 = M4 / 4;
+    const int N = A.N, M = A.M, G = (N + RW * RPW - 1) / (RW * RPW), Mp = VPL * 256, M4 = sk_coop_m4(M), NG4 = M4 / 4;
     float* s_col = reinterpret_cast<float*>(sk_smem);             // [RW][Mp + 4] column partials of the waves; later the M4 column sums
     float* s_red = s_col + RW * (Mp + 4);                         // [RW][8]
     __shared__ int s_cnt[2];
@@ -1179,65 +1181,86 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     const float mu = expf(normf), muN = expf(logf((float)ns) + normf), nu = mu, nuM = expf(logf((float)ms) + normf);
     const double xmin_d = A.shift ? A.shift[tile] : 0.0;
 
-    // ---- the wave's row: scores -> exponentials in registers.  Lane l owns columns 4 (l + 64 k) + c, k < VPL, c < 4.
-    const int i = RW * g + w;
-    const bool rowok = i < N, rowmasked = rowok && sm && !sm[i];
+    // ---- the wave's rows: scores -> exponentials in registers.  Lane l owns columns 4 (l + 64 k) + c, k < VPL, c < 4, of each of them.
+    const int i0 = RW * RPW * g + RPW * w;
     const bool vec_in = (M & 3) == 0 && ((uintptr_t)src % (4 * sizeof(TIn))) == 0;
-    float E[VPL][4];
+    float E[RPW][VPL][4], ed[RPW];
+    bool rowok[RPW], a_zero[RPW];
     unsigned colmask = 0;                                         // bit 4 k + c: column exists and is not masked (ragged: b = 0 there)
-    float m = alpha;
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        const int jb = 4 * (lane + 64 * k);
-        TIn raw[4] = {0, 0, 0, 0};
-        if (rowok && vec_in && jb < M) SkLd4<TIn>::ld(src + (size_t)i * M + jb, raw);
+    for (int r = 0; r < RPW; ++r) {
+        const int i = i0 + r;
+        rowok[r] = i < N;
+        const bool rowmasked = rowok[r] && sm && !sm[i];
+        float m = alpha;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = jb + c;
-            float v = -INFINITY;
-            if (j < M && rowok) {
-                const TIn r = vec_in ? raw[c] : src[(size_t)i * M + j];
-                v = (float)((double)r - xmin_d);                 // (float inputs: exact; float64 state: shifted in float64 like the other paths)
-                if (apply && (rowmasked || (tm && !tm[j]))) v = -INFINITY;
+        for (int k = 0; k < VPL; ++k) {
+            const int jb = 4 * (lane + 64 * k);
+            TIn raw[4] = {0, 0, 0, 0};
+            if (rowok[r] && vec_in && jb < M) SkLd4<TIn>::ld(src + (size_t)i * M + jb, raw);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = jb + c;
+                float v = -INFINITY;
+                if (j < M && rowok[r]) {
+                    const TIn x = vec_in ? raw[c] : src[(size_t)i * M + j];
+                    v = (float)((double)x - xmin_d);             // (float inputs: exact; float64 state: shifted in float64 like the other paths)
+                    if (apply && (rowmasked || (tm && !tm[j]))) v = -INFINITY;
+                }
+                if (r == 0 && j < M && !(tm && !tm[j])) colmask |= 1u << (4 * k + c);
+                E[r][k][c] = v;
+                m = fmaxf(m, v);
             }
-            if (j < M && !(tm && !tm[j])) colmask |= 1u << (4 * k + c);
-            E[k][c] = v;
-            m = fmaxf(m, v);
         }
+        m = wave_max(m);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) E[r][k][c] = __builtin_amdgcn_exp2f((E[r][k][c] - m) * LOG2E);   // exp(-inf) = 0: masked / absent entries
+        ed[r] = rowok[r] ? __builtin_amdgcn_exp2f((alpha - m) * LOG2E) : 0.f;   // the row's dustbin-column entry
+        a_zero[r] = !rowok[r] || (ragged && rowmasked);
     }
-    m = wave_max(m);
-#pragma unroll
-    for (int k = 0; k < VPL; ++k)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) E[k][c] = __builtin_amdgcn_exp2f((E[k][c] - m) * LOG2E);      // exp(-inf) = 0: masked / absent entries
-    const float ed = rowok ? __builtin_amdgcn_exp2f((alpha - m) * LOG2E) : 0.f;   // the row's dustbin-column entry
-    const bool a_zero = !rowok || (ragged && rowmasked);
 
     float b[VPL][4];
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
 #pragma unroll
         for (int c = 0; c < 4; ++c) b[k][c] = (!ragged || ((colmask >> (4 * k + c)) & 1)) ? 1.f : 0.f;
-    float bM = 1.f, aN = muN / ((ragged ? (float)ns : (float)M) + 1.f), ai = 0.f;
+    float bM = 1.f, aN = muN / ((ragged ? (float)ns : (float)M) + 1.f), ai[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) ai[r] = 0.f;
     // this workgroup's slice of the column sums: float4 groups [g0, g1)
     const int gpw = (NG4 + G - 1) / G, g0 = min(NG4, g * gpw), g1 = min(NG4, g0 + gpw);
     for (int it = 0; it < A.iters; ++it) {
         // a_i = mu / (sum_j E_ij b_j + ed bM)
-        float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < VPL; ++k)
+        for (int r = 0; r < RPW; ++r) {
+            float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s = fmaf(E[k][c], b[k][c], s);
-        s = wave_sum(s);
-        ai = a_zero ? 0.f : mu / (s + ed * bM);
-        // column partials of the 4 rows -> P[g] (the dustbin column rides at index M)
+            for (int k = 0; k < VPL; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = fmaf(E[r][k][c], b[k][c], s);
+            s = wave_sum(s);
+            ai[r] = a_zero[r] ? 0.f : mu / (s + ed[r] * bM);
+        }
+        // column partials of the workgroup's rows -> P[g] (the dustbin column rides at index M)
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             float4 cp;
-            cp.x = E[k][0] * ai; cp.y = E[k][1] * ai; cp.z = E[k][2] * ai; cp.w = E[k][3] * ai;
+            cp.x = E[0][k][0] * ai[0]; cp.y = E[0][k][1] * ai[0]; cp.z = E[0][k][2] * ai[0]; cp.w = E[0][k][3] * ai[0];
+#pragma unroll
+            for (int r = 1; r < RPW; ++r) {
+                cp.x = fmaf(E[r][k][0], ai[r], cp.x); cp.y = fmaf(E[r][k][1], ai[r], cp.y);
+                cp.z = fmaf(E[r][k][2], ai[r], cp.z); cp.w = fmaf(E[r][k][3], ai[r], cp.w);
+            }
             *reinterpret_cast<float4*>(s_col + w * (Mp + 4) + 4 * (lane + 64 * k)) = cp;
         }
-        if (lane == 0) s_col[w * (Mp + 4) + M] = ed * ai;         // (column M is no column of E: its partial there was 0 or absent)
+        if (lane == 0) {                                           // (column M is no column of E: its partial there was 0 or absent)
+            float dsum = ed[0] * ai[0];
+#pragma unroll
+            for (int r = 1; r < RPW; ++r) dsum = fmaf(ed[r], ai[r], dsum);
+            s_col[w * (Mp + 4) + M] = dsum;
+        }
         __syncthreads();
         for (int q4 = t; q4 < NG4; q4 += NT) {
             float4 v = *reinterpret_cast<const float4*>(s_col + 4 * q4);
@@ -1318,52 +1341,66 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         __syncthreads();                                          // s_col is rewritten by the next pass
     }
     // ---- out_ij = E_ij a_i b_j e^-norm
-    if (!rowok) return;
-    const float S = expf(-normf) * ai;
-    TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (size_t)i * M;
     const bool vec_out = (M & 3) == 0 && ((uintptr_t)A.out % (4 * sizeof(TOut))) == 0;
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        const int jb = 4 * (lane + 64 * k);
-        float o[4];
+    for (int r = 0; r < RPW; ++r) {
+        if (!rowok[r]) continue;
+        const float S = expf(-normf) * ai[r];
+        TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (size_t)(i0 + r) * M;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = E[k][c] * S * b[k][c];
-        if (vec_out) { if (jb < M) SkSt4<TOut>::st(dst + jb, o); }
-        else
+        for (int k = 0; k < VPL; ++k) {
+            const int jb = 4 * (lane + 64 * k);
+            float o[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (jb + c < M) dst[jb + c] = (TOut)o[c];
+            for (int c = 0; c < 4; ++c) o[c] = E[r][k][c] * S * b[k][c];
+            if (vec_out) { if (jb < M) SkSt4<TOut>::st(dst + jb, o); }
+            else
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (jb + c < M) dst[jb + c] = (TOut)o[c];
+        }
     }
 }
 
-static bool coop_path(int B, int N, int M, int flags) {
-    if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return false;
-    if (M > 2048 || !env_knob("DR_SK_COOP", 1)) return false;
+// rows per wave of the co-resident form for a batch: 1 if the launch is then resident beside a second one, else 2 (tiles of up to 768
+// columns: two rows of 3 float4s per lane are 123-125 registers, inside the 128 of two workgroups per CU; 4 float4s are 139), else 0 = not this form
+static int coop_rows_per_wave(int B, int N, int M, int flags) {
+    if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return 0;
+    if (M > 2048 || !env_knob("DR_SK_COOP", 1)) return 0;
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     // 512-thread workgroups with 8 (VPL 256 + 4) floats of LDS: 2 per CU by threads, 2 at VPL = 8 by LDS
-    return (long)B * sk_coop_g(N) <= 2L * n_cu / SK_COOP_SHARE;
+    const long lim = 2L * n_cu / SK_COOP_SHARE;
+    if ((long)B * sk_coop_g(N) <= lim) return 1;
+    if (M <= 768 && (long)B * ((N + 2 * SK_COOP_RW - 1) / (2 * SK_COOP_RW)) <= lim && env_knob("DR_SK_COOP", 1) != 2) return 2;
+    return 0;
 }
+static bool coop_path(int B, int N, int M, int flags) { return coop_rows_per_wave(B, N, M, flags) != 0; }
 
 template <typename TIn, typename TOut>
 static int launch_coop(const SkArgs& a, hipStream_t st) {
-    const int G = sk_coop_g(a.N), vpl = (a.M + 255) / 256;
+    const int rpw = coop_rows_per_wave(a.B, a.N, a.M, a.flags);
+    if (!rpw) return DR_EINVAL;
+    const int G = (a.N + SK_COOP_RW * rpw - 1) / (SK_COOP_RW * rpw), vpl = (a.M + 255) / 256;
     const size_t tf = sk_coop_tile_floats(a.N, a.M);
-    // counters + status of every tile start at zero
+    // flags + status of every tile start at zero (they sit behind the G partials and the column sums of THIS launch's G)
     for (int b = 0; b < a.B; ++b)
         DR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<float*>(a.ws) + (size_t)b * tf + (size_t)(G + 1) * sk_coop_m4(a.M), 0,
                                     (2 * (size_t)sk_coop_g64(a.N) + 64) * 4, st));
     const dim3 grid(G, a.B), blk(64 * SK_COOP_RW);
-#define SK_COOP_CASE(V)                                                                                                      \
-    case V: {                                                                                                                \
+#define SK_COOP_LAUNCH(V, R)                                                                                                 \
+    {                                                                                                                        \
         const size_t lds = ((size_t)SK_COOP_RW * (V * 256 + 4) + 8 * SK_COOP_RW + 8) * sizeof(float);                        \
-        if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_COOP_RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_COOP_RW>), grid, blk, lds, st, a);                               \
-        break;                                                                                                               \
+        if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_COOP_RW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_COOP_RW, R>), grid, blk, lds, st, a);                            \
     }
+#define SK_COOP_CASE(V) case V: SK_COOP_LAUNCH(V, 1) break;
+#define SK_COOP_CASE2(V) case V: if (rpw == 2) SK_COOP_LAUNCH(V, 2) else SK_COOP_LAUNCH(V, 1) break;
     switch (vpl) {
-        SK_COOP_CASE(1) SK_COOP_CASE(2) SK_COOP_CASE(3) SK_COOP_CASE(4) SK_COOP_CASE(5) SK_COOP_CASE(6) SK_COOP_CASE(7) SK_COOP_CASE(8)
+        SK_COOP_CASE2(1) SK_COOP_CASE2(2) SK_COOP_CASE2(3) SK_COOP_CASE(4) SK_COOP_CASE(5) SK_COOP_CASE(6) SK_COOP_CASE(7) SK_COOP_CASE(8)
         default: return DR_ENOSUP;
     }
 #undef SK_COOP_CASE
+#undef SK_COOP_CASE2
+#undef SK_COOP_LAUNCH
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

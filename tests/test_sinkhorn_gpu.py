@@ -66,6 +66,28 @@ def test_log_output_matches_oracle(N, M, nv, mv, dt):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("B,N,M,nv,mv", [(2, 564, 629, 564, 629), (4, 564, 629, 564, 629), (6, 648, 655, 601, 540), (8, 512, 512, 470, 512),
+                                         (3, 300, 1000, 300, 1000)])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_batched_large_tiles_coresident(B, N, M, nv, mv, dt):
+    """Tiles beyond 256 x 256 run in ONE co-resident launch while all their workgroups fit the chip beside a second launch: one row
+    per wave for small batches (B ceil(N / 8) <= 256 workgroups), two rows per wave up to 768 columns beyond that (4 real-size pairs,
+    cfg3's 8 x 512 x 512), the multi-launch grid form otherwise.  Every tile of the batch is held to the oracle on its own scores."""
+    from diffreg_hip import lib
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    a = torch.tensor(1.0)
+    raw = torch.cat([T(3.0 * synth.hash_normal(7 + b, N * 1000 + M, (1, N, M))) for b in range(B)]).to(tdt)
+    sm = torch.arange(N)[None].expand(B, N) < torch.tensor([nv - 3 * b for b in range(B)])[:, None]
+    tm = torch.arange(M)[None].expand(B, M) < torch.tensor([mv - 5 * b for b in range(B)])[:, None]
+    got = lib.sinkhorn(raw.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True)
+    assert got.dtype == tdt and got.shape == (B, N, M)
+    for b in range(B):
+        sc = raw[b:b + 1].masked_fill(~(sm[b][None, :, None] & tm[b][None, None, :]), float("-inf"))
+        ref = orc.sinkhorn_log(sc, a, 3, sm[b:b + 1], tm[b:b + 1]).exp()[:, :-1, :-1]
+        ae, re_ = rel_err(got[b:b + 1], ref)
+        assert re_ < 2e-5 and ae < 1e-6, (b, ae, re_)
+
+
 def test_minshift_and_batch_of_different_masks():
     from diffreg_hip import lib
     B, N, M = 5, 256, 256
