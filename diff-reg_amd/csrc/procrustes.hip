@@ -31,7 +31,7 @@ struct ProcArgs {
     float* R; float* t; float* Rf; float* tf;   // [P,9] [P,3] [P,9] [P,3]
     double* cond;             // [P]
     int* ok;                  // [P]
-    int* topk_idx;            // optional [P, K] flat indices of the selected entries (index order)
+    int* topk_idx;            // optional [P, K] flat indices of the selected entries (a set: written in arrival order)
     int N, M, K_fixed, use_mask_len;
     float sample_rate, max_cond;
     // large tiles (N*M > 65536) with a workspace: the K selected entries, written in index order by proc_take_kernel

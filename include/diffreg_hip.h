@@ -225,7 +225,10 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
  *   use_mask_len: 0 = K from the padded sizes (3D, 2D3D), 1 = K from the mask sums (4D variant,
  *                 4D/models/procrustes.py:61-62)
  *   R,t = solution; R_forwd,t_forwd = solution or identity when cond >= max_condition_num;
- *   topk_idx (optional, [P,K]) flat indices i*M+j of the selected entries in index order
+ *   topk_idx (optional, [P,K]) flat indices i*M+j of the selected entries (a set: unordered)
+ *   Ties at the K-th value: the lowest flat indices are taken (torch.topk leaves that choice implementation-defined).
+ *   Tiles beyond 256 x 256 select with the whole chip and take their scratch from the stream's memory pool
+ *   (hipMallocAsync / hipFreeAsync on `stream`: stream-ordered, capturable, nothing cached across calls).
  */
 int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_pcd, const float* tgt_pcd,
                       const uint8_t* src_mask, const uint8_t* tgt_mask, int use_mask_len, float sample_rate,
@@ -236,7 +239,9 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
  * declared in include/diffreg_hip_debug.h.  The library reads no environment variable unless dr_debug_enable_env(1) was called. */
 
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
- * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid). */
+ * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid), ascending (i, j); the first
+ * occurrence wins an arg-max tie.  N + M <= 4096.  From 32 rows on the arg-maxima come from row-block workgroups over the
+ * whole chip; their scratch is taken from the stream's memory pool (hipMallocAsync / hipFreeAsync on `stream`). */
 int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream);
 int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream);
 
