@@ -406,7 +406,18 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         n32 += (long)((g.p[i].rows + 31) / 32) * ((g.p[i].ncols + 31) / 32) * (g.p[i].nbatch > 1 ? g.p[i].nbatch : 1);
     }
     const int direct_max = env_knob("DR_GEMM_DIRECT_MAX", 2048);   // (1193 rows x 1296 columns = 1558 tiles: 21 us against 36 us for the LDS-staged tiles)
-    if (g_force_cfg < 0 && n32 <= direct_max && maxK <= 16 * 8 * 7) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
+    if (g_force_cfg < 0 && n32 <= direct_max && maxK <= 16 * 8 * 7) {
+        // latency form or the 64 x 64 staged tiles?  Two fitted costs in us (tools/gemm_small.py, SHAPES=mid, 14 shapes between 1 024 x 256 x 256
+        // and 2 048 x 864 x 864: the rule picks the faster kernel on every one of them):
+        //   staged: 5 + rounds (0.0244 K), rounds = ceil(64 x 64 tiles / CUs): a workgroup per CU and round, MFMA-bound in it; it moves
+        //           half the L2 bytes per output tile
+        //   latency form: K <= 448 (8 waves):  2.5 + 0.0145 tiles;   K <= 896 (16 waves, 2 workgroups per CU): 11 up to 512 tiles, then 10 + 0.026 tiles
+        // (2D-3D loop, 3 072 x 256 x 256: 13.5 -> 10.8 us per launch; 2 048 x 864 x 864: 55 -> 42; a single pair's 512 or 1 193 rows keep the latency form)
+        static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+        const double t_staged = 5.0 + (double)((nM + n_cu - 1) / n_cu) * 0.0244 * maxK;
+        const double t_direct = maxK <= 8 * 8 * 7 ? 2.5 + 0.0145 * (double)n32 : (n32 <= 512 ? 11.0 : 10.0 + 0.026 * (double)n32);
+        if (t_direct <= t_staged || nM < 128) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
+    }
     int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
                                      // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
     const int env_cfg = env_knob("DR_GEMM_CFG", -1);   // tools/: tile experiments

@@ -365,11 +365,15 @@ def test_cfg3_4dmatch_512_batch8_20_steps(golden):
     assert np.abs(Rf_all[:, 0].numpy() - g["R_forwd"]).max() < 1e-4
     assert np.abs(tf_all[:, 0].numpy() - g["t_forwd"]).max() < 1e-4
     against_reference("conf", conf_all[0].numpy())
-    # batched x_start of pair 0 against its own B = 1 run: plain 1e-4 outside the fixture's committed exemption list
+    # batched x_start of pair 0: held to the REFERENCE by the same rule as the B = 1 run (1e-4 outside the fixture's committed exemption
+    # list); the two runs -- plane kernels in the batch, f32-MFMA kernels alone -- are then within 2e-4 of each other by the triangle
+    # inequality, which is what is asserted between them (a plain 1e-4 between two paths that are each 1e-4 from the reference held only
+    # while both happened to err on the same side: 1.13e-4 at one entry once the single pair's 1 024 x 528 x 528 GEMMs moved to the staged tiles)
+    against_reference("x0_last", x0_last_all[0].numpy())
     dd = (one["x0"][-1, 0].cpu() - x0_last_all[0]).abs().numpy().ravel()
     plain = np.ones(dd.size, dtype=bool)
     plain[np.asarray(ex["x0_last"]["index"], dtype=np.int64)] = False
-    assert dd[plain].max() <= 1e-4 and dd.max() < 1e-3, (dd[plain].max(), dd.max())
+    assert dd[plain].max() <= 2e-4 and dd.max() < 1e-3, (dd[plain].max(), dd.max())
     # ---- pair 1 against the oracle
     i = 1
     q = prs[i]

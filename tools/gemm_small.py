@@ -4,7 +4,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from diffreg_hip import lib
 lib.ensure_init()
 dev = "cuda:0"
-for rows, ncols, K in [(256, 432, 432), (512, 432, 432), (256, 864, 864), (512, 864, 864), (256, 432, 864), (512, 432, 864), (1024, 432, 432), (2048, 432, 432), (256, 256, 432)]:
+SHAPES = [(256, 432, 432), (512, 432, 432), (256, 864, 864), (512, 864, 864), (256, 432, 864), (512, 432, 864), (1024, 432, 432), (2048, 432, 432), (256, 256, 432)]
+if os.environ.get("SHAPES") == "mid":     # the 2D-3D loop (3 072 token rows, C = 256), a real-size pair (1 193 rows, C = 432), 2-4 pairs of 256 x 256
+    SHAPES = [(3072, 256, 256), (3072, 512, 256), (3072, 256, 512), (2048, 256, 256), (1024, 256, 256), (3072, 768, 256),
+              (1193, 432, 432), (1193, 864, 864), (1193, 432, 864), (1193, 1296, 432), (1024, 432, 432), (1024, 864, 864), (2048, 864, 864), (2048, 432, 864)]
+for rows, ncols, K in SHAPES:
     x = torch.randn(rows, K, device=dev); W = torch.randn(ncols, K, device=dev) / K ** 0.5
     ref = x.double() @ W.double().T
     line = "%5d x %4d x %4d :" % (rows, ncols, K)
