@@ -31,10 +31,26 @@ def test_image_round_trip_and_bounds(rows, C):
     assert torch.equal(bnd, x.abs().amax(1))
 
 
+@pytest.fixture
+def row_block(request):
+    """force the plane GEMM's workgroup height through the debug knob (include/diffreg_hip_debug.h): 0 = 128 rows, 2 = 64;
+    None = the launcher's own rule (64 rows while the launch has fewer 128-row blocks than CUs)"""
+    import os
+    mode = request.param
+    if mode is not None:
+        lib.raw().dr_debug_enable_env(1)
+        os.environ["DR_PG_HALF"] = str(mode)
+    yield mode
+    if mode is not None:
+        os.environ.pop("DR_PG_HALF", None)
+        lib.raw().dr_debug_enable_env(0)
+
+
+@pytest.mark.parametrize("row_block", [None, 0, 2], indirect=True)
 @pytest.mark.parametrize("rows,C", [(1000, 432), (300, 528), (129, 256)])
-def test_layer_chain_against_float64(rows, C):
+def test_layer_chain_against_float64(rows, C, row_block):
     """q|k|v with rotary (DR_PL_F32), merge + LayerNorm (DR_PL_LN), mlp0 on [x | msg] + ReLU (DR_PL_PLANES), mlp2 + LayerNorm +
-    residual (DR_PL_LN): one GeometryAttentionLayer's GEMMs (transformero.py:60-96) through the plane ops."""
+    residual (DR_PL_LN): one GeometryAttentionLayer's GEMMs (transformero.py:60-96) through the plane ops, in each workgroup height."""
     torch.manual_seed(rows)
     x = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
     img, bnd = lib.planes_from_f32(x)
