@@ -132,15 +132,14 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     u32x4 fa0[2], fa1[2], fx[TNW / 2][2], fy[TNW - TNW / 2][2];
 
-    // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream but keep
-    // their DMA issue -- ~100 cycles of the wave's instruction stream per 1 KB instruction, ~500 per stage, as much again as its
-    // MFMA issue -- in OPPOSITE halves of a stage, with the stage's one barrier between the halves:
-    //   group 0 (wn = 0): tiles 0, 1 + its DMA pieces | barrier | tiles 2 .. 6            (issues stage s + 2)
-    //   group 1 (wn = 1): tiles 0 .. 4                | barrier | tiles 5, 6 + DMA pieces (issues stage s + 3)
-    // so one wave of the SIMD is MFMA-dense while its partner feeds the DMA (in lockstep both halves serialise: measured
-    // 2.2 us per stage pair against 1.04 us of staging alone and 1.2 us of MFMAs alone).  Pieces: group 1 copies the A block
-    // (8 instructions, the longer-latency stream: it has 1.5 stages to land) and the first WB_CNT weight instructions, group 0
-    // the rest of the weights (L2 hits; one stage to land).
+    // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream -- burst 1 = tiles
+    // 0 .. TNW / 2 - 1, the stage's one barrier, burst 2 = the other tiles -- and differ in what they feed to the DMA:
+    //   128-row workgroups on a 4-slot ring (ALL0): group 0 (wn = 0) issues every piece of stage s + 2 in the gaps of burst 1 of stage s,
+    //     group 1 only computes;
+    //   64-row workgroups and 3-slot rings: group 0 issues its half of the weight pieces in burst 1 (4 slots: stage s + 2) or burst 2
+    //     (3 slots), group 1 the A block and the other half in burst 2 (stage s + NST - 1).
+    // (In lockstep -- both waves of a SIMD issuing in the same gaps -- the halves serialise: 2.2 us per stage pair against 1.04 us of
+    // staging alone and 1.2 us of MFMAs alone.  What the staging costs is the bytes it moves into the LDS, r03_pgemm_overlap_ablation.json.)
     auto run = [&](auto grp_t) __attribute__((always_inline)) {
         constexpr int GRP = decltype(grp_t)::value;
         // EARLY: group 0 issues stage s + NST - 2 in the FIRST burst of stage s (its slot is free since the barrier of stage s - 1).
@@ -148,18 +147,26 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         // both groups issue stage s + 2 in the second burst and wait for everything at the next barrier.
         constexpr bool EARLY = GRP == 0 && NST >= 4;
         constexpr int AHEAD = EARLY ? NST - 2 : NST - 1;             // stages in flight beyond the current one after the prologue
-        constexpr int WB_CNT = (GG::NB + GG::NA) / 2 - GG::NA;       // weight instructions of group 1
+        // ALL0 (128-row workgroups on a 4-slot ring, round 3): group 0 issues EVERY piece of a stage -- its 2 A pieces and 7 weight pieces
+        // per wave, one per gap of the first burst -- and group 1 only computes.  Measured on one box against the even split below (A +
+        // 10 weight instructions from group 1 in the second burst, 18 from group 0 in the first): qkv 357 -> 348 us, merge 95.3 -> 92.2,
+        // mlp0 280.7 -> 271.1, mlp2 190.9 -> 185.5 per launch at 65 536 rows (shifting 6 or 10 weight instructions to group 0 lands in
+        // between): the pieces issued behind the barrier, next to the reads of the next stage's fragments, are the dear ones.
+        constexpr bool ALL0 = NST >= 4 && WMN == 4;
+        constexpr int AG = ALL0 ? 0 : 1;                             // the group that copies the A block
+        constexpr int WB_CNT = ALL0 ? 0 : (GG::NB + GG::NA) / 2 - GG::NA;       // weight instructions of group 1
         constexpr int NW0 = GG::NB - WB_CNT;                         // weight instructions of group 0
-        constexpr int NPIECE = GRP ? 2 + (WB_CNT + WMN - 1) / WMN : (NW0 + WMN - 1) / WMN;
-        constexpr int NFULLP = GRP ? 2 + WB_CNT / WMN : NW0 / WMN;   // pieces every wave of the group issues
+        constexpr int NAP = GRP == AG ? 2 : 0;                       // A pieces of a wave of this group
+        constexpr int NPIECE = GRP ? NAP + (WB_CNT + WMN - 1) / WMN : NAP + (NW0 + WMN - 1) / WMN;
+        constexpr int NFULLP = GRP ? NAP + WB_CNT / WMN : NAP + NW0 / WMN;   // pieces every wave of the group issues
         constexpr int PSTEP = (2 * NPIECE <= 3 * (TNW - TNW / 2)) ? 2 : 1;   // gaps between two pieces issued in the second burst
-        static_assert(PSTEP * NPIECE <= 3 * (TNW - TNW / 2), "the DMA pieces of a stage must fit the gaps of the second burst");
-        static_assert(NPIECE <= 3 * (TNW / 2), "... and those of the early group the gaps of the first");
+        static_assert(EARLY || PSTEP * NPIECE <= 3 * (TNW - TNW / 2), "the DMA pieces of a stage must fit the gaps of the second burst");
+        static_assert(!EARLY || NPIECE <= 3 * (TNW / 2), "... and those of the early group the gaps of the first");
         constexpr int REMP = GRP ? WB_CNT % WMN : NW0 % WMN;         // waves (local index) < REMP issue one more
         const int wl = w % WMN;
         // DMA pieces of this wave (1 KB instructions; `ins` = index inside the A block / the weight block of a stage):
-        //   group 1: A instructions 2 wl, 2 wl + 1, then weight instructions st0 .. (WB_CNT dealt 3, 3, 2, 2)
-        //   group 0: weight instructions st0 .. (the other NB - WB_CNT dealt 5, 5, 4, 4)
+        //   the A group (group 0 when ALL0, else group 1): A instructions 2 wl, 2 wl + 1, then its weight instructions st0 ..
+        //   even split (64-row workgroups, 3-slot rings): group 1 A + WB_CNT weight instructions, group 0 the other NB - WB_CNT
         // issued in the SGPR-base + VGPR-offset + immediate form: per piece an s_mov to M0 and the load, nothing else
         const int st0 = GRP ? wl * (WB_CNT / WMN) + min(wl, WB_CNT % WMN) : WB_CNT + wl * (NW0 / WMN) + min(wl, NW0 % WMN);
         const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * wl * 1024;
@@ -173,9 +180,9 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         auto dma_piece = [&](int p, unsigned dstb) __attribute__((always_inline)) {   // dstb = LDS address of the slot of stage ti
             const unsigned m0w = dstb + A_ST + st0 * 1024;
             // weight piece pw of a wave: the immediate reaches 3 KB, every 4 pieces move the register base by 4 KB
-            const int pw = GRP ? p - 2 : p;
+            const int pw = p - NAP;
             const unsigned hop = (unsigned)(pw >> 2) * 4096;
-            if (GRP && p < 2) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024);
+            if (p < NAP) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, p * 1024);
             else if (pw < (GRP ? WB_CNT : NW0) / WMN || wl < (GRP ? WB_CNT : NW0) % WMN) PG_DMA(m0w + hop, voffW + hop, gb, (pw & 3) * 1024);
         };
         auto dma_advance = [&]() __attribute__((always_inline)) {
