@@ -151,7 +151,8 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         // per wave, one per gap of the first burst -- and group 1 only computes.  Measured on one box against the even split below (A +
         // 10 weight instructions from group 1 in the second burst, 18 from group 0 in the first): qkv 357 -> 348 us, merge 95.3 -> 92.2,
         // mlp0 280.7 -> 271.1, mlp2 190.9 -> 185.5 per launch at 65 536 rows (shifting 6 or 10 weight instructions to group 0 lands in
-        // between): the pieces issued behind the barrier, next to the reads of the next stage's fragments, are the dear ones.
+        // between; group 1 issuing its even share before the barrier too, in alternate gaps, is 3 % SLOWER than the even split's
+        // successor here): one issuing wave per SIMD pair whose partner never issues is what pays, not the burst the pieces sit in.
         constexpr bool ALL0 = NST >= 4 && WMN == 4;
         constexpr int AG = ALL0 ? 0 : 1;                             // the group that copies the A block
         constexpr int WB_CNT = ALL0 ? 0 : (GG::NB + GG::NA) / 2 - GG::NA;       // weight instructions of group 1
