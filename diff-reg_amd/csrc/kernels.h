@@ -116,8 +116,6 @@ int launch_procrustes(const float* conf, const float* src_pcd, const float* tgt_
                       float* R, float* t, float* Rf, float* tf, double* cond, int* ok, int* topk_idx, hipStream_t st,
                       void* ws = nullptr, size_t ws_bytes = 0);
 
-int read_proc_stamps(long long* h_out);
-
 // ---------------------------------------------------------------------------------------------
 // diffusion-state kernels (stateops.hip)
 // ---------------------------------------------------------------------------------------------

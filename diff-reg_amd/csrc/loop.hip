@@ -710,44 +710,45 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
     return DR_OK;
 }
 
+size_t dr_procrustes_workspace_bytes(int P, int N, int M) {
+    return (P < 1 || N < 1 || M < 1) ? 0 : procrustes_workspace_bytes(P, N, M);
+}
+
 int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_pcd, const float* tgt_pcd,
                       const uint8_t* src_mask, const uint8_t* tgt_mask, int use_mask_len, float sample_rate,
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd, double* condition,
-                      int32_t* solution_mask, int32_t* topk_idx, void* stream) {
+                      int32_t* solution_mask, int32_t* topk_idx, void* workspace, size_t workspace_bytes, void* stream) {
     if (P < 0 || N < 1 || M < 1 || !conf || !src_pcd || !tgt_pcd || !R || !t || !R_forwd || !t_forwd || !condition || !solution_mask)
         return DR_EINVAL;
-    // tiles beyond 256 x 256 select with the whole chip: their scratch is stream-ordered (nothing cached across calls)
+    if (P == 0) return DR_OK;
+    // tiles beyond 256 x 256 select with the whole chip: the caller's scratch (header contract: the caller owns every buffer)
     const size_t wsb = procrustes_workspace_bytes(P, N, M);
-    void* ws = nullptr;
-    if (wsb) DR_HIP_CHECK(hipMallocAsync(&ws, wsb, (hipStream_t)stream));
-    const int rc = launch_procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, P, N, M, use_mask_len, sample_rate, max_condition_num,
-                                     R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream, ws, wsb);
-    if (ws) DR_HIP_CHECK(hipFreeAsync(ws, (hipStream_t)stream));
-    return rc;
+    if (wsb && (!workspace || workspace_bytes < wsb)) return DR_EWORKSPACE;
+    return launch_procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, P, N, M, use_mask_len, sample_rate, max_condition_num,
+                             R, t, R_forwd, t_forwd, condition, solution_mask, topk_idx, (hipStream_t)stream, wsb ? workspace : nullptr, wsb);
 }
 
-/* diagnostics: wall-clock phase stamps (100 MHz ticks) of the last dr_procrustes launch, pair 0 */
-int dr_debug_procrustes_stamps(long long* h_out8) { return read_proc_stamps(h_out8); }
+size_t dr_top1_union_workspace_bytes(int P, int N, int M, int elem_bytes) {
+    return (P < 1 || N < 1 || M < 1 || (elem_bytes != 4 && elem_bytes != 8)) ? 0 : top1_union_workspace_bytes(P, N, M, (size_t)elem_bytes);
+}
 
 }  // extern "C"
-// stream-ordered scratch for the stand-alone entries (nothing cached across calls)
 template <typename T>
-static int top1_union_scratch(const T* conf, int P, int N, int M, int64_t* matches, int32_t* count, hipStream_t st) {
+static int top1_union_entry(const T* conf, int P, int N, int M, int64_t* matches, int32_t* count, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
+    if (P == 0) return DR_OK;
     const size_t wsb = top1_union_workspace_bytes(P, N, M, sizeof(T));
-    void* ws = nullptr;
-    if (wsb) DR_HIP_CHECK(hipMallocAsync(&ws, wsb, st));
-    const int rc = launch_top1_union<T>(conf, P, N, M, (long long*)matches, count, st, nullptr, nullptr, ws, wsb);
-    if (ws) DR_HIP_CHECK(hipFreeAsync(ws, st));
-    return rc;
+    if (wsb && (!ws || ws_bytes < wsb)) return DR_EWORKSPACE;
+    return launch_top1_union<T>(conf, P, N, M, (long long*)matches, count, st, nullptr, nullptr, wsb ? ws : nullptr, wsb);
 }
 extern "C" {
-int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream) {
-    if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
-    return top1_union_scratch<double>(conf, P, N, M, matches, count, (hipStream_t)stream);
+int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    return top1_union_entry<double>(conf, P, N, M, matches, count, workspace, workspace_bytes, (hipStream_t)stream);
 }
-int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream) {
-    if (P < 0 || N < 1 || M < 1 || !conf || !matches || !count) return DR_EINVAL;
-    return top1_union_scratch<float>(conf, P, N, M, matches, count, (hipStream_t)stream);
+int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    return top1_union_entry<float>(conf, P, N, M, matches, count, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static int check_cfg(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M) {

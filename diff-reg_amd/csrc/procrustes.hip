@@ -57,10 +57,6 @@ __device__ __forceinline__ float key_value(unsigned k) {
 
 constexpr int CAND_MAX = 4096;   // candidate list held in LDS
 
-// phase stamps of pair 0 (wall clock, 100 MHz ticks) for tools/: written by one lane, never read by kernels
-__device__ long long g_proc_stamps[8];
-#define PROC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_proc_stamps[i] = wall_clock64(); } while (0)
-
 // radix select over the keys enumerated by `for_each` (4 x 8-bit digits, run-length aggregated LDS
 // atomics, parallel bin search by wave 0): on return tau = key of the K-th largest, remaining = how
 // many keys == tau belong to the top K.  Block-wide; K >= 1 and K <= number of enumerated keys.
@@ -415,7 +411,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     const int N = A.N, M = A.M, NM = N * M;
     const float* conf = A.conf + (size_t)pair * NM;
 
-    PROC_STAMP(0);
     unsigned key[REG ? 64 : 1];
     // register image: key[4 q + c] is element e = 4 (1024 q + t) + c  (16 coalesced 16-byte loads per thread)
     const bool vec4 = REG && (NM % 4 == 0) && (((uintptr_t)conf & 15) == 0);
@@ -482,7 +477,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         acc[13] += wv * y2 * x0; acc[14] += wv * y2 * x1; acc[15] += wv * y2 * x2;
         if (A.topk_idx) A.topk_idx[(size_t)pair * K + atomicAdd(&s_nsel, 1)] = e;
     };
-    PROC_STAMP(1);
     if (K > 0) {
         // ---- level 1: lower bound L from the per-thread maxima ---------------------------------------------
         unsigned L = 0, dummy;
@@ -522,7 +516,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
             // list would be read uninitialised when N M <= CAND_MAX)
             ncand = CAND_MAX + 1;
         }
-        PROC_STAMP(2);
         unsigned tau = 0, remaining = 0;
         if (ncand > CAND_MAX) {
             // ---- fallback: exact select over the whole tile, then compact the K selected entries ------------
@@ -599,7 +592,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         };
         n_listed = ncand;
         if (ncand > K) radix_select(for_cand, (unsigned)K, s_hist, s_pr, tau, remaining);
-        PROC_STAMP(3);
         int ties = 0;
         for_cand([&](unsigned k, int e) {
             if (k > tau) take(k, e);
@@ -618,7 +610,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0;
     }
-    PROC_STAMP(4);
     // only the waves that own list entries (entry c belongs to thread c % 1024) hold non-zero sums
     if (w * 64 < n_listed) {
 #pragma unroll
@@ -661,9 +652,7 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) Aw[a][b] = Sxy[a][b];
-    PROC_STAMP(5);
     svd3_jacobi(Aw, U, D, V);
-    PROC_STAMP(6);
     const double cond = D[0] / D[2];
     const double dd = det3(U) * det3(V);
     double Rm[3][3];
@@ -700,12 +689,6 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
     }
     A.cond[pair] = cond;
     A.ok[pair] = good ? 1 : 0;
-    PROC_STAMP(7);
-}
-
-int read_proc_stamps(long long* h_out) {
-    DR_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_proc_stamps), sizeof(long long) * 8));
-    return DR_OK;
 }
 
 // slices of a large tile: a workgroup of the selection passes each, about 512 of them over the batch (all co-resident: the levels'

@@ -32,6 +32,7 @@ struct SkArgs {
     void* ws;
     const double* shift;   // per-tile value subtracted from the scores on load (nullable)
     int B, N, M, iters, flags, vec_in, vec_out;
+    unsigned spin_limit;   // co-resident form: polls a workgroup makes before it gives up (dr_device_status)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(1024) void sk_stream_kernel(SkArgs A) {
         for (int j = lane; j < M; j += WAVE) {
             T e = t_exp<T>(zval(i, j) - m);
             Ew[(size_t)i * M + j] = e;
+            rs += e;
         }
         rs = wave_sum(rs);
         if (lane == 0) {
@@ -1080,27 +1082,37 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
 //   partials  P[g][0..M] of the workgroup's 4 rows (+ the dustbin column)            -> arrive on counter A
 //   slices    workgroup g sums the G partials of ITS slice of columns (fixed order)   -> arrive on counter B
 //   everyone reads the M + 1 column sums.
-// No atomics on data (bit-reproducible); the exchanged floats are written and read past the L1 and the XCD's L2 (sc1), the
-// counters are agent-scope atomics polled by one lane per workgroup, every spin is bounded (a status word reports a timeout
-// instead of hanging the queue).  All workgroups of the launch must be resident: 256-thread workgroups with <= 32 KB of LDS and
-// <= 64 VGPRs fit 4 per CU, the launcher takes this form only for B ceil(N / 4) <= 4 x CUs / SK_COOP_SHARE, so SK_COOP_SHARE
-// concurrent launches of it (the engine's streams) still fit the chip together.
+// No atomics on data (bit-reproducible); the exchanged floats are written and read past the L1 and the XCD's L2 (sc1), arrival
+// is one sc1 flag word per workgroup polled by the first wave of every workgroup, every spin is bounded.  All workgroups of the
+// launch must be resident: 512-thread workgroups (8 rows, one wave each) with <= 128 VGPRs and <= 66 KB of LDS fit 2 per CU; the
+// launcher asks the occupancy API for the instantiation it is about to launch (coop_blocks_per_cu) and takes this form only while
+// B G <= blocks per CU x CUs / SK_COOP_SHARE, so that SK_COOP_SHARE concurrent launches of it (the engine's streams) still fit
+// the chip together -- otherwise the multi-launch grid form.
+// A workgroup whose poll gives up (something else holds the CUs: a foreign kernel, a CU mask, a third stream) does NOT carry on
+// silently: it sets the sticky device flag g_sk_status (dr_device_status -> DR_ETIMEOUT) and writes NaN to every output entry it
+// owns, so the failure is in the data as well.
 // ---------------------------------------------------------------------------------------------
 constexpr int SK_COOP_SHARE = 2;
 constexpr unsigned SK_COOP_SPIN = 1u << 22;
+__device__ unsigned g_sk_status;                                   // sticky: bit 0 = a co-resident Sinkhorn timed out
+static unsigned g_sk_spin_limit = SK_COOP_SPIN;                    // (dr_debug_sinkhorn_spin_limit: the timeout test)
 
 // arrival flags instead of a counter: a workgroup announces "my stores of pass p have left" by ONE sc1 store of p to its own word
 // (no read-modify-write: 256 agent-scope adds to one address serialise at the memory side, ~12 us per hop measured), and the first
 // wave of every workgroup polls the whole flag array, 64 words per instruction, until every word has reached p.  Bounded.
-__device__ __forceinline__ void sk_wait_flags(const unsigned* flags, int G, unsigned target, int* status) {
+// (wave-uniform) false = gave up after `limit` polls: the sticky flag and the tile's status word are set, *s_bad (LDS) tells the workgroup
+__device__ __forceinline__ bool sk_wait_flags(const unsigned* flags, int G, unsigned target, unsigned limit, int* status, int* s_bad) {
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     while (true) {
         bool ok = true;
         for (int q = lane; q < G; q += 64) ok = ok && __hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
-        if (__all(ok)) break;
+        if (__all(ok)) return true;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > SK_COOP_SPIN) { if (lane == 0) *status = 1; break; }
+        if (++spins > limit) {
+            if (lane == 0) { *status = 1; *s_bad = 1; atomicOr(&g_sk_status, 1u); }
+            return false;
+        }
     }
 }
 // exchanged data moves as 16-byte accesses that bypass the L1 and the writer's L2 (sc1): two loads per round trip
@@ -1152,6 +1164,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     float* s_col = reinterpret_cast<float*>(sk_smem);             // [RW][Mp + 4] column partials of the waves; later the M4 column sums
     float* s_red = s_col + RW * (Mp + 4);                         // [RW][8]
     __shared__ int s_cnt[2];
+    __shared__ int s_bad;                                         // a poll of this workgroup gave up: its outputs become NaN
     const int tile = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
     float* wsb = reinterpret_cast<float*>(A.ws) + (size_t)tile * sk_coop_tile_floats(N, M);
     float* P = wsb;                                               // [G][M4]
@@ -1167,6 +1180,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
 
     // ---- marginals (float32, quirk Q22) from the mask counts
     if (t < 2) s_cnt[t] = 0;
+    if (t == 2) s_bad = 0;
     __syncthreads();
     {
         int c0 = 0, c1 = 0;
@@ -1274,7 +1288,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                          // every store of the workgroup has left
         if (t == 0) __hip_atomic_store(flagA + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), status);
+        if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad);
         __syncthreads();
         // this workgroup's slice: column sums over the G partials; thread = partial (G <= 256 per pass), two float4 groups per
         // round trip; lanes are summed by the butterfly, the 4 waves in fixed order: bit-reproducible
@@ -1308,7 +1322,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_store(flagB + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == 0) sk_wait_flags(flagB, G, (unsigned)(it + 1), status);
+        if (w == 0) sk_wait_flags(flagB, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad);
         __syncthreads();
         // the M + 1 column sums -> LDS (two float4 groups per thread per round trip), then b_j = nu / (cb_j + a_N), b_M likewise;
         // a_N of the NEXT pass from the new b
@@ -1342,10 +1356,11 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     }
     // ---- out_ij = E_ij a_i b_j e^-norm
     const bool vec_out = (M & 3) == 0 && ((uintptr_t)A.out % (4 * sizeof(TOut))) == 0;
+    const bool bad = s_bad != 0;                                  // (every wait above is followed by a workgroup barrier)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         if (!rowok[r]) continue;
-        const float S = expf(-normf) * ai[r];
+        const float S = bad ? __builtin_nanf("") : expf(-normf) * ai[r];
         TOut* dst = reinterpret_cast<TOut*>(A.out) + (size_t)tile * N * M + (size_t)(i0 + r) * M;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
@@ -1363,14 +1378,55 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
 
 // rows per wave of the co-resident form for a batch: 1 if the launch is then resident beside a second one, else 2 (tiles of up to 768
 // columns: two rows of 3 float4s per lane are 123-125 registers, inside the 128 of two workgroups per CU; 4 float4s are 139), else 0 = not this form
+static size_t coop_lds_bytes(int vpl) { return ((size_t)SK_COOP_RW * (vpl * 256 + 4) + 8 * SK_COOP_RW + 8) * sizeof(float); }
+// resident workgroups per CU of the instantiation (VPL, RPW) as the occupancy API reports them for its registers and LDS, the least
+// over the four (input, output) type pairs, capped by the 2 that 512-thread workgroups of <= 128 registers allow; 0 = not built
+static int coop_blocks_per_cu(int vpl, int rpw) {
+    static int cache[9][3];                                       // 0 = not asked yet, -1 = not built / query failed
+    if (vpl < 1 || vpl > 8 || rpw < 1 || rpw > 2 || (rpw == 2 && vpl > 3)) return 0;
+    int& c = cache[vpl][rpw];
+    if (c == 0) {
+        int least = 2;
+        bool ok = true;
+        auto ask = [&](const void* fn) {
+            int nb = 0;
+            const size_t lds = coop_lds_bytes(vpl);
+            if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ok = false;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * SK_COOP_RW, lds) != hipSuccess) ok = false;
+            least = nb < least ? nb : least;
+        };
+#define SK_COOP_ASK(V, R)                                                         \
+    ask((const void*)sk_coop_kernel<float, float, V, SK_COOP_RW, R>);             \
+    ask((const void*)sk_coop_kernel<double, float, V, SK_COOP_RW, R>);            \
+    ask((const void*)sk_coop_kernel<double, double, V, SK_COOP_RW, R>);
+        switch (vpl * 4 + rpw) {
+            case 1 * 4 + 1: SK_COOP_ASK(1, 1) break;
+            case 1 * 4 + 2: SK_COOP_ASK(1, 2) break;
+            case 2 * 4 + 1: SK_COOP_ASK(2, 1) break;
+            case 2 * 4 + 2: SK_COOP_ASK(2, 2) break;
+            case 3 * 4 + 1: SK_COOP_ASK(3, 1) break;
+            case 3 * 4 + 2: SK_COOP_ASK(3, 2) break;
+            case 4 * 4 + 1: SK_COOP_ASK(4, 1) break;
+            case 5 * 4 + 1: SK_COOP_ASK(5, 1) break;
+            case 6 * 4 + 1: SK_COOP_ASK(6, 1) break;
+            case 7 * 4 + 1: SK_COOP_ASK(7, 1) break;
+            case 8 * 4 + 1: SK_COOP_ASK(8, 1) break;
+            default: ok = false;
+        }
+#undef SK_COOP_ASK
+        c = (ok && least > 0) ? least : -1;
+    }
+    return c > 0 ? c : 0;
+}
 static int coop_rows_per_wave(int B, int N, int M, int flags) {
     if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return 0;
     if (M > 2048 || !env_knob("DR_SK_COOP", 1)) return 0;
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-    // 512-thread workgroups with 8 (VPL 256 + 4) floats of LDS: 2 per CU by threads, 2 at VPL = 8 by LDS
-    const long lim = 2L * n_cu / SK_COOP_SHARE;
-    if ((long)B * sk_coop_g(N) <= lim) return 1;
-    if (M <= 768 && (long)B * ((N + 2 * SK_COOP_RW - 1) / (2 * SK_COOP_RW)) <= lim && env_knob("DR_SK_COOP", 1) != 2) return 2;
+    const int vpl = (M + 255) / 256;
+    // residency as the runtime reports it for the instantiation that would run, shared with SK_COOP_SHARE - 1 other launches
+    if ((long)B * sk_coop_g(N) <= (long)coop_blocks_per_cu(vpl, 1) * n_cu / SK_COOP_SHARE) return 1;
+    if (M <= 768 && env_knob("DR_SK_COOP", 1) != 2 &&
+        (long)B * ((N + 2 * SK_COOP_RW - 1) / (2 * SK_COOP_RW)) <= (long)coop_blocks_per_cu(vpl, 2) * n_cu / SK_COOP_SHARE) return 2;
     return 0;
 }
 static bool coop_path(int B, int N, int M, int flags) { return coop_rows_per_wave(B, N, M, flags) != 0; }
@@ -1388,7 +1444,7 @@ static int launch_coop(const SkArgs& a, hipStream_t st) {
     const dim3 grid(G, a.B), blk(64 * SK_COOP_RW);
 #define SK_COOP_LAUNCH(V, R)                                                                                                 \
     {                                                                                                                        \
-        const size_t lds = ((size_t)SK_COOP_RW * (V * 256 + 4) + 8 * SK_COOP_RW + 8) * sizeof(float);                        \
+        const size_t lds = coop_lds_bytes(V);                                                                                \
         if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_COOP_RW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_COOP_RW, R>), grid, blk, lds, st, a);                            \
     }
@@ -1505,6 +1561,7 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
     SkArgs a;
     a.scores = scores; a.src_mask = src_mask; a.tgt_mask = tgt_mask; a.bin_score = bin_score;
     a.out = out; a.ws = ws; a.shift = shift; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
+    a.spin_limit = g_sk_spin_limit;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: read the score tile once, write the conf tile once
     ProfScope ps(PK_SINKHORN, (double)B * N * M * (sizeof(TIn) + (out32 ? 4.0 : 8.0)), st);
@@ -1551,9 +1608,25 @@ int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift,
     return sinkhorn_dispatch<double>(B, N, M, scores, shift, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
 }
 
+// waits for the stream, reads (and clears) the sticky flag
+int sinkhorn_device_status(hipStream_t st, bool clear) {
+    DR_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned h = 0;
+    DR_HIP_CHECK(hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_sk_status), sizeof(h)));
+    if (h && clear) {
+        const unsigned z = 0;
+        DR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_status), &z, sizeof(z)));
+    }
+    return (h & 1u) ? DR_ETIMEOUT : DR_OK;
+}
+
 }  // namespace dr
 
 extern "C" {
+
+int dr_device_status(void* stream, int clear) { return dr::sinkhorn_device_status((hipStream_t)stream, clear != 0); }
+/* diagnostics (include/diffreg_hip_debug.h): polls before the co-resident Sinkhorn gives up; 0 = the default */
+void dr_debug_sinkhorn_spin_limit(unsigned polls) { dr::g_sk_spin_limit = polls ? polls : dr::SK_COOP_SPIN; }
 
 size_t dr_sinkhorn_workspace_bytes(int B, int N, int M, int elem_bytes, int flags) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;

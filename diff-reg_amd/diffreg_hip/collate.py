@@ -43,13 +43,19 @@ def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_
 def encoder_levels(architecture):
     """The encoder half of a KPFCN architecture string list as resolution levels: [(wide_conv, down, wide_down), ...].
     A level is the run of convolution blocks at one point density; it ends at the block that changes the density (a 'pool' or
-    'strided' block: `down` = True) or where the decoder starts ('upsample' / 'global', or the end of the list).
+    'strided' block: `down` = True) or where the decoder starts ('upsample', or the end of the list; convolutions in front of a
+    'global' block are dropped, as the reference's loop drops them).
     wide_conv: the level's convolutions search the deformable radius -- the case when a block BEFORE the level's last convolution
     is deformable (the rule of 3D/datasets/dataloader.py:141-146); wide_down: the density-changing block itself is deformable.
     A level without convolution blocks (two density changes in a row) has wide_conv = None: it gets no neighbour matrix."""
     levels, convs = [], []
     for name in architecture:
-        if "global" in name or "upsample" in name:
+        if "global" in name:
+            # the reference's loop `continue`s over the convolutions in front of a 'global' block (their successor is not an
+            # 'upsample') and then breaks on it: that trailing level is never emitted (dataloader.py:137-146)
+            convs = []
+            break
+        if "upsample" in name:
             break
         if "pool" in name or "strided" in name:
             levels.append((any("deformable" in c for c in convs[:-1]) if convs else None, True, "deformable" in name))

@@ -297,6 +297,7 @@ class DenoiseEngine:
         out = self.run(fs, ft, ps, pt, xT, sm, tm, noise=nz, graph=graph, ragged=True, borrow=True)
         res = []
         cnt = out["match_count"].cpu().tolist() if "match_count" in out else None
+        lib.device_status(self.device)          # (the count read above synchronised already)
         for i in range(P):
             r = dict(conf_matrix_pred=out["conf_matrix_pred"][i, :Ns[i], :Ms[i]].clone(), R_final=out["R_final"][i].clone(),
                      t_final=out["t_final"][i].clone())
@@ -307,8 +308,9 @@ class DenoiseEngine:
 
     @staticmethod
     def match_list(out):
-        """[K_p,3] int64 tensors (one host sync)."""
+        """[K_p,3] int64 tensors (one host sync; raises if a kernel of the run reported a device-side failure)."""
         cnt = out["match_count"].cpu().tolist()
+        lib.device_status(out["match_count"].device)
         return [out["matches_padded"][p, :cnt[p]] for p in range(len(cnt))]
 
 

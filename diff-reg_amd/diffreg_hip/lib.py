@@ -118,11 +118,13 @@ SIGNATURES.update({
     "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
-    "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 8),
+    "dr_procrustes_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "dr_device_status": (c_int, [c_void_p, c_int]),
+    "dr_debug_sinkhorn_spin_limit": (None, [ctypes.c_uint]),
     "dr_debug_enable_env": (None, [c_int]),
     "dr_debug_launch_chain": (c_int, [c_int, c_int, c_int, c_void_p]),
     "dr_debug_gemm_config": (None, [c_int]),
-    "dr_debug_procrustes_stamps": (c_int, [c_void_p]),
     "dr_debug_attention_config": (None, [c_int]),
     "dr_debug_attention_split": (None, [c_int]),
     "dr_pnp_ransac_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -154,8 +156,9 @@ SIGNATURES.update({
     "dr_scatter_rows_f32": (c_int, [c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "dr_mutual_match_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_mutual_match_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_top1_union_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dr_top1_union_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dr_top1_union_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dr_loop_prepack_bytes": (c_size_t, [_P(LoopConfig)]),
     "dr_loop_prepack": (c_int, [_P(LoopConfig), _P(LoopWeights), c_void_p, c_size_t, c_void_p]),
     "dr_denoise_loop_workspace_bytes": (c_size_t, [_P(LoopConfig), c_int, c_int, c_int]),
@@ -218,6 +221,14 @@ def check(code):
         if code == -2:
             msg += ": " + _lib.dr_last_hip_error().decode()
         raise RuntimeError("libdiffreg_hip: %s (%d)" % (msg, code))
+
+
+def device_status(device=None, clear=True):
+    """Waits for the current stream of `device` and raises if a kernel reported a device-side failure since the last check
+    (DR_ETIMEOUT: the single-launch Sinkhorn gave up waiting for a workgroup that was not resident; its outputs are NaN).
+    Called wherever the host mirrors synchronise anyway (match counts)."""
+    st = torch.cuda.current_stream(device).cuda_stream
+    check(_lib.dr_device_status(c_void_p(st), 1 if clear else 0))
 
 
 def ptr(t):
@@ -737,9 +748,11 @@ def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond
     K = int(float(torch.tensor(float(max(N, M)), dtype=torch.float32) * sample_rate))
     idx = torch.empty(P, K, dtype=torch.int32, device=dev) if want_topk else None
     sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    wsb = _lib.dr_procrustes_workspace_bytes(P, N, M)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
     check(_lib.dr_procrustes_f32(P, N, M, ptr(conf), ptr(src_pcd.contiguous().float()), ptr(tgt_pcd.contiguous().float()),
                                  ptr(sm), ptr(tm), 1 if use_mask_len else 0, float(sample_rate), float(max_condition_num),
-                                 ptr(R), ptr(t), ptr(Rf), ptr(tf), ptr(cond), ptr(ok), ptr(idx), stream_of(conf)))
+                                 ptr(R), ptr(t), ptr(Rf), ptr(tf), ptr(cond), ptr(ok), ptr(idx), ptr(ws), wsb, stream_of(conf)))
     res = (R, t, Rf, tf, cond, ok.bool())
     return res + (idx,) if want_topk else res
 
@@ -751,8 +764,11 @@ def top1_union(conf):
     P, N, M = conf.shape
     out = torch.empty(P, N + M, 3, dtype=torch.int64, device=conf.device)
     cnt = torch.empty(P, dtype=torch.int32, device=conf.device)
-    fn = _lib.dr_top1_union_f64 if conf.dtype == torch.float64 else _lib.dr_top1_union_f32
-    check(fn(P, N, M, ptr(conf), ptr(out), ptr(cnt), stream_of(conf)))
+    f64 = conf.dtype == torch.float64
+    fn = _lib.dr_top1_union_f64 if f64 else _lib.dr_top1_union_f32
+    wsb = _lib.dr_top1_union_workspace_bytes(P, N, M, 8 if f64 else 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=conf.device) if wsb else None
+    check(fn(P, N, M, ptr(conf), ptr(out), ptr(cnt), ptr(ws), wsb, stream_of(conf)))
     counts = cnt.cpu().tolist()
     return [out[p, :counts[p]] for p in range(P)]
 

@@ -181,6 +181,8 @@ class Pipeline(nn.Module):
             seg = seg.clone()
             seg[:, :, 0] = torch.arange(P, device=dev)[:, None]
             data.update({"match_pred": seg[keep]})
+        from diffreg_hip import lib as _drlib
+        _drlib.device_status(dev)      # raises on a device-side failure of the run (DR_ETIMEOUT); the mask index above synchronised
         if self.strict_reference:
             R = torch.eye(3, dtype=torch.float64, device=dev)[None].repeat(P, 1, 1)
             t = torch.zeros(P, 3, 1, dtype=torch.float64, device=dev)

@@ -29,10 +29,21 @@ extern "C" {
 #define DR_ELAUNCH (-2)  /* a HIP launch or API call failed (dr_last_hip_error has detail) */
 #define DR_ENOSUP (-3)   /* shape not supported by this build                               */
 #define DR_EWORKSPACE (-4) /* workspace too small                                           */
+#define DR_ETIMEOUT (-5) /* a kernel gave up waiting for another workgroup (dr_device_status) */
 
 int dr_version(void);                 /* major*10000 + minor*100 + patch */
 const char* dr_strerror(int code);
 const char* dr_last_hip_error(void);  /* text of the last failing HIP call on this thread */
+
+/* Device-side failures.  Every call above returns when its kernels are ENQUEUED, so a failure that only a running kernel can
+ * detect cannot come back as a return value.  There is one such failure: the single-launch Sinkhorn of tiles beyond 256 x 256
+ * exchanges column sums between workgroups that must all be resident; its spins are bounded, and a workgroup that gives up
+ * writes NaN to every output entry it owns (the failure is visible in the data) and sets a sticky flag on the device.
+ * dr_device_status is the ONE entry point that synchronises: it waits for `stream`, reads the flag (clearing it when `clear`
+ * is non-zero) and returns DR_OK or DR_ETIMEOUT.  The host mirrors call it wherever they already synchronise to read a match
+ * count.  (The launcher checks residency with the occupancy API and takes the multi-launch form when the launch would not
+ * fit beside a second one, so the flag means something else holds the CUs: a foreign kernel, a CU mask, a partitioned device.) */
+int dr_device_status(void* stream, int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * Sinkhorn with dustbins.  Replaces log_optimal_transport + exp + [:-1,:-1] slice
@@ -227,13 +238,15 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
  *   R,t = solution; R_forwd,t_forwd = solution or identity when cond >= max_condition_num;
  *   topk_idx (optional, [P,K]) flat indices i*M+j of the selected entries (a set: unordered)
  *   Ties at the K-th value: the lowest flat indices are taken (torch.topk leaves that choice implementation-defined).
- *   Tiles beyond 256 x 256 select with the whole chip and take their scratch from the stream's memory pool
- *   (hipMallocAsync / hipFreeAsync on `stream`: stream-ordered, capturable, nothing cached across calls).
+ *   workspace: dr_procrustes_workspace_bytes(P, N, M) bytes (0 for tiles up to 256 x 256: pass NULL); tiles beyond that select
+ *   with the whole chip and need it -- DR_EWORKSPACE when it is missing or too small.
  */
+size_t dr_procrustes_workspace_bytes(int P, int N, int M);
 int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_pcd, const float* tgt_pcd,
                       const uint8_t* src_mask, const uint8_t* tgt_mask, int use_mask_len, float sample_rate,
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
-                      double* condition, int32_t* solution_mask, int32_t* topk_idx, void* stream);
+                      double* condition, int32_t* solution_mask, int32_t* topk_idx, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* Diagnostics (kernel-forcing setters, phase stamps, the environment switch) are NOT part of the drop-in boundary: they are
  * declared in include/diffreg_hip_debug.h.  The library reads no environment variable unless dr_debug_enable_env(1) was called. */
@@ -241,9 +254,13 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
 /* mutual_topk_select(conf, k=1, largest=True, threshold=None, mutual=False) + the [0,i,j] rows of
  * 3D/models/pipeline.py:275-278.  matches [P, N+M, 3] int64 (first count[p] rows valid), ascending (i, j); the first
  * occurrence wins an arg-max tie.  N + M <= 4096.  From 32 rows on the arg-maxima come from row-block workgroups over the
- * whole chip; their scratch is taken from the stream's memory pool (hipMallocAsync / hipFreeAsync on `stream`). */
-int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* stream);
-int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* stream);
+ * whole chip, which need dr_top1_union_workspace_bytes(P, N, M, elem_bytes) bytes of workspace (elem_bytes 4 / 8; 0 = none
+ * needed, pass NULL); DR_EWORKSPACE when it is missing or too small. */
+size_t dr_top1_union_workspace_bytes(int P, int N, int M, int elem_bytes);
+int dr_top1_union_f64(int P, int N, int M, const double* conf, int64_t* matches, int32_t* count, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int dr_top1_union_f32(int P, int N, int M, const float* conf, int64_t* matches, int32_t* count, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Pipeline.split_feats (3D/models/pipeline.py:350-379): dst[dst_index[i]][:] = src[src_index[i]][:], i < n, rows of C floats
  * (the stacked coarse features / points of the backbone scattered into the zero-padded [B * N_max, C] tensors).

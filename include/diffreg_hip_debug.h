@@ -21,8 +21,9 @@ void dr_debug_gemm_config(int c);
 void dr_debug_attention_config(int flash_min_workgroups);
 /* flash attention arithmetic: 1 = split-operand bf16 MFMA products (default), 0 = f32-input MFMA, -1 = default */
 void dr_debug_attention_split(int on);
-/* 8 wall-clock stamps (100 MHz ticks) of the phases of the last dr_procrustes_f32 launch (pair 0); synchronises the device. */
-int dr_debug_procrustes_stamps(long long* h_out8);
+/* polls before a workgroup of the single-launch Sinkhorn gives up waiting for the others (0 = the default, 2^22); the timeout test
+ * sets 1 so that the first failed poll already gives up (tests/test_errors_gpu.py) */
+void dr_debug_sinkhorn_spin_limit(unsigned polls);
 /* n dependent launches of an empty kernel (tools/launch_floor.py) */
 int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream);
 

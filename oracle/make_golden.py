@@ -62,7 +62,7 @@ def ref_config(variant, steps, max_cond):
         SAMPLE_STEP=steps))
 
 
-def run_tree(variant):
+def run_tree(variant, family="main"):
     import torch
     sys.modules["open3d"] = MagicMock()
     for m in ("easydict", "tensorboardX", "nibabel", "cv2"):
@@ -89,83 +89,94 @@ def run_tree(variant):
     os.makedirs(OUT, exist_ok=True)
     save = lambda name, **kw: np.savez_compressed(os.path.join(OUT, "%s_%s.npz" % (variant, name)), **kw)
 
-    # ---------------- F1: log_optimal_transport -------------------------------------------
-    if variant == "3dmatch":
-        f1 = {}
-        for (N, M, nv, mv, alpha, dt) in [(128, 128, 128, 128, 1.0, "f32"), (128, 128, 128, 128, 1.0, "f64"),
-                                          (200, 256, 200, 256, 0.37, "f32"), (96, 80, 70, 61, 1.0, "f32"),
-                                          (96, 80, 70, 61, 0.37, "f64"), (256, 256, 256, 256, 1.0, "f32"),
-                                          (5, 7, 5, 7, 1.0, "f32"), (1, 1, 1, 1, 1.0, "f32")]:
-            tdt = torch.float32 if dt == "f32" else torch.float64
-            sc = T(3.0 * synth.hash_normal(1, N * 1000 + M, (1, N, M))).to(tdt)
-            sm = torch.arange(N)[None] < nv
-            tm = torch.arange(M)[None] < mv
-            sc = sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf"))
-            Z = log_optimal_transport(sc, torch.tensor(alpha, dtype=torch.float32), 3, sm, tm)
-            assert Z.dtype == tdt
-            f1["logZ_%d_%d_%d_%d_%s_%s" % (N, M, nv, mv, str(alpha).replace(".", "p"), dt)] = Z.numpy()
-            # (the mask=None branch of the reference raises: `(ms + ns).log()` on python ints,
-            #  3D/models/matching.py:65-67,79 -- quirk Q21; masks are always passed on the path)
-        save("sinkhorn", **f1)
+    def components():
+        """F1 .. F6: the ops one by one (main family only)"""
+        # ---------------- F1: log_optimal_transport -------------------------------------------
+        if variant == "3dmatch":
+            f1 = {}
+            for (N, M, nv, mv, alpha, dt) in [(128, 128, 128, 128, 1.0, "f32"), (128, 128, 128, 128, 1.0, "f64"),
+                                              (200, 256, 200, 256, 0.37, "f32"), (96, 80, 70, 61, 1.0, "f32"),
+                                              (96, 80, 70, 61, 0.37, "f64"), (256, 256, 256, 256, 1.0, "f32"),
+                                              (5, 7, 5, 7, 1.0, "f32"), (1, 1, 1, 1, 1.0, "f32")]:
+                tdt = torch.float32 if dt == "f32" else torch.float64
+                sc = T(3.0 * synth.hash_normal(1, N * 1000 + M, (1, N, M))).to(tdt)
+                sm = torch.arange(N)[None] < nv
+                tm = torch.arange(M)[None] < mv
+                sc = sc.masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf"))
+                Z = log_optimal_transport(sc, torch.tensor(alpha, dtype=torch.float32), 3, sm, tm)
+                assert Z.dtype == tdt
+                f1["logZ_%d_%d_%d_%d_%s_%s" % (N, M, nv, mv, str(alpha).replace(".", "p"), dt)] = Z.numpy()
+                # (the mask=None branch of the reference raises: `(ms + ns).log()` on python ints,
+                #  3D/models/matching.py:65-67,79 -- quirk Q21; masks are always passed on the path)
+            save("sinkhorn", **f1)
 
-    # ---------------- F2: position code ----------------------------------------------------
-    cfg_t = ref_config(variant, 20, 200).coarse_transformer
-    pe_mod = VolumetricPositionEncoding(cfg_t)
-    pair = synth.make_pair(64, 48, C, seed=3)
-    ps, pt = T(pair["s_pcd"])[None], T(pair["t_pcd"])[None]
-    code = pe_mod(ps)
-    feat = T(pair["src_feats"])[None]
-    rot = VolumetricPositionEncoding.embed_rotary(feat, code[..., 0], code[..., 1])
-    save("pe", cos=code[0, :16, :, 0].numpy(), sin=code[0, :16, :, 1].numpy(), rot=rot[0, :16].numpy())
+        # ---------------- F2: position code ----------------------------------------------------
+        cfg_t = ref_config(variant, 20, 200).coarse_transformer
+        pe_mod = VolumetricPositionEncoding(cfg_t)
+        pair = synth.make_pair(64, 48, C, seed=3)
+        ps, pt = T(pair["s_pcd"])[None], T(pair["t_pcd"])[None]
+        code = pe_mod(ps)
+        feat = T(pair["src_feats"])[None]
+        rot = VolumetricPositionEncoding.embed_rotary(feat, code[..., 0], code[..., 1])
+        save("pe", cos=code[0, :16, :, 0].numpy(), sin=code[0, :16, :, 1].numpy(), rot=rot[0, :16].numpy())
 
-    # ---------------- F3/F4/F5: attention layer, denoiser, matching head -------------------
-    Wnp = synth.make_weights(C, seed=7, head_gain=HEAD_GAIN)
-    cfg_t2 = to_attr(dict(cfg_t))
-    cfg_t2["layer_types"] = list(synth.LAYER_TYPES)
-    den = RepositioningTransformer(cfg_t2)
-    den.load_state_dict({k[len("denoising_transformer."):]: T(a) for k, a in Wnp.items()
-                         if k.startswith("denoising_transformer.")})
-    head = Matching(ref_config(variant, 20, 200).coarse_matching)
-    head.load_state_dict({k[len("denoising_coarse_matching."):]: T(a) for k, a in Wnp.items()
-                          if k.startswith("denoising_coarse_matching.")})
-    den.eval(); head.eval()
-    fs, ft = T(pair["src_feats"])[None], T(pair["tgt_feats"])[None]
-    sm_full = torch.ones(1, 64, dtype=torch.bool); tm_full = torch.ones(1, 48, dtype=torch.bool)
-    sm_part = torch.arange(64)[None] < 50; tm_part = torch.arange(48)[None] < 41
-    with torch.no_grad():
-        pes, pet = pe_mod(ps), pe_mod(pt)
-        lay = den.layers[1]
-        f3 = dict(
-            self_full=lay(fs, fs, pes, pes, sm_full, sm_full)[0].numpy(),
-            cross_full=lay(fs, ft, pes, pet, sm_full, tm_full)[0].numpy(),
-            self_mask=lay(fs, fs, pes, pes, sm_part, sm_part)[0].numpy(),
-            cross_mask=lay(fs, ft, pes, pet, sm_part, tm_part)[0].numpy())
-        save("attn_layer", **f3)
-        d = {}
-        os_, ot_, pe_s, pe_t = den(fs, ft, ps, pt, sm_full, tm_full, d)
-        conf, _ = head(os_, ot_, pe_s, pe_t, sm_full, tm_full, d, pe_type="rotary")
-        d = {}
-        om_s, om_t, pe_s2, pe_t2 = den(fs, ft, ps, pt, sm_part, tm_part, d)
-        confm, _ = head(om_s, om_t, pe_s2, pe_t2, sm_part, tm_part, d, pe_type="rotary")
-        save("denoiser", f_s=os_[0].numpy(), f_t=ot_[0].numpy(), conf=conf[0].numpy(),
-             f_s_mask=om_s[0].numpy(), f_t_mask=om_t[0].numpy(), conf_mask=confm[0].numpy())
+        # ---------------- F3/F4/F5: attention layer, denoiser, matching head -------------------
+        Wnp = Wnp_main
+        cfg_t2 = to_attr(dict(cfg_t))
+        cfg_t2["layer_types"] = list(synth.LAYER_TYPES)
+        den = RepositioningTransformer(cfg_t2)
+        den.load_state_dict({k[len("denoising_transformer."):]: T(a) for k, a in Wnp.items()
+                             if k.startswith("denoising_transformer.")})
+        head = Matching(ref_config(variant, 20, 200).coarse_matching)
+        head.load_state_dict({k[len("denoising_coarse_matching."):]: T(a) for k, a in Wnp.items()
+                              if k.startswith("denoising_coarse_matching.")})
+        den.eval(); head.eval()
+        fs, ft = T(pair["src_feats"])[None], T(pair["tgt_feats"])[None]
+        sm_full = torch.ones(1, 64, dtype=torch.bool); tm_full = torch.ones(1, 48, dtype=torch.bool)
+        sm_part = torch.arange(64)[None] < 50; tm_part = torch.arange(48)[None] < 41
+        with torch.no_grad():
+            pes, pet = pe_mod(ps), pe_mod(pt)
+            lay = den.layers[1]
+            f3 = dict(
+                self_full=lay(fs, fs, pes, pes, sm_full, sm_full)[0].numpy(),
+                cross_full=lay(fs, ft, pes, pet, sm_full, tm_full)[0].numpy(),
+                self_mask=lay(fs, fs, pes, pes, sm_part, sm_part)[0].numpy(),
+                cross_mask=lay(fs, ft, pes, pet, sm_part, tm_part)[0].numpy())
+            save("attn_layer", **f3)
+            d = {}
+            os_, ot_, pe_s, pe_t = den(fs, ft, ps, pt, sm_full, tm_full, d)
+            conf, _ = head(os_, ot_, pe_s, pe_t, sm_full, tm_full, d, pe_type="rotary")
+            d = {}
+            om_s, om_t, pe_s2, pe_t2 = den(fs, ft, ps, pt, sm_part, tm_part, d)
+            confm, _ = head(om_s, om_t, pe_s2, pe_t2, sm_part, tm_part, d, pe_type="rotary")
+            save("denoiser", f_s=os_[0].numpy(), f_t=ot_[0].numpy(), conf=conf[0].numpy(),
+                 f_s_mask=om_s[0].numpy(), f_t_mask=om_t[0].numpy(), conf_mask=confm[0].numpy())
 
-    # ---------------- F6: SoftProcrustesLayer ----------------------------------------------
-    pr = synth.make_pair(128, 128, C, seed=5)
-    gtm = np.zeros((128, 128)); gtm[pr["gt_matches"][:, 0], pr["gt_matches"][:, 1]] = 6.0
-    sc = T(gtm + synth.hash_normal(5, 77, (128, 128)))[None].float()
-    smk = torch.arange(128)[None] < 120; tmk = torch.arange(128)[None] < 111
-    Z = log_optimal_transport(sc.masked_fill(~(smk[:, :, None] & tmk[:, None, :]), float("-inf")),
-                              torch.tensor(1.0), 3, smk, tmk)
-    cf = Z.exp()[:, :-1, :-1].contiguous()
-    f6 = {}
-    for mc in (0, 40, 200):
-        layer = SoftProcrustesLayer(to_attr(dict(sample_rate=1.0, max_condition_num=mc)))
-        R, t, Rf, tf, cond, ok = layer(cf.clone(), T(pr["s_pcd"])[None], T(pr["t_pcd"])[None], smk, tmk)
-        f6.update({"R_%d" % mc: R.numpy(), "t_%d" % mc: t.numpy(), "Rf_%d" % mc: Rf.numpy(),
-                   "tf_%d" % mc: tf.numpy(), "cond_%d" % mc: cond.numpy(), "ok_%d" % mc: ok.numpy()})
-    f6["R_gt"], f6["t_gt"] = pr["R_gt"], pr["t_gt"]
-    save("procrustes", **f6)
+        # ---------------- F6: SoftProcrustesLayer ----------------------------------------------
+        pr = synth.make_pair(128, 128, C, seed=5)
+        gtm = np.zeros((128, 128)); gtm[pr["gt_matches"][:, 0], pr["gt_matches"][:, 1]] = 6.0
+        sc = T(gtm + synth.hash_normal(5, 77, (128, 128)))[None].float()
+        smk = torch.arange(128)[None] < 120; tmk = torch.arange(128)[None] < 111
+        Z = log_optimal_transport(sc.masked_fill(~(smk[:, :, None] & tmk[:, None, :]), float("-inf")),
+                                  torch.tensor(1.0), 3, smk, tmk)
+        cf = Z.exp()[:, :-1, :-1].contiguous()
+        f6 = {}
+        for mc in (0, 40, 200):
+            layer = SoftProcrustesLayer(to_attr(dict(sample_rate=1.0, max_condition_num=mc)))
+            R, t, Rf, tf, cond, ok = layer(cf.clone(), T(pr["s_pcd"])[None], T(pr["t_pcd"])[None], smk, tmk)
+            f6.update({"R_%d" % mc: R.numpy(), "t_%d" % mc: t.numpy(), "Rf_%d" % mc: Rf.numpy(),
+                       "tf_%d" % mc: tf.numpy(), "cond_%d" % mc: cond.numpy(), "ok_%d" % mc: ok.numpy()})
+        f6["R_gt"], f6["t_gt"] = pr["R_gt"], pr["t_gt"]
+        save("procrustes", **f6)
+
+
+    Wnp_main = synth.make_weights(C, seed=7, head_gain=HEAD_GAIN)
+    if family == "main":
+        components()
+    # the "soft" family (round 4): the same scenes with the matching head at a checkpoint-like scale (HEAD_GAIN_SOFT: matching logits
+    # O(10) instead of thousands), where the reference's own float32 run is within 2e-5 of the float64 evaluation on EVERY entry, so
+    # that the loop is held to the reference by a plain 1e-4 bound with an empty exemption list (tests/golden/loop_exemptions.json)
+    Wnp = Wnp_main if family == "main" else synth.make_weights(C, seed=7, head_gain=HEAD_GAIN_SOFT)
 
     # ---------------- F7: the loop through Pipeline.forward --------------------------------
     from models.pipeline import Pipeline
@@ -257,6 +268,13 @@ def run_tree(variant):
         print(tag, "conf", conf.dtype, "max %.4f" % float(c.max()), "rowmax mean %.4f" % float(c.max(1)[0].mean()),
               "cond", rec["cond"][:3], "R_s2t", rec["R_s2t_pred"].ravel()[:3])
 
+    if family == "soft":
+        if variant == "3dmatch":
+            run_loop(128, 128, 128, 128, 1, 200, seed=11, tag="soft_n128_s1_mc200")      # cfg1
+            run_loop(256, 256, 256, 256, 20, 200, seed=13, tag="soft_n256_s20_mc200")    # cfg2
+        else:
+            run_loop(512, 512, 470, 391, 20, 40, seed=62, tag="soft_n512_s20_mc40_masked")   # cfg3's pair 0
+        return
     if variant == "3dmatch":
         run_loop(128, 128, 128, 128, 1, 200, seed=11, tag="n128_s1_mc200")      # cfg1
         run_loop(128, 128, 128, 128, 20, 0, seed=11, tag="n128_s20_mc0")        # shipped test yaml (Q4)
@@ -373,10 +391,13 @@ def run_2d3d():
 
 HEAD_GAIN_2D3D = 16.0
 HEAD_GAIN = 24.0   # sharpens x_start so the synthetic scenes give near-permutation matrices (section 8c F7)
+HEAD_GAIN_SOFT = 3.0   # the "soft" family: logits O(10), nothing ill-conditioned (no exemptions), still row maxima ~ 0.57
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run_2d3d() if sys.argv[1] == "2d3d" else run_tree(sys.argv[1])
+        run_2d3d() if sys.argv[1] == "2d3d" else run_tree(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "main")
     else:
         for v in list(TREES) + ["2d3d"]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), v])
+        for v in TREES:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), v, "soft"])

@@ -60,3 +60,38 @@ def test_subsample_properties():
     # idempotent up to float rounding: every barycentre lies in its own voxel, one point per voxel
     sp2, sl2 = co.grid_subsample_batch(sp, sl, 1e-4)
     assert np.array_equal(sl2, sl)
+
+
+def _reference_levels(architecture):
+    """The level rule of the reference's collate loop (3D/datasets/dataloader.py:134-211) restated as the descriptors encoder_levels
+    returns: walk the blocks, a level is emitted at a density-changing block, or at a convolution that is the last block or is
+    followed by an 'upsample'; 'global' / 'upsample' end the walk."""
+    out, blocks = [], []
+    for i, b in enumerate(architecture):
+        if "global" in b or "upsample" in b:
+            break
+        if not ("pool" in b or "strided" in b):
+            blocks.append(b)
+            if i < len(architecture) - 1 and "upsample" not in architecture[i + 1]:
+                continue
+        down = "pool" in b or "strided" in b
+        wide = any("deformable" in x for x in blocks[:-1]) if blocks else None
+        out.append((wide, down, down and "deformable" in b))
+        blocks = []
+    return out
+
+
+def test_encoder_levels_follow_the_reference_rule():
+    from diffreg_hip.collate import encoder_levels
+    archs = [
+        ["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb", "resnetb_strided", "resnetb", "resnetb", "resnetb_strided",
+         "resnetb", "resnetb", "nearest_upsample", "unary", "nearest_upsample", "unary", "nearest_upsample", "unary"],   # 3D/configs/models.py:3-21
+        ["simple", "resnetb_deformable", "resnetb", "resnetb_deformable_strided", "resnetb", "nearest_upsample", "unary"],
+        ["simple", "resnetb_strided", "max_pool", "resnetb", "resnetb"],                      # two density changes in a row; ends on convs
+        ["simple", "resnetb", "resnetb_strided", "resnetb", "global_average", "unary"],       # convs in front of 'global' are dropped
+        ["simple", "resnetb"],
+        ["resnetb_strided"],
+    ]
+    for a in archs:
+        assert encoder_levels(a) == _reference_levels(a), a
+    assert len(encoder_levels(archs[0])) == 4 and len(encoder_levels(archs[3])) == 1

@@ -13,14 +13,14 @@ from tests.test_loop_gpu import engine
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-OK, EINVAL, ELAUNCH, ENOSUP, EWORKSPACE = 0, -1, -2, -3, -4
+OK, EINVAL, ELAUNCH, ENOSUP, EWORKSPACE, ETIMEOUT = 0, -1, -2, -3, -4, -5
 
 
 def test_status_strings():
     from diffreg_hip import lib
     r = lib.raw()
     assert r.dr_strerror(OK).decode() == "ok"
-    for code in (EINVAL, ELAUNCH, ENOSUP, EWORKSPACE):
+    for code in (EINVAL, ELAUNCH, ENOSUP, EWORKSPACE, ETIMEOUT):
         assert r.dr_strerror(code).decode() not in ("ok", "unknown error")
     assert r.dr_strerror(-99).decode() == "unknown error"
 
@@ -110,3 +110,80 @@ def test_mutual_topk_refuses_k_beyond_the_matrix():
     assert r.dr_mutual_topk_select_f32(2, 4, 3, lib.ptr(sc), 3, 1, 0, 0.0, 1, None, None, lib.ptr(idx), lib.ptr(s), 64, lib.ptr(tot), lib.ptr(ws), wsb,
                                        lib.stream_of(sc)) == OK
     torch.cuda.synchronize()
+
+
+def test_coresident_sinkhorn_fails_loudly():
+    """The single-launch Sinkhorn of tiles beyond 256 x 256 waits for column sums of other workgroups with bounded spins.  With the spin bound
+    at ONE poll (debug header) the first failed poll already gives up: the workgroup must then poison its outputs (NaN) and raise the sticky
+    device flag that dr_device_status turns into DR_ETIMEOUT -- never a silent wrong matrix with DR_OK.  Afterwards the flag is clear and the
+    same call gives the oracle's result again."""
+    from diffreg_hip import lib
+    from oracle import diffreg_oracle as orc
+    r = lib.raw()
+    lib.ensure_init()
+    x = torch.randn(1, 1024, 2048, device=DEV) * 2
+    a = torch.tensor(1.0, device=DEV)
+    good = lib.sinkhorn(x, a, 3)
+    assert r.dr_device_status(lib.stream_of(x), 1) == OK and torch.isfinite(good).all()
+    r.dr_debug_sinkhorn_spin_limit(1)
+    try:
+        timed_out = False
+        for _ in range(20):                          # 128 workgroups polling once each: some poll fails in practically every launch
+            bad = lib.sinkhorn(x, a, 3)
+            rc = r.dr_device_status(lib.stream_of(x), 0)        # (not cleared: the flag is sticky)
+            if rc != OK:
+                assert rc == ETIMEOUT and r.dr_strerror(rc).decode() not in ("ok", "unknown error")
+                assert torch.isnan(bad).any()        # the failure is in the data too
+                with pytest.raises(RuntimeError, match="gave up waiting"):
+                    lib.device_status(x.device)      # the host mirror raises, and clears
+                assert r.dr_device_status(lib.stream_of(x), 0) == OK
+                timed_out = True
+                break
+            assert torch.equal(bad, good)            # no timeout -> the ordinary, bit-reproducible result
+        assert timed_out
+    finally:
+        r.dr_debug_sinkhorn_spin_limit(0)
+        r.dr_device_status(lib.stream_of(x), 1)
+    again = lib.sinkhorn(x, a, 3)
+    assert r.dr_device_status(lib.stream_of(x), 1) == OK
+    assert torch.equal(again, good)
+    sm, tm = torch.ones(1, 1024, dtype=torch.bool), torch.ones(1, 2048, dtype=torch.bool)
+    ref = orc.sinkhorn_conf(x.cpu(), torch.tensor(1.0), 3, sm, tm)
+    assert ((again.cpu() - ref).abs() / ref.clamp_min(1e-30))[ref > 1e-12 * ref.max()].max().item() < 2e-5
+
+
+def test_procrustes_and_readout_take_caller_workspaces():
+    """dr_procrustes_f32 / dr_top1_union_* allocate nothing: tiles beyond 256 x 256 (read-out: from 32 rows on) need the caller's
+    workspace of dr_*_workspace_bytes, DR_EWORKSPACE without it; small tiles need none."""
+    from diffreg_hip import lib
+    r = lib.raw()
+    lib.ensure_init()
+    P, N, M = 2, 300, 400
+    conf = torch.rand(P, N, M, device=DEV)
+    sp, tp = torch.randn(P, N, 3, device=DEV), torch.randn(P, M, 3, device=DEV)
+    R = torch.empty(P, 9, device=DEV); t = torch.empty(P, 3, device=DEV); Rf = torch.empty_like(R); tf = torch.empty_like(t)
+    cond = torch.empty(P, dtype=torch.float64, device=DEV); ok = torch.empty(P, dtype=torch.int32, device=DEV)
+    st = lib.stream_of(conf)
+    need = r.dr_procrustes_workspace_bytes(P, N, M)
+    assert need > 0 and r.dr_procrustes_workspace_bytes(P, 256, 256) == 0
+
+    def fit(ws, nbytes, n=N, m=M, c=conf):
+        return r.dr_procrustes_f32(P, n, m, lib.ptr(c), lib.ptr(sp), lib.ptr(tp), None, None, 0, 1.0, 200.0, lib.ptr(R), lib.ptr(t), lib.ptr(Rf),
+                                   lib.ptr(tf), lib.ptr(cond), lib.ptr(ok), None, lib.ptr(ws), nbytes, st)
+    assert fit(None, 0) == EWORKSPACE
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    assert fit(ws, need - 1) == EWORKSPACE
+    assert fit(ws, need) == OK
+    assert fit(None, 0, 200, 256, torch.rand(P, 200, 256, device=DEV)) == OK          # register-resident tiles need none
+    out = torch.empty(P, N + M, 3, dtype=torch.int64, device=DEV); cnt = torch.empty(P, dtype=torch.int32, device=DEV)
+    need1 = r.dr_top1_union_workspace_bytes(P, N, M, 4)
+    assert need1 > 0 and r.dr_top1_union_workspace_bytes(P, 16, M, 4) == 0 and r.dr_top1_union_workspace_bytes(P, N, M, 3) == 0
+    assert r.dr_top1_union_f32(P, N, M, lib.ptr(conf), lib.ptr(out), lib.ptr(cnt), None, 0, st) == EWORKSPACE
+    ws1 = torch.empty(need1, dtype=torch.uint8, device=DEV)
+    assert r.dr_top1_union_f32(P, N, M, lib.ptr(conf), lib.ptr(out), lib.ptr(cnt), lib.ptr(ws1), need1, st) == OK
+    torch.cuda.synchronize()
+    rows = conf.argmax(2)
+    got = lib.top1_union(conf)
+    for p in range(P):
+        have = set(map(tuple, got[p][:, 1:].cpu().tolist()))
+        assert all((i, int(rows[p, i])) in have for i in range(N))

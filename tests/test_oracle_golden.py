@@ -6,7 +6,7 @@ import torch
 
 from diffreg_hip import synth
 from oracle import diffreg_oracle as orc
-from tests.helpers import T, weights, pair, masks, sinkhorn_case
+from tests.helpers import assert_match_list_is_the_references, T, weights, pair, masks, sinkhorn_case
 
 SK_CASES = [(128, 128, 128, 128, 1.0, "f32"), (128, 128, 128, 128, 1.0, "f64"), (200, 256, 200, 256, 0.37, "f32"),
             (96, 80, 70, 61, 1.0, "f32"), (96, 80, 70, 61, 0.37, "f64"), (256, 256, 256, 256, 1.0, "f32"),
@@ -127,6 +127,39 @@ def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, 
         for i in solid_rows:
             assert (0, int(i), int(am[i])) in got
         assert len(ref ^ got) <= 0.02 * len(ref)
+
+
+SOFT = [("3dmatch", 128, 128, 128, 128, 1, 200, 11, "soft_n128_s1_mc200"),
+        ("3dmatch", 256, 256, 256, 256, 20, 200, 13, "soft_n256_s20_mc200"),
+        ("4dmatch", 512, 512, 470, 391, 20, 40, 62, "soft_n512_s20_mc40_masked")]
+
+
+@pytest.mark.parametrize("variant,N,M,nv,mv,steps,mc,seed,tag", SOFT)
+def test_soft_family_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, tag):
+    """The "soft" fixture family (round 4): the same scenes with the matching head at a checkpoint-like scale (logits O(10)), minted by
+    the reference itself like the others.  Nothing is ill-conditioned there, so everything is a plain bound -- and the match list
+    must be the reference's, entry for entry, wherever the read-out's arg-maxima are decided by more than the conf error."""
+    g = golden("%s_loop_%s" % (variant, tag))
+    v = synth.VARIANTS[variant]
+    W = weights(variant, "soft")
+    _, p = pair(variant, N, M, seed)
+    ms, mt = masks(N, M, nv, mv)
+    noise = T(synth.step_noise(N, M, seed, steps))[:, None]
+    trace = []
+    out = orc.denoise_loop(W, v, p["f_s"], p["f_t"], p["p_s"], p["p_t"], ms, mt, p["x_T"], steps, mc, variant=variant, noise=noise, trace=trace)
+    conf = out["conf_matrix_pred"]
+    assert str(conf.dtype) == str(g["conf_dtype"])
+    x0 = torch.stack([r["x0"][0] for r in trace])
+    np.testing.assert_allclose(x0[:, :16, :16].numpy(), g["x0_corner"], atol=2e-5)
+    np.testing.assert_allclose(x0[-1].numpy(), g["x0_last"], atol=2e-5)
+    np.testing.assert_allclose(torch.stack([r["R_forwd"][0] for r in trace]).numpy(), g["R_forwd"], atol=2e-5)
+    np.testing.assert_allclose(torch.stack([r["t_forwd"][0] for r in trace]).numpy(), g["t_forwd"], atol=2e-5)
+    c, ref = conf[0].numpy(), g["conf"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(c))
+    np.testing.assert_allclose(c[fin], ref[fin], atol=1e-6, rtol=1e-4)
+    if "match_pred" in g.files:
+        assert_match_list_is_the_references(set(map(tuple, out["match_pred"].tolist())), g, np.abs(c[fin] - ref[fin]).max())
 
 
 def test_schedule_and_time_pairs():
