@@ -33,6 +33,8 @@ import torch  # noqa: E402
 
 HEAD_GAIN = 24.0
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA
+KERNEL_BOUNDARY_US = 1.5             # a dependent kernel boundary on this part (MI355X_MICROARCH.md, price list row "boundary": 1.1-1.9 us):
+                                     # the floor a chain of n launches is priced against
 DEP_LAUNCH_FLOOR_US = 4.7            # the cheapest kernels of the single-pair chain (LayerNorm of 512 rows, casts, an attention launch
                                      # that returns at once): 4.7-4.9 us each; an empty kernel in an idle chain: 1.53 us
                                      # (profiles/r02_b1_launch_floor.json, DESIGN section 5 "Single pair")
@@ -133,17 +135,19 @@ def cpu_baseline(variant, N, M, steps, mc, budget_s=25.0):
     ms = torch.ones(1, N, dtype=torch.bool)
     mt = torch.ones(1, M, dtype=torch.bool)
 
-    kept = []                                         # (seed, match_pred, inlier ratio) of the timed pairs: the parity sample
+    kept = []                  # (seed, match_pred, inlier ratio, conf, per-step R_forwd) of the timed pairs: the parity sample
 
     def one(seed):
         p = synth.make_pair(N, M, v["C"], seed=seed)
         T = lambda a: torch.from_numpy(a)[None]
+        tr = []
         t0 = time.perf_counter()
         o = orc.denoise_loop(W, v, T(p["src_feats"]), T(p["tgt_feats"]), T(p["s_pcd"]), T(p["t_pcd"]), ms, mt, T(p["x_T"]),
-                             steps, mc, variant=variant)
+                             steps, mc, variant=variant, trace=tr)
         dt = time.perf_counter() - t0
         if "match_pred" in o:
-            kept.append((seed, o["match_pred"], orc.inlier_ratio(o["match_pred"], T(p["s_pcd"]), T(p["t_pcd"]), p["R_gt"], p["t_gt"])))
+            kept.append((seed, o["match_pred"], orc.inlier_ratio(o["match_pred"], T(p["s_pcd"]), T(p["t_pcd"]), p["R_gt"], p["t_gt"]),
+                         o["conf_matrix_pred"][0].clone(), torch.stack([r["R_forwd"][0] for r in tr])))
         return dt
     t_start = time.perf_counter()
     times = [one(1000)]                               # warm-up pair (kept only if the budget is already spent)
@@ -166,7 +170,7 @@ def ir_fmr_parity(eng, variant, N, M, kept, device):
     seeds = [k[0] for k in kept]
     prs, inp = make_inputs(variant, len(seeds), N, M, seed0=seeds[0], device=device)
     assert seeds == list(range(seeds[0], seeds[0] + len(seeds)))
-    out = eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False)
+    out = eng.run(inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"], graph=False, trace=True)
     torch.cuda.synchronize()
     ml = eng.match_list(out)
     # the same matches through the device harness (dr_inlier_ratio_f32, dr_ransac_corr_f64): IR on the device,
@@ -179,22 +183,208 @@ def ir_fmr_parity(eng, variant, N, M, kept, device):
     ir_dev = ev["ir"].cpu().numpy()
     rot_err = (ev["rot"].float() - rot_gt).abs().amax(dim=(1, 2)).cpu().numpy()
     trn_err = (ev["trn"][:, :, 0].float() - trn_gt).abs().amax(dim=1).cpu().numpy()
-    ir_hip, ir_ref, jac = [], [], []
-    for i, (seed, mref, irr) in enumerate(kept):
+    ir_hip, ir_ref, jac, per_pair = [], [], [], []
+    for i, (seed, mref, irr, cref, Rref) in enumerate(kept):
         p = prs[i]
         mh = ml[i].cpu()
         ir_hip.append(orc.inlier_ratio(mh, torch.from_numpy(p["s_pcd"])[None], torch.from_numpy(p["t_pcd"])[None], p["R_gt"], p["t_gt"]))
         ir_ref.append(irr)
         a, b = set(map(tuple, mh[:, 1:].tolist())), set(map(tuple, mref[:, 1:].tolist()))
         jac.append(len(a & b) / max(1, len(a | b)))
+        # where the two runs part, if they do: per-step pose deviation (the trajectory), the final matrix, and how DECIDED the
+        # read-out's arg-maxima are (a column of an unmatched target holds nearly equal entries: margins below 1e-7 -- its
+        # arg-maximum, hence its match-list entry, is noise in ANY float32 evaluation)
+        dR = (out["R_forwd"][:, i].cpu() - Rref).abs().amax(dim=(1, 2))
+        first = int(torch.nonzero(dR > 1e-4)[0]) if bool((dR > 1e-4).any()) else None
+        dconf = float((out["conf_matrix_pred"][i].cpu() - cref).abs().max())
+        c = cref.numpy()
+        sr, sc = np.sort(c, 1), np.sort(c, 0)
+        tol = 10.0 * max(dconf, 1e-12)
+        und_r, und_c = set(np.nonzero(sr[:, -1] - sr[:, -2] <= tol)[0].tolist()), set(np.nonzero(sc[-1] - sc[-2] <= tol)[0].tolist())
+        diff = a ^ b
+        decided_diff = [e for e in diff if not (e[0] in und_r or e[1] in und_c)]
+        per_pair.append(dict(seed=seed, jaccard=jac[-1], max_abs_dconf=dconf, max_abs_dR_forwd=float(dR.max()), first_step_R_differs_1e4=first,
+                             matches_hip=len(a), matches_oracle=len(b), differing_entries=len(diff),
+                             undecided_rows=len(und_r), undecided_columns=len(und_c), differing_entries_at_decided_argmaxima=len(decided_diff)))
     ir_hip, ir_ref = np.array(ir_hip), np.array(ir_ref)
+    # control for the pair with the lowest Jaccard: the SAME comparison between two runs of the oracle itself, float32 vs float64
+    worst = int(np.argmin(jac))
+    control = None
+    try:
+        from diffreg_hip import synth
+        v = synth.VARIANTS[variant]
+        W64 = {k: torch.from_numpy(a).double() for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
+        p = prs[worst]
+        T = lambda a_: torch.from_numpy(a_)[None]
+        one_s, one_t = torch.ones(1, N, dtype=torch.bool), torch.ones(1, M, dtype=torch.bool)
+        o64 = orc.denoise_loop(W64, v, T(p["src_feats"]).double(), T(p["tgt_feats"]).double(), T(p["s_pcd"]), T(p["t_pcd"]), one_s, one_t,
+                               T(p["x_T"]).double(), eng.steps, float(eng.cfg.max_condition_num), variant=variant)
+        b32 = set(map(tuple, kept[worst][1][:, 1:].tolist()))
+        b64 = set(map(tuple, o64["match_pred"][:, 1:].tolist()))
+        control = dict(seed=kept[worst][0], what="oracle float32 vs oracle float64 (weights, features, state) on the pair with the lowest HIP-vs-oracle Jaccard",
+                       jaccard=len(b32 & b64) / max(1, len(b32 | b64)),
+                       max_abs_dconf=float((kept[worst][3] - o64["conf_matrix_pred"][0]).abs().max()))
+    except Exception as e:
+        control = {"error": "%s: %s" % (type(e).__name__, e)}
     return dict(pairs=len(kept), ir_hip=float(ir_hip.mean()), ir_oracle=float(ir_ref.mean()),
                 max_abs_ir_diff=float(np.abs(ir_hip - ir_ref).max()), fmr_hip=float((ir_hip > 0.05).mean()),
                 fmr_oracle=float((ir_ref > 0.05).mean()), match_set_jaccard_min=float(min(jac)),
+                per_pair=per_pair, control_oracle_f32_vs_f64=control,
+                match_set_note="a match list is row arg-maxima united with column arg-maxima; columns of unmatched targets hold nearly equal "
+                               "entries (margins < 1e-7), so their arg-maxima differ between any two float32 evaluations -- see the control; "
+                               "differing_entries_at_decided_argmaxima counts the differences that are NOT of that kind (expected 0)",
                 ir_hip_device_kernel=float(ir_dev.mean()), max_abs_ir_device_vs_host=float(np.abs(ir_dev - ir_hip).max()),
                 ransac_50000=dict(max_abs_R_err=float(rot_err.max()), max_abs_t_err=float(trn_err.max()),
                                   mean_fitness=float(ev["fitness"].mean())),
                 tolerance="IR / FMR within 0.1 (north_star)", note="synthetic scenes, generator ground truth; oracle = CPU restatement pinned to the reference")
+
+
+def _families(prof):
+    tot = sum(v[1] for v in prof.values()) or 1.0
+    return {k: {"launches": v[0], "ms": v[1], "share": v[1] / tot} for k, v in prof.items() if v[0]}
+
+
+def _mfma_roofline(prof, kernel_split, kernel_attn):
+    """roofline objects of the two MFMA families of a profiled call: the plane GEMM against the 3-product fp16 ceiling, attention against
+    the ceiling of the pipe it runs on (plane attention: the same 3-product ceiling; the f32-input kernels: the f32 MFMA peak)"""
+    out = {}
+    c, ms_, work = prof.get("gemm_split", (0, 0.0, 0.0))
+    if c:
+        ach = work / (ms_ * 1e-3) / 1e12
+        out["roofline"] = {"kernel": kernel_split, "bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_SPLIT_TFLOPS, "avg_us_per_launch": ms_ / c * 1e3, "traffic": None}
+    c, ms_, work = prof.get("attention", (0, 0.0, 0.0))
+    if c:
+        ach = work / (ms_ * 1e-3) / 1e12
+        out["attention"] = {"kernel": kernel_attn, "bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "avg_us_per_launch": ms_ / c * 1e3}
+    c, ms_, work = prof.get("gemm", (0, 0.0, 0.0))
+    if c:
+        ach = work / (ms_ * 1e-3) / 1e12
+        out["gemm_f32"] = {"kernel": "gemm_nt_* (f32-input MFMA)", "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_MFMA_F32_TFLOPS, "avg_us_per_launch": ms_ / c * 1e3}
+    return out
+
+
+def _time_calls(fn, warm=2, reps=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def bench_cfg3(dev):
+    """BASELINE configs[2]: 4DMatch N = M = 512, C = 528 (d_head 132), 20 denoise steps, batch of 8 pairs per call (masks all-true, sigma*xi
+    active): one captured call on one stream, and two such calls on two streams (how cfg2's headline fills the chip)."""
+    from diffreg_hip import lib, synth
+    from diffreg_hip.engine import DenoiseEngine
+    variant, N, M, steps, mc, P = "4dmatch", 512, 512, 20, 40.0, 8
+    v = synth.VARIANTS[variant]
+    W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
+    eng = DenoiseEngine(W, variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps, sk_iters=v["skh_iters"],
+                        sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=dev)
+
+    def group(seed0):
+        prs = [synth.make_pair(N, M, v["C"], seed=seed0 + i) for i in range(P)]
+        st = lambda k: torch.from_numpy(np.stack([p[k] for p in prs])).to(dev)
+        noise = torch.from_numpy(np.stack([synth.step_noise(N, M, seed0 + i, steps) for i in range(P)], 1)).to(dev)
+        return dict(src_feats=st("src_feats"), tgt_feats=st("tgt_feats"), s_pcd=st("s_pcd"), t_pcd=st("t_pcd"), x_T=st("x_T"),
+                    src_mask=torch.ones(P, N, dtype=torch.bool, device=dev), tgt_mask=torch.ones(P, M, dtype=torch.bool, device=dev), noise=noise)
+    g0, g1 = group(300), group(320)
+    one = _time_calls(lambda: eng.run(graph=True, borrow=True, **g0), warm=3, reps=5)
+    two = _time_calls(lambda: eng.run_streams([g0, g1], 2), warm=3, reps=5)
+    res = {"workload": "cfg3: 4DMatch N=M=512, C=528 (d_head 132), %d denoise steps, %d pairs per call, max_condition_num=%g" % (steps, P, mc),
+           "ms_per_call": one * 1e3, "pairs_per_s": P / one,
+           "two_concurrent_calls": {"ms_per_pass": two * 1e3, "pairs_per_s": 2 * P / two,
+                                    "what": "two independent 8-pair calls, one captured graph each, on two HIP streams (16 pairs in flight)"}}
+    eng.run(graph=False, borrow=True, **g0)
+    torch.cuda.synchronize()
+    lib.prof_enable(True)
+    eng.run(graph=False, borrow=True, **g0)
+    prof = lib.prof_collect()
+    lib.prof_enable(False)
+    res["kernel_families"] = _families(prof)
+    res.update(_mfma_roofline(prof, "pgemm_kernel<9,3,*,2> (576-column geometry, 64-row workgroups)", "attention_planes_kernel<9,5> (d = 132)"))
+    res["measured_on"] = "one eager 8-pair call (HIP events on the launch stream)"
+    return res
+
+
+def bench_cfg5(dev, batches=(1, 8)):
+    """BASELINE configs[4]: 2D-3D, N = 1024 point nodes x M = 2048 image patches, C = 256, 10 denoise steps, warp active: one pair per call
+    (f32-input MFMA kernels) and 8 pairs per call (plane-image path: 24 576 token rows)."""
+    from diffreg_hip import lib, synth
+    from diffreg_hip.engine import DenoiseEngine2D3D
+    N, M, steps, mc = 1024, 2048, 10, 200.0
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in Wn.items()}
+    eng = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=dev)
+    distinct = [synth.make_pair_2d3d(N, M, 60 + i, weights=Wn) for i in range(min(4, max(batches)))]
+    res = {"workload": "cfg5: 2D-3D N=1024 x M=2048, C=256 (d_head 64), %d denoise steps, max_condition_num=%g" % (steps, mc), "per_batch": {}}
+    for P in batches:
+        prs = [distinct[i % len(distinct)] for i in range(P)]
+        args = [torch.from_numpy(np.stack([p[k] for p in prs])).to(dev) for k in ("img_feats", "img_dino", "img_pixels", "pcd_feats", "s_pcd", "t_pcd_da", "x_T")]
+        dt = _time_calls(lambda: eng.run(*args), warm=2, reps=4)
+        ent = {"ms_per_call": dt * 1e3, "pairs_per_s": P / dt, "ms_per_pair": dt * 1e3 / P,
+               "distinct_scenes": min(P, len(distinct)), "path": "plane images" if P * (N + M) >= 4096 else "f32-input MFMA kernels"}
+        lib.prof_enable(True)
+        eng.run(*args)
+        prof = lib.prof_collect()
+        lib.prof_enable(False)
+        ent["kernel_families"] = _families(prof)
+        ent.update(_mfma_roofline(prof, "pgemm_kernel<4,4> (256-column geometry; bias / post-add LayerNorm epilogues)",
+                                  "attention_planes_kernel<4,2> (d = 64)" if P * (N + M) >= 4096 else "attention_kernel / attention_flash_kernel (f32-input MFMA, d = 64)"))
+        res["per_batch"]["P%d" % P] = ent
+    best = max(res["per_batch"].values(), key=lambda e: e["pairs_per_s"])
+    res["pairs_per_s"] = best["pairs_per_s"]
+    if "roofline" in best:
+        res["roofline"] = best["roofline"]
+    elif "gemm_f32" in best:
+        res["roofline"] = best["gemm_f32"]
+    return res
+
+
+def bench_b1_real_size(dev):
+    """the literal inference mode of the reference's tester (B = 1, 3D/lib/tester.py:115) at a real 3DMatch pair's coarse size
+    (564 x 629 superpoints): latency of one 20-step loop, graph replay"""
+    from diffreg_hip import lib, synth
+    from diffreg_hip.engine import DenoiseEngine
+    variant, N, M, steps, mc = "3dmatch", 564, 629, 20, 200.0
+    v = synth.VARIANTS[variant]
+    W = {k: torch.from_numpy(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN).items()}
+    eng = DenoiseEngine(W, variant=variant, C=v["C"], H=v["H"], voxel=v["voxel"], origin=v["origin"], steps=steps, sk_iters=v["skh_iters"],
+                        sample_rate=v["sample_rate"], max_condition_num=mc, n_layers=v["n_layers"], device=dev)
+    p = synth.make_pair(N, M, v["C"], seed=9000)
+    a = [torch.from_numpy(p[k])[None].to(dev) for k in ("src_feats", "tgt_feats", "s_pcd", "t_pcd", "x_T")]
+    dt = _time_calls(lambda: eng.run(*a, graph=True, borrow=True), warm=3, reps=10)
+    lib.prof_enable(True)
+    eng.run(*a, graph=False, borrow=True)
+    prof = lib.prof_collect()
+    lib.prof_enable(False)
+    n = sum(v_[0] for v_ in prof.values())
+    fl = sum(v_[2] for k, v_ in prof.items() if k in ("gemm", "gemm_split", "attention"))
+    return {"workload": "one 3DMatch pair at its real coarse size (N=564 x M=629, C=432), 20 denoise steps, B = 1, graph replay",
+            "ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt, "kernel_families": _families(prof),
+            "roofline": {"bound": "dependent-launch chain", "launches": n, "boundary_us": KERNEL_BOUNDARY_US,
+                         "floor_ms": n * KERNEL_BOUNDARY_US * 1e-3, "frac": n * KERNEL_BOUNDARY_US * 1e-6 / dt,
+                         "mfma_TFLOPs": fl / dt / 1e12, "mfma_frac_of_f32_peak": fl / dt / 1e12 / PEAK_MFMA_F32_TFLOPS}}
+
+
+def other_configs(dev):
+    """BASELINE's other configurations inside the driver's own run (short runs, each with its own roofline object): what
+    tools/bench_cfg3.py / bench_2d3d.py / bench_e2e.py report at length"""
+    out = {}
+    for name, fn in (("cfg3", bench_cfg3), ("cfg5", bench_cfg5), ("b1_real_size", bench_b1_real_size)):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(dev)
+        except Exception as e:                      # a secondary line must not take the headline down with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[name]["wall_s_incl_setup"] = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -217,6 +407,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg3 / cfg5 / real-size B = 1 runs (other_configs)")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="shard this many pairs round-robin over the ranks (ranks may differ by one pair: BASELINE configs[3] = 64 "
                          "pairs over 8 GPUs) instead of --pairs per rank")
@@ -299,9 +490,9 @@ def main():
 
     if args.breakdown_only:
         use_graph = False
-        args.no_single_pair = args.no_cpu_baseline = True
+        args.no_single_pair = args.no_cpu_baseline = args.no_other_configs = True
     if stub:
-        args.no_single_pair = args.no_cpu_baseline = args.no_breakdown = True
+        args.no_single_pair = args.no_cpu_baseline = args.no_breakdown = args.no_other_configs = True
     # the Sinkhorn roofline micro-benchmark (batched tiles, HBM-bound) runs first: behind the MFMA-heavy loop the
     # same launch is 8 % slower (the chip is then at its power limit), which would measure the loop's heat, not the kernel
     sk_roof = None
@@ -357,7 +548,7 @@ def main():
         # (N > 1: rank 0 still measures the roofline of its own GPU after the timed region; single-pair latency, the
         #  Sinkhorn micro-benchmark and the CPU baseline are N = 1 only)
         if world > 1:
-            args.no_single_pair = args.no_cpu_baseline = True
+            args.no_single_pair = args.no_cpu_baseline = args.no_other_configs = True
         # ---- single-pair latency (the literal "batch=1" of configs[1]) -------------------------------
         if not args.no_single_pair:
             prs1, inp1 = make_inputs(variant, 1, N, M, seed0=7000, device=dev)
@@ -381,8 +572,9 @@ def main():
             n1 = sum(v[0] for v in p1.values())
             fl1 = sum(v[2] for k, v in p1.items() if k in ("gemm", "gemm_split", "attention"))
             result["single_pair"]["roofline"] = {
-                "bound": "dependent-launch chain", "launches": n1, "launch_floor_us": DEP_LAUNCH_FLOOR_US,
-                "floor_ms": n1 * DEP_LAUNCH_FLOOR_US * 1e-3, "frac": n1 * DEP_LAUNCH_FLOOR_US * 1e-6 / lat,
+                "bound": "dependent-launch chain", "launches": n1, "boundary_us": KERNEL_BOUNDARY_US,
+                "floor_ms": n1 * KERNEL_BOUNDARY_US * 1e-3, "frac": n1 * KERNEL_BOUNDARY_US * 1e-6 / lat,
+                "cheapest_real_kernel_us": DEP_LAUNCH_FLOOR_US, "frac_vs_cheapest_real_kernel": n1 * DEP_LAUNCH_FLOOR_US * 1e-6 / lat,
                 "mfma_TFLOPs": fl1 / lat / 1e12, "mfma_frac_of_f32_peak": fl1 / lat / 1e12 / PEAK_MFMA_F32_TFLOPS}
 
         if not args.no_breakdown:
@@ -439,6 +631,11 @@ def main():
             result["sinkhorn_roofline"] = sk_roof
         if "roofline" not in result and "sinkhorn_roofline" in result:
             result["roofline"] = result["sinkhorn_roofline"]
+        if not args.no_other_configs:
+            del outs, out
+            eng._graphs.clear()                     # the headline's 2 x 128-pair static buffers and graphs are not needed any more
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs(dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"], kept = cpu_baseline(variant, N, M, S, args.max_condition_num)
             if kept:

@@ -50,12 +50,17 @@ struct PgProblem {
     const float* grp_bnd; int grp_mask, grp_first, grp_rows;
     int relu;
     // PG_LN: y = LayerNorm(acc) * gamma + beta (+ resid[row][col]);  bound = (bnd_res ? bnd_res[row] : 0) + *lnB
+    //        ln_postadd (the vision3d layer, vision3d/layers/transformer.py:188-196, 262-271): y = LayerNorm(acc + resid) * gamma + beta;  bound = *lnB
     const float* gamma; const float* beta; const float* resid; int ldr; const float* bnd_res; const float* lnB;
+    int ln_postadd;
+    // nn.Linear bias (all modes): acc + bias[nb * C + col] before rotary / ReLU / LayerNorm; bias_max[nb] >= max |bias| of block nb
+    // (added to the bound a PG_PLANES image is scaled by)
+    const float* bias; const float* bias_max;
 };
 struct PgBatch { PgProblem p[3]; int n; };
 
 bool pgemm_shape_ok(int C);                      // column-block widths the kernel is built for
-int pgemm_bn(int C);                             // rows of a packed weight block (448 for C <= 448, 576 above)
+int pgemm_bn(int C);                             // rows of a packed weight block (256 for C <= 256, 448 for C <= 448, 576 above)
 int launch_pgemm(const PgBatch& g, hipStream_t st);
 int pgemm_configure();
 
@@ -74,5 +79,7 @@ int launch_planes_from_f32(const float* x, int ldx, int rows, int K, char* img, 
 int launch_planes_to_f32(const char* img, const float* bnd, int rows, int K, float* out, int ldo, hipStream_t st);
 // *out = sqrt(C) max|gamma| + max|beta|: an upper bound of |LayerNorm(.) gamma + beta|
 int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hipStream_t st);
+// out[b] = max |x[b * n .. b * n + n - 1]| * (1 + 1e-4), b < nblk  (bias_max of a stacked bias vector)
+int launch_absmax_blocks(const float* x, int nblk, int n, float* out, hipStream_t st);
 
 }  // namespace dr

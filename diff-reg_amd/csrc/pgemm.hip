@@ -339,6 +339,20 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         wave_fence();
     };
     const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
+    // nn.Linear bias of the lane's columns (read before any store of this wave, like every other epilogue operand)
+    const bool has_bias = P.bias != nullptr;
+    float4 bias4[NI];
+    if (has_bias) {
+        const float* bp = P.bias + (size_t)nb * C;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bias4[i] = colw + 16 * i < C ? *reinterpret_cast<const float4*>(bp + colw + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto add_bias = [&](float4 (&dst)[NI]) __attribute__((always_inline)) {
+        if (has_bias) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { dst[i].x += bias4[i].x; dst[i].y += bias4[i].y; dst[i].z += bias4[i].z; dst[i].w += bias4[i].w; }
+        }
+    };
     int grow[2];
     grow[0] = rb * BM + wm * 32 + lr;
     grow[1] = grow[0] + 16;
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 }
             }
             transpose_round(rr, v[rr]);
+            add_bias(v[rr]);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 float4 x = v[rr][i];
@@ -407,9 +422,23 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             }
             return;
         }
+        if (mode == PG_PLANES && P.out) {                        // optional fp32 copy of the block (the residual stream of a consumer)
+            float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (grow[rr] >= rows) continue;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int col = colw + 16 * i;
+                    if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                }
+            }
+        }
     } else {
         transpose_round(0, v[0]);
         transpose_round(1, v[1]);
+        add_bias(v[0]);
+        add_bias(v[1]);
     }
 
     if (mode == PG_LN) {
@@ -439,6 +468,16 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 const int col = colw + 16 * i;
                 r0[i] = col < C ? *reinterpret_cast<const float4*>(rp0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        const bool postadd = res && P.ln_postadd;                // LayerNorm(acc + resid): the residual joins BEFORE the statistics
+        if (postadd) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const float4 r4 = rr == 0 ? r0[i] : *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
+                    v[rr][i].x += r4.x; v[rr][i].y += r4.y; v[rr][i].z += r4.z; v[rr][i].w += r4.w;
+                }
         }
         float mean[2], rstd[2];
 #pragma unroll
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                     float4 y;
                     y.x = (v[rr][i].x - mean[rr]) * rstd[rr] * g4.x + b4.x; y.y = (v[rr][i].y - mean[rr]) * rstd[rr] * g4.y + b4.y;
                     y.z = (v[rr][i].z - mean[rr]) * rstd[rr] * g4.z + b4.z; y.w = (v[rr][i].w - mean[rr]) * rstd[rr] * g4.w + b4.w;
-                    if (res) {
+                    if (res && !postadd) {
                         const float4 r4 = rr == 0 ? r0[i] : *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
@@ -501,7 +540,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         const int rowc = min(grow[rr], rows - 1);
         const bool per_blk = P.pimg_blk_stride != 0;
         float bound;
-        if (mode == PG_LN) bound = (P.bnd_res ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
+        if (mode == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
         else {
             // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
             // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
@@ -512,7 +551,13 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             float wn_ = P.W.wnorm[nb];
             if (!per_blk)
                 for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
-            bound = bin * wn_ * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+            float bm = 0.f;                                      // |x W^T + b| <= bound(x) ||W|| + max |b|  (same rule for blocks sharing an image)
+            if (P.bias_max) {
+                bm = P.bias_max[nb];
+                if (!per_blk)
+                    for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
+            }
+            bound = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
         }
         if (P.pbnd && rok && (nb == 0 || per_blk) && wn == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
         const float sc = pow2i(scale_exp(bound));
@@ -657,7 +702,9 @@ __global__ __launch_bounds__(256) void ln_bound_kernel(const float* __restrict__
     }
 }
 
-using G7 = PgGeom<7, 4>;     // column blocks of up to 448 (3DMatch: C = 432; 2D-3D: 256), 4-slot ring
+using G4 = PgGeom<4, 4>;     // column blocks of up to 256 (2D-3D: C = 256, expand = two blocks): a stage is 8 KB of A + 16 KB of W
+using G4H = PgGeom<4, 4, 2>;
+using G7 = PgGeom<7, 4>;     // column blocks of up to 448 (3DMatch: C = 432), 4-slot ring
 using G9 = PgGeom<9, 3>;     // column blocks of up to 576 (4DMatch: C = 528), 3-slot ring (the stage is 44 KB)
 using G7H = PgGeom<7, 4, 2>; // the same with 64-row workgroups (4 waves): launches that would leave CUs idle
 using G9H = PgGeom<9, 3, 2>;
@@ -665,7 +712,7 @@ using G9H = PgGeom<9, 3, 2>;
 }  // namespace
 
 bool pgemm_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= G9::BN; }
-int pgemm_bn(int C) { return C <= G7::BN ? G7::BN : G9::BN; }
+int pgemm_bn(int C) { return C <= G4::BN ? G4::BN : (C <= G7::BN ? G7::BN : G9::BN); }
 static size_t pg_bst(int C) { return (size_t)pgemm_bn(C) * 64; }
 
 // The 576-column geometry exists in the 64-row form only: its 128-row form (8 waves, 256 registers per wave: 144 accumulators + two fragment
@@ -679,7 +726,10 @@ static int configure_mode() {
     return DR_OK;
 }
 int pgemm_configure() {
-    int rc = configure_mode<7, 4, PG_F32>();
+    int rc = configure_mode<4, 4, PG_F32>();
+    if (rc == DR_OK) rc = configure_mode<4, 4, PG_PLANES>();
+    if (rc == DR_OK) rc = configure_mode<4, 4, PG_LN>();
+    if (rc == DR_OK) rc = configure_mode<7, 4, PG_F32>();
     if (rc == DR_OK) rc = configure_mode<7, 4, PG_PLANES>();
     if (rc == DR_OK) rc = configure_mode<7, 4, PG_LN>();
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>();
@@ -700,7 +750,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 3) return DR_EINVAL;
     int maxt = 0;
     double flops = 0;
-    const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G7::BN ? G7::NST : G9::NST;
+    const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G9::BN ? G9::NST : G7::NST;
     // 64-row workgroups when the launch would not give every CU a 128-row one (DR_PG_HALF under dr_debug_enable_env: 0 never, 2 always)
     const int half_env = env_knob("DR_PG_HALF", 1);
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
@@ -722,6 +772,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
     const dim3 grid(maxt, g.n);
     if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, g);
+    else if (bn == G4::BN) { if (half) pg_launch<4, 4, 2>(mode, grid, st, g); else pg_launch<4, 4, 4>(mode, grid, st, g); }
     else { if (half) pg_launch<7, 4, 2>(mode, grid, st, g); else pg_launch<7, 4, 4>(mode, grid, st, g); }
     DR_LAUNCH_CHECK();
     return DR_OK;
@@ -807,6 +858,22 @@ int launch_planes_to_f32(const char* img, const float* bnd, int rows, int K, flo
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
+__global__ __launch_bounds__(256) void absmax_blocks_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float sm[4];
+    const float* xb = x + (size_t)blockIdx.x * n;
+    float m = 0.f;
+    for (int c = threadIdx.x; c < n; c += 256) m = fmaxf(m, fabsf(xb[c]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) * 1.0001f;
+}
+int launch_absmax_blocks(const float* x, int nblk, int n, float* out, hipStream_t st) {
+    if (nblk < 1) return DR_OK;
+    hipLaunchKernelGGL(absmax_blocks_kernel, dim3(nblk), dim3(256), 0, st, x, n, out);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
 int launch_ln_bound(const float* gamma, const float* beta, int C, float* out, hipStream_t st) {
     hipLaunchKernelGGL(ln_bound_kernel, dim3(1), dim3(256), 0, st, gamma, beta, C, out);
     DR_LAUNCH_CHECK();
@@ -873,6 +940,11 @@ int dr_ln_bound_f32(int C, const float* gamma, const float* beta, float* out, vo
     return launch_ln_bound(gamma, beta, C, out, (hipStream_t)stream);
 }
 
+int dr_bias_max_f32(int nblk, int n, const float* bias, float* out, void* stream) {
+    if (nblk < 1 || n < 1 || !bias || !out) return DR_EINVAL;
+    return launch_absmax_blocks(bias, nblk, n, out, (hipStream_t)stream);
+}
+
 int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
     if (!a || a->rows < 1 || a->nblk < 1 || !a->a0 || !a->bound0 || !a->packed || a->k0 % 16 || (a->a1 && (a->k1 % 16 || !a->bound1))) return DR_EINVAL;
     if (a->mode < 0 || a->mode > 2) return DR_EINVAL;
@@ -888,12 +960,17 @@ int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
     p.pimg = (char*)a->out_image; p.p_nct = a->out_image_k / 16; p.p_kc0 = a->out_k0 / 16; p.pbnd = a->out_bound;
     p.relu = a->relu;
     p.gamma = a->gamma; p.beta = a->beta; p.resid = a->resid; p.ldr = a->ldr; p.bnd_res = a->bound_resid; p.lnB = a->ln_bound;
+    p.bias = a->bias; p.bias_max = a->bias_max; p.ln_postadd = a->ln_postadd;
+    if (p.bias && p.mode == PG_PLANES && !p.bias_max) return DR_EINVAL;
+    if (p.bias && (((uintptr_t)p.bias & 15) || a->C % 4)) return DR_EINVAL;
+    if (p.mode == PG_PLANES && p.out && (p.ldo % 4 || p.blk_stride % 4 || ((uintptr_t)p.out & 15))) return DR_EINVAL;
     if (p.mode == PG_F32 && (!p.out || p.ldo % 4 || p.blk_stride % 4 || ((uintptr_t)p.out & 15))) return DR_EINVAL;
     if (p.mode == PG_F32 && p.rot_mask && (!p.cosT || !p.sinT || p.rot_C % 4)) return DR_EINVAL;
     if (p.mode != PG_F32 && p.pimg && (!p.pbnd || a->out_image_k % 16 || a->out_k0 % 16 || a->out_k0 + a->nblk * a->C > a->out_image_k)) return DR_EINVAL;
     if (p.mode == PG_LN && (!p.gamma || !p.beta || !p.lnB || a->nblk != 1 || (p.out && (p.ldo % 4 || ((uintptr_t)p.out & 15))) ||
                             (p.resid && (p.ldr % 4 || ((uintptr_t)p.resid & 15))))) return DR_EINVAL;
     if (p.mode != PG_F32 && !p.pimg && !p.out) return DR_EINVAL;
+    if (p.mode == PG_PLANES && !p.pimg) return DR_EINVAL;
     g.n = 1;
     return launch_pgemm(g, (hipStream_t)stream);
 }

@@ -333,11 +333,14 @@ class DenoiseEngine2D3D:
 
     def __init__(self, state, *, C=256, H=4, n_layers=6, img_dim=512, dino_dim=1024, pcd_dim=512, steps=10, sk_iters=3,
                  sample_rate=1.0, max_condition_num=200.0, device="cuda:0", strict_f64=False,
-                 prefix_t="denoising_transformer.", prefix_m="denoising_coarse_matching."):
+                 prefix_t="denoising_transformer.", prefix_m="denoising_coarse_matching.", planes=None, prepack=True):
+        """planes: None = the size rule picks the GEMM / attention path (plane images from 4096 token rows on: two cfg5 pairs per call);
+        True / False = DR_LOOP_PLANES_FORCE / DR_LOOP_PLANES_OFF.  The weights are snapshotted (copy=True) and, for the plane path,
+        packed once (dr_loop2d3d_prepack): build a new engine when the parameters change."""
         lib.ensure_init()
         self.device = torch.device(device)
         self.C, self.steps = C, steps
-        f = lambda k: state[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+        f = lambda k: state[k].detach().to(device=self.device, dtype=torch.float32, copy=True).contiguous()
         self._keep = []
         self._layers = (lib.FusionLayerWeights * n_layers)()
         for l in range(n_layers):
@@ -362,8 +365,17 @@ class DenoiseEngine2D3D:
         self._ac = np.ascontiguousarray(cosine_alphas_cumprod().numpy())
         self._cfgs = {}
         self._base = dict(C=C, H=H, n_layers=n_layers, img_dim=img_dim, dino_dim=dino_dim, pcd_dim=pcd_dim, sk_iters=sk_iters,
-                          sample_rate=sample_rate, max_condition_num=max_condition_num, flags=1 if strict_f64 else 0)
+                          sample_rate=sample_rate, max_condition_num=max_condition_num,
+                          flags=(1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0))
         self._ws = None
+        self._packed = None
+        cfg0 = self._cfg(steps)
+        nb = lib.raw().dr_loop2d3d_prepack_bytes(ctypes.byref(cfg0))
+        if nb and prepack and planes is not False:
+            self._packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            lib.check(lib.raw().dr_loop2d3d_prepack(ctypes.byref(cfg0), ctypes.byref(self.w), self._packed.data_ptr(), nb,
+                                                    ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            self.w.prepacked = self._packed.data_ptr()
 
     def _cfg(self, steps):
         if steps not in self._cfgs:

@@ -59,7 +59,7 @@ class FusionWeights(ctypes.Structure):
     _fields_ = [("layers", ctypes.POINTER(FusionLayerWeights))] + \
                [(n, c_void_p) for n in ("img_emb_w", "img_emb_b", "pcd_emb_w", "pcd_emb_b", "img_in_w", "img_in_b", "dino_w",
                                         "dino_b", "all_w", "all_b", "pcd_in_w", "pcd_in_b", "out_w", "out_b", "src_proj",
-                                        "bin_score")]
+                                        "bin_score", "prepacked")]
 
 
 class PlanesLinear(ctypes.Structure):
@@ -73,7 +73,7 @@ class PlanesLinear(ctypes.Structure):
                 ("out_image", c_void_p), ("out_image_k", c_int), ("out_k0", c_int), ("out_bound", c_void_p),
                 ("relu", c_int),
                 ("gamma", c_void_p), ("beta", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("bound_resid", c_void_p),
-                ("ln_bound", c_void_p)]
+                ("ln_bound", c_void_p), ("bias", c_void_p), ("bias_max", c_void_p), ("ln_postadd", c_int)]
 
 
 class Loop2D3DConfig(ctypes.Structure):
@@ -105,6 +105,9 @@ SIGNATURES.update({
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_ln_bound_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_planes_f32": (c_int, [ctypes.POINTER(PlanesLinear), c_void_p]),
+    "dr_bias_max_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_loop2d3d_prepack_bytes": (c_size_t, [ctypes.POINTER(Loop2D3DConfig)]),
+    "dr_loop2d3d_prepack": (c_int, [ctypes.POINTER(Loop2D3DConfig), ctypes.POINTER(FusionWeights), c_void_p, c_size_t, c_void_p]),
     "dr_gemm_nt_batched_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong,
                                        c_float, c_void_p]),
     "dr_linear_ex_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -335,7 +338,8 @@ def ln_bound(gamma, beta):
 
 def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, k1=0, out=None, ldo=0, blk_stride=0, cos_t=None,
                   sin_t=None, rot_mask=0, rot_C=0, scale=1.0, out_image=None, out_image_k=0, out_k0=0, out_bound=None, relu=False,
-                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None):
+                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None, bias=None, ln_postadd=False):
+    """dr_linear_planes_f32; bias [nblk * C]: its per-block maxima are computed here (dr_bias_max_f32)"""
     a = PlanesLinear()
     a.rows, a.C, a.nblk = rows, C, nblk
     dp = lambda t_: None if t_ is None else t_.data_ptr()
@@ -347,6 +351,12 @@ def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, 
     a.out_image, a.out_image_k, a.out_k0, a.out_bound = dp(out_image), out_image_k, out_k0, dp(out_bound)
     a.relu = 1 if relu else 0
     a.gamma, a.beta, a.resid, a.ldr, a.bound_resid, a.ln_bound = dp(gamma), dp(beta), dp(resid), ldr, dp(bound_resid), dp(lnb)
+    bmax = None
+    if bias is not None:
+        bias = bias.contiguous().float()
+        bmax = torch.empty(nblk, device=bias.device)
+        check(_lib.dr_bias_max_f32(nblk, C, ptr(bias), ptr(bmax), stream_of(a0)))
+    a.bias, a.bias_max, a.ln_postadd = dp(bias), dp(bmax), 1 if ln_postadd else 0
     check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
 
 

@@ -124,7 +124,8 @@ int dr_linear_f32(int rows, int ncols, int K, const float* x, const float* W, fl
 
 /* ---------------------------------------------------------------------------------------------
  * Plane images: the layer nn.Linears of the loop with BOTH operands pre-split into fp16 hi / lo planes (the
- * default path of dr_denoise_loop for C <= 448, C % 16 == 0; 3D/models/transformero.py:26-96).
+ * default path of dr_denoise_loop for C <= 576, C % 16 == 0; 3D/models/transformero.py:26-96; column-block geometries of
+ * 256 / 448 / 576 columns: C <= 256 -- the 2D-3D layer -- packs 256-row weight blocks).
  * Image of X [rows, K] (K % 16 == 0, rows padded to a multiple of 128): [row / 128][k / 16][row % 128][64 bytes], the
  * 64 bytes = 16-byte units (hi k 0..7 | hi k 8..15 | lo k 0..7 | lo k 8..15) stored at unit ^ ((row >> 2) & 3);
  * hi = fp16(x 2^s), lo = fp16(x 2^s - hi), s = 14 - floor(log2(bound[row])) with bound[row] >= max |x[row][:]| (an
@@ -170,8 +171,17 @@ typedef struct {
     void* out_image; int out_image_k; int out_k0; float* out_bound;   /* block nb -> columns out_k0 + nb * C ..        */
     int relu;
     const float* gamma; const float* beta; const float* resid; int ldr; const float* bound_resid; const float* ln_bound;
+    /* nn.Linear bias [nblk * C] (NULL = none), added before rotary / ReLU / LayerNorm; bias_max [nblk] (device, dr_bias_max_f32):
+     * an upper bound of |bias| per block, needed with DR_PL_PLANES (it enters the bound the image is scaled by) */
+    const float* bias; const float* bias_max;
+    /* DR_PL_LN with resid: 0 = y = LayerNorm(acc) gamma + beta + resid (3D/models/transformero.py:94-96);
+     *                      1 = y = LayerNorm(acc + resid) gamma + beta (the vision3d layer, vision3d/layers/transformer.py:188-196, 262-271) */
+    int ln_postadd;
+    /* DR_PL_PLANES: `out` (optional) also receives the block as fp32 rows (ldo, blk_stride as in DR_PL_F32) */
 } dr_planes_linear;
 int dr_linear_planes_f32(const dr_planes_linear* args, void* stream);
+/* out[b] = max |bias[b n .. b n + n - 1]| (1 + 1e-4), b < nblk */
+int dr_bias_max_f32(int nblk, int n, const float* bias, float* out, void* stream);
 
 /* strided batch of the same product: out[z] [rows, ncols] = A[z] [rows, K] W[z]^T (W[z] [ncols, K]) * scale, z < nbatch, operands contiguous with the
  * given strides (floats); K % 4 == 0.  The N x M similarity of a batch of pairs (matching.py:190-196); the per-head products of the training backward. */
@@ -510,6 +520,8 @@ typedef struct {
     const float *out_w, *out_b;              /* out_proj         [C, C]                                     */
     const float* src_proj;                   /* denoising_coarse_matching.src_proj.weight [C,C] (Q1)        */
     const float* bin_score;
+    const void* prepacked;                   /* dr_loop2d3d_prepack image of THESE weights (device, 256-byte aligned) or NULL: calls that
+                                              * take the plane path then pack them into the workspace every time                      */
 } dr_fusion_weights;
 
 typedef struct {
@@ -522,6 +534,12 @@ typedef struct {
     const int32_t* h_times;
 } dr_loop2d3d_config;
 
+/* Calls of at least 4096 token rows (P (N + M); cfg5: two pairs or more) run the layer's nn.Linears and its attention on fp16 hi / lo
+ * plane images like dr_denoise_loop does ("Plane images" above; biases, the post-add LayerNorms and the ReLU feed-forward of the vision3d
+ * layer are epilogue modes of the same GEMM); DR_LOOP_PLANES_FORCE / DR_LOOP_PLANES_OFF in cfg->flags take the decision away from the size
+ * rule.  The packed weights: once per engine with dr_loop2d3d_prepack (0 bytes = this configuration has no plane path). */
+size_t dr_loop2d3d_prepack_bytes(const dr_loop2d3d_config* cfg);
+int dr_loop2d3d_prepack(const dr_loop2d3d_config* cfg, const dr_fusion_weights* w, void* packed, size_t packed_bytes, void* stream);
 size_t dr_denoise_loop_2d3d_workspace_bytes(const dr_loop2d3d_config* cfg, int P, int N, int M);
 
 /* inputs : img_feats [P,M,img_dim], img_dino [P,M,dino_dim], img_pixels [P,M,2], pcd_feats [P,N,pcd_dim],

@@ -25,23 +25,29 @@ def pair(variant, N, M, seed):
 
 
 def assert_match_list_is_the_references(got, g, conf_err):
-    """match_pred (3D/models/pipeline.py:12-65, 275-280: row arg-maxima united with column arg-maxima) is index work: it must
-    equal the reference's list exactly wherever the arg-maxima are decided, i.e. on every row / column whose best and second-best
-    confidence are further apart than 10 x the largest conf deviation.  If that holds for ALL rows and columns (it does for every
-    3D fixture), the two lists must be equal as sets."""
+    """match_pred (3D/models/pipeline.py:12-65, 275-280: row arg-maxima united with column arg-maxima) is index work, so it is
+    compared with the reference's list EXACTLY: the two lists must be equal as sets, except that an entry may differ where the
+    arg-maximum itself is undecided -- a row / column whose best and second-best confidence are closer than 10 x the largest conf
+    deviation (in practice: exact ties, e.g. rows whose mass sits on the dustbin and whose entries are bit-equal; torch's pick among
+    equal values is implementation-defined).  An entry of the symmetric difference must lie in such a row or column AND be within that
+    margin of its maximum.  -> (undecided rows, undecided columns)."""
     ref, conf = set(map(tuple, g["match_pred"].tolist())), g["conf"]
     tol = 10.0 * max(conf_err, 1e-12)
     srt_r, srt_c = np.sort(conf, 1), np.sort(conf, 0)
-    rows = np.nonzero(srt_r[:, -1] - srt_r[:, -2] > tol)[0]
-    cols = np.nonzero(srt_c[-1] - srt_c[-2] > tol)[0]
+    und_r = set(np.nonzero(srt_r[:, -1] - srt_r[:, -2] <= tol)[0].tolist())
+    und_c = set(np.nonzero(srt_c[-1] - srt_c[-2] <= tol)[0].tolist())
     am_r, am_c = conf.argmax(1), conf.argmax(0)
-    for i in rows:
-        assert (0, int(i), int(am_r[i])) in got, ("row", i)
-    for j in cols:
-        assert (0, int(am_c[j]), int(j)) in got, ("column", j)
-    if len(rows) == conf.shape[0] and len(cols) == conf.shape[1]:
-        assert got == ref, (len(got ^ ref), "entries differ although every arg-maximum is decided")
-    return len(rows) == conf.shape[0] and len(cols) == conf.shape[1]
+    for i in range(conf.shape[0]):
+        if i not in und_r:
+            assert (0, int(i), int(am_r[i])) in got, ("decided row arg-maximum missing", i)
+    for j in range(conf.shape[1]):
+        if j not in und_c:
+            assert (0, int(am_c[j]), int(j)) in got, ("decided column arg-maximum missing", j)
+    for (_, i, j) in got ^ ref:
+        ok_r = i in und_r and conf[i, j] >= srt_r[i, -1] - tol
+        ok_c = j in und_c and conf[i, j] >= srt_c[-1, j] - tol
+        assert ok_r or ok_c, ("match lists differ at a decided entry", i, j, len(got ^ ref))
+    return len(und_r), len(und_c)
 
 
 def masks(N, M, nv=None, mv=None):

@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def setup(N, M, seed, steps, mc):
+def setup(N, M, seed, steps, mc, planes=None):
+    """planes: None = the size rule (plane images from 4096 token rows on), True = the plane path forced (fp16 hi / lo plane-image GEMMs with
+    bias / post-add-LayerNorm epilogues + plane attention at d = 64, the path of batched cfg5 calls), False = the f32-input MFMA kernels"""
     from diffreg_hip.engine import DenoiseEngine2D3D
     Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
     W = {k: T(a) for k, a in Wn.items()}
-    eng = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=DEV)
+    eng = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=DEV, planes=planes)
     pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
     q = lambda k: T(pr[k])[None]
     return W, eng, q
@@ -28,9 +30,10 @@ def setup(N, M, seed, steps, mc):
 
 @pytest.mark.parametrize("N,M,nv,mv,mv_da,steps,mc,seed,tag", [(96, 160, 90, 150, 141, 3, 200, 31, "n96x160_s3_masked"),
                                                                  (128, 192, 128, 192, 192, 10, 0, 32, "n128x192_s10_mc0")])
-def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, seed, tag):
+@pytest.mark.parametrize("planes", [False, True])
+def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, seed, tag, planes):
     g = golden("2d3d_loop_" + tag)
-    W, eng, q = setup(N, M, seed, steps, mc)
+    W, eng, q = setup(N, M, seed, steps, mc, planes)
     ms, mt = masks(N, M, nv, mv)
     mt_da = torch.arange(M)[None] < mv_da
     dmask = (ms.to(DEV), mt.to(DEV), mt_da.to(DEV))
@@ -57,16 +60,18 @@ def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, 
     assert got == set(map(tuple, orc.top1_union(out["conf_matrix_pred"][0].cpu())[:, 1:].tolist()))
 
 
-def test_2d3d_two_pairs_equal_single_pairs():
-    W, eng, q1 = setup(96, 160, 41, 2, 200)
-    _, _, q2 = setup(96, 160, 42, 2, 200)
+@pytest.mark.parametrize("planes", [False, True])
+def test_2d3d_two_pairs_equal_single_pairs(planes):
+    W, eng, q1 = setup(96, 160, 41, 2, 200, planes)
+    _, _, q2 = setup(96, 160, 42, 2, 200, planes)
     cat = lambda k: torch.cat([q1(k), q2(k)]).to(DEV)
     both = eng.run(cat("img_feats"), cat("img_dino"), cat("img_pixels"), cat("pcd_feats"), cat("s_pcd"), cat("t_pcd_da"), cat("x_T"))
     c_both = both["conf_matrix_pred"].clone()
     for i, q in enumerate((q1, q2)):
         d = lambda k: q(k).to(DEV)
         one = eng.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"))
-        assert (one["conf_matrix_pred"][0] - c_both[i]).abs().max().item() < 1e-6
+        # (f32 kernels: the same tiles either way; plane path: the group bound of the k / v images is per pair, the row blocks differ)
+        assert (one["conf_matrix_pred"][0] - c_both[i]).abs().max().item() < (2e-6 if planes else 1e-6)
 
 
 def kth_boundary_gap(conf, ms, mt_da):
@@ -76,7 +81,8 @@ def kth_boundary_gap(conf, ms, mt_da):
     return float((v[K - 1] - v[K]) / v[K - 1])
 
 
-def test_cfg5_1024x2048_10_steps():
+@pytest.mark.parametrize("planes", [False, True])
+def test_cfg5_1024x2048_10_steps(planes):
     """BASELINE configs[4] at its stated size: N = 1024 point nodes x M = 2048 image patches (tiles beyond the register-resident
     Sinkhorn / Procrustes paths), 10 denoise steps, warp active, padding masks on both sides and a different (non-trivial)
     tgt_mask_da for the warp, against the oracle step by step: the -inf persistence of masked entries (quirk Q8), the fp64 state
@@ -90,7 +96,7 @@ def test_cfg5_1024x2048_10_steps():
     run; from that step on the poses are only required to be proper and the matrices to stay doubly sub-stochastic.  The tie-free
     trajectory at this size is test_cfg5_identity_warp_against_reference_and_oracle."""
     N, M, steps, mc = 1024, 2048, 10, 200
-    W, eng, q = setup(N, M, 51, steps, mc)
+    W, eng, q = setup(N, M, 51, steps, mc, planes)
     ms, mt = masks(N, M, 1000, 2000)
     mt_da = torch.arange(M)[None] < 1900
     d = lambda k: q(k).to(DEV)
@@ -129,7 +135,8 @@ def test_cfg5_1024x2048_10_steps():
     assert torch.isfinite(conf).all() and conf.min().item() >= 0 and conf.sum(1).max().item() <= 1 + 1e-9 and conf.sum(0).max().item() <= 1 + 1e-9
 
 
-def test_cfg5_identity_warp_against_reference_and_oracle(golden):
+@pytest.mark.parametrize("planes", [False, True])
+def test_cfg5_identity_warp_against_reference_and_oracle(golden, planes):
     """cfg5's size with the identity warp (max_condition_num 0: the top-K of a tied step cannot feed back): the whole 10-step
     trajectory -- both large-tile Sinkhorn calls of every step, the read-out, the large-tile top-K behind cond -- against the
     REFERENCE's own components (compact fixture 2d3d_loop_n1024x2048_s10_mc0_masked, oracle/make_golden.py) and, entry by entry,
@@ -137,7 +144,7 @@ def test_cfg5_identity_warp_against_reference_and_oracle(golden):
     from tests.test_oracle_golden import cfg5_compact_checks
     N, M, steps, mc = 1024, 2048, 10, 0
     g = golden("2d3d_loop_n1024x2048_s10_mc0_masked")
-    W, eng, q = setup(N, M, 51, steps, mc)
+    W, eng, q = setup(N, M, 51, steps, mc, planes)
     ms, mt = masks(N, M, 1000, 2000)
     mt_da = torch.arange(M)[None] < 1900
     d = lambda k: q(k).to(DEV)
@@ -222,7 +229,7 @@ def test_overlay_for_unmodified_model(golden, N, M, nv, mv, mv_da, steps, mc, se
     out = host(q, ms.to(DEV), mt.to(DEV), mt_da.to(DEV), q("x_T"))
     conf = out["conf_matrix_pred"][0].cpu().numpy()
     assert out["conf_matrix_pred"].dtype == torch.float64
-    assert (np.abs(conf - g["conf"]) > 1e-4).mean() <= 1e-3
+    assert np.abs(conf - g["conf"]).max() <= 1e-4            # every entry (the fixture's exemption list is empty: loop_exemptions.json)
     # ... and it is the engine's own result: same x_start sequence, the host's DDIM arithmetic on top
     from diffreg_hip.engine import DenoiseEngine2D3D
     eng = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=DEV)
@@ -258,3 +265,39 @@ def test_2d3d_tiny_and_odd_shapes(N, M):
         assert (out["t_forwd"][k, 0].cpu() - tr[k]["t_forwd"][0]).abs().max().item() < 1e-4, k
     dc = (out["conf_matrix_pred"][0].cpu() - ref["conf_matrix_pred"][0]).abs()
     assert float(dc.max()) < 1e-4, float(dc.max())
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_cfg5_batch_of_pairs_on_the_plane_path(golden, P):
+    """BASELINE configs[4] batched (P pairs of 1024 x 2048 per call = 6144 / 12288 token rows: the size rule selects the plane path by
+    itself, the Sinkhorn runs the multi-launch grid form, the top-K the chip-wide selection over P tiles): pair 0 is the reference fixture's
+    pair (identity warp) and is held to the reference's own components; every pair to its own B = 1 run through the f32 kernels by a
+    plain 1e-4 on every entry of every step's x_start, of conf and of the final state."""
+    from tests.test_oracle_golden import cfg5_compact_checks
+    N, M, steps, mc = 1024, 2048, 10, 0
+    g = golden("2d3d_loop_n1024x2048_s10_mc0_masked")
+    seeds = [51, 52, 53, 54][:P]
+    W, eng, _ = setup(N, M, 51, steps, mc)                      # planes=None: chosen by the size rule
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    prs = [synth.make_pair_2d3d(N, M, sd, weights=Wn) for sd in seeds]
+    cat = lambda k: torch.stack([T(p[k]) for p in prs]).to(DEV)
+    nv, mv, mda = [1000, 1024, 900, 1011][:P], [2000, 2048, 2048, 1777][:P], [1900, 2048, 2000, 1700][:P]
+    ms = torch.stack([torch.arange(N) < n for n in nv]); mt = torch.stack([torch.arange(M) < m for m in mv])
+    mt_da = torch.stack([torch.arange(M) < m for m in mda])
+    out = eng.run(cat("img_feats"), cat("img_dino"), cat("img_pixels"), cat("pcd_feats"), cat("s_pcd"), cat("t_pcd_da"), cat("x_T"),
+                  (ms.to(DEV), mt.to(DEV), mt_da.to(DEV)), trace=True)
+    torch.cuda.synchronize()
+    cfg5_compact_checks(g, out["x0"][-1, 0].cpu().numpy(), out["conf_matrix_pred"][0].cpu().numpy(), out["R_forwd"][:, 0].cpu().numpy(),
+                        out["t_forwd"][:, 0].cpu().numpy(), out["cond"][:, 0].cpu().tolist())
+    assert np.abs(out["x0"][:, 0, :16, :16].cpu().numpy() - g["x0_corner"]).max() <= 1e-4
+    x0_all, conf_all, xf_all = out["x0"].cpu(), out["conf_matrix_pred"].cpu(), out["x_final"].cpu()
+    eng1 = setup(N, M, 51, steps, mc, False)[1]
+    for i in range(P):
+        d = lambda k: T(prs[i][k])[None].to(DEV)
+        one = eng1.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"),
+                       (ms[i:i + 1].to(DEV), mt[i:i + 1].to(DEV), mt_da[i:i + 1].to(DEV)), trace=True)
+        assert (one["x0"][:, 0].cpu() - x0_all[:, i]).abs().max().item() <= 1e-4, i
+        assert (one["conf_matrix_pred"][0].cpu() - conf_all[i]).abs().max().item() <= 1e-4, i
+        a, b = one["x_final"][0].cpu(), xf_all[i]
+        fin = torch.isfinite(a)
+        assert torch.equal(fin, torch.isfinite(b)) and (a[fin] - b[fin]).abs().max().item() <= 1e-4, i

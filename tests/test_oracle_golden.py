@@ -139,6 +139,7 @@ def test_soft_family_loop_matches_reference(golden, variant, N, M, nv, mv, steps
     """The "soft" fixture family (round 4): the same scenes with the matching head at a checkpoint-like scale (logits O(10)), minted by
     the reference itself like the others.  Nothing is ill-conditioned there, so everything is a plain bound -- and the match list
     must be the reference's, entry for entry, wherever the read-out's arg-maxima are decided by more than the conf error."""
+    # (how many arg-maxima are NOT decided in these fixtures is printed by the GPU test; the oracle shares torch's tie rule)
     g = golden("%s_loop_%s" % (variant, tag))
     v = synth.VARIANTS[variant]
     W = weights(variant, "soft")

@@ -206,3 +206,72 @@ def test_column_blocks_sharing_one_image_share_one_scale(gain1):
     chk_o()
     refo = torch.nn.functional.layer_norm(refh @ W2.double().t(), (C,), g1.double(), b1.double())
     assert float(((o32.double() - refo).abs().amax(1) / refo.abs().amax(1)).max()) < 1e-5
+
+
+@pytest.mark.parametrize("row_block", [None, 0, 2], indirect=True)
+@pytest.mark.parametrize("rows,C", [(1000, 256), (129, 256), (4500, 256), (300, 128), (700, 432)])
+def test_vision3d_layer_chain_against_float64(rows, C, row_block):
+    """The GEMMs of one vision3d TransformerLayer (Diff-Reg-2d3d/vision3d/layers/transformer.py:58-158, 188-301) through the plane ops'
+    round-4 epilogue modes: q | k | v with BIASES and no rotary (DR_PL_PLANES into three images, plus an fp32 copy), the output projection
+    with bias and z = LayerNorm(linear(h) + x) (DR_PL_LN, ln_postadd), expand with bias + ReLU (two column blocks), squeeze with bias and
+    out = LayerNorm(z + squeeze(...)).  C = 256 / 128 run the 256-column geometry (pgemm_kernel<4,4>), C = 432 the 448-column one."""
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
+    img, bnd = lib.planes_from_f32(x)
+    # ---- q | k | v with biases -> three images (each its own bound array) + fp32 copy
+    W = torch.randn(3 * C, C, device=DEV) / C ** 0.5
+    b = torch.randn(3 * C, device=DEV) * 0.3
+    big, chk_big = image_like(rows, 3 * C)
+    bb, chk_bb = guarded((1, rows), torch.float32, DEV, fill=0)
+    o32, chk_o = guarded((3, rows, C), torch.float32, DEV, fill=float("nan"))
+    pk = lib.pack_weight_planes(W, 3, C)
+    bmax = torch.empty(3, device=DEV)
+    lib.check(lib.raw().dr_bias_max_f32(3, C, lib.ptr(b), lib.ptr(bmax), lib.stream_of(b)))
+    assert torch.allclose(bmax.cpu(), b.view(3, C).abs().amax(1).cpu() * 1.0001, rtol=1e-6)
+    lib.linear_planes(rows, C, 3, img, bnd, C, pk, lib.PL_PLANES, out=o32, ldo=C, blk_stride=rows * C, out_image=big, out_image_k=3 * C,
+                      out_bound=bb[0], bias=b)
+    # (one image of 3 C columns here: blocks side by side; the loop's per-block images are covered by the loop tests)
+    chk_big(); chk_bb(); chk_o()
+    ref = x.double() @ W.double().t() + b.double()
+    assert not torch.isnan(o32).any()
+    assert rel(o32.permute(1, 0, 2).reshape(rows, 3 * C), ref) < 2e-6
+    back = lib.planes_to_f32(big, bb[0], rows, 3 * C)
+    assert rel(back, ref) < 3e-6 and bool((bb[0].double() >= ref.abs().amax(1)).all())
+    # ---- z = LayerNorm(h W_lin^T + b_lin + x)
+    h = torch.randn(rows, C, device=DEV) * 2
+    himg, hb = lib.planes_from_f32(h)
+    Wl = torch.randn(C, C, device=DEV) / C ** 0.5
+    bl = torch.randn(C, device=DEV) * 0.2
+    g1, b1 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+    lnb = lib.ln_bound(g1, b1)
+    z32, chk_z = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+    z_img, chk_zi = image_like(rows, C)
+    z_b, chk_zb = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 1, himg, hb, C, lib.pack_weight_planes(Wl, 1, C), lib.PL_LN, out=z32, ldo=C, out_image=z_img, out_image_k=C,
+                      out_bound=z_b, gamma=g1, beta=b1, resid=x, ldr=C, bound_resid=bnd, lnb=lnb, bias=bl, ln_postadd=True)
+    chk_z(); chk_zi(); chk_zb()
+    refz = torch.nn.functional.layer_norm(h.double() @ Wl.double().t() + bl.double() + x.double(), (C,), g1.double(), b1.double())
+    assert rel(z32, refz) < 3e-6 and rel(lib.planes_to_f32(z_img, z_b, rows, C), refz) < 3e-6
+    assert bool((z_b.double() >= refz.abs().amax(1)).all())
+    # ---- hidden = relu(expand(z)): two column blocks of C, ONE image of 2 C columns
+    We = torch.randn(2 * C, C, device=DEV) / C ** 0.5
+    be = torch.randn(2 * C, device=DEV) * 0.2
+    hid_img, chk_h = image_like(rows, 2 * C)
+    hid_b, chk_hb = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 2, z_img, z_b, C, lib.pack_weight_planes(We, 2, C), lib.PL_PLANES, out_image=hid_img, out_image_k=2 * C,
+                      out_bound=hid_b, relu=True, bias=be)
+    chk_h(); chk_hb()
+    refh = torch.relu(refz @ We.double().t() + be.double())
+    assert rel(lib.planes_to_f32(hid_img, hid_b, rows, 2 * C), refh) < 4e-6 and bool((hid_b.double() >= refh.abs().amax(1)).all())
+    # ---- out = LayerNorm(z + squeeze(hidden))
+    Ws = torch.randn(C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    bs = torch.randn(C, device=DEV) * 0.2
+    o2, chk_o2 = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+    o_img, chk_oi = image_like(rows, C)
+    o_b, _ = guarded((rows,), torch.float32, DEV, fill=0)
+    lib.linear_planes(rows, C, 1, hid_img, hid_b, 2 * C, lib.pack_weight_planes(Ws, 1, C), lib.PL_LN, out=o2, ldo=C, out_image=o_img,
+                      out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, resid=z32, ldr=C, bound_resid=z_b, lnb=lnb, bias=bs, ln_postadd=True)
+    chk_o2(); chk_oi()
+    refo = torch.nn.functional.layer_norm(refz + refh @ Ws.double().t() + bs.double(), (C,), g1.double(), b1.double())
+    assert rel(o2, refo) < 4e-6 and rel(lib.planes_to_f32(o_img, o_b, rows, C), refo) < 4e-6
+    assert bool((o_b.double() >= refo.abs().amax(1)).all())
