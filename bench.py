@@ -326,9 +326,14 @@ def bench_cfg5(dev, batches=(1, 8)):
     for P in batches:
         prs = [distinct[i % len(distinct)] for i in range(P)]
         args = [torch.from_numpy(np.stack([p[k] for p in prs])).to(dev) for k in ("img_feats", "img_dino", "img_pixels", "pcd_feats", "s_pcd", "t_pcd_da", "x_T")]
-        dt = _time_calls(lambda: eng.run(*args), warm=2, reps=4)
-        ent = {"ms_per_call": dt * 1e3, "pairs_per_s": P / dt, "ms_per_pair": dt * 1e3 / P,
+        kw = dict(zip(eng._ARGS, args))
+        dt = _time_calls(lambda: eng.run_static(slot=0, graph=True, **kw), warm=3, reps=4)
+        ent = {"ms_per_call": dt * 1e3, "pairs_per_s": P / dt, "ms_per_pair": dt * 1e3 / P, "launch": "one captured HIP graph per call",
                "distinct_scenes": min(P, len(distinct)), "path": "plane images" if P * (N + M) >= 4096 else "f32-input MFMA kernels"}
+        if P > 1:
+            two = _time_calls(lambda: eng.run_streams([kw, kw], 2), warm=3, reps=4)
+            ent["two_concurrent_calls"] = {"ms_per_pass": two * 1e3, "pairs_per_s": 2 * P / two,
+                                           "what": "two independent %d-pair calls, one captured graph each, on two HIP streams" % P}
         lib.prof_enable(True)
         eng.run(*args)
         prof = lib.prof_collect()
@@ -338,7 +343,7 @@ def bench_cfg5(dev, batches=(1, 8)):
                                   "attention_planes_kernel<4,2> (d = 64)" if P * (N + M) >= 4096 else "attention_kernel / attention_flash_kernel (f32-input MFMA, d = 64)"))
         res["per_batch"]["P%d" % P] = ent
     best = max(res["per_batch"].values(), key=lambda e: e["pairs_per_s"])
-    res["pairs_per_s"] = best["pairs_per_s"]
+    res["pairs_per_s"] = max(best["pairs_per_s"], best.get("two_concurrent_calls", {}).get("pairs_per_s", 0.0))
     if "roofline" in best:
         res["roofline"] = best["roofline"]
     elif "gemm_f32" in best:

@@ -80,7 +80,7 @@ struct PgGeom {
     static constexpr int EP_S = (BNW - 48 + 63) / 64 * 64 + 48;   // row stride of the transposition, = 48 mod 64 floats: conflict-free float4 reads
     static constexpr int EP_BYTES = 2 * WMN * 16 * EP_S * 4;
     static constexpr int WORK = RING > EP_BYTES ? RING : EP_BYTES;
-    static constexpr int SMEM = WORK + 6 * 128 * 4 + 2 * BN * 4;   // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta [2][BN]
+    static constexpr int SMEM = WORK + 6 * 128 * 4 + 3 * BN * 4;   // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta | bias [3][BN]
     static constexpr int MID = (TNW - 1) / 2 - 1 < 0 ? 0 : (TNW - 1) / 2 - 1;   // the barrier sits after this tile (2 of 7)
 };
 
@@ -111,6 +111,14 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     float* const s_rinv = s_fac + 128;                               // 2^-s of the rows (last segment)
     float* const s_sum = s_rinv + 128;                               // [2][128] LayerNorm partial sums of the two column waves
     float* const s_sq = s_sum + 256;                                 // [2][128] partial squares
+    // nn.Linear bias of the block: staged in LDS (behind gamma | beta) and read piece by piece in the epilogue -- held in registers
+    // (14 float4 per lane) it made the 128-row q|k|v / mlp0 instantiations spill
+    const bool has_bias = P.bias != nullptr;
+    float* const s_bias = s_sq + 256 + 2 * BN;
+    if (has_bias) {
+        const float* bp = P.bias + (size_t)nb * C;
+        for (int c = t; c < BN; c += NTHR) s_bias[c] = c < C ? bp[c] : 0.f;
+    }
     if (t < BM) {
         const int row = min(rb * BM + t, rows - 1);
         const int e0 = scale_exp(P.bnd0[row]);
@@ -339,18 +347,13 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         wave_fence();
     };
     const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
-    // nn.Linear bias of the lane's columns (read before any store of this wave, like every other epilogue operand)
-    const bool has_bias = P.bias != nullptr;
-    float4 bias4[NI];
-    if (has_bias) {
-        const float* bp = P.bias + (size_t)nb * C;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bias4[i] = colw + 16 * i < C ? *reinterpret_cast<const float4*>(bp + colw + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     auto add_bias = [&](float4 (&dst)[NI]) __attribute__((always_inline)) {
         if (has_bias) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) { dst[i].x += bias4[i].x; dst[i].y += bias4[i].y; dst[i].z += bias4[i].z; dst[i].w += bias4[i].w; }
+            for (int i = 0; i < NI; ++i) {
+                const float4 b4 = *reinterpret_cast<const float4*>(s_bias + colw + 16 * i);
+                dst[i].x += b4.x; dst[i].y += b4.y; dst[i].z += b4.z; dst[i].w += b4.w;
+            }
         }
     };
     int grow[2];

@@ -427,3 +427,76 @@ class DenoiseEngine2D3D:
 
     def run(self, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, x_T, masks=None, trace=False):
         return self._call(self.steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace)
+
+    # ------------------------------------------------------------------------------------------
+    _ARGS = ("img_feats", "img_dino", "img_pixels", "pcd_feats", "s_pcd", "t_pcd_da", "x_T")
+
+    def _slot(self, slot, kw):
+        """static buffers (inputs, outputs, a PRIVATE workspace) + captured graph of one concurrent batch"""
+        shapes = tuple(tuple(kw[k].shape) for k in self._ARGS)
+        masked = kw.get("masks") is not None
+        if not hasattr(self, "_slots"):
+            self._slots = {}
+        ent = self._slots.get(slot)
+        if ent is None or ent["shapes"] != shapes or ent["masked"] != masked:
+            P, M, _ = kw["img_feats"].shape
+            N = kw["pcd_feats"].shape[1]
+            dev = self.device
+            cfg = self._cfg(self.steps)
+            need = lib.raw().dr_denoise_loop_2d3d_workspace_bytes(ctypes.byref(cfg), P, N, M)
+            ent = dict(shapes=shapes, masked=masked, P=P, N=N, M=M, g=None, uses=0, need=need,
+                       ws=torch.empty(need, dtype=torch.uint8, device=dev),
+                       inp={k: torch.empty(kw[k].shape, dtype=torch.float32, device=dev) for k in self._ARGS},
+                       masks=tuple(torch.empty(m.shape, dtype=torch.uint8, device=dev) for m in kw["masks"]) if masked else None,
+                       conf=torch.empty(P, N, M, dtype=torch.float64, device=dev), xf=torch.empty(P, N, M, dtype=torch.float64, device=dev),
+                       matches=torch.zeros(P, N + M, 3, dtype=torch.int64, device=dev), cnt=torch.zeros(P, dtype=torch.int32, device=dev),
+                       img_out=torch.empty(P, M, self.C, device=dev), pcd_out=torch.empty(P, N, self.C, device=dev))
+            self._slots[slot] = ent
+        return ent
+
+    def _enqueue_slot(self, e):
+        cfg = self._cfg(self.steps)
+        i, m = e["inp"], e["masks"] or (None, None, None)
+        lib.check(lib.raw().dr_denoise_loop_2d3d(
+            ctypes.byref(cfg), ctypes.byref(self.w), e["P"], e["N"], e["M"], lib.ptr(i["img_feats"]), lib.ptr(i["img_dino"]), lib.ptr(i["img_pixels"]),
+            lib.ptr(i["pcd_feats"]), lib.ptr(i["s_pcd"]), lib.ptr(i["t_pcd_da"]), lib.ptr(m[0]), lib.ptr(m[1]), lib.ptr(m[2]), lib.ptr(i["x_T"]),
+            lib.ptr(e["conf"]), lib.ptr(e["xf"]), lib.ptr(e["matches"]), lib.ptr(e["cnt"]), lib.ptr(e["img_out"]), lib.ptr(e["pcd_out"]),
+            None, lib.ptr(e["ws"]), e["need"], lib.stream_of(e["conf"])))
+
+    def run_static(self, slot=0, graph=True, **kw):
+        """run() on static buffers with the whole loop captured in a HIP graph on the SECOND pass of a slot (the first runs eagerly:
+        warm-up) and replayed afterwards.  Returns the slot's static output tensors (overwritten by its next pass)."""
+        e = self._slot(slot, kw)
+        for k in self._ARGS:
+            e["inp"][k].copy_(kw[k])
+        if e["masked"]:
+            for dst, src in zip(e["masks"], kw["masks"]):
+                dst.copy_(lib.mask_u8(src))
+        if graph and e["g"] is None and e["uses"] >= 1:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_slot(e)
+            e["g"] = g
+        if graph and e["g"] is not None:
+            e["g"].replay()
+        else:
+            self._enqueue_slot(e)
+        e["uses"] += 1
+        return dict(conf_matrix_pred=e["conf"], x_final=e["xf"], matches_padded=e["matches"], match_count=e["cnt"])
+
+    def run_streams(self, groups, n_streams=2):
+        """Several independent batches of pairs concurrently (DenoiseEngine.run_streams for the 2D-3D loop): one captured graph per batch,
+        replayed on `n_streams` HIP streams, each batch with its own workspace.  groups: list of dicts with run()'s tensor arguments."""
+        cur = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_streams") or len(self._streams) < n_streams:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        outs = []
+        for gi, kw in enumerate(groups):
+            st = self._streams[gi % n_streams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.run_static(slot=gi, graph=True, **kw))
+        for st in self._streams[:n_streams]:
+            cur.wait_stream(st)
+        return outs
