@@ -815,6 +815,8 @@ __device__ __forceinline__ int attn_scale_exp(float bound) {
     return (bound > 0.f && e < 128) ? min(max(14 - e, -100), 100) : 0;
 }
 
+// (d = 64 uses 141 registers: three workgroups per CU.  Forced into 128 -- four per CU -- it spills 13 registers and measured 1-5 % slower
+//  at every cfg5 shape: profiles/r04_attention_planes_softmax_trims.json)
 template <int KS, int NDT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_planes_kernel(AttnArgs A) {
     using G = AttnPlGeom<KS, NDT>;
@@ -923,39 +925,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_h, sc, 0, 0, 0);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile)
-        const unsigned kbits = attn_mask_bits(mbyte) >> (4 * h);
+        // The softmax is a serial VALU stretch between the two MFMA blocks of a tile and it does not shrink with the head dim: at d = 64
+        // it outweighs the MFMAs.  Two trims: a tile with all 32 keys present and unmasked (wave-uniform test) skips the per-register drop
+        // logic and folds the scale into the exponent's argument, p = exp2(fma(s, sfac, -m)) (one rounding instead of two: the last bit
+        // of p may differ from the masked path's); and the accumulators are rescaled only when some query's running maximum moved in
+        // this tile (alpha = 1 exactly for every lane otherwise).
+        const unsigned kbits_all = attn_mask_bits(mbyte);
+        const bool full_tile = kt * 32 + 32 <= Lk && kbits_all == 0xFFFFFFFFu;       // (the ballot covers both lane halves: bits 0..31 twice)
         float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float s = sc[r];
-            const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
-            s = drop ? -INFINITY : s * sfac;
-            sc[r] = s;
-            mx = fmaxf(mx, s);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
         float alpha = 1.f, psum = 0.f;
-        if (m_new == -INFINITY) {
+        float m_new;
+        if (full_tile) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-        } else {
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sfac;           // sfac > 0: the maximum commutes with the scale
+            m_new = fmaxf(m_run, mx);
             alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sfac, -m_new));
                 sc[r] = p;
                 psum += p;
+            }
+        } else {
+            const unsigned kbits = kbits_all >> (4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float s = sc[r];
+                const bool drop = kk >= Lk || (q_valid && !((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u));     // transformero.py:82
+                s = drop ? -INFINITY : s * sfac;
+                sc[r] = s;
+                mx = fmaxf(mx, s);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_new = fmaxf(m_run, mx);
+            if (m_new == -INFINITY) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            } else {
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                    sc[r] = p;
+                    psum += p;
+                }
             }
         }
         psum += __shfl_xor(psum, 32);
         l_run = l_run * alpha + psum;
+        if (__any(m_new != m_run)) {                             // (alpha == 1 exactly in every lane otherwise: exp2(0))
+#pragma unroll
+            for (int i = 0; i < NDT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < NDT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
         // ---- O^T += V^T P^T : k-step s contracts the keys of score registers 8 s .. 8 s + 7
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1012,6 +1038,7 @@ static int configure_attn() {
                                      (int)FlashSplitGeom<KS, NDT>::SMEM));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)AttnPlGeom<KS, NDT>::SMEM));
+
     return DR_OK;
 }
 

@@ -868,7 +868,7 @@ struct SkGridArgs {
 
 template <typename T>
 __host__ __device__ inline size_t sk_grid_tile_elems(int N, int M, int G, int iters) {
-    return (size_t)N * M + 3 * (size_t)N + 1 + (size_t)G * M + G + iters + 2 + (size_t)M + 1 + 8;
+    return ((size_t)N * M + 3 * (size_t)N + 1 + (size_t)G * M + G + iters + 2 + (size_t)M + 1 + 8 + 3) & ~(size_t)3;   // (tiles start 16-byte aligned)
 }
 
 // column sums over the row blocks, between two phases: cb[j] = sum_g cpart[g][j], cb[M] = sum_g dpart[g]
@@ -892,7 +892,21 @@ __global__ __launch_bounds__(256) void sk_grid_reduce_kernel(SkGridArgs GA) {
     }
 }
 
-template <typename TIn, typename T, typename TOut, int CPL>
+// four consecutive elements as one or two 16-byte accesses (the vector form of the grid kernel: M % 4 == 0, 16-byte aligned tiles)
+template <typename TS, typename TD> __device__ __forceinline__ void sk_ld4v(const TS* p, TD (&v)[4]) {
+    if constexpr (sizeof(TS) == 4) { const float4 x = *reinterpret_cast<const float4*>(p); v[0] = (TD)x.x; v[1] = (TD)x.y; v[2] = (TD)x.z; v[3] = (TD)x.w; }
+    else { const double2 x = *reinterpret_cast<const double2*>(p), y = *reinterpret_cast<const double2*>(p + 2); v[0] = (TD)x.x; v[1] = (TD)x.y; v[2] = (TD)y.x; v[3] = (TD)y.y; }
+}
+template <typename TD, typename TS> __device__ __forceinline__ void sk_st4v(TD* p, const TS (&v)[4]) {
+    if constexpr (sizeof(TD) == 4) *reinterpret_cast<float4*>(p) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    else { *reinterpret_cast<double2*>(p) = make_double2((double)v[0], (double)v[1]); *reinterpret_cast<double2*>(p + 2) = make_double2((double)v[2], (double)v[3]); }
+}
+
+// VEC: lane l owns columns 4 (l + 64 q) + c (q < CPL / 4, c < 4) and moves them as 16-byte accesses -- 1 KB contiguous per wave
+// instruction instead of 256 B (batches of large tiles, e.g. 8 x 1024 x 2048 of the batched 2D-3D loop, are HBM-bound passes);
+// the scalar form (lane l owns columns l + 64 k) serves M % 4 != 0 and unaligned tiles.  The column a register holds differs, the
+// arithmetic per column and every summation order over ROWS do not; the row sums associate differently, so the last bits may.
+template <typename TIn, typename T, typename TOut, int CPL, bool VEC>
 __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     const SkArgs& A = GA.k;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -935,6 +949,7 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     const T mu = t_exp<T>((T)normf), muN = t_exp<T>((T)lmuN), nu = mu, nuM = t_exp<T>((T)lnuM);
     const T xmin = A.shift ? (T)A.shift[tile] : (T)0;
     const int r0 = g * GA.R, r1 = min(N, r0 + GA.R);
+    auto colj = [&](int k) { return VEC ? 4 * (lane + WAVE * (k >> 2)) + (k & 3) : lane + WAVE * k; };
 
     // ---- b of the previous pass from the column partials of every block (phases 1, 2) ---------------------
     T aN = muN / ((ragged ? (T)ns : (T)M) + (T)1), bM = 1;
@@ -968,7 +983,17 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
             const T S = t_exp<T>(-(T)normf);
             for (int i = r0 + w; i < r1; i += 4) {
                 const T ai = g_a[i] * S;
-                for (int j = lane; j < M; j += WAVE) dst[(size_t)i * M + j] = (TOut)(Ew[(size_t)i * M + j] * ai * s_b[j]);
+                if (VEC) {
+                    for (int jb = 4 * lane; jb < M; jb += 4 * WAVE) {
+                        T e4[4], o4[4];
+                        sk_ld4v(Ew + (size_t)i * M + jb, e4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o4[c] = e4[c] * ai * s_b[jb + c];
+                        sk_st4v(dst + (size_t)i * M + jb, o4);
+                    }
+                } else {
+                    for (int j = lane; j < M; j += WAVE) dst[(size_t)i * M + j] = (TOut)(Ew[(size_t)i * M + j] * ai * s_b[j]);
+                }
             }
         }
         return;
@@ -993,12 +1018,22 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
         T ai, ed;
         if (GA.phase == 0) {
             T m = alpha;
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const int jb = 4 * (lane + WAVE * q);
+                    T raw[4] = {0, 0, 0, 0};
+                    if (jb < M) sk_ld4v(src + (size_t)i * M + jb, raw);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[4 * q + c] = raw[c];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
-                const int j = lane + WAVE * k;
+                const int j = colj(k);
                 T v = -(T)INFINITY;
                 if (j < M) {
-                    v = (T)src[(size_t)i * M + j] - xmin;
+                    v = (VEC ? e[k] : (T)src[(size_t)i * M + j]) - xmin;
                     if (apply && ((sm && !sm[i]) || (tm && !tm[j]))) v = -(T)INFINITY;
                 }
                 e[k] = v;
@@ -1008,11 +1043,19 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
             T rs = 0;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
-                const int j = lane + WAVE * k;
+                const int j = colj(k);
                 const T ex = (j < M) ? t_exp<T>(e[k] - m) : (T)0;
                 e[k] = ex;
-                if (j < M) Ew[(size_t)i * M + j] = ex;
+                if (!VEC && j < M) Ew[(size_t)i * M + j] = ex;
                 rs += ex;
+            }
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const int jb = 4 * (lane + WAVE * q);
+                    const T e4[4] = {e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+                    if (jb < M) sk_st4v(Ew + (size_t)i * M + jb, e4);
+                }
             }
             rs = wave_sum(rs);
             ed = t_exp<T>(alpha - m);
@@ -1020,12 +1063,23 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
             if (lane == 0) { g_rho[i] = m; g_ed[i] = ed; g_a[i] = ai; }
         } else {
             T rs = 0;
+            if (VEC) {
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const int j = lane + WAVE * k;
-                const T ex = (j < M) ? Ew[(size_t)i * M + j] : (T)0;
-                e[k] = ex;
-                rs += (j < M) ? ex * s_b[j] : (T)0;
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const int jb = 4 * (lane + WAVE * q);
+                    T e4[4] = {0, 0, 0, 0};
+                    if (jb < M) sk_ld4v(Ew + (size_t)i * M + jb, e4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { e[4 * q + c] = e4[c]; rs += (jb < M) ? e4[c] * s_b[jb + c] : (T)0; }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int j = lane + WAVE * k;
+                    const T ex = (j < M) ? Ew[(size_t)i * M + j] : (T)0;
+                    e[k] = ex;
+                    rs += (j < M) ? ex * s_b[j] : (T)0;
+                }
             }
             rs = wave_sum(rs);
             ed = g_ed[i];
@@ -1039,7 +1093,7 @@ __global__ __launch_bounds__(256) void sk_grid_kernel(SkGridArgs GA) {
     // column partials of the block: 4 waves -> LDS -> workspace
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        const int j = lane + WAVE * k;
+        const int j = colj(k);
         if (j < M) s_col[(size_t)w * M + j] = cacc[k];
     }
     if (lane == 0) s_scr[8 + w] = dacc;
@@ -1059,8 +1113,14 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
     ga.k = a; ga.G = G; ga.R = (a.N + G - 1) / G;
     ga.tile_stride = sk_grid_tile_elems<T>(a.N, a.M, G, a.iters);
     const size_t lds = ((size_t)5 * a.M + 1 + 16) * sizeof(T) + 16;
-    if (lds > 64 * 1024)
-        DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_grid_kernel<TIn, T, TOut, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // 16-byte accesses when every row of every tile starts 16-byte aligned in the scores, the workspace copy and the output
+    const bool log_out = (a.flags & DR_SK_OUT_LOG) != 0;
+    const bool vec = a.M % 4 == 0 && !log_out && ((uintptr_t)a.scores % (4 * sizeof(TIn))) == 0 && ((uintptr_t)a.out % (4 * sizeof(TOut))) == 0 &&
+                     ((uintptr_t)a.ws % 32) == 0 && ga.tile_stride % 4 == 0 && env_knob("DR_SK_GRID_VEC", 1);
+    if (lds > 64 * 1024) {
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_grid_kernel<TIn, T, TOut, CPL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_grid_kernel<TIn, T, TOut, CPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     for (int ph = 0; ph <= a.iters; ++ph) {
         ga.phase = ph == 0 ? 0 : (ph == a.iters ? 2 : 1);
         ga.it = ph;                                              // phase 1/2 read g_aN[it - 1], phases 0/1 write g_aN[it]
@@ -1068,7 +1128,8 @@ static int launch_grid_cpl(const SkArgs& a, int G, hipStream_t st) {
             hipLaunchKernelGGL((sk_grid_reduce_kernel<T>), dim3((a.M + 1 + 255) / 256, a.B), dim3(256), 0, st, ga);
             DR_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((sk_grid_kernel<TIn, T, TOut, CPL>), dim3(G, a.B), dim3(256), lds, st, ga);
+        if (vec) hipLaunchKernelGGL((sk_grid_kernel<TIn, T, TOut, CPL, true>), dim3(G, a.B), dim3(256), lds, st, ga);
+        else hipLaunchKernelGGL((sk_grid_kernel<TIn, T, TOut, CPL, false>), dim3(G, a.B), dim3(256), lds, st, ga);
         DR_LAUNCH_CHECK();
     }
     return DR_OK;

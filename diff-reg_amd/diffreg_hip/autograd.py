@@ -190,8 +190,8 @@ def geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask=None, sou
 class _Procrustes(torch.autograd.Function):
     """SoftProcrustesLayer.forward (3D/models/procrustes.py:17-93) with its gradient into the confidence matrix.  Forward = dr_procrustes_f32 (top-K
     selection, weighted Kabsch, fp64 3 x 3 SVD on the device).  Backward: the K selected confidences are the weights of the fit; their gradient is
-    taken through a float64 re-evaluation of the fit on the K gathered pairs with torch.svd on the host -- the reference's own arithmetic and
-    autograd path (`Sxy.cpu().double().svd()`, :35-36) -- and scattered back to the selected entries."""
+    dr_procrustes_backward_f32 -- the closed-form adjoint of the fit (SVD adjoint for 3 x 3 matrices) in float64 on the device, one workgroup
+    per pair, replacing the reference's autograd path through `Sxy.cpu().double().svd()` (:35-36)."""
 
     @staticmethod
     def forward(ctx, conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond, use_mask_len=False):
@@ -200,37 +200,18 @@ class _Procrustes(torch.autograd.Function):
         ctx.save_for_backward(conf.detach(), src_pcd, tgt_pcd, idx, ok)
         ctx.entry_max = None
         if use_mask_len:                 # 4D (models/procrustes.py:61-76): K from the mask sums, weights beyond a pair's own count are zeroed
-            ctx.entry_max = (torch.maximum(src_mask.sum(1), tgt_mask.sum(1)).float() * sample_rate).int().cpu()
+            ctx.entry_max = (torch.maximum(src_mask.sum(1), tgt_mask.sum(1)).float() * sample_rate).int()
         ctx.mark_non_differentiable(cond, ok)
         return R, t, Rf, tf, cond, ok
 
     @staticmethod
     def backward(ctx, gR, gt, gRf, gtf, _gc, _gk):
         conf, ps, pt, idx, ok = ctx.saved_tensors
-        B, N, M = conf.shape
-        idx = idx.long()
+        B = conf.shape[0]
         okf = ok.view(B, 1, 1).to(gR.dtype)
         gR_eff, gt_eff = gR + gRf * okf, gt + gtf * okf                    # R_forwd = R where the condition gate passes, identity elsewhere (:85-90)
-        bi = torch.arange(B, device=conf.device).view(B, 1).expand_as(idx)
-        with torch.enable_grad():
-            w0 = conf.reshape(B, -1).gather(1, idx).double().cpu().requires_grad_(True)
-            w = w0
-            if ctx.entry_max is not None:
-                w = w0 * (torch.arange(idx.shape[1]).view(1, -1) < ctx.entry_max.view(-1, 1)).double()
-            X, Y = ps[bi, idx // M].double().cpu(), pt[bi, idx % M].double().cpu()
-            wn = (w / (w.abs().sum(1, keepdim=True) + 1e-4))[..., None]
-            mx, my = (wn * X).sum(1, keepdim=True), (wn * Y).sum(1, keepdim=True)
-            S = (Y - my).transpose(1, 2) @ (wn * (X - mx))
-            U, D, Vh = torch.linalg.svd(S)
-            V = Vh.transpose(1, 2)
-            fix = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
-            fix[:, 2, 2] = (U.det() * V.det()).detach()
-            Rr = U @ (fix @ V.transpose(1, 2))
-            tr_ = my.transpose(1, 2) - Rr @ mx.transpose(1, 2)
-            gw, = torch.autograd.grad((Rr, tr_), w0, (gR_eff.double().cpu(), gt_eff.double().cpu()))
-        g_conf = torch.zeros(B, N * M, device=conf.device)
-        g_conf.scatter_add_(1, idx, gw.float().to(conf.device))
-        return g_conf.view(B, N, M), None, None, None, None, None, None, None
+        g_conf = lib.procrustes_backward(conf, ps, pt, idx, gR_eff, gt_eff, k_count=ctx.entry_max)
+        return g_conf, None, None, None, None, None, None, None
 
 
 def procrustes_fit(layer, conf, src_pcd, tgt_pcd, src_mask, tgt_mask):

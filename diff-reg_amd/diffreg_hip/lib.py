@@ -118,12 +118,19 @@ SIGNATURES.update({
     "dr_norm_apply_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
                                   c_int, c_void_p, c_int, c_void_p]),
     "dr_gather_pool_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "dr_kpconv_gather_backward_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                              c_void_p, c_int, c_void_p, c_void_p]),
+    "dr_norm_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dr_norm_backward_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_float, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "dr_gather_pool_backward_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "dr_device_status": (c_int, [c_void_p, c_int]),
+    "dr_procrustes_backward_f32": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 9),
     "dr_debug_sinkhorn_spin_limit": (None, [ctypes.c_uint]),
     "dr_debug_enable_env": (None, [c_int]),
     "dr_debug_launch_chain": (c_int, [c_int, c_int, c_int, c_void_p]),
@@ -713,6 +720,44 @@ def gather_pool(x, inds, first_only=False):
     return out
 
 
+def kpconv_gather_backward(q_pts, s_pts, neighb_inds, x, kernel_points, extent, grad_weighted):
+    """d loss / d x [Ns, Cin] of kpconv_gather (grad_weighted [Nq, ceil4(K*Cin)])"""
+    ensure_init()
+    Nq, H = neighb_inds.shape
+    K, Cin = kernel_points.shape[0], x.shape[1]
+    gw = grad_weighted.contiguous()
+    gx = torch.empty_like(x)
+    check(_lib.dr_kpconv_gather_backward_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()), ptr(neighb_inds.contiguous()),
+                                             ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent), ptr(gw), gw.shape[1], ptr(gx), stream_of(x)))
+    return gx
+
+
+def norm_backward(grad_out, out, a, stats_a, b=None, stats_b=None, slope=0.1, activate=True):
+    """backward of norm_apply -> (grad_a, grad_b or None)"""
+    ensure_init()
+    N, C = a.shape
+    g = grad_out.contiguous()
+    ga = torch.empty(N, C, device=a.device)
+    gb = torch.empty(N, C, device=a.device) if b is not None else None
+    mb, rb = stats_b if stats_b is not None else (None, None)
+    wsb = _lib.dr_norm_backward_workspace_bytes(N, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    check(_lib.dr_norm_backward_f32(N, C, ptr(g), C, ptr(out), out.stride(0) if out is not None else 0, ptr(a), a.stride(0), ptr(stats_a[0]), ptr(stats_a[1]),
+                                    ptr(b), b.stride(0) if b is not None else 0, ptr(mb), ptr(rb), float(slope), 1 if activate else 0, ptr(ga), C,
+                                    ptr(gb), C, ptr(ws), wsb, stream_of(a)))
+    return ga, gb
+
+
+def gather_pool_backward(x, inds, grad_out, first_only=False):
+    """backward of gather_pool -> grad_x (shape of x)"""
+    ensure_init()
+    n2, H = inds.shape
+    gx = torch.empty_like(x)
+    check(_lib.dr_gather_pool_backward_f32(n2, H, H, x.shape[1], ptr(x.contiguous()), x.shape[0], ptr(inds.contiguous()), 1 if first_only else 0,
+                                           ptr(grad_out.contiguous()), ptr(gx), stream_of(x)))
+    return gx
+
+
 _LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
                "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
 
@@ -765,6 +810,20 @@ def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond
                                  ptr(R), ptr(t), ptr(Rf), ptr(tf), ptr(cond), ptr(ok), ptr(idx), ptr(ws), wsb, stream_of(conf)))
     res = (R, t, Rf, tf, cond, ok.bool())
     return res + (idx,) if want_topk else res
+
+
+def procrustes_backward(conf, src_pcd, tgt_pcd, topk_idx, grad_R, grad_t, k_count=None):
+    """d loss / d conf [P,N,M] of the weighted Procrustes fit on the entries `topk_idx` [P,K] (int32) selected by procrustes(..., want_topk=True)"""
+    ensure_init()
+    conf = conf.contiguous().float()
+    P, N, M = conf.shape
+    K = topk_idx.shape[1]
+    g = torch.empty(P, N, M, device=conf.device)
+    kc = k_count.to(device=conf.device, dtype=torch.int32).contiguous() if k_count is not None else None
+    check(_lib.dr_procrustes_backward_f32(P, N, M, K, ptr(conf), ptr(src_pcd.contiguous().float()), ptr(tgt_pcd.contiguous().float()),
+                                          ptr(topk_idx.contiguous()), ptr(kc), ptr(grad_R.contiguous().float().reshape(P, 9)),
+                                          ptr(grad_t.contiguous().float().reshape(P, 3)), ptr(g), stream_of(conf)))
+    return g
 
 
 def top1_union(conf):

@@ -5,8 +5,9 @@ The module tree reproduces the reference's parameter names (encoder_blocks.{i}.K
 .unary1/.unary2/.unary_shortcut.mlp.weight, decoder_blocks.{i}.mlp.weight, coarse_out / coarse_in / fine_out), so the
 `backbone.*` part of a Diff-Reg checkpoint loads unchanged; the kernel point dispositions come from the checkpoint
 (the reference regenerates them from kernels/dispositions/*.ply, 3D/models/blocks.py:199-212).  forward(batch,
-phase='coarse') returns the coarse features exactly as the reference does; other phases / the training path are not
-accelerated (the reference's own fine branch is commented out upstream, backbone.py:161-180).
+phase='coarse') returns the coarse features exactly as the reference does -- under .train() with gradients enabled as the
+head of an autograd graph whose backward runs on the library's kernels too (diffreg_hip/backbone_autograd.py); other phases are
+not accelerated (the reference's own fine branch is commented out upstream, backbone.py:161-180).
 """
 import torch
 import torch.nn as nn
@@ -99,11 +100,14 @@ class KPFCN(nn.Module):
             self._engine_key = key
         return self._engine
 
-    @torch.no_grad()
     def forward(self, batch, phase="encode"):
         if phase != "coarse":
             raise NotImplementedError("only phase='coarse' exists (the reference's other branches are commented out, backbone.py:161-180)")
-        if self.training:
-            raise NotImplementedError("the training path of the backbone is outside the accelerated path")
+        if self.training and torch.is_grad_enabled():
+            # training: the same kernels as a chain of autograd Functions with backward kernels (diffreg_hip/backbone_autograd.py):
+            # gradients reach every parameter of the coarse phase
+            from diffreg_hip.backbone_autograd import kpfcn_coarse
+            return kpfcn_coarse(self, batch, arch=self.arch, cfg=self.cfg)
         dev = batch["points"][0].device
-        return self._get_engine(dev).forward(batch)
+        with torch.no_grad():
+            return self._get_engine(dev).forward(batch)

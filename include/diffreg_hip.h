@@ -219,6 +219,22 @@ int dr_norm_apply_f32(int N, int C, const float* a, int lda, const float* mean_a
 int dr_gather_pool_f32(int n2, int H, int ld_inds, int d, const float* x, int n1, const int64_t* inds, int first_only,
                        float* out, void* stream);
 
+/* Backward of the three ops above (the backbone's training path; the nn.Linear halves are products on dr_linear_*):
+ * dr_kpconv_gather_backward_f32: grad_x [Ns, Cin] (zeroed here, then fp32 atomics) from grad_weighted [Nq, ld_weighted]; kernel points and
+ *   point positions carry no gradient (the shipped configuration: rigid kernels), the neighbour count is piecewise constant.
+ * dr_norm_backward_f32: out = act(xhat_a + [xhat_b | b | 0]) as dr_norm_apply_f32 computed it -> grad_a (and grad_b when b took part);
+ *   `out` is the forward result (the LeakyReLU's derivative is read off its sign).  Two float64 column reductions over a fixed grid.
+ * dr_gather_pool_backward_f32: the gradient of a pooled row goes to its first maximal neighbour (torch.max) / its first neighbour. */
+int dr_kpconv_gather_backward_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
+                                  const float* x, const float* kernel_points, float extent, const float* grad_weighted, int ld_weighted,
+                                  float* grad_x, void* stream);
+size_t dr_norm_backward_workspace_bytes(int N, int C);
+int dr_norm_backward_f32(int N, int C, const float* grad_out, int ldg, const float* out, int ldo, const float* a, int lda, const float* mean_a,
+                         const float* rstd_a, const float* b, int ldb, const float* mean_b, const float* rstd_b, float leaky_slope, int activate,
+                         float* grad_a, int ldga, float* grad_b, int ldgb, void* workspace, size_t workspace_bytes, void* stream);
+int dr_gather_pool_backward_f32(int n2, int H, int ld_inds, int d, const float* x, int n1, const int64_t* inds, int first_only, const float* grad_out,
+                                float* grad_x, void* stream);
+
 /* weights of one GeometryAttentionLayer in the reference state-dict layout ([out,in] row-major;
  * 3D/models/transformero.py:26-41): host struct of device pointers */
 typedef struct {
@@ -257,6 +273,14 @@ int dr_procrustes_f32(int P, int N, int M, const float* conf, const float* src_p
                       float max_condition_num, float* R, float* t, float* R_forwd, float* t_forwd,
                       double* condition, int32_t* solution_mask, int32_t* topk_idx, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* d loss / d conf of the fit above (4DMatch trains its L1 motion term through (R, t), 3D/models/loss.py:108-128): the K
+ * entries dr_procrustes_f32 selected (topk_idx [P,K]) are the fit's weights, everything else gets 0.  grad_R [P,9], grad_t [P,3] are the
+ * gradients of R and t (for R_forwd / t_forwd add them where solution_mask is set); k_count [P] (optional): entries of a pair that carry
+ * weight (the 4D variant's K from the mask sums).  The adjoint of the 3 x 3 SVD in float64 on the device, replacing the reference's
+ * autograd path through `Sxy.cpu().double().svd()` (procrustes.py:35-36).  grad_conf [P,N,M] is zeroed here. */
+int dr_procrustes_backward_f32(int P, int N, int M, int K, const float* conf, const float* src_pcd, const float* tgt_pcd, const int32_t* topk_idx,
+                               const int32_t* k_count, const float* grad_R, const float* grad_t, float* grad_conf, void* stream);
 
 /* Diagnostics (kernel-forcing setters, phase stamps, the environment switch) are NOT part of the drop-in boundary: they are
  * declared in include/diffreg_hip_debug.h.  The library reads no environment variable unless dr_debug_enable_env(1) was called. */

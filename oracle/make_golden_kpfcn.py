@@ -67,13 +67,44 @@ def main():
     err = (mine - out).abs().max().item()
     print("reference coarse feats", tuple(out.shape), "abs max %.3f" % out.abs().max().item(), "| oracle - reference max abs %.2e" % err)
     assert err < 2e-4 * max(1.0, out.abs().max().item())
+    # ---- gradients (row f3): the reference backbone under autograd, loss = sum(coarse * G) with a hash-generated G -> d loss / d every
+    # parameter of the coarse phase and d loss / d input features; stored per tensor as its norm and 256 sampled entries (hash indices)
+    for p_ in net.parameters():
+        p_.grad = None
+    feats_in = tb["features"].clone().requires_grad_(True)
+    tb_g = dict(tb, features=feats_in)
+    out_g = net(tb_g, phase="coarse")
+    G = torch.from_numpy(synth.hash_normal(77, 1, tuple(out_g.shape)).astype(np.float32))
+    (out_g * G).sum().backward()
+    grads = {}
+    named = dict(net.named_parameters())
+    for k in sorted(named):
+        if not k.startswith(used) or named[k].grad is None:
+            continue
+        g_ = named[k].grad.detach().reshape(-1)
+        idx = (synth.hash_u01(78, len(grads) + 1, 256) * g_.numel()).astype(np.int64)
+        grads["gnorm:" + k] = np.array(float(g_.double().norm()))
+        grads["gidx:" + k] = idx
+        grads["gval:" + k] = g_[torch.from_numpy(idx)].numpy()
+        grads["gmax:" + k] = np.array(float(g_.abs().max()))
+    assert feats_in.grad is None          # (the reference detaches the input features, backbone.py:124: they are constants of its graph)
+    # the oracle (torch CPU restatement) under autograd must give the same gradients
+    tsd_g = {k: torch.from_numpy(v).clone().requires_grad_(k.startswith(used) and not k.endswith("kernel_points")) for k, v in sd.items()}
+    fin2 = tb["features"].clone().requires_grad_(True)
+    (ko.kpfcn_coarse(tsd_g, dict(tb, features=fin2)) * G).sum().backward()
+    worst = 0.0
+    for k in sorted(named):
+        if ("gnorm:" + k) in grads:
+            worst = max(worst, float((tsd_g[k].grad - named[k].grad).abs().max() / (named[k].grad.abs().max() + 1e-30)))
+    print("parameter tensors with gradients:", sum(1 for k in grads if k.startswith("gnorm:")), "| oracle-vs-reference worst relative gradient deviation %.2e" % worst)
+    assert worst < 1e-3
     os.makedirs(OUT, exist_ok=True)
     keys = sorted(ref_sd.keys())
     np.savez_compressed(os.path.join(OUT, "kpfcn_coarse.npz"), coarse=out.numpy(),
                         enc0=inter["enc0"][:64], enc1=inter["enc1"][:64], enc2=inter["enc2"][:64], enc10=inter["enc10"][:, :256],
                         # the reference module's parameter names and shapes (state-dict compatibility of models/backbone.py)
                         sd_keys=np.array(keys), sd_shapes=np.array([";".join(map(str, ref_sd[k].shape)) for k in keys]),
-                        **{"kp:" + k: v for k, v in kp.items()})
+                        **{"kp:" + k: v for k, v in kp.items()}, **grads)
     print("wrote", os.path.join(OUT, "kpfcn_coarse.npz"))
 
 

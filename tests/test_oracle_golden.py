@@ -261,3 +261,31 @@ def test_kpfcn_backbone_matches_reference(golden):
     out = ko.kpfcn_coarse(sd, tb)
     assert tuple(out.shape) == g["coarse"].shape
     assert np.abs(out.numpy() - g["coarse"]).max() < 2e-5
+
+
+def kpfcn_reference_gradients(g):
+    """{parameter name: (norm, sampled indices, sampled values, max |grad|)} of the reference backbone's own backward (oracle/make_golden_kpfcn.py)"""
+    return {k[6:]: (float(g[k]), g["gidx:" + k[6:]], g["gval:" + k[6:]], float(g["gmax:" + k[6:]])) for k in g.files if k.startswith("gnorm:")}
+
+
+def assert_gradients_match_reference(grads, g, tol=1e-4):
+    """every parameter tensor's gradient: norm within `tol` relative, 256 sampled entries within `tol` of the tensor's largest entry"""
+    ref = kpfcn_reference_gradients(g)
+    assert len(ref) >= 30
+    for name, (norm, idx, val, gmax) in ref.items():
+        got = grads[name].detach().double().reshape(-1).cpu()
+        assert abs(float(got.norm()) - norm) <= tol * norm, (name, float(got.norm()), norm)
+        assert float((got[torch.from_numpy(idx)] - torch.from_numpy(val).double()).abs().max()) <= tol * gmax, name
+
+
+def test_kpfcn_backward_oracle_matches_reference(golden):
+    """SURVEY row f3 (second half): autograd through the restatement gives the gradients autograd through the reference backbone gave
+    (loss = sum(coarse * G), G hash-generated), for all 38 parameter tensors the coarse phase trains on the synthetic batch."""
+    from oracle import kpfcn_oracle as ko
+    g, sd, tb = kpfcn_inputs(golden)
+    used = ("encoder_blocks.", "decoder_blocks.1.", "coarse_out.")
+    psd = {k: v.clone().requires_grad_(k.startswith(used) and not k.endswith("kernel_points")) for k, v in sd.items()}
+    out = ko.kpfcn_coarse(psd, tb)
+    G = T(synth.hash_normal(77, 1, tuple(out.shape)).astype(np.float32))
+    (out * G).sum().backward()
+    assert_gradients_match_reference({k: v.grad for k, v in psd.items() if v.grad is not None}, g)
