@@ -475,7 +475,7 @@ __global__ __launch_bounds__(1024) void procrustes_kernel(ProcArgs A) {
         acc[7] += wv * y0 * x0; acc[8] += wv * y0 * x1; acc[9] += wv * y0 * x2;
         acc[10] += wv * y1 * x0; acc[11] += wv * y1 * x1; acc[12] += wv * y1 * x2;
         acc[13] += wv * y2 * x0; acc[14] += wv * y2 * x1; acc[15] += wv * y2 * x2;
-        if (A.topk_idx) A.topk_idx[(size_t)pair * K + atomicAdd(&s_nsel, 1)] = e;
+        if (A.topk_idx) A.topk_idx[(size_t)pair * A.K_fixed + atomicAdd(&s_nsel, 1)] = e;     // (row stride = the caller's K, also where a pair's own K is smaller: 4D)
     };
     if (K > 0) {
         // ---- level 1: lower bound L from the per-thread maxima ---------------------------------------------

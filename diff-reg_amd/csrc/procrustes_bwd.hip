@@ -41,16 +41,16 @@ __global__ __launch_bounds__(256) void procrustes_backward_kernel(ProcBwdArgs A)
     const int* idx = A.idx + (size_t)pair * K;
     const int kmax = A.kcount ? min(K, A.kcount[pair]) : K;
     auto weight = [&](int k) -> double { return k < kmax ? (double)conf[idx[k]] : 0.0; };
-    // ---- moments: Z, sum w X, sum w Y, sum w Y X^T (13 block reductions of K terms; K <= 4096)
-    double acc[16];
+    // ---- moments: Z, sum w X, sum w Y, sum w Y X^T, sum w (17 block reductions of K terms; K <= 4096)
+    double acc[17];                                // |w|, w X [3], w Y [3], w Y X^T [9], w
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-    for (int k = t; k < K; k += 256) {
+    for (int i = 0; i < 17; ++i) acc[i] = 0.0;
+    for (int k = t; k < kmax; k += 256) {          // (entries beyond a pair's own count carry no weight and their indices are unspecified)
         const double w = weight(k);
         const int e = idx[k], i = e / M, j = e % M;
         const double X[3] = {ps[i * 3], ps[i * 3 + 1], ps[i * 3 + 2]}, Y[3] = {pt[j * 3], pt[j * 3 + 1], pt[j * 3 + 2]};
         acc[0] += fabs(w);
-        acc[15] += w;
+        acc[16] += w;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             acc[1 + a] += w * X[a];
@@ -59,10 +59,10 @@ __global__ __launch_bounds__(256) void procrustes_backward_kernel(ProcBwdArgs A)
             for (int b = 0; b < 3; ++b) acc[7 + 3 * a + b] += w * Y[a] * X[b];
         }
     }
-    double sum[16];
+    double sum[17];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum[i] = blk_sum(acc[i], s_red, t);
-    const double Z = sum[0] + 1e-4, c = sum[15] / Z;
+    for (int i = 0; i < 17; ++i) sum[i] = blk_sum(acc[i], s_red, t);
+    const double Z = sum[0] + 1e-4, c = sum[16] / Z;
     if (t == 0) {
         double mx[3], my[3], S[3][3], U[3][3], V[3][3], D[3];
 #pragma unroll

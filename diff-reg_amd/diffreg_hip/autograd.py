@@ -104,9 +104,10 @@ _LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight"
 
 
 class _GeometryAttentionLayer(torch.autograd.Function):
-    """GeometryAttentionLayer.forward (3D/models/transformero.py:43-96, rotary code) with the attention matrix made explicit, and its backward:
-    LayerNorm / softmax / ReLU / rotary backward kernels (csrc/train.hip) + every product on dr_linear_f32.  A first, unfused backward: it
-    keeps [B,H,L,S] matrices in memory (the per-head products are strided-batch launches of the library's GEMM)."""
+    """GeometryAttentionLayer.forward (3D/models/transformero.py:43-96, rotary code) and its backward: the attention itself is FUSED both ways
+    (forward = the inference kernels, dr_attention_f32; backward = dr_attention_backward_f32, flash-style: per-query log-sum-exp + delta, then dQ by
+    query blocks and dK | dV by key blocks on the f32-input MFMA -- no [B,H,L,S] matrix exists in either direction); LayerNorm / ReLU / rotary
+    backward kernels (csrc/train.hip); every projection and its weight gradient on dr_linear_f32."""
 
     @staticmethod
     def forward(ctx, x, source, cx, sx, cy, sy, x_mask, source_mask, H, Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2):
@@ -120,26 +121,23 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         qpre, kpre = lib.linear(x2, Wq), lib.linear(s2, Wk)
         qw, kw = lib.rotary(qpre, cx, sx), lib.rotary(kpre, cy, sy)
         vw = lib.linear(s2, Wv)
-        heads = lambda t, n: t.view(B, n, H, d).permute(0, 2, 1, 3).contiguous()
-        q4, k4, v4 = heads(qw, L), heads(kw, S), heads(vw, S)
-        scores = lib.bmm_nt(q4, k4)                                                                              # [B,H,L,S], one launch
+        # fused attention in the token layout (head h in columns h d ..): no [B,H,L,S] matrix, no head permutes
+        o2 = lib.attention(qw.view(B, L, C), kw.view(B, S, C), vw.view(B, S, C), H, x_mask, source_mask).view(B * L, C)
         scale = 1.0 / d ** 0.5
-        P = lib.softmax_rows(scores, scale, x_mask, source_mask)
-        o4 = lib.bmm_nt(P, v4.transpose(-1, -2))                                                                 # P V  [B,H,L,d]
-        o2 = o4.permute(0, 2, 1, 3).reshape(B * L, C).contiguous()
         m_pre = lib.linear(o2, Wm)
         m, st1 = lib.layernorm(m_pre, g1, b1)
         cat = torch.cat([x2, m], 1)
         h = lib.linear(cat, W0, epilogue=1)
         f_pre = lib.linear(h, W2)
         f, st2 = lib.layernorm(f_pre, g2, b2)
-        ctx.save_for_backward(x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2, qpre, kpre)
+        ctx.save_for_backward(x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, qw, kw, vw, o2, m_pre, st1, cat, h, f_pre, st2)
         ctx.dims = (B, L, S, C, H, d, scale)
+        ctx.masks = (x_mask, source_mask)
         return (x2 + f).view(B, L, C)
 
     @staticmethod
     def backward(ctx, ge):
-        (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, q4, k4, v4, P, o2, m_pre, st1, cat, h, f_pre, st2, qpre, kpre) = ctx.saved_tensors
+        (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, qw, kw, vw, o2, m_pre, st1, cat, h, f_pre, st2) = ctx.saved_tensors
         B, L, S, C, H, d, scale = ctx.dims
         tr = lambda t: t.transpose(-1, -2).contiguous()
         ge = ge.contiguous().float().reshape(B * L, C)
@@ -152,17 +150,11 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         g_mpre, gg1, gb1 = lib.layernorm_backward(m_pre, g1, st1, g_cat[:, C:].contiguous())
         g_o2 = _mm(g_mpre, tr(Wm))
         gWm = _mm(tr(g_mpre), tr(o2))
-        g_o4 = g_o2.view(B, L, H, d).permute(0, 2, 1, 3).contiguous()
-        dV = lib.bmm_nt(tr(P), tr(g_o4))                                          # P^T dO   [B,H,S,d]
-        dP = lib.bmm_nt(g_o4, v4)                                                 # dO V^T   [B,H,L,S]
-        dS = lib.softmax_backward(P, dP, scale)
-        dQ = lib.bmm_nt(dS, tr(k4))                                               # dS K     [B,H,L,d]
-        dK = lib.bmm_nt(tr(dS), tr(q4))                                           # dS^T Q   [B,H,S,d]
-        merge = lambda t, n: t.permute(0, 2, 1, 3).reshape(B * n, C).contiguous()
-        g_qw, g_kw = merge(dQ, L), merge(dK, S)
+        xm, sm_ = ctx.masks
+        g_qw, g_kw, g_vw = lib.attention_backward(qw.view(B, L, C), kw.view(B, S, C), vw.view(B, S, C), o2.view(B, L, C), g_o2.view(B, L, C), H, xm, sm_)
+        g_qw, g_kw, g_vw = g_qw.view(B * L, C), g_kw.view(B * S, C), g_vw.view(B * S, C)
         g_qpre = lib.rotary(g_qw, cx, sx, inverse=True)
         g_kpre = lib.rotary(g_kw, cy, sy, inverse=True)
-        g_vw = merge(dV, S)
         gcx = gsx = gcy = gsy = None        # (position codes are constants of the graph: the reference detaches them, position_encoding.py:83-84)
         g_x = g_x + _mm(g_qpre, tr(Wq))
         g_s = _mm(g_kpre, tr(Wk)) + _mm(g_vw, tr(Wv))

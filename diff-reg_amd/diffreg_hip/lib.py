@@ -155,6 +155,9 @@ SIGNATURES.update({
     "dr_layernorm_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "dr_layernorm_backward_workspace_bytes": (c_size_t, [c_int]),
     "dr_layernorm_backward_f32": (c_int, [c_int, c_int] + [c_void_p] * 9),
+    "dr_attention_f32": (c_int, [c_int] * 5 + [c_void_p] * 3 + [c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "dr_attention_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_attention_backward_f32": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 3 + [c_void_p, c_size_t, c_void_p]),
     "dr_softmax_rows_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_softmax_backward_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dr_relu_backward_f32": (c_int, [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -498,6 +501,31 @@ def layernorm_backward(x, gamma, mean_rstd, grad_y):
     return gx, gg, gb
 
 
+def attention(q, k, v, H, q_mask=None, k_mask=None):
+    """fused softmax(q k^T / sqrt(d)) v per head: q [B,L,C], k / v [B,S,C] (token layout, head h in columns h d ..) -> [B,L,C]"""
+    ensure_init()
+    B, L, C = q.shape
+    S, d = k.shape[1], C // H
+    q, k, v = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
+    out = torch.empty_like(q)
+    check(_lib.dr_attention_f32(B, H, L, S, d, ptr(q), ptr(k), ptr(v), C, ptr(mask_u8(q_mask)), ptr(mask_u8(k_mask)), 1.0 / d ** 0.5, ptr(out), stream_of(q)))
+    return out
+
+
+def attention_backward(q, k, v, o, grad_o, H, q_mask=None, k_mask=None):
+    """backward of attention(): -> (grad_q, grad_k, grad_v), fused (dr_attention_backward_f32)"""
+    ensure_init()
+    B, L, C = q.shape
+    S, d = k.shape[1], C // H
+    q, k, v, o, g = (t_.contiguous().float() for t_ in (q, k, v, o, grad_o))
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    wsb = _lib.dr_attention_backward_workspace_bytes(B, H, L)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    check(_lib.dr_attention_backward_f32(B, H, L, S, d, ptr(q), ptr(k), ptr(v), ptr(o), ptr(g), C, ptr(mask_u8(q_mask)), ptr(mask_u8(k_mask)), 1.0 / d ** 0.5,
+                                         ptr(gq), ptr(gk), ptr(gv), ptr(ws), wsb, stream_of(q)))
+    return gq, gk, gv
+
+
 def softmax_rows(scores, scale, q_mask=None, k_mask=None):
     """scores [B,H,L,S] -> softmax over S of scale * scores with the layer's key mask"""
     ensure_init()
@@ -801,7 +829,7 @@ def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_cond
     cond = torch.empty(P, dtype=torch.float64, device=dev)
     ok = torch.empty(P, dtype=torch.int32, device=dev)
     K = int(float(torch.tensor(float(max(N, M)), dtype=torch.float32) * sample_rate))
-    idx = torch.empty(P, K, dtype=torch.int32, device=dev) if want_topk else None
+    idx = torch.zeros(P, K, dtype=torch.int32, device=dev) if want_topk else None     # (a pair's own K may be smaller -- 4D: the tail stays 0)
     sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
     wsb = _lib.dr_procrustes_workspace_bytes(P, N, M)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None

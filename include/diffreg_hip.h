@@ -636,6 +636,17 @@ int dr_layernorm_f32(int rows, int C, const float* x, const float* gamma, const 
 size_t dr_layernorm_backward_workspace_bytes(int C);
 int dr_layernorm_backward_f32(int rows, int C, const float* x, const float* gamma, const float* mean_rstd, const float* grad_y, float* grad_x,
                               float* grad_gamma, float* grad_beta, void* workspace, void* stream);
+/* softmax(q k^T scale) v per head, fused (no [B,H,L,S] matrix): forward on the inference kernels, and its backward (3D/models/transformero.py:79-85
+ * under autograd).  Token layout: q / out / grad_o [B L, ld], k / v [B S, ld], head h in columns [h d, (h + 1) d); masks [B L] / [B S] uint8 (both
+ * or none): key j is dead for query l when q_mask[l] && !k_mask[j], as the training forward applies them.  The backward is three launches on the
+ * f32-input MFMA (per-query log-sum-exp and delta; dQ by query blocks; dK | dV by key blocks), fixed summation orders (bit-reproducible);
+ * workspace: dr_attention_backward_workspace_bytes(B, H, L).  d % 4 == 0, d <= 160. */
+int dr_attention_f32(int B, int H, int L, int S, int d, const float* q, const float* k, const float* v, int ld, const uint8_t* q_mask,
+                     const uint8_t* k_mask, float scale, float* out, void* stream);
+size_t dr_attention_backward_workspace_bytes(int B, int H, int L);
+int dr_attention_backward_f32(int B, int H, int L, int S, int d, const float* q, const float* k, const float* v, const float* o, const float* grad_o,
+                              int ld, const uint8_t* q_mask, const uint8_t* k_mask, float scale, float* grad_q, float* grad_k, float* grad_v,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int dr_softmax_rows_f32(int B, int H, int L, int S, const float* scores, float scale, const uint8_t* q_mask, const uint8_t* k_mask, float* P, void* stream);
 int dr_softmax_backward_f32(int rows, int cols, const float* P, const float* grad_P, float scale, float* grad_scores, void* stream);
 int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float* grad_x, void* stream);

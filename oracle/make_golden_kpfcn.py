@@ -98,6 +98,21 @@ def main():
             worst = max(worst, float((tsd_g[k].grad - named[k].grad).abs().max() / (named[k].grad.abs().max() + 1e-30)))
     print("parameter tensors with gradients:", sum(1 for k in grads if k.startswith("gnorm:")), "| oracle-vs-reference worst relative gradient deviation %.2e" % worst)
     assert worst < 1e-3
+    # the same gradients from a FLOAT64 evaluation of the restatement (same sampled entries): the reference's own float32 backward is up to
+    # 1.8e-3 of a tensor's largest entry away from it (eleven blocks of InstanceNorm backward over 182 .. 32k points in float32), which is
+    # what a float32 implementation can be held to against the reference; against float64 the bar is a plain 1e-4
+    t64 = {k: (torch.from_numpy(v).double() if v.dtype.kind == "f" else torch.from_numpy(v)).clone().requires_grad_(k.startswith(used) and not k.endswith("kernel_points"))
+           for k, v in sd.items()}
+    tb64 = dict(tb, points=[p.double() for p in tb["points"]], features=tb["features"].double())
+    (ko.kpfcn_coarse(t64, tb64) * G.double()).sum().backward()
+    dev32 = 0.0
+    for k in sorted(named):
+        if ("gnorm:" + k) in grads:
+            g64 = t64[k].grad.reshape(-1)
+            grads["g64val:" + k] = g64[torch.from_numpy(grads["gidx:" + k])].numpy()
+            grads["g64norm:" + k] = np.array(float(g64.norm()))
+            dev32 = max(dev32, float(np.abs(grads["g64val:" + k] - grads["gval:" + k]).max() / grads["gmax:" + k]))
+    print("reference float32 gradients vs float64 evaluation: worst sampled deviation %.2e of a tensor's largest entry" % dev32)
     os.makedirs(OUT, exist_ok=True)
     keys = sorted(ref_sd.keys())
     np.savez_compressed(os.path.join(OUT, "kpfcn_coarse.npz"), coarse=out.numpy(),

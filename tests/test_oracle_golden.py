@@ -264,18 +264,30 @@ def test_kpfcn_backbone_matches_reference(golden):
 
 
 def kpfcn_reference_gradients(g):
-    """{parameter name: (norm, sampled indices, sampled values, max |grad|)} of the reference backbone's own backward (oracle/make_golden_kpfcn.py)"""
-    return {k[6:]: (float(g[k]), g["gidx:" + k[6:]], g["gval:" + k[6:]], float(g["gmax:" + k[6:]])) for k in g.files if k.startswith("gnorm:")}
+    """{parameter name: (norm, sampled indices, sampled values, max |grad|, float64 norm, float64 sampled values)}: the reference backbone's own
+    backward and a float64 evaluation of the same loss on the same entries (oracle/make_golden_kpfcn.py)"""
+    return {k[6:]: (float(g[k]), g["gidx:" + k[6:]], g["gval:" + k[6:]], float(g["gmax:" + k[6:]]), float(g["g64norm:" + k[6:]]), g["g64val:" + k[6:]])
+            for k in g.files if k.startswith("gnorm:")}
 
 
-def assert_gradients_match_reference(grads, g, tol=1e-4):
-    """every parameter tensor's gradient: norm within `tol` relative, 256 sampled entries within `tol` of the tensor's largest entry"""
+def assert_gradients_match_reference(grads, g, tol=1e-4, float32_twin=False):
+    """Every parameter tensor's gradient, norm and 256 sampled entries.  The reference's float32 backward is itself up to 1.8e-3 (of a
+    tensor's largest entry) from a float64 evaluation of the same graph -- eleven blocks of InstanceNorm backward in float32 -- so a plain
+    1e-4 against it is not a property any float32 implementation has.  The rule (that of the loop tests' exemption lists): per tensor the
+    result must be at least as close to FLOAT64 as the reference's own float32 backward is (largest sampled deviation of the tensor), or
+    within `tol`, whichever is larger; and within `tol` + twice that deviation of the reference itself."""
     ref = kpfcn_reference_gradients(g)
     assert len(ref) >= 30
-    for name, (norm, idx, val, gmax) in ref.items():
+    for name, (norm, idx, val, gmax, norm64, val64) in ref.items():
         got = grads[name].detach().double().reshape(-1).cpu()
-        assert abs(float(got.norm()) - norm) <= tol * norm, (name, float(got.norm()), norm)
-        assert float((got[torch.from_numpy(idx)] - torch.from_numpy(val).double()).abs().max()) <= tol * gmax, name
+        smp = got[torch.from_numpy(idx)].numpy()
+        if float32_twin:            # the float32 restatement on the same torch build rounds like the reference: held to IT, plainly
+            assert abs(float(got.norm()) - norm) <= tol * norm and np.abs(smp - val).max() <= tol * gmax, name
+            continue
+        e_ref = float(np.abs(val - val64).max())
+        assert abs(float(got.norm()) - norm64) <= max(tol * norm64, abs(norm - norm64)), (name, "norm vs float64", float(got.norm()), norm64, norm)
+        assert np.abs(smp - val64).max() <= max(tol * gmax, e_ref), (name, "vs float64", float(np.abs(smp - val64).max() / gmax), e_ref / gmax)
+        assert np.abs(smp - val).max() <= tol * gmax + 2.0 * e_ref, (name, "vs reference", float(np.abs(smp - val).max() / gmax), e_ref / gmax)
 
 
 def test_kpfcn_backward_oracle_matches_reference(golden):
@@ -288,4 +300,4 @@ def test_kpfcn_backward_oracle_matches_reference(golden):
     out = ko.kpfcn_coarse(psd, tb)
     G = T(synth.hash_normal(77, 1, tuple(out.shape)).astype(np.float32))
     (out * G).sum().backward()
-    assert_gradients_match_reference({k: v.grad for k, v in psd.items() if v.grad is not None}, g)
+    assert_gradients_match_reference({k: v.grad for k, v in psd.items() if v.grad is not None}, g, float32_twin=True)

@@ -417,8 +417,13 @@ def test_training_step_on_the_device():
     info = crit.forward_train(model.forward_train(batch()))
     assert abs(float(info["loss"].detach()) - float(ref_info["loss"])) <= 1e-4 * float(ref_info["loss"])
     info["loss"].backward()
-    with_grad = [k for k, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0]
-    assert len(with_grad) == 104, len(with_grad)
+    # every parameter behind the backbone receives a gradient; non-zero for all of them except possibly a dustbin score: with the sharp
+    # synthetic head (logits in the thousands) d loss / d bin_score is ~1e-10 and may underflow to an exact 0 (measured: 2.0e-10 / 0.0)
+    with_grad = [k for k, p in model.named_parameters()
+                 if p.grad is not None and (float(p.grad.abs().max()) > 0 or (k.endswith("bin_score") and bool(torch.isfinite(p.grad).all())))]
+    expected = [k for k, _ in model.named_parameters() if not (k.startswith("coarse_transformer.layers.2.") or k.endswith("tgt_proj.weight") or k.startswith("backbone."))]
+    missing = sorted(set(expected) - set(with_grad))
+    assert len(with_grad) == 104, (len(with_grad), "without a gradient:", [(k, dict(model.named_parameters())[k].grad) for k in missing])
     assert not any(k.startswith("coarse_transformer.layers.2.") or k.endswith("tgt_proj.weight") for k in with_grad)
     params = [p for p in model.parameters() if p.grad is not None]
     opt = torch.optim.SGD(params, lr=2e-3)
@@ -430,3 +435,81 @@ def test_training_step_on_the_device():
         info["loss"].backward()
         losses.append(float(info["loss"].detach()))
     assert losses[-1] < losses[0], losses
+
+
+def _procrustes_adjoint_by_autograd(conf, ps, pt, idx, gR, gt, entry_max=None):
+    """the fit re-evaluated in float64 with torch on the K selected pairs (the reference's own arithmetic, procrustes.py:17-44) under autograd"""
+    B, N, M = conf.shape
+    idx = idx.long().cpu()
+    conf, ps, pt = conf.cpu(), ps.cpu(), pt.cpu()
+    bi = torch.arange(B).view(B, 1).expand_as(idx)
+    w0 = conf.reshape(B, -1).gather(1, idx).double().requires_grad_(True)
+    w = w0
+    if entry_max is not None:
+        w = w0 * (torch.arange(idx.shape[1]).view(1, -1) < entry_max.cpu().view(-1, 1)).double()
+    X, Y = ps[bi, idx // M].double(), pt[bi, idx % M].double()
+    wn = (w / (w.abs().sum(1, keepdim=True) + 1e-4))[..., None]
+    mx, my = (wn * X).sum(1, keepdim=True), (wn * Y).sum(1, keepdim=True)
+    S = (Y - my).transpose(1, 2) @ (wn * (X - mx))
+    U, D, Vh = torch.linalg.svd(S)
+    V = Vh.transpose(1, 2)
+    fix = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
+    fix[:, 2, 2] = (U.det() * V.det()).detach()
+    Rr = U @ (fix @ V.transpose(1, 2))
+    tr_ = my.transpose(1, 2) - Rr @ mx.transpose(1, 2)
+    gw, = torch.autograd.grad((Rr, tr_), w0, (gR.double().cpu(), gt.double().cpu().reshape(B, 3, 1)))
+    g = torch.zeros(B, N * M, dtype=torch.float64)
+    g.scatter_add_(1, idx, gw)
+    return g.view(B, N, M)
+
+
+@pytest.mark.parametrize("P,N,M,use_len", [(1, 96, 80, False), (3, 128, 128, False), (2, 300, 257, False), (2, 128, 100, True)])
+def test_procrustes_backward_matches_autograd(P, N, M, use_len):
+    """dr_procrustes_backward_f32 (the closed-form adjoint of the weighted Kabsch fit incl. the 3 x 3 SVD, float64 on the device) against torch
+    autograd through the reference's arithmetic on the same K selected entries; 3D form and the 4D form (weights beyond a pair's own K zeroed)."""
+    from diffreg_hip import lib
+    g = torch.Generator().manual_seed(P * 1000 + N)
+    conf = torch.rand(P, N, M, generator=g).pow(6).to(DEV)                  # a few dominant entries, like a matching matrix
+    ps, pt = torch.randn(P, N, 3, generator=g).to(DEV), torch.randn(P, M, 3, generator=g).to(DEV)
+    sm = (torch.arange(N)[None] < torch.tensor([N - 7 * b for b in range(P)])[:, None]).to(DEV)
+    tm = (torch.arange(M)[None] < torch.tensor([M - 5 * b for b in range(P)])[:, None]).to(DEV)
+    conf = conf * (sm[:, :, None] & tm[:, None, :])
+    R, t, Rf, tf, cond, ok, idx = lib.procrustes(conf, ps, pt, sm, tm, 1.0, 1e9, use_mask_len=use_len, want_topk=True)
+    gR, gt = torch.randn(P, 3, 3, generator=g).to(DEV), torch.randn(P, 3, 1, generator=g).to(DEV)
+    kc = (torch.maximum(sm.sum(1), tm.sum(1)).float() * 1.0).int() if use_len else None
+    got = lib.procrustes_backward(conf, ps, pt, idx, gR, gt, k_count=kc).double().cpu()
+    ref = _procrustes_adjoint_by_autograd(conf, ps, pt, idx, gR, gt, kc)
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), float((got - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("B,L,S,H,d", [(1, 96, 80, 4, 108), (2, 256, 256, 4, 108), (2, 130, 70, 4, 132), (1, 64, 200, 4, 64), (3, 33, 31, 2, 16)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_fused_attention_forward_and_backward(B, L, S, H, d, masked):
+    """dr_attention_f32 / dr_attention_backward_f32 (flash-style: no [B,H,L,S] matrix either way) against torch autograd in float64 through
+    softmax(q k^T / sqrt(d)) v per head with the training forward's mask rule (key j dead for query l when q_mask[l] && !k_mask[j])."""
+    from diffreg_hip import lib
+    g = torch.Generator().manual_seed(B * 100 + L + d)
+    C = H * d
+    q = torch.randn(B, L, C, generator=g); k = torch.randn(B, S, C, generator=g); v = torch.randn(B, S, C, generator=g) * 2
+    go = torch.randn(B, L, C, generator=g)
+    qm = km = None
+    if masked:
+        qm = torch.ones(B, L, dtype=torch.bool); km = torch.ones(B, S, dtype=torch.bool)
+        qm[:, L - 5:] = False; km[:, S - 7:] = False; km[0, :3] = False
+    qd, kd, vd = (t_.double().requires_grad_(True) for t_ in (q, k, v))
+    qh, kh, vh = (z.view(B, -1, H, d).transpose(1, 2) for z in (qd, kd, vd))
+    logit = qh @ kh.transpose(-1, -2) / d ** 0.5
+    if masked:
+        dead = qm[:, None, :, None] & ~km[:, None, None, :]
+        logit = logit.masked_fill(dead, float("-inf"))
+    ref = (torch.softmax(logit, -1) @ vh).transpose(1, 2).reshape(B, L, C)
+    gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), go.double())
+    dev = lambda t_: None if t_ is None else t_.to(DEV)
+    out = lib.attention(dev(q), dev(k), dev(v), H, dev(qm), dev(km))
+    assert float((out.double().cpu() - ref.detach()).abs().max()) < 1e-5 * float(ref.abs().max())
+    dq, dk, dv = lib.attention_backward(dev(q), dev(k), dev(v), out, dev(go), H, dev(qm), dev(km))
+    for got, want, nm in ((dq, gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
+        err = float((got.double().cpu() - want).abs().max()) / float(want.abs().max())
+        assert err < 1e-5, (nm, err)
+    dq2, dk2, dv2 = lib.attention_backward(dev(q), dev(k), dev(v), out, dev(go), H, dev(qm), dev(km))
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)          # fixed summation orders: bit-reproducible
