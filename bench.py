@@ -377,11 +377,84 @@ def bench_b1_real_size(dev):
                          "mfma_TFLOPs": fl / dt / 1e12, "mfma_frac_of_f32_peak": fl / dt / 1e12 / PEAK_MFMA_F32_TFLOPS}}
 
 
+class _Attr(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _attr(d):
+    return _Attr({k: _attr(v) for k, v in d.items()}) if isinstance(d, dict) else d
+
+
+def bench_train_step(dev):
+    """one training step of the WHOLE 3DMatch model on the device -- Pipeline.forward_train (KPFCN backbone's coarse phase on a
+    synthetic stacked cloud, both transformers, both matching heads, Procrustes fits) + MatchMotionLoss.forward_train + .backward() into all
+    44.9 M parameters (3D/models/pipeline.py:182-216, loss.py:80-170).  B = 1; random-init weights; a made-up ground-truth match list."""
+    from diffreg_hip import synth
+    from models.loss import MatchMotionLoss
+    from models.pipeline import Pipeline
+    v = synth.VARIANTS["3dmatch"]
+    matching = dict(feature_dim=v["C"], confidence_threshold=0.2, entangled=False, dsmax_temperature=0.1, match_type="sinkhorn", skh_init_bin_score=1.0,
+                    skh_iters=3, skh_prefilter=False)
+    cfg = _attr(dict(dataset="3dmatch", coarse_matching=matching, SAMPLE_STEP=20,
+                     kpfcn_config=dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), KP_influence="linear", aggregation_mode="sum", deformable=False,
+                                       use_batch_norm=True, fine_feature_dim=264, coarse_level=-2),
+                     coarse_transformer=dict(feature_dim=v["C"], n_head=v["H"], layer_types=["self", "cross", "positioning", "self", "cross"],
+                                             positioning_type="procrustes", pe_type="rotary", vol_bnds=[list(v["origin"]), [1.093, 0.78, 2.92]],
+                                             voxel_size=v["voxel"], feature_matching=dict(matching), entangled=False,
+                                             procrustes=dict(max_condition_num=200.0, sample_rate=1.0))))
+    torch.manual_seed(0)
+    model = Pipeline(cfg)
+    with torch.no_grad():                          # the overlay backbone's KPConv parameters start as zeros (they come from a checkpoint): random init
+        for name, p_ in model.named_parameters():
+            if name.endswith("KPConv.weights"):
+                p_.normal_(0.0, (p_.shape[0] * p_.shape[1]) ** -0.5)
+            elif name.endswith("KPConv.kernel_points"):
+                lvl_extent = 0.03                  # (positions inside the first conv radius; the timing does not depend on them)
+                p_.copy_(torch.randn_like(p_) * lvl_extent)
+                p_[0].zero_()
+    model = model.to(dev).train()
+    b = synth.make_kpfcn_batch(n_src=9000, n_tgt=9000, extent=2.0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ns, nt = b["stack_lengths"][2]
+    K = min(ns, nt) // 2
+    data0 = {k: [T(x) for x in b[k]] for k in ("points", "neighbors", "pools", "upsamples")}
+    data0["features"] = T(b["features"])
+    data0.update({"src_mask": torch.ones(1, ns, dtype=torch.bool, device=dev), "tgt_mask": torch.ones(1, nt, dtype=torch.bool, device=dev),
+                  "src_ind_coarse_split": torch.arange(ns, device=dev), "tgt_ind_coarse_split": torch.arange(nt, device=dev),
+                  "src_ind_coarse": torch.arange(ns, device=dev), "tgt_ind_coarse": torch.arange(ns, ns + nt, device=dev),
+                  "coarse_matches": [torch.stack([torch.arange(K), (torch.arange(K) * 7) % nt]).to(dev)], "batched_rot": torch.eye(3, device=dev)[None],
+                  "batched_trn": torch.zeros(1, 3, 1, device=dev)})
+    crit = MatchMotionLoss(dict(focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0, neg_weight=1.0, motion_loss_type="L1", motion_weight=0.1, match_weight=1,
+                                match_type="sinkhorn", positioning_type="procrustes", confidence_threshold_metric=0.05, mutual_nearest=False, inlier_thr=0.1,
+                                fmr_thr=0.05, registration_threshold=0.2, dataset="3dmatch"))
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-9)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        info = crit.forward_train(model.forward_train(dict(data0)))
+        info["loss"].backward()
+        opt.step()
+        return float(info["loss"].detach())
+    dt = _time_calls(step, warm=2, reps=5)
+    with_grad = sum(p.numel() for p in params if p.grad is not None)
+    with torch.no_grad():
+        model.eval()
+        fwd = _time_calls(lambda: model.backbone(dict(data0), phase="coarse"), warm=1, reps=5)
+    return {"workload": "one training step, B = 1: %d + %d raw points -> %d x %d superpoints; KPFCN coarse phase + heads, forward_train + loss + backward + SGD step"
+                        % (len(b["points"][0]) - b["stack_lengths"][0][1], b["stack_lengths"][0][1], ns, nt),
+            "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "parameters_with_gradients": with_grad, "parameters_total": sum(p.numel() for p in params),
+            "backbone_forward_only_ms": fwd * 1e3,
+            "note": "first, unfused backward apart from the attention (flash-style) and the Procrustes adjoint: every projection's two backward products "
+                    "are separate launches of the f32-input MFMA GEMM with explicit transposes; not a tuned path"}
+
+
 def other_configs(dev):
     """BASELINE's other configurations inside the driver's own run (short runs, each with its own roofline object): what
     tools/bench_cfg3.py / bench_2d3d.py / bench_e2e.py report at length"""
     out = {}
-    for name, fn in (("cfg3", bench_cfg3), ("cfg5", bench_cfg5), ("b1_real_size", bench_b1_real_size)):
+    for name, fn in (("cfg3", bench_cfg3), ("cfg5", bench_cfg5), ("b1_real_size", bench_b1_real_size), ("train_step", bench_train_step)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(dev)

@@ -1,6 +1,7 @@
-"""torch.autograd wrappers of the kernels that have a backward (first backward kernels): the matching head's
-Sinkhorn read-out and its focal loss.  Forward and backward both run in libdiffreg_hip; the rest of the training graph (projections,
-attention layers, Procrustes) has no backward kernels yet, so these are the differentiable tail of the model, not a trainer.
+"""torch.autograd wrappers of the kernels that have a backward: the matching heads (Sinkhorn read-out, focal loss), the
+GeometryAttentionLayer with its attention fused in both directions, the weighted Procrustes fit (closed-form adjoint on the device), the L1 motion
+term, the row scatter of split_feats; the KPFCN backbone's chain lives in backbone_autograd.py.  Forward and backward both run in libdiffreg_hip:
+`Pipeline.forward_train` + `MatchMotionLoss.forward_train` assemble a training step whose .backward() reaches every parameter the reference trains.
 
     conf = sinkhorn_conf(sim_matrix, bin_score, iters, src_mask, tgt_mask)        # = exp(log_optimal_transport(...))[:, :-1, :-1]
     loss = focal_loss(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0)   # compute_correspondence_loss, sinkhorn form
@@ -88,6 +89,32 @@ class _MatchingHead(torch.autograd.Function):
         g_W = lib.linear(pad4(tr(g_sp)), pad4(tr(sf.reshape(B * N, C)))) + lib.linear(pad4(tr(g_tp)), pad4(tr(tf.reshape(B * M, C))))   # g^T x, both sides
         gcs = gss = gct = gst = None        # (position codes: constants, as in the reference)
         return g_src, g_tgt, g_W, ga.reshape(bin_score.shape).to(bin_score.dtype), gcs, gss, gct, gst, None, None, None
+
+
+class _ScatterRows(torch.autograd.Function):
+    """dst[dst_index[i]] = src[src_index[i]] into a zero tensor of n_dst rows (Pipeline.split_feats, 3D/models/pipeline.py:350-379); backward: the
+    same kernel with the index lists swapped (the lists are injective: every destination row has one source)"""
+
+    @staticmethod
+    def forward(ctx, src, src_index, dst_index, n_dst, status):
+        srcd = src.detach().float().contiguous()
+        dst = torch.zeros(n_dst, srcd.shape[1], device=srcd.device)
+        lib.scatter_rows(srcd, src_index, dst_index, dst, validate=False, status=status)
+        ctx.save_for_backward(src_index, dst_index)
+        ctx.n_src = srcd.shape[0]
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        si, di = ctx.saved_tensors
+        gs = torch.zeros(ctx.n_src, g.shape[1], device=g.device)
+        lib.scatter_rows(g.contiguous().float(), di, si, gs, validate=False)
+        return gs, None, None, None, None
+
+
+def scatter_rows(src, src_index, dst_index, n_dst, status=None):
+    """differentiable lib.scatter_rows into a fresh zero tensor [n_dst, C]"""
+    return _ScatterRows.apply(src, src_index, dst_index, int(n_dst), status)
 
 
 def _mm(a, b):

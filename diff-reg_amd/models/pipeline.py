@@ -220,14 +220,15 @@ class Pipeline(nn.Module):
         return data
 
     def forward_train(self, data):
-        """The training forward WITH a graph (forward() is value-only): the backbone runs frozen (no backward kernels for KPFCN), everything behind its
-        features -- coarse_transformer, coarse_matching, soft_procrustes, the denoising transformer and matching on the noised ground-truth matrix -- is
-        differentiable on the device (diffreg_hip.autograd).  Writes the keys of pipeline.py:182-216 into `data`; `models.loss.MatchMotionLoss.forward_train`
+        """The training forward WITH a graph (forward() is value-only): the KPFCN backbone's coarse phase, the scatter into padded batches and everything
+        behind the features -- coarse_transformer, coarse_matching, soft_procrustes, the denoising transformer and matching on the noised ground-truth
+        matrix -- are differentiable on the device (diffreg_hip.backbone_autograd, diffreg_hip.autograd).  Writes the keys of pipeline.py:182-216 into `data`; `models.loss.MatchMotionLoss.forward_train`
         turns them into a loss whose .backward() fills the gradients of every parameter the reference's training updates behind the backbone."""
         from diffreg_hip import autograd as dag, lib
-        with torch.no_grad():
-            coarse_feats = self.backbone(data, phase="coarse")
-            src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask = self.split_feats(coarse_feats, data)
+        # the overlay backbone (models.backbone.KPFCN) is differentiable under .train() (diffreg_hip/backbone_autograd.py); any other backbone
+        # module takes part in the graph as far as its own forward does (a reference-tree KPFCN on torch ops, a stub returning constants)
+        coarse_feats = self.backbone(data, phase="coarse")
+        src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask = self.split_feats(coarse_feats, data)
         data.update({"s_pcd": s_pcd, "t_pcd": t_pcd})
         dev = src_feats.device
         P, N, _ = src_feats.shape
@@ -279,8 +280,13 @@ class Pipeline(nn.Module):
         tgt_pcd = torch.zeros(b_size * tgt_max, 3, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)      # one out-of-range flag for the four scatters, read once
         kw = dict(validate=False, status=status)
-        lib.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], src_feats, **kw)     # dr_scatter_rows_f32
-        lib.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_feats, **kw)
+        if geo_feats.requires_grad and torch.is_grad_enabled():     # training with a differentiable backbone: the same kernel with a backward
+            from diffreg_hip import autograd as dag
+            src_feats = dag.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], b_size * src_max, status)
+            tgt_feats = dag.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], b_size * tgt_max, status)
+        else:
+            lib.scatter_rows(geo_feats, data["src_ind_coarse"], data["src_ind_coarse_split"], src_feats, **kw)     # dr_scatter_rows_f32
+            lib.scatter_rows(geo_feats, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_feats, **kw)
         lib.scatter_rows(pcd, data["src_ind_coarse"], data["src_ind_coarse_split"], src_pcd, **kw)
         lib.scatter_rows(pcd, data["tgt_ind_coarse"], data["tgt_ind_coarse_split"], tgt_pcd, **kw)
         lib.scatter_rows_check(status)                              # IndexError where the reference's indexed assignment raises

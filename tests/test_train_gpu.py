@@ -513,3 +513,70 @@ def test_fused_attention_forward_and_backward(B, L, S, H, d, masked):
         assert err < 1e-5, (nm, err)
     dq2, dk2, dv2 = lib.attention_backward(dev(q), dev(k), dev(v), out, dev(go), H, dev(qm), dev(km))
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)          # fixed summation orders: bit-reproducible
+
+
+def test_training_step_updates_the_whole_model(golden):
+    """SURVEY row f3, complete: Pipeline(config) with its own KPFCN backbone (models.backbone.KPFCN) in .train() on a collate-style batch --
+    forward_train + MatchMotionLoss.forward_train + .backward() on the device reach EVERY parameter the reference trains: the 38 tensors of
+    the backbone's coarse phase (KPConv weights, unary blocks, coarse_out), the 42 of the coarse transformer + matching, the 62 of the
+    denoising transformer + matching; an SGD step changes all of them and lowers the loss.  (Gradient VALUES are pinned piecewise against
+    autograd through the reference's own modules: test_kpfcn_backward_matches_reference, test_coarse_branch_backward_with_motion_term,
+    test_denoising_branch_backward_end_to_end.)"""
+    from models.loss import MatchMotionLoss
+    from models.pipeline import Pipeline
+    from tests.test_models_api_gpu import to_attr
+    from tests.test_oracle_golden import kpfcn_inputs
+    g, bsd, tb = kpfcn_inputs(golden)
+    cfg = ref_like_config("3dmatch", 20, 200.0)
+    cfg.kpfcn_config = to_attr(dict(synth.KPFCN_CFG, architecture=list(synth.KPFCN_ARCH), KP_influence="linear", aggregation_mode="sum",
+                                    deformable=False, use_batch_norm=True, fine_feature_dim=264, coarse_level=-2))
+    model = Pipeline(cfg)
+    sd = model.state_dict()
+    sd.update(train_weights())
+    sd.update({"backbone." + k: v for k, v in bsd.items()})
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    b = synth.make_kpfcn_batch()
+    ns, nt = b["stack_lengths"][2]
+    K = min(ns, nt) // 2
+    matches = torch.stack([torch.arange(K), (torch.arange(K) * 7) % nt]).to(DEV)                 # a made-up ground-truth list (src i <-> tgt 7 i mod nt)
+    gen = torch.Generator().manual_seed(5)
+    Rg = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0][None].to(DEV)
+    randn = torch.randn(1, ns, nt, generator=gen).to(DEV)
+
+    def batch():
+        d = {k: [t_.to(DEV) for t_ in v] for k, v in tb.items() if isinstance(v, list)}
+        d["features"] = tb["features"].to(DEV)
+        d.update({"src_mask": torch.ones(1, ns, dtype=torch.bool, device=DEV), "tgt_mask": torch.ones(1, nt, dtype=torch.bool, device=DEV),
+                  "src_ind_coarse_split": torch.arange(ns, device=DEV), "tgt_ind_coarse_split": torch.arange(nt, device=DEV),
+                  "src_ind_coarse": torch.arange(ns, device=DEV), "tgt_ind_coarse": torch.arange(ns, ns + nt, device=DEV),
+                  "coarse_matches": [matches], "batched_rot": Rg, "batched_trn": torch.zeros(1, 3, 1, device=DEV),
+                  "ts": torch.tensor([300], device=DEV), "randn": randn})
+        return d
+    crit = MatchMotionLoss(dict(LOSS_CFG, motion_weight=0.1))
+    info = crit.forward_train(model.forward_train(batch()))
+    info["loss"].backward()
+    named = dict(model.named_parameters())
+    got = {k for k, p in named.items() if p.grad is not None and bool(torch.isfinite(p.grad).all()) and (float(p.grad.abs().max()) > 0 or k.endswith("bin_score"))}
+    backbone = {k for k in named if k.startswith("backbone.") and k[len("backbone."):].startswith(("encoder_blocks.", "decoder_blocks.1.", "coarse_out."))
+                and not k.endswith("kernel_points")}
+    assert len(backbone) == 38 and backbone <= got, sorted(backbone - got)
+    head = {k for k in named if not k.startswith("backbone.") and not k.startswith("coarse_transformer.layers.2.") and not k.endswith("tgt_proj.weight")}
+    assert len(head) == 104 and head <= got, sorted(head - got)
+    n_params = sum(named[k].numel() for k in got)
+    before = {k: named[k].detach().clone() for k in got}
+    losses = [float(info["loss"].detach())]
+    for _ in range(2):
+        # plain gradient descent with the step sized from the gradient itself (first-order decrease of 2 % of the loss): the tensors' gradient
+        # scales differ by orders of magnitude between the first KPConv and the matching heads, so no fixed rate suits a 2-step check
+        g2 = sum(float((named[k].grad.double() ** 2).sum()) for k in got)
+        opt = torch.optim.SGD([named[k] for k in sorted(got)], lr=0.02 * losses[-1] / g2)
+        opt.step()
+        opt.zero_grad()
+        info = crit.forward_train(model.forward_train(batch()))
+        info["loss"].backward()
+        losses.append(float(info["loss"].detach()))
+    changed = sum(1 for k in got if not torch.equal(before[k], named[k].detach()))
+    assert changed >= 0.9 * len(got), (changed, len(got))      # (a step this small rounds away on the few tensors whose gradient is tiny next to their values)
+    assert losses[2] < losses[1] < losses[0], losses
+    assert n_params > 40e6, n_params                      # 44.9 M parameters in all: the whole trainable model of the 3DMatch configuration
