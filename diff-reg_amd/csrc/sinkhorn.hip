@@ -1525,8 +1525,9 @@ static int launch_coop(const SkArgs& a, hipStream_t st) {
 static int sk_grid_blocks(int B, int N) {
     // enough workgroups for the chip, at least 8 rows (two per wave) per block, at most 128 blocks (the column
     // partials are G x M values per tile)
-    int G = (768 + B - 1) / B;
-    if (G > 128) G = 128;
+    const int target = env_knob("DR_SK_GRID_WGS", 512), cap = env_knob("DR_SK_GRID_CAP", 128);   // (512 = two workgroups per CU: 8 x 1024 x 2048 takes 203 us against 222 at 768 and 292 at 1536, profiles/r04_sinkhorn_grid_vec.txt)
+    int G = (target + B - 1) / B;
+    if (G > cap) G = cap;
     if (G > (N + 7) / 8) G = (N + 7) / 8;
     return G < 1 ? 1 : G;
 }
