@@ -817,7 +817,9 @@ __device__ __forceinline__ int attn_scale_exp(float bound) {
 
 // (d = 64 uses 141 registers: three workgroups per CU.  Forced into 128 -- four per CU -- it spills 13 registers and measured 1-5 % slower
 //  at every cfg5 shape: profiles/r04_attention_planes_softmax_trims.json)
-template <int KS, int NDT>
+// F16 (opt-in, DR_LOOP_ATTN_F16): ONE fp16 product per contraction -- the hi planes of q, k, v and of P only -- instead of the three that make an
+// fp32-grade product: what BASELINE's cfg3 / cfg5 wording ("bf16 / fp16 MFMA attention") literally asks for.  11-bit operands: not the default.
+template <int KS, int NDT, bool F16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_planes_kernel(AttnArgs A) {
     using G = AttnPlGeom<KS, NDT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -920,8 +922,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const ah16x8 kh = *reinterpret_cast<const ah16x8*>(kb + s * G::KCH + ((h ^ swk) << 4));
             const ah16x8 kl = *reinterpret_cast<const ah16x8*>(kb + s * G::KCH + (((2 + h) ^ swk) << 4));
             const ah16x8 q_h = __builtin_bit_cast(ah16x8, qh[s]), q_l = __builtin_bit_cast(ah16x8, ql[s]);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, q_h, sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_l, sc, 0, 0, 0);
+            if (!F16) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, q_h, sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_l, sc, 0, 0, 0);
+            }
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, q_h, sc, 0, 0, 0);
         }
         // ---- mask, scale, running softmax (register r holds key (r&3) + 8(r>>2) + 4h of the tile)
@@ -1003,8 +1007,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const as16x8 vh8 = {ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
                 const as16x8 vl8 = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
                 const ah16x8 v_h = __builtin_bit_cast(ah16x8, vh8), v_l = __builtin_bit_cast(ah16x8, vl8);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l, acc[i], 0, 0, 0);
+                if (!F16) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l, acc[i], 0, 0, 0);
+                }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h, acc[i], 0, 0, 0);
             }
         }
@@ -1037,6 +1043,8 @@ static int configure_attn() {
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_flash_split_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)FlashSplitGeom<KS, NDT>::SMEM));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)AttnPlGeom<KS, NDT>::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)AttnPlGeom<KS, NDT>::SMEM));
 
     return DR_OK;
@@ -1073,7 +1081,8 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         constexpr int KS = (DG * 8 + 15) / 16;
         if (a.p_dp != 16 * KS || !a.pimg[0]) return DR_EINVAL;
         const size_t plds = AttnPlGeom<KS, NDT>::SMEM;
-        hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, a);
+        if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true>), fgrid, dim3(256), plds, st, a);
+        else hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, a);
         DR_LAUNCH_CHECK();
         return DR_OK;
     }

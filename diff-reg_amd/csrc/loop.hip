@@ -243,6 +243,7 @@ struct PlCtx {
     int C, H, P, N, M;
     const float *cosT, *sinT;
     const uint8_t* tokmask;
+    int attn_f16;                            // DR_LOOP_ATTN_F16
 };
 static PgW pgw_blocks(const PgW& v, int b0, int C) {
     PgW r = v;
@@ -320,6 +321,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         a.kimg[0] = kimg; a.kimg[1] = kimg + pw.side_att;
         a.vimg[0] = kimg + pw.qkv_stride; a.vimg[1] = kimg + pw.qkv_stride + pw.side_att;
         a.qbnd = pw.qkv_bnd; a.kgb = kb; a.vgb = kb + T;
+        a.f16_single = X.attn_f16;
     }
     rc = launch_attention(a, st);
     if (rc) return rc;
@@ -395,7 +397,7 @@ static int fill_tgt_cache(const dr_loop_config& cfg, const dr_loop_weights& w, i
     const int C = cfg.C, H = cfg.H, PN = P * N, PM = P * M;
     const Family self_t{PN, M, PN, M};
     if (ws.pl.on) {
-        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask};
+        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask, (cfg.flags & DR_LOOP_ATTN_F16) ? 1 : 0};
         int rc = layer_call_planes(X, w.layers[0], 0, ws.pl.feat0, SIDE_TGT, ws.pl.feat0, SIDE_TGT, ws.pl.tgt_l0, self_t, nullptr, st);
         if (rc || cfg.n_layers < 2) return rc;
         return layer_call_planes(X, w.layers[1], 1, ws.pl.tgt_l0, 0, ws.pl.tgt_l0, SIDE_TGT, ws.pl.tgt_l0, self_t, nullptr, st, nullptr, ws.kv_l1);
@@ -412,7 +414,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
                             bool use_cache = false) {
     const int C = cfg.C, H = cfg.H, T = P * (N + M), PN = P * N, PM = P * M;
     if (ws.pl.on) {
-        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask};
+        const PlCtx X{ws.pp, &ws.pl, &ws.lw, C, H, P, N, M, ws.cosT, ws.sinT, tokmask, (cfg.flags & DR_LOOP_ATTN_F16) ? 1 : 0};
         const Family self_s{0, N, 0, N}, self_t{PN, M, PN, M}, cross_s{0, N, PN, M}, cross_t{PN, M, 0, N};
         const Tok* cur = &ws.pl.feat0;
         const Tok* bufs[2] = {&ws.pl.fa, &ws.pl.fb};

@@ -219,7 +219,7 @@ static int fusion_layer(const dr_fusion_layer_weights& W, int C, int H, int P, c
 // ---- one vision3d TransformerLayer call on plane images: five launches ---------------------------------------------------------
 enum { SIDE_IMG = 1, SIDE_PCD = 2, SIDE_BOTH2 = 3 };
 struct Fam2 { int q0, Lq, k0, Lk; };
-struct P2Ctx { const Prepack2* pp; const Planes2* pw; int C, H, P, N, M; };
+struct P2Ctx { const Prepack2* pp; const Planes2* pw; int C, H, P, N, M; int attn_f16; };
 static PgW pgw_blocks2(const PgW& v, int b0, int C) {
     PgW r = v;
     r.img += (size_t)b0 * v.nct * pgemm_bn(C) * 64; r.cinv += (size_t)b0 * pgemm_bn(C); r.wnorm += b0;
@@ -275,6 +275,7 @@ static int fusion_layer_planes(const P2Ctx& X, const dr_fusion_layer_weights& W,
     a.kimg[0] = pw.qkv_img + pw.qkv_stride; a.kimg[1] = a.kimg[0] + pw.side_C;
     a.vimg[0] = pw.qkv_img + 2 * pw.qkv_stride; a.vimg[1] = a.vimg[0] + pw.side_C;
     a.qbnd = pw.qkv_bnd; a.kgb = pw.qkv_bnd + T; a.vgb = pw.qkv_bnd + 2 * (size_t)T;
+    a.f16_single = X.attn_f16;
     rc = launch_attention(a, st);
     if (rc) return rc;
     // ---- z = LayerNorm(linear(h) + b + x)   (transformer.py:188-196)
@@ -394,7 +395,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
         Prepack2::carve(buf, *cfg, &pp);
         rc = launch_planes_from_f32(L.tok0, C, PM, C, L.pl.tok0.img, L.pl.tok0.bnd, st);
         if (rc) return rc;
-        const P2Ctx X{&pp, &L.pl, C, H, P, N, M};
+        const P2Ctx X{&pp, &L.pl, C, H, P, N, M, (cfg->flags & DR_LOOP_ATTN_F16) ? 1 : 0};
         const Fam2 self_i{0, M, 0, M};
         rc = fusion_layer_planes(X, w->layers[0], 0, L.pl.tok0, SIDE_IMG, L.pl.tok0, SIDE_IMG, L.pl.l0, self_i, nullptr, st);
         if (rc) return rc;
@@ -408,7 +409,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
         if (r) return r;
         if (L.pl.on) {
             const Planes2& pw = L.pl;
-            const P2Ctx X{&pp, &pw, C, H, P, N, M};
+            const P2Ctx X{&pp, &pw, C, H, P, N, M, (cfg->flags & DR_LOOP_ATTN_F16) ? 1 : 0};
             const Fam2 self_i{0, M, 0, M}, self_p{PM, N, PM, N}, cross_i{0, M, PM, N}, cross_p{PM, N, 0, M};
             // the point tokens of this step -> their part of the token image (row maxima as bounds)
             r = launch_planes_from_f32(L.tok0 + (size_t)PM * C, C, PN, C, pw.tok0.img + pw.side_C, pw.tok0.bnd + PM, st);

@@ -34,7 +34,7 @@ def sampling_times(steps, timesteps=1000):
 class DenoiseEngine:
     def __init__(self, state, *, variant, C, H, voxel, origin, steps, sk_iters=3, sample_rate=1.0, max_condition_num=0.0,
                  n_layers=6, device="cuda:0", strict_f64=False, prefix_t="denoising_transformer.",
-                 prefix_m="denoising_coarse_matching.", prepack=True, planes=None, cache_entries=4):
+                 prefix_m="denoising_coarse_matching.", prepack=True, planes=None, cache_entries=4, attn_f16=False):
         """state: mapping name -> tensor in the reference state-dict layout.
         cache_entries: run() keeps static buffers (and, with graph=True, a captured HIP graph) per call shape; at most this many
         shapes stay cached, least recently used first out (its buffers and graph are freed)."""
@@ -71,7 +71,8 @@ class DenoiseEngine:
         cfg.origin[0], cfg.origin[1], cfg.origin[2] = origin
         cfg.sample_rate, cfg.max_condition_num = sample_rate, max_condition_num
         # planes: None = the size rule picks the GEMM path; True / False = DR_LOOP_PLANES_FORCE / DR_LOOP_PLANES_OFF
-        cfg.flags = (1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0)
+        # attn_f16: the OPT-IN reduced-precision attention of the plane path (DR_LOOP_ATTN_F16: one fp16 product per contraction)
+        cfg.flags = (1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0) | (16 if attn_f16 else 0)
         cfg.h_alphas_cumprod = self._ac.ctypes.data
         cfg.h_times = self._times.ctypes.data
         self.cfg = cfg
@@ -333,7 +334,7 @@ class DenoiseEngine2D3D:
 
     def __init__(self, state, *, C=256, H=4, n_layers=6, img_dim=512, dino_dim=1024, pcd_dim=512, steps=10, sk_iters=3,
                  sample_rate=1.0, max_condition_num=200.0, device="cuda:0", strict_f64=False,
-                 prefix_t="denoising_transformer.", prefix_m="denoising_coarse_matching.", planes=None, prepack=True):
+                 prefix_t="denoising_transformer.", prefix_m="denoising_coarse_matching.", planes=None, prepack=True, attn_f16=False):
         """planes: None = the size rule picks the GEMM / attention path (plane images from 4096 token rows on: two cfg5 pairs per call);
         True / False = DR_LOOP_PLANES_FORCE / DR_LOOP_PLANES_OFF.  The weights are snapshotted (copy=True) and, for the plane path,
         packed once (dr_loop2d3d_prepack): build a new engine when the parameters change."""
@@ -366,7 +367,7 @@ class DenoiseEngine2D3D:
         self._cfgs = {}
         self._base = dict(C=C, H=H, n_layers=n_layers, img_dim=img_dim, dino_dim=dino_dim, pcd_dim=pcd_dim, sk_iters=sk_iters,
                           sample_rate=sample_rate, max_condition_num=max_condition_num,
-                          flags=(1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0))
+                          flags=(1 if strict_f64 else 0) | (4 if planes is True else 0) | (8 if planes is False else 0) | (16 if attn_f16 else 0))
         self._ws = None
         self._packed = None
         cfg0 = self._cfg(steps)

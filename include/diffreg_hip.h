@@ -331,6 +331,11 @@ int dr_mutual_match_f32(int P, int N, int M, const float* conf, float thr, int m
  * flags take the decision away from the size rule (tests hold the small golden loops to the reference through both paths) */
 #define DR_LOOP_PLANES_FORCE 0x4
 #define DR_LOOP_PLANES_OFF 0x8
+/* OPT-IN reduced precision (never set by the host mirrors' defaults): on the plane path, the attention's two contractions (q k^T, P v) take ONE
+ * fp16 MFMA product of the operands' hi planes instead of the three products that make an fp32-grade one -- what BASELINE's configs[2] / [4]
+ * word as "bf16 / fp16 MFMA attention".  Softmax and accumulation stay fp32, the GEMMs keep three products.  11-bit operands: conf_matrix_pred
+ * moves by ~1e-3 (bench.py other_configs reports the measured deviation and IR / FMR beside the rate); outside the 1e-4 contract by design. */
+#define DR_LOOP_ATTN_F16 0x10
 
 typedef struct {
     int variant;               /* DR_VARIANT_*                                              */

@@ -595,3 +595,19 @@ def test_cfg4_share_8_pairs_is_exactly_the_plane_threshold():
         assert torch.equal(out["conf_matrix_pred"], out2["conf_matrix_pred"]) and torch.equal(out["conf_matrix_pred"], out3["conf_matrix_pred"])
         for pi in (0, count - 1):
             _hold_to_own_b1_run(eng1, variant, N, M, steps, mc, seeds[pi], ps[pi], out["conf_matrix_pred"][pi], out["R_final"][pi], out["t_final"][pi])
+
+
+def test_opt_in_f16_attention_is_a_bounded_deviation(golden):
+    """DR_LOOP_ATTN_F16 (opt-in, never a default): the plane attention with ONE fp16 product per contraction.  Not held to the 1e-4 contract --
+    held to being a small, bounded deviation of the default path on cfg2's soft fixture: x_start of the last step (range [-1, 1]) within 0.15 at its worst entry, the poses of
+    every step within 2e-2, the inlier ratio of its match list within 0.1 of the default's (north_star's IR / FMR tolerance)."""
+    variant, N, M, steps, mc, seed = "3dmatch", 256, 256, 20, 200, 13
+    raw, p = pair(variant, N, M, seed)
+    run = lambda e: e.run(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV), p["x_T"].to(DEV), trace=True)
+    e0, e1 = engine(variant, steps, mc, family="soft", planes=True), engine(variant, steps, mc, family="soft", planes=True, attn_f16=True)
+    a, b = run(e0), run(e1)
+    dx = (a["x0"][-1, 0] - b["x0"][-1, 0]).abs().max().item()
+    dR = (a["R_forwd"] - b["R_forwd"]).abs().max().item()
+    assert 1e-7 < dx <= 0.15 and dR <= 2e-2, (dx, dR)                   # different arithmetic (the mode is on), close results
+    ir = [orc.inlier_ratio(e.match_list(o)[0].cpu(), p["p_s"], p["p_t"], raw["R_gt"], raw["t_gt"]) for e, o in ((e0, a), (e1, b))]
+    assert abs(ir[0] - ir[1]) <= 0.1 and ir[0] > 0.2, ir
