@@ -80,14 +80,18 @@ struct PgGeom {
     static constexpr int EP_S = (BNW - 48 + 63) / 64 * 64 + 48;   // row stride of the transposition, = 48 mod 64 floats: conflict-free float4 reads
     static constexpr int EP_BYTES = 2 * WMN * 16 * EP_S * 4;
     static constexpr int WORK = RING > EP_BYTES ? RING : EP_BYTES;
-    static constexpr int SMEM = WORK + 6 * 128 * 4 + 3 * BN * 4;   // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta | bias [3][BN]
+    // + fac[128], rinv[128], partial sums [2][128], partial squares [2][128], gamma | beta | bias | cinv [4][BN], the rows' image bounds [128]
+    static constexpr int SMEM = WORK + 7 * 128 * 4 + 4 * BN * 4;
+    static constexpr int SMEM16 = WORK + 11 * 128 * 4 + 4 * BN * 4; // the 16x16x32 form: four column waves -> partial sums / squares [4][128]
     static constexpr int MID = (TNW - 1) / 2 - 1 < 0 ? 0 : (TNW - 1) / 2 - 1;   // the barrier sits after this tile (2 of 7)
 };
 
 #define PG_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
 #define PG_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
 
-template <int TNW, int NST, int MODE, int WMN = 4>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TNW, int NST, int MODE, int WMN = 4, bool M16 = false>
 __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN / 2, WMN / 2))) void pgemm_kernel(PgBatch G) {
     using GG = PgGeom<TNW, NST, WMN>;
     constexpr int BNW = GG::BNW, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, NI = GG::NI, EP_S = GG::EP_S, BM = GG::BM, NTHR = GG::NTHR;
@@ -109,23 +113,67 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 
     float* const s_fac = reinterpret_cast<float*>(lds + GG::WORK);   // 2^(s1 - s0) of the rows (two-segment A operand)
     float* const s_rinv = s_fac + 128;                               // 2^-s of the rows (last segment)
-    float* const s_sum = s_rinv + 128;                               // [2][128] LayerNorm partial sums of the two column waves
-    float* const s_sq = s_sum + 256;                                 // [2][128] partial squares
+    constexpr int NCW = M16 ? 4 : 2;                                 // column waves of a row (LayerNorm partials)
+    float* const s_sum = s_rinv + 128;                               // [NCW][128] LayerNorm partial sums of the column waves
+    float* const s_sq = s_sum + NCW * 128;                           // [NCW][128] partial squares
     // nn.Linear bias of the block: staged in LDS (behind gamma | beta) and read piece by piece in the epilogue -- held in registers
     // (14 float4 per lane) it made the 128-row q|k|v / mlp0 instantiations spill
     const bool has_bias = P.bias != nullptr;
-    float* const s_bias = s_sq + 256 + 2 * BN;
+    float* const s_bias = s_sq + NCW * 128 + 2 * BN;
     if (has_bias) {
         const float* bp = P.bias + (size_t)nb * C;
         for (int c = t; c < BN; c += NTHR) s_bias[c] = c < C ? bp[c] : 0.f;
     }
+    // Everything else the epilogue needs from memory that does not depend on the accumulators is fetched HERE, in front of the main loop:
+    // the columns' 2^-s_c, gamma | beta, and the bound each row's image is scaled by.  (Round 4: the bound's loads -- row bounds, weight norms,
+    // group bounds: a chain of dependent loads per round of rows, each behind the previous round's stores -- were ~10 exposed memory latencies
+    // per round in the epilogue.)
+    float* const s_gam = s_sq + NCW * 128;                           // gamma | beta of the block (PG_LN)
+    float* const s_bet = s_gam + BN;
+    float* const s_cinv = s_bias + BN;                               // 2^-s_c of the block's columns
+    float* const s_bound = s_cinv + BN;                              // [128] bound of the row's output image
+    {
+        const float* cp = P.W.cinv + (size_t)nb * BN;
+        for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
+        if (MODE == PG_LN)
+            for (int c = t; c < BN; c += NTHR) {
+                s_gam[c] = c < C ? P.gamma[c] : 0.f;
+                s_bet[c] = c < C ? P.beta[c] : 0.f;
+            }
+    }
+    const bool rot = MODE != PG_LN && ((P.rot_mask >> nb) & 1);
+    const bool per_blk = P.pimg_blk_stride != 0;
     if (t < BM) {
         const int row = min(rb * BM + t, rows - 1);
-        const int e0 = scale_exp(P.bnd0[row]);
+        const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
+        const int e0 = scale_exp(b0);
         int e1 = e0;
-        if (nc1 > 0) e1 = scale_exp(P.bnd1[row]);
+        if (nc1 > 0) e1 = scale_exp(b1);
         s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
         s_rinv[t] = pow2i(-e1);
+        if (P.pimg) {
+            float bound;
+            if (MODE == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[row] : 0.f) + P.lnB[0];
+            else {
+                // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
+                // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
+                const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + row / P.grp_rows] : fmaxf(b0, b1);
+                // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
+                // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
+                // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
+                float wn_ = P.W.wnorm[nb];
+                if (!per_blk)
+                    for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
+                float bm = 0.f;                                  // |x W^T + b| <= bound(x) ||W|| + max |b|  (same rule for blocks sharing an image)
+                if (P.bias_max) {
+                    bm = P.bias_max[nb];
+                    if (!per_blk)
+                        for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
+                }
+                bound = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+            }
+            s_bound[t] = bound;
+        }
     }
 
     // ---- fragment addresses: a lane reads 16 bytes = 8 k of "its" row; lane half h takes k 8 h .. 8 h + 7
@@ -139,6 +187,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     u32x4 fa0[2], fa1[2], fx[TNW / 2][2], fy[TNW - TNW / 2][2];
+    f32x4 c16[M16 ? 4 : 1][M16 ? 7 : 1];                        // M16: the wave's 4 x 7 accumulator tiles of 16 x 16
 
     // The two waves of a SIMD (w and w + 4: the column halves wn = 0 / 1 of one 32-row strip) run the same MFMA stream -- burst 1 = tiles
     // 0 .. TNW / 2 - 1, the stage's one barrier, burst 2 = the other tiles -- and differ in what they feed to the DMA:
@@ -314,89 +363,261 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             if (s + 1 < nst) stage(s + 1, std::false_type{}, fa1, fa0);
         }
     };
-    if (wn == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
+    // ---- M16: the same product on v_mfma_f32_16x16x32_f16 (round 4; the guide's DVFS notes: the chip holds a higher clock on this shape, and
+    // fewer LDS read bytes per MFMA raise it further).  A wave = 64 rows x 112 columns = 4 x 7 tiles of 16 x 16 (22 fragment reads per 84 MFMAs
+    // instead of 32); one MFMA contracts TWO k-chunks: lane group g = lane / 16 reads unit (g >> 1) of chunk c + (g & 1) -- with this k order
+    // the 16-row b128 fragment read is conflict-free on the image's unit swizzle (the read's lane groups {0-3, 12-15, 20-27}, .. hit 16
+    // different (row % 4, position) pairs; with the natural order k = 8 g .. it is 2-way).  A stage = a chunk PAIR (72 KB): two buffers in
+    // the 4-slot ring, ONE barrier per pair, in front of the last of the stage's four passes (pass i = row tile i x all 7 column tiles x 3
+    // products); behind it the pair's slots are free and the next pair has landed: the last pass reads the next stage's weight fragments
+    // into the registers its own MFMAs have just released, the issuing waves (one per SIMD, as ALL0 above) feed the DMA of pair p + 2
+    // in that pass and in the next stage's first two.
+    // A segment with an odd number of chunks is closed by a VIRTUAL chunk: nothing is copied, its lane groups' A fragments are zeroed
+    // (the slot's stale weight planes are finite), so pairs stay aligned with the ring and with the segment boundary's rescale.
+    auto run16 = [&](auto iss_t) __attribute__((always_inline)) {
+        constexpr bool ISS = decltype(iss_t)::value;
+        const int l15 = lane & 15, g = lane >> 4, cs = g & 1, uh = g >> 1, sw16 = (l15 >> 2) & 3;
+        const int wn4 = w & 3, wm2 = w >> 2;
+        const unsigned oAh = cs * STAGE + (wm2 * 64 + l15) * 64 + ((uh ^ sw16) << 4), oAl = cs * STAGE + (wm2 * 64 + l15) * 64 + (((2 + uh) ^ sw16) << 4);
+        const unsigned oBh = cs * STAGE + A_ST + (wn4 * 112 + l15) * 64 + ((uh ^ sw16) << 4), oBl = cs * STAGE + A_ST + (wn4 * 112 + l15) * 64 + (((2 + uh) ^ sw16) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) c16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 fb[7][2], fa[2][2];
+        const int nv0 = (nc0 + 1) & ~1, nvt = nv0 + ((nc1 + 1) & ~1), npair = nvt >> 1;      // virtual chunk counts (segments padded to pairs)
+        const int z0 = (nc0 & 1) ? nv0 - 1 : -1, z1 = (nc1 & 1) ? nvt - 1 : -1;              // the virtual (zero) chunks
+        const int wl = w & 3, st0 = wl * 7;
+        const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * wl * 1024;
+        const char* ga = P.A0 + (size_t)rb128 * nc0 * GG::A_IMG + sub * 64;
+        const char* gb = P.W.img + (size_t)nb * nst * GG::B_ST;
+        const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb128 * nc1 * GG::A_IMG + sub * 64 : nullptr;
+        int ti = 0, tr = 0;                                              // next virtual chunk to issue, real chunks issued
+        auto piece = [&](int q) __attribute__((always_inline)) {        // q = 0 .. 8 of chunk ti
+            if (ti == z0 || ti == z1) return;
+            const unsigned dstb = lds_base + (unsigned)(ti % NST) * STAGE;
+            const unsigned m0w = dstb + A_ST + st0 * 1024;
+            const int pw = q - 2;
+            const unsigned hop = (unsigned)(pw >> 2) * 4096;
+            if (q < 2) PG_DMA(dstb + 2 * wl * 1024, voffA, ga, q * 1024);
+            else PG_DMA(m0w + hop, voffW + hop, gb, (pw & 3) * 1024);
+        };
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (ti != z0 && ti != z1) {
+                ++tr;
+                gb += GG::B_ST;
+                ga = (tr == nc0) ? ga1 : ga + GG::A_IMG;
+            }
+            ++ti;
+        };
+        auto stage = [&](int p, auto steady_t) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_t)::value;
+            // the pair's second chunk is virtual: the lane groups that contract it get zero A fragments (one AND per fragment register; a second
+            // copy of the stage behind a branch made the register allocator spill the accumulators)
+            const unsigned zm = ((2 * p + 1 == z0 || 2 * p + 1 == z1) && cs) ? 0u : ~0u;
+            const unsigned sb = lds_base + (unsigned)(p & 1) * 2 * STAGE, sbn = lds_base + (unsigned)((p + 1) & 1) * 2 * STAGE;
+            const bool has_next = STEADY || p + 1 < npair;
+            if (2 * p == nv0 && nc1 > 0) {
+                const unsigned fb0 = lds_base + GG::WORK + (wm2 * 64 + 4 * g) * 4;     // rows 16 i + 4 g + r of the wave's 64
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32x4 f;
+                    PG_READ(f, fb0, i * 64);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c16[i][j][r] *= __uint_as_float(f[r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto gap = [&](int m) __attribute__((always_inline)) {
+                const int pass = m / 21, gi = m % 21;
+                // fragment reads
+                if (pass < 3) {
+                    if (gi == 0) PG_READ(fa[(pass + 1) & 1][0], sb + oAh, (pass + 1) * 1024);
+                    if (gi == 1) PG_READ(fa[(pass + 1) & 1][1], sb + oAl, (pass + 1) * 1024);
+                } else if (has_next) {
+                    if (gi == 0) PG_READ(fa[0][0], sbn + oAh, 0);
+                    if (gi == 1) PG_READ(fa[0][1], sbn + oAl, 0);
+                    if (gi >= 1 && gi <= 7) PG_READ(fb[gi - 1][1], sbn + oBl, (gi - 1) * 1024);
+                    if (gi >= 15 && gi <= 20) PG_READ(fb[gi - 15][0], sbn + oBh, (gi - 15) * 1024);
+                    if (gi == 20) PG_READ(fb[6][0], sbn + oBh, 6 * 1024);
+                }
+                // DMA pieces (issuing waves): pair p + 2's first 7 in the read-free gaps of pass 3, pair p + 1's other 11 in passes 0 / 1
+                if (ISS) {
+                    if (pass == 3 && gi >= 8 && gi <= 14) {
+                        if (STEADY || ti < nvt) piece(gi - 8);
+                    }
+                    if (pass == 0 && gi % 3 == 2) {                     // gaps 2, 5, .., 20: q = 7 .. 13
+                        const int q = 7 + gi / 3;
+                        if (STEADY || ti < nvt) {
+                            piece(q < 9 ? q : q - 9);
+                            if (q == 8) advance();
+                        }
+                    }
+                    if (pass == 1 && gi % 3 == 2 && gi <= 11) {         // q = 14 .. 17
+                        const int q = 14 + gi / 3;
+                        if (STEADY || ti < nvt) {
+                            piece(q - 9);
+                            if (q == 17) advance();
+                        }
+                    }
+                }
+                if (pass == 2 && gi == 17) {                            // the pair's barrier: pair p + 1 has landed, pair p's slots are free behind it
+                    if (ISS && has_next) PG_VMCNT(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            };
+#define PG_MFMA16(X, Y, m)                                                              \
+    c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X, Y, c16[i][j], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    gap(m);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // pass i: A tile i in fa[i & 1]; the weights' lo fragments landed long ago, the hi ones of a new pair need the 7-deep wait
+                if (i == 0) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 a_h = fa[i & 1][0] & zm, a_l = fa[i & 1][1] & zm;
+                const f16x8 ah = __builtin_bit_cast(f16x8, a_h), al = __builtin_bit_cast(f16x8, a_l);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { PG_MFMA16(ah, __builtin_bit_cast(f16x8, fb[j][1]), 21 * i + j) }
+                if (i == 0) { asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { PG_MFMA16(al, __builtin_bit_cast(f16x8, fb[j][0]), 21 * i + 7 + j) }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { PG_MFMA16(ah, __builtin_bit_cast(f16x8, fb[j][0]), 21 * i + 14 + j) }
+            }
+#undef PG_MFMA16
+        };
+        // prologue: pair 0 and the first 7 pieces of pair 1 in flight, pair 0 landed
+        if (ISS) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) piece(q);
+            advance();
+#pragma unroll
+            for (int q = 0; q < 9; ++q) piece(q);
+            advance();
+#pragma unroll
+            for (int q = 0; q < 7; ++q) piece(q);
+            PG_VMCNT(7);
+        }
+        __builtin_amdgcn_s_barrier();
+        PG_READ(fa[0][0], lds_base + oAh, 0);
+        PG_READ(fa[0][1], lds_base + oAl, 0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) PG_READ(fb[j][1], lds_base + oBl, j * 1024);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) PG_READ(fb[j][0], lds_base + oBh, j * 1024);
+        int p = 0;
+        for (; p < npair - 2; ++p) stage(p, std::true_type{});
+        for (; p < npair; ++p) stage(p, std::false_type{});
+    };
+    if constexpr (M16) {
+        if (w < 4) run16(std::true_type{});
+        else run16(std::false_type{});
+    } else {
+        if (wn == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
     __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // The MFMA result has a lane's 16 values in 16 different rows.  Each wave transposes its 32 x 224 strip in two rounds of
     // 16 rows through a private [16][EP_S] float region; afterwards lane (lr = lane / 4, q = lane % 4) owns the float4s
     // 16 i + 4 q (i = 0 .. 13) of row 16 round + lr: a row is in ONE lane quad, so row statistics are two DPP steps.
+    // M16: a wave holds 64 rows x 112 columns as 4 x 7 tiles of 16 x 16 (lane (l15, g): rows 4 g + r of a tile, column l15): FOUR rounds of 16
+    // rows x 112 columns, 7 float4 per lane and round; the transposition stores tile row 4 g + r at region row g + 4 r (conflict-free
+    // ds_write_b32: the lane groups g = 0 / 1 of a half land 16 banks apart), so the lane quad lr owns row 4 (lr & 3) + (lr >> 2) of the round.
     const int lr = lane >> 2, q = lane & 3;
-    float* const ep = reinterpret_cast<float*>(lds) + w * (16 * EP_S);
-    const float* cinv = P.W.cinv + (size_t)nb * BN + wn * BNW + l31;
-    float cv[TNW];
+    constexpr int NR = M16 ? 4 : 2, NIE = M16 ? 7 : NI, EPS = M16 ? 112 : EP_S;
+    const int wcol0 = M16 ? (w & 3) * 112 : wn * BNW, wrow0 = M16 ? (w >> 2) * 64 : wm * 32, wcw = M16 ? (w & 3) : wn;
+    const int lrow = M16 ? 4 * (lr & 3) + (lr >> 2) : lr;
+    float* const ep = reinterpret_cast<float*>(lds) + w * (16 * EPS);
+    float cv[TNW];                                               // 2^-s_c of the lane's accumulator columns
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) cv[j] = cinv[32 * j];
-    auto transpose_round = [&](int rr, float4 (&dst)[NI]) __attribute__((always_inline)) {
+    for (int j = 0; j < TNW; ++j) cv[j] = M16 ? s_cinv[wcol0 + (lane & 15) + 16 * j] : s_cinv[wn * BNW + l31 + 32 * j];
+    auto transpose_round = [&](int rr, float4 (&dst)[NIE]) __attribute__((always_inline)) {
+        if constexpr (M16) {
+            const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < TNW; ++j)
+            for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int r = 8 * rr + r8;
-                ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * EP_S + 32 * j + l31] = acc[j][r] * cv[j];
-            }
+                for (int r = 0; r < 4; ++r) ep[(g + 4 * r) * EPS + 16 * j + l15] = c16[rr][j][r] * cv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = 8 * rr + r8;
+                    ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * EPS + 32 * j + l31] = acc[j][r] * cv[j];
+                }
+        }
         wave_fence();
-        const float rinv = s_rinv[wm * 32 + 16 * rr + lr];       // undo the operand scales: exact powers of two
+        const float rinv = s_rinv[wrow0 + 16 * rr + lrow];       // undo the operand scales: exact powers of two
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float4 x = *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
+        for (int i = 0; i < NIE; ++i) {
+            float4 x = *reinterpret_cast<const float4*>(ep + lr * EPS + 16 * i + 4 * q);
             x.x *= rinv; x.y *= rinv; x.z *= rinv; x.w *= rinv;
             dst[i] = x;
         }
         wave_fence();
     };
-    const int colw = wn * BNW + 4 * q;                           // first column of piece 0 inside the block
-    auto add_bias = [&](float4 (&dst)[NI]) __attribute__((always_inline)) {
+    const int colw = wcol0 + 4 * q;                              // first column of piece 0 inside the block
+    auto add_bias = [&](float4 (&dst)[NIE]) __attribute__((always_inline)) {
         if (has_bias) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NIE; ++i) {
                 const float4 b4 = *reinterpret_cast<const float4*>(s_bias + colw + 16 * i);
                 dst[i].x += b4.x; dst[i].y += b4.y; dst[i].z += b4.z; dst[i].w += b4.w;
             }
         }
     };
-    int grow[2];
-    grow[0] = rb * BM + wm * 32 + lr;
-    grow[1] = grow[0] + 16;
+    int grow[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) grow[rr] = rb * BM + wrow0 + 16 * rr + lrow;
     constexpr int mode = MODE;                                  // (one instantiation per epilogue: each gets its own register allocation)
 
-    float4 v[2][NI];
-    bool rot = false;
+    float4 v[NR][NIE];
     if (mode != PG_LN) {
-        rot = (P.rot_mask >> nb) & 1;
         const int halfC = P.rot_C >> 1, rpad = P.rot_piece_pad, rlen = P.rot_piece_len;
+        const unsigned rmagic = rpad > 0 ? ((1u << 20) + rpad - 1) / rpad : 0u;   // col / rpad = (col * rmagic) >> 20 for col < 4096, rpad < 1024
         const float scale = P.scale;
         // Every rotary table load precedes the wave's first store: vmcnt retires in order, so a load behind a store would wait
         // for the store to reach memory (loading the tables piece by piece between the stores cost 37 us on the q|k|v launch).
         // Order: tables 0 | round 0 -> rotated in place | tables 1 | round 1 | all stores.
         // Head-padded outputs (rot_piece_pad > 0: column c' = pad (c / len) + c % len of the image is column c of the nn.Linear):
         // the table index follows the nn.Linear's column.
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            float4 tb[NI];
-            if (rot) {
-                const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;
-                const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;
-                const float* pp = P.csT ? P.csT + (size_t)min(grow[rr], rows - 1) * halfC * 2 : nullptr;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    int col = min(colw + 16 * i, C - 4);
-                    if (rpad > 0) col = (col / rpad) * rlen + min(col % rpad, rlen - 4);
-                    const int ridx = (col % P.rot_C) >> 1;
-                    if (pp) {
-                        const float4 cs = *reinterpret_cast<const float4*>(pp + 2 * ridx);        // (cos_k, sin_k, cos_k+1, sin_k+1)
-                        tb[i] = make_float4(cs.x, cs.z, cs.y, cs.w);
-                    } else {
-                        const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx);
-                        tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
-                    }
-                }
-            }
-            transpose_round(rr, v[rr]);
+        // the table entries of piece i of a row: (cos_k, cos_k+1, sin_k, sin_k+1)
+#define PG_TABLE_INDEX(i)                                                                                                   \
+    int col = min(colw + 16 * (i), C - 4);                                                                                  \
+    if (rpad > 0) { const int hq = (int)(((unsigned)col * rmagic) >> 20); col = hq * rlen + min(col - hq * rpad, rlen - 4); } \
+    const int ridx = (col % P.rot_C) >> 1;
+#define PG_LOAD_TABLES(rr, tb)                                                                                              \
+    {                                                                                                                       \
+    if (P.csT) { /* one 16-byte load per piece: (cos_k, sin_k, cos_k+1, sin_k+1) */                                         \
+        const float* pp = P.csT + (size_t)min(grow[rr], rows - 1) * halfC * 2;                                              \
+        _Pragma("unroll") for (int i = 0; i < NIE; ++i) {                                                                   \
+            PG_TABLE_INDEX(i)                                                                                               \
+            const float4 cs = *reinterpret_cast<const float4*>(pp + 2 * ridx);                                              \
+            tb[i] = make_float4(cs.x, cs.z, cs.y, cs.w);                                                                    \
+        }                                                                                                                   \
+    } else {                                                                                                                \
+        const float* cp = P.cosT + (size_t)min(grow[rr], rows - 1) * halfC;                                                 \
+        const float* sp = P.sinT + (size_t)min(grow[rr], rows - 1) * halfC;                                                 \
+        _Pragma("unroll") for (int i = 0; i < NIE; ++i) {                                                                   \
+            PG_TABLE_INDEX(i)                                                                                               \
+            const float2 c = *reinterpret_cast<const float2*>(cp + ridx), sn = *reinterpret_cast<const float2*>(sp + ridx); \
+            tb[i] = make_float4(c.x, c.y, sn.x, sn.y);                                                                      \
+        }                                                                                                                   \
+    }                                                                                                                       \
+    }
+        auto finish_round = [&](int rr, const float4 (&tb)[NIE]) __attribute__((always_inline)) {
             add_bias(v[rr]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NIE; ++i) {
                 float4 x = v[rr][i];
                 if (rot) {
                     // x cos + swap(x) sin, swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]  (position_encoding.py:25-35)
@@ -410,15 +631,44 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 if (mode == PG_PLANES && P.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
                 v[rr][i] = x;
             }
-            __builtin_amdgcn_sched_barrier(0);                   // keep the stores below behind the loads of the next round
+        };
+        if constexpr (!M16) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                float4 tb[NIE];
+                if (rot) PG_LOAD_TABLES(rr, tb)
+                transpose_round(rr, v[rr]);
+                finish_round(rr, tb);
+                __builtin_amdgcn_sched_barrier(0);               // keep the stores below behind the loads of the next round
+            }
+        } else {
+            // four rounds of 7 pieces: the tables of TWO rounds are in flight while those two rounds are transposed, i.e. two exposed load
+            // latencies per workgroup as in the two-round form: tables 0, 1 | rounds 0, 1 | rotate 0 | tables 2 | rotate 1 | tables 3 | ..
+            float4 tb0[NIE], tb1[NIE];
+            if (rot) { PG_LOAD_TABLES(0, tb0) PG_LOAD_TABLES(1, tb1) }
+            transpose_round(0, v[0]);
+            transpose_round(1, v[1]);
+            finish_round(0, tb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rot) PG_LOAD_TABLES(2, tb0)
+            finish_round(1, tb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rot) PG_LOAD_TABLES(3, tb1)
+            transpose_round(2, v[2]);
+            transpose_round(3, v[3]);
+            finish_round(2, tb0);
+            finish_round(3, tb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef PG_LOAD_TABLES
+#undef PG_TABLE_INDEX
         if (mode == PG_F32) {
             float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < NR; ++rr) {
                 if (grow[rr] >= rows) continue;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
+                for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
                     if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
@@ -428,95 +678,103 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         if (mode == PG_PLANES && P.out) {                        // optional fp32 copy of the block (the residual stream of a consumer)
             float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < NR; ++rr) {
                 if (grow[rr] >= rows) continue;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
+                for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
                     if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
         }
     } else {
-        transpose_round(0, v[0]);
-        transpose_round(1, v[1]);
-        add_bias(v[0]);
-        add_bias(v[1]);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) transpose_round(rr, v[rr]);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) add_bias(v[rr]);
     }
 
     if (mode == PG_LN) {
         // nn.LayerNorm over the C columns of the block (biased variance, eps inside the sqrt; transformero.py:88-94)
-        float* const s_gam = s_sq + 256;                         // gamma | beta of the block, staged once per workgroup
-        float* const s_bet = s_gam + BN;
-        for (int c = t; c < BN; c += NTHR) {
-            s_gam[c] = c < C ? P.gamma[c] : 0.f;
-            s_bet[c] = c < C ? P.beta[c] : 0.f;
-        }
         // Residual rows: EVERY load is issued here, before the first store of this wave -- vmcnt retires in order, so a load
-        // behind a store waits for the store to reach memory (the interleaved form cost 40 us per launch).  Round 0 stays in
-        // registers, round 1 is parked in the wave's transposition region (free now).
+        // behind a store waits for the store to reach memory (the interleaved form cost 40 us per launch).  The first half of the rounds
+        // stays in registers, the other half is parked in LDS (the wave's transposition region, free now; M16: a second region behind the eight).
         const float* __restrict__ res = P.resid;
-        float4 r0[NI];
+        constexpr int NRR = NR / 2;                              // rounds whose residual rows stay in registers
+        float4 r0[NRR][NIE];
+        auto park = [&](int rr) __attribute__((always_inline)) { return ep + (rr - NRR) * (8 * 16 * EPS) + lr * EPS + 4 * q; };
         if (res) {
-            const float* rp1 = res + (size_t)min(grow[1], rows - 1) * P.ldr;
-            const float* rp0 = res + (size_t)min(grow[0], rows - 1) * P.ldr;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int col = colw + 16 * i;
-                const float4 x = col < C ? *reinterpret_cast<const float4*>(rp1 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(ep + lr * EP_S + 16 * i + 4 * q) = x;
+            for (int rr = NRR; rr < NR; ++rr) {
+                const float* rp = res + (size_t)min(grow[rr], rows - 1) * P.ldr;
+#pragma unroll
+                for (int i = 0; i < NIE; ++i) {
+                    const int col = colw + 16 * i;
+                    const float4 x = col < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(park(rr) + 16 * i) = x;
+                }
             }
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int col = colw + 16 * i;
-                r0[i] = col < C ? *reinterpret_cast<const float4*>(rp0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = 0; rr < NRR; ++rr) {
+                const float* rp = res + (size_t)min(grow[rr], rows - 1) * P.ldr;
+#pragma unroll
+                for (int i = 0; i < NIE; ++i) {
+                    const int col = colw + 16 * i;
+                    r0[rr][i] = col < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         const bool postadd = res && P.ln_postadd;                // LayerNorm(acc + resid): the residual joins BEFORE the statistics
         if (postadd) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const float4 r4 = rr == 0 ? r0[i] : *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
+                for (int i = 0; i < NIE; ++i) {
+                    const float4 r4 = rr < NRR ? r0[rr < NRR ? rr : 0][i] : *reinterpret_cast<const float4*>(park(rr) + 16 * i);
                     v[rr][i].x += r4.x; v[rr][i].y += r4.y; v[rr][i].z += r4.z; v[rr][i].w += r4.w;
                 }
         }
-        float mean[2], rstd[2];
+        float mean[NR], rstd[NR];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < NR; ++rr) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NIE; ++i)
                 if (colw + 16 * i < C) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
             s += dpp_xor1f(s);
             s += dpp_xor2f(s);
-            if (q == 0) s_sum[wn * 128 + wm * 32 + 16 * rr + lr] = s;
+            if (q == 0) s_sum[wcw * 128 + wrow0 + 16 * rr + lrow] = s;
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int rl = wm * 32 + 16 * rr + lr;
-            mean[rr] = (s_sum[rl] + s_sum[128 + rl]) / (float)C;
+        for (int rr = 0; rr < NR; ++rr) {
+            const int rl = wrow0 + 16 * rr + lrow;
+            float tot = s_sum[rl];
+#pragma unroll
+            for (int c = 1; c < NCW; ++c) tot += s_sum[c * 128 + rl];
+            mean[rr] = tot / (float)C;
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NIE; ++i)
                 if (colw + 16 * i < C) {
                     const float d0 = v[rr][i].x - mean[rr], d1 = v[rr][i].y - mean[rr], d2 = v[rr][i].z - mean[rr], d3 = v[rr][i].w - mean[rr];
                     s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
                 }
             s += dpp_xor1f(s);
             s += dpp_xor2f(s);
-            if (q == 0) s_sq[wn * 128 + rl] = s;
+            if (q == 0) s_sq[wcw * 128 + rl] = s;
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int rl = wm * 32 + 16 * rr + lr;
-            rstd[rr] = 1.0f / sqrtf((s_sq[rl] + s_sq[128 + rl]) / (float)C + 1e-5f);
+        for (int rr = 0; rr < NR; ++rr) {
+            const int rl = wrow0 + 16 * rr + lrow;
+            float tot = s_sq[rl];
+#pragma unroll
+            for (int c = 1; c < NCW; ++c) tot += s_sq[c * 128 + rl];
+            rstd[rr] = 1.0f / sqrtf(tot / (float)C + 1e-5f);
             const bool rok = grow[rr] < rows;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NIE; ++i) {
                 const int col = colw + 16 * i;
                 if (col < C) {
                     const float4 g4 = *reinterpret_cast<const float4*>(s_gam + col), b4 = *reinterpret_cast<const float4*>(s_bet + col);
@@ -524,7 +782,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                     y.x = (v[rr][i].x - mean[rr]) * rstd[rr] * g4.x + b4.x; y.y = (v[rr][i].y - mean[rr]) * rstd[rr] * g4.y + b4.y;
                     y.z = (v[rr][i].z - mean[rr]) * rstd[rr] * g4.z + b4.z; y.w = (v[rr][i].w - mean[rr]) * rstd[rr] * g4.w + b4.w;
                     if (res && !postadd) {
-                        const float4 r4 = rr == 0 ? r0[i] : *reinterpret_cast<const float4*>(ep + lr * EP_S + 16 * i + 4 * q);
+                        const float4 r4 = rr < NRR ? r0[rr < NRR ? rr : 0][i] : *reinterpret_cast<const float4*>(park(rr) + 16 * i);
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
                     v[rr][i] = y;
@@ -538,39 +796,18 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     // ---- plane image of the result.  Piece i of lane q is columns 16 i + 4 q .. + 3 of chunk (wn BNW / 16 + i): the lanes
     // q and q ^ 1 hold the two halves of one hi unit and of one lo unit (16 bytes each); the even lane stores the hi unit, the odd one the lo unit.
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < NR; ++rr) {
         const bool rok = grow[rr] < rows;
-        const int rowc = min(grow[rr], rows - 1);
-        const bool per_blk = P.pimg_blk_stride != 0;
-        float bound;
-        if (mode == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[rowc] : 0.f) + P.lnB[0];
-        else {
-            // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
-            // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
-            const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + rowc / P.grp_rows] : fmaxf(P.bnd0[rowc], nc1 > 0 ? P.bnd1[rowc] : 0.f);
-            // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
-            // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
-            // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
-            float wn_ = P.W.wnorm[nb];
-            if (!per_blk)
-                for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
-            float bm = 0.f;                                      // |x W^T + b| <= bound(x) ||W|| + max |b|  (same rule for blocks sharing an image)
-            if (P.bias_max) {
-                bm = P.bias_max[nb];
-                if (!per_blk)
-                    for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
-            }
-            bound = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
-        }
-        if (P.pbnd && rok && (nb == 0 || per_blk) && wn == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
+        const float bound = s_bound[wrow0 + 16 * rr + lrow];
+        if (P.pbnd && rok && (nb == 0 || per_blk) && wcw == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
         const float sc = pow2i(scale_exp(bound));
-        const int rl = sub + wm * 32 + 16 * rr + lr, swz = (rl >> 2) & 3;       // row inside the 128-row image block
+        const int rl = sub + wrow0 + 16 * rr + lrow, swz = (rl >> 2) & 3;       // row inside the 128-row image block
         char* const rowp = P.pimg + (size_t)nb * P.pimg_blk_stride +
-                           (((size_t)rb128 * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + wn * (BNW >> 4)) * 128 + rl) * 64;
+                           (((size_t)rb128 * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + (wcol0 >> 4)) * 128 + rl) * 64;
         const unsigned uh = (unsigned)(((q >> 1) ^ swz) << 4), ul = (unsigned)(((2 + (q >> 1)) ^ swz) << 4);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (wn * BNW + 16 * i >= C) continue;
+        for (int i = 0; i < NIE; ++i) {
+            if (wcol0 + 16 * i >= C) continue;
             unsigned h0, l0, h1, l1;
             split2(v[rr][i].x * sc, v[rr][i].y * sc, h0, l0);
             split2(v[rr][i].z * sc, v[rr][i].w * sc, h1, l1);
@@ -725,6 +962,8 @@ template <int TNW, int NST, int MODE>
 static int configure_mode() {
     if constexpr (TNW <= 7)
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM));
+    if constexpr (TNW == 7)
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM16));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 2>::SMEM));
     return DR_OK;
 }
@@ -776,7 +1015,18 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     const dim3 grid(maxt, g.n);
     if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, g);
     else if (bn == G4::BN) { if (half) pg_launch<4, 4, 2>(mode, grid, st, g); else pg_launch<4, 4, 4>(mode, grid, st, g); }
-    else { if (half) pg_launch<7, 4, 2>(mode, grid, st, g); else pg_launch<7, 4, 4>(mode, grid, st, g); }
+    else {
+        // the 16x16x32 main loop (128-row workgroups): a virtual chunk's slot must have held real weight planes before (segments of >= 5 chunks)
+        bool m16 = env_knob("DR_PG_M16", 1) != 0;
+        for (int i = 0; i < g.n; ++i) m16 = m16 && g.p[i].nc0 >= 5 && (!g.p[i].A1 || g.p[i].nc1 >= 5);
+        if (half) pg_launch<7, 4, 2>(mode, grid, st, g);
+        else if (m16) {
+            using GG = PgGeom<7, 4, 4>;
+            if (mode == PG_F32) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_F32, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
+            else if (mode == PG_PLANES) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_PLANES, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
+            else hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_LN, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
+        } else pg_launch<7, 4, 4>(mode, grid, st, g);
+    }
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
