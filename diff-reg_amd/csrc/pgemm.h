@@ -57,7 +57,7 @@ struct PgProblem {
     // (added to the bound a PG_PLANES image is scaled by)
     const float* bias; const float* bias_max;
 };
-struct PgBatch { PgProblem p[3]; int n; };
+struct PgBatch { PgProblem p[3]; int n; int dbg; };   // dbg (debug knob DR_PG_NOEPI): 1 = return behind the main loop (timing builds)
 
 bool pgemm_shape_ok(int C);                      // column-block widths the kernel is built for
 int pgemm_bn(int C);                             // rows of a packed weight block (256 for C <= 256, 448 for C <= 448, 576 above)

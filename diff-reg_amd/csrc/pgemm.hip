@@ -135,7 +135,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     {
         const float* cp = P.W.cinv + (size_t)nb * BN;
         for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
-        if (MODE == PG_LN)
+        if (MODE == PG_LN && P.gamma)
             for (int c = t; c < BN; c += NTHR) {
                 s_gam[c] = c < C ? P.gamma[c] : 0.f;
                 s_bet[c] = c < C ? P.beta[c] : 0.f;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         s_rinv[t] = pow2i(-e1);
         if (P.pimg) {
             float bound;
-            if (MODE == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[row] : 0.f) + P.lnB[0];
+            if (MODE == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[row] : 0.f) + (P.lnB ? P.lnB[0] : 0.f);
             else {
                 // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
                 // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
@@ -418,16 +418,11 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             const unsigned sb = lds_base + (unsigned)(p & 1) * 2 * STAGE, sbn = lds_base + (unsigned)((p + 1) & 1) * 2 * STAGE;
             const bool has_next = STEADY || p + 1 < npair;
             if (2 * p == nv0 && nc1 > 0) {
-                const unsigned fb0 = lds_base + GG::WORK + (wm2 * 64 + 4 * g) * 4;     // rows 16 i + 4 g + r of the wave's 64
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    u32x4 f;
-                    PG_READ(f, fb0, i * 64);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const float f = s_fac[wm2 * 64 + 16 * i + l15];                     // row 16 i + l15 of the wave's 64
 #pragma unroll
-                    for (int j = 0; j < 7; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) c16[i][j][r] *= __uint_as_float(f[r]);
+                    for (int j = 0; j < 7; ++j) c16[i][j] *= f;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -469,8 +464,10 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                     __builtin_amdgcn_s_barrier();
                 }
             };
+    // (the WEIGHT fragment is the MFMA's first operand: a lane then owns four consecutive output COLUMNS 16 j + 4 g .. + 3 of token row 16 i + l15
+    // -- the layout the epilogue works in -- instead of four rows of one column, and no transposition through LDS is needed)
 #define PG_MFMA16(X, Y, m)                                                              \
-    c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X, Y, c16[i][j], 0, 0, 0);       \
+    c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Y, X, c16[i][j], 0, 0, 0);       \
     __builtin_amdgcn_sched_barrier(0);                                                  \
     gap(m);                                                                             \
     __builtin_amdgcn_sched_barrier(0);
@@ -522,30 +519,51 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         if (wn == 0) run(std::integral_constant<int, 0>{});
         else run(std::integral_constant<int, 1>{});
     }
+    if (G.dbg & 1) {                                             // timing builds: the main loop alone (the result must stay alive)
+        float keep = 0.f;
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) keep += c16[i][j][0] + c16[i][j][1] + c16[i][j][2] + c16[i][j][3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[j][r];
+        }
+        if (keep == 123.456f && P.out) P.out[0] = keep;
+        return;
+    }
     __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // The MFMA result has a lane's 16 values in 16 different rows.  Each wave transposes its 32 x 224 strip in two rounds of
     // 16 rows through a private [16][EP_S] float region; afterwards lane (lr = lane / 4, q = lane % 4) owns the float4s
     // 16 i + 4 q (i = 0 .. 13) of row 16 round + lr: a row is in ONE lane quad, so row statistics are two DPP steps.
-    // M16: a wave holds 64 rows x 112 columns as 4 x 7 tiles of 16 x 16 (lane (l15, g): rows 4 g + r of a tile, column l15): FOUR rounds of 16
-    // rows x 112 columns, 7 float4 per lane and round; the transposition stores tile row 4 g + r at region row g + 4 r (conflict-free
-    // ds_write_b32: the lane groups g = 0 / 1 of a half land 16 banks apart), so the lane quad lr owns row 4 (lr & 3) + (lr >> 2) of the round.
-    const int lr = lane >> 2, q = lane & 3;
+    // M16: a wave holds 64 rows x 112 columns as 4 x 7 tiles of 16 x 16, and -- the weights being the MFMA's first operand -- lane (l15, g) holds
+    // columns 4 g .. 4 g + 3 of row l15 of every tile: the accumulators ARE in the epilogue's layout (row lr = l15, float4 q = g of piece i = tile
+    // column j; FOUR rounds = row tiles of 7 pieces).  No transposition; a row's four lanes are 16 apart (v_permlane16/32_swap instead of DPP).
+    const int lr = M16 ? (lane & 15) : (lane >> 2), q = M16 ? (lane >> 4) : (lane & 3);
     constexpr int NR = M16 ? 4 : 2, NIE = M16 ? 7 : NI, EPS = M16 ? 112 : EP_S;
     const int wcol0 = M16 ? (w & 3) * 112 : wn * BNW, wrow0 = M16 ? (w >> 2) * 64 : wm * 32, wcw = M16 ? (w & 3) : wn;
-    const int lrow = M16 ? 4 * (lr & 3) + (lr >> 2) : lr;
+    const int lrow = lr;
     float* const ep = reinterpret_cast<float*>(lds) + w * (16 * EPS);
-    float cv[TNW];                                               // 2^-s_c of the lane's accumulator columns
+    float cv[M16 ? 1 : TNW];                                     // 2^-s_c of the lane's accumulator columns (M16: read per piece)
+    if constexpr (!M16) {
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) cv[j] = M16 ? s_cinv[wcol0 + (lane & 15) + 16 * j] : s_cinv[wn * BNW + l31 + 32 * j];
+        for (int j = 0; j < TNW; ++j) cv[j] = s_cinv[wn * BNW + l31 + 32 * j];
+    }
     auto transpose_round = [&](int rr, float4 (&dst)[NIE]) __attribute__((always_inline)) {
         if constexpr (M16) {
-            const int l15 = lane & 15, g = lane >> 4;
+            const float rinv = s_rinv[wrow0 + 16 * rr + lrow];
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(g + 4 * r) * EPS + 16 * j + l15] = c16[rr][j][r] * cv[j];
+            for (int i = 0; i < NIE; ++i) {
+                const float4 c4 = *reinterpret_cast<const float4*>(s_cinv + wcol0 + 16 * i + 4 * q);
+                const f32x4 a = c16[rr][i];
+                dst[i] = make_float4(a[0] * c4.x * rinv, a[1] * c4.y * rinv, a[2] * c4.z * rinv, a[3] * c4.w * rinv);
+            }
+            return;
         } else {
 #pragma unroll
             for (int j = 0; j < TNW; ++j)
@@ -581,6 +599,22 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     constexpr int mode = MODE;                                  // (one instantiation per epilogue: each gets its own register allocation)
 
     float4 v[NR][NIE];
+    // sum over the four lanes that hold one row: a quad (DPP), or lanes 16 apart (M16: two lane-row swaps)
+    auto row_sum4 = [&](float s) __attribute__((always_inline)) {
+        if constexpr (M16) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const unsigned u = __float_as_uint(s);
+            const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // (rows 0 0 2 2), (rows 1 1 3 3)
+            const float t2 = __uint_as_float(a.x) + __uint_as_float(a.y);
+            const unsigned w2 = __float_as_uint(t2);
+            const u32x2 b = __builtin_amdgcn_permlane32_swap(w2, w2, false, false);     // (low low), (high high)
+            return __uint_as_float(b.x) + __uint_as_float(b.y);
+        } else {
+            s += dpp_xor1f(s);
+            s += dpp_xor2f(s);
+            return s;
+        }
+    };
     if (mode != PG_LN) {
         const int halfC = P.rot_C >> 1, rpad = P.rot_piece_pad, rlen = P.rot_piece_len;
         const unsigned rmagic = rpad > 0 ? ((1u << 20) + rpad - 1) / rpad : 0u;   // col / rpad = (col * rmagic) >> 20 for col < 4096, rpad < 1024
@@ -636,7 +670,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 float4 tb[NIE];
-                if (rot) PG_LOAD_TABLES(rr, tb)
+                if (rot && !(G.dbg & 32)) PG_LOAD_TABLES(rr, tb)
                 transpose_round(rr, v[rr]);
                 finish_round(rr, tb);
                 __builtin_amdgcn_sched_barrier(0);               // keep the stores below behind the loads of the next round
@@ -645,15 +679,15 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             // four rounds of 7 pieces: the tables of TWO rounds are in flight while those two rounds are transposed, i.e. two exposed load
             // latencies per workgroup as in the two-round form: tables 0, 1 | rounds 0, 1 | rotate 0 | tables 2 | rotate 1 | tables 3 | ..
             float4 tb0[NIE], tb1[NIE];
-            if (rot) { PG_LOAD_TABLES(0, tb0) PG_LOAD_TABLES(1, tb1) }
+            if (rot && !(G.dbg & 32)) { PG_LOAD_TABLES(0, tb0) PG_LOAD_TABLES(1, tb1) }
             transpose_round(0, v[0]);
             transpose_round(1, v[1]);
             finish_round(0, tb0);
             __builtin_amdgcn_sched_barrier(0);
-            if (rot) PG_LOAD_TABLES(2, tb0)
+            if (rot && !(G.dbg & 32)) PG_LOAD_TABLES(2, tb0)
             finish_round(1, tb1);
             __builtin_amdgcn_sched_barrier(0);
-            if (rot) PG_LOAD_TABLES(3, tb1)
+            if (rot && !(G.dbg & 32)) PG_LOAD_TABLES(3, tb1)
             transpose_round(2, v[2]);
             transpose_round(3, v[3]);
             finish_round(2, tb0);
@@ -670,7 +704,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                    if (col < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
             return;
@@ -683,7 +717,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    if (col < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                    if (col < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
         }
@@ -703,7 +737,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         constexpr int NRR = NR / 2;                              // rounds whose residual rows stay in registers
         float4 r0[NRR][NIE];
         auto park = [&](int rr) __attribute__((always_inline)) { return ep + (rr - NRR) * (8 * 16 * EPS) + lr * EPS + 4 * q; };
-        if (res) {
+        if (res && !(G.dbg & 16)) {
 #pragma unroll
             for (int rr = NRR; rr < NR; ++rr) {
                 const float* rp = res + (size_t)min(grow[rr], rows - 1) * P.ldr;
@@ -741,8 +775,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
             for (int i = 0; i < NIE; ++i)
                 if (colw + 16 * i < C) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
-            s += dpp_xor1f(s);
-            s += dpp_xor2f(s);
+            s = row_sum4(s);
             if (q == 0) s_sum[wcw * 128 + wrow0 + 16 * rr + lrow] = s;
         }
         __syncthreads();
@@ -760,8 +793,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                     const float d0 = v[rr][i].x - mean[rr], d1 = v[rr][i].y - mean[rr], d2 = v[rr][i].z - mean[rr], d3 = v[rr][i].w - mean[rr];
                     s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
                 }
-            s += dpp_xor1f(s);
-            s += dpp_xor2f(s);
+            s = row_sum4(s);
             if (q == 0) s_sq[wcw * 128 + rl] = s;
         }
         __syncthreads();
@@ -786,7 +818,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                         y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w;
                     }
                     v[rr][i] = y;
-                    if (P.out && rok) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
+                    if (P.out && rok && !(G.dbg & 4)) *reinterpret_cast<float4*>(P.out + (size_t)grow[rr] * P.ldo + col) = y;
                 }
             }
         }
@@ -815,12 +847,19 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             // unit -- every lane stores, a wave instruction covers 16 rows x 64 contiguous bytes (two stores by half the lanes before:
             // 39 of the family's 108 ms per pass were these stores, measured by ablation in round 2)
             const bool odd = q & 1;
-            const unsigned r0_ = dpp_xor1(odd ? h0 : l0), r1_ = dpp_xor1(odd ? h1 : l1);      // what the partner stores of mine <-> what I store of the partner's
-            if (rok) {
-                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-                const u32x4v U = odd ? u32x4v{r0_, r1_, l0, l1} : u32x4v{h0, h1, r0_, r1_};
-                __builtin_nontemporal_store(U, reinterpret_cast<u32x4v*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)));
+            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+            u32x4v U;
+            if constexpr (M16) {
+                // the partner is 16 lanes away: v_permlane16_swap exchanges the odd lane rows of its first operand with the even ones of its second --
+                // the even lane ends with (own hi, partner's hi), the odd one with (partner's lo, own lo): both store {x0, x1, y0, y1}
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 e0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false), e1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+                U = u32x4v{e0.x, e1.x, e0.y, e1.y};
+            } else {
+                const unsigned r0_ = dpp_xor1(odd ? h0 : l0), r1_ = dpp_xor1(odd ? h1 : l1);  // what the partner stores of mine <-> what I store of the partner's
+                U = odd ? u32x4v{r0_, r1_, l0, l1} : u32x4v{h0, h1, r0_, r1_};
             }
+            if (rok && !(G.dbg & 8)) __builtin_nontemporal_store(U, reinterpret_cast<u32x4v*>(rowp + (size_t)i * 8192 + (odd ? ul : uh)));
         }
     }
 }
@@ -962,8 +1001,9 @@ template <int TNW, int NST, int MODE>
 static int configure_mode() {
     if constexpr (TNW <= 7)
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM));
-    if constexpr (TNW == 7)
+    if constexpr (TNW == 7) {
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 4>::SMEM16));
+    }
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm_kernel<TNW, NST, MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeom<TNW, NST, 2>::SMEM));
     return DR_OK;
 }
@@ -1013,19 +1053,21 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     for (int i = 1; i < g.n; ++i)
         if (g.p[i].mode != mode) return DR_EINVAL;           // one epilogue per launch
     const dim3 grid(maxt, g.n);
-    if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, g);
-    else if (bn == G4::BN) { if (half) pg_launch<4, 4, 2>(mode, grid, st, g); else pg_launch<4, 4, 4>(mode, grid, st, g); }
+    PgBatch gd = g;
+    gd.dbg = env_knob("DR_PG_NOEPI", 0);
+    if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, gd);
+    else if (bn == G4::BN) { if (half) pg_launch<4, 4, 2>(mode, grid, st, gd); else pg_launch<4, 4, 4>(mode, grid, st, gd); }
     else {
         // the 16x16x32 main loop (128-row workgroups): a virtual chunk's slot must have held real weight planes before (segments of >= 5 chunks)
         bool m16 = env_knob("DR_PG_M16", 1) != 0;
         for (int i = 0; i < g.n; ++i) m16 = m16 && g.p[i].nc0 >= 5 && (!g.p[i].A1 || g.p[i].nc1 >= 5);
-        if (half) pg_launch<7, 4, 2>(mode, grid, st, g);
+        if (half) pg_launch<7, 4, 2>(mode, grid, st, gd);
         else if (m16) {
             using GG = PgGeom<7, 4, 4>;
-            if (mode == PG_F32) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_F32, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
-            else if (mode == PG_PLANES) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_PLANES, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
-            else hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_LN, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, g);
-        } else pg_launch<7, 4, 4>(mode, grid, st, g);
+            if (mode == PG_F32) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_F32, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, gd);
+            else if (mode == PG_PLANES) hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_PLANES, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, gd);
+            else hipLaunchKernelGGL((pgemm_kernel<7, 4, PG_LN, 4, true>), grid, dim3(GG::NTHR), GG::SMEM16, st, gd);
+        } else pg_launch<7, 4, 4>(mode, grid, st, gd);
     }
     DR_LAUNCH_CHECK();
     return DR_OK;

@@ -9,6 +9,7 @@ import ctypes
 import math
 
 import numpy as np
+import os
 import torch
 
 from . import lib
@@ -262,12 +263,15 @@ class DenoiseEngine:
         cur = torch.cuda.current_stream(self.device)
         if not hasattr(self, "_streams") or len(self._streams) < n_streams:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self._skew_cycles = int(float(os.environ.get("DR_STREAM_SKEW_US", "0")) * 2000)
         self._cache_entries = max(self._cache_entries, len(groups) + 2)        # every group keeps its own slot
         outs = []
         for gi, kw in enumerate(groups):
             st = self._streams[gi % n_streams]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
+                if self._skew_cycles and gi % n_streams:
+                    torch.cuda._sleep(self._skew_cycles * (gi % n_streams))
                 outs.append(self.run(graph=True, _slot=gi, borrow=True, **kw))
         for st in self._streams[:n_streams]:
             cur.wait_stream(st)
