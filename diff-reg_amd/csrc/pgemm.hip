@@ -1038,7 +1038,9 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     long wg128 = 0;
     for (int i = 0; i < g.n; ++i) wg128 += (long)((g.p[i].rows + 127) / 128) * g.p[i].nblk;
-    const bool half = bn == G9::BN || half_env == 2 || (half_env == 1 && wg128 < n_cu);
+    // 64-row workgroups up to HALF a chip of 128-row ones: above that they would run in two rounds, slower than one round of 128-row workgroups on
+    // some of the CUs (cfg5 at 8 pairs: 192 of them, 28.4 -> 27.6 ms per call; DR_PG_HALF_PCT: the threshold in percent of the CU count)
+    const bool half = bn == G9::BN || half_env == 2 || (half_env == 1 && wg128 * 100 < (long)n_cu * env_knob("DR_PG_HALF_PCT", 51));
     const int bm = half ? 64 : 128;
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];

@@ -2,8 +2,10 @@
  * NOT part of the drop-in boundary (include/diffreg_hip.h): nothing a deployment calls is declared here.
  *
  * The library reads no environment variable unless dr_debug_enable_env(1) was called: the DR_* tuning variables of tools/
- * (DR_GEMM_*, DR_ATTN_*, DR_PLANES*, DR_PG_HALF, DR_SK_PERSIST_GRID) cannot change which kernels a deployment runs.  Once enabled they are
- * re-read on every launch (nothing is latched).  Per-call choices of the product path are arguments: dr_loop_config.flags
+ * (DR_GEMM_*, DR_ATTN_*, DR_PLANES*, DR_PG_*, DR_SK_PERSIST_GRID) cannot change which kernels a deployment runs.  Once enabled they are
+ * re-read on every launch (nothing is latched).  The plane GEMM's: DR_PG_HALF (0 / 2: never / always 64-row workgroups), DR_PG_HALF_PCT (the
+ * 64-row rule's threshold in percent of the CU count), DR_PG_M16 (0: the 32x32x16 main loop instead of the 16x16x32 one), DR_PG_NOEPI (timing
+ * ablations, WRONG results: bit 0 return behind the main loop, 2 no fp32 row stores, 3 no image stores, 4 no residual loads, 5 no rotary tables).  Per-call choices of the product path are arguments: dr_loop_config.flags
  * (DR_LOOP_PLANES_FORCE / _OFF, DR_LOOP_STRICT_F64, DR_LOOP_RAGGED), DR_SK_* flags.  The setters below are process-wide and meant
  * for single-threaded tools and tests only. */
 #ifndef DIFFREG_HIP_DEBUG_H

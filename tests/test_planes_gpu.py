@@ -275,3 +275,47 @@ def test_vision3d_layer_chain_against_float64(rows, C, row_block):
     refo = torch.nn.functional.layer_norm(refz + refh @ Ws.double().t() + bs.double(), (C,), g1.double(), b1.double())
     assert rel(o2, refo) < 4e-6 and rel(lib.planes_to_f32(o_img, o_b, rows, C), refo) < 4e-6
     assert bool((o_b.double() >= refo.abs().amax(1)).all())
+
+
+@pytest.mark.parametrize("row_block", [0], indirect=True)
+@pytest.mark.parametrize("m16", ["1", "0"])
+@pytest.mark.parametrize("k0,k1", [(432, 0), (448, 0), (432, 432), (448, 432), (432, 448), (864, 0), (80, 432), (64, 0)])
+def test_chunk_pairs_and_virtual_chunks(k0, k1, m16, row_block):
+    """The 128-row plane GEMM contracts k-chunks in PAIRS (v_mfma_f32_16x16x32_f16, DR_PG_M16=1: the default): segments with an even and an odd
+    number of 16-deep chunks, alone and as [A0 | A1] with different row scales (the odd ones end in a virtual zero chunk; the accumulators are
+    rescaled at the segment boundary), a segment shorter than five chunks (falls back to the 32x32x16 loop), both loops against float64 --
+    through all three epilogues (fp32 rows, plane image + ReLU, LayerNorm + residual)."""
+    import os
+    os.environ["DR_PG_M16"] = m16
+    try:
+        rows, C = 300, 432
+        torch.manual_seed(k0 + 7 * k1)
+        x0 = torch.randn(rows, k0, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
+        x1 = torch.randn(rows, k1, device=DEV) * (torch.rand(rows, 1, device=DEV) * 300 + 1e-3) if k1 else None
+        i0, b0 = lib.planes_from_f32(x0)
+        i1, b1 = lib.planes_from_f32(x1) if k1 else (None, None)
+        X = torch.cat([x0, x1], 1).double() if k1 else x0.double()
+        K = k0 + k1
+        W = torch.randn(C, K, device=DEV) / K ** 0.5
+        pk = lib.pack_weight_planes(W, 1, C)
+        ref = X @ W.double().t()
+        out, chk = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+        lib.linear_planes(rows, C, 1, i0, b0, k0, pk, lib.PL_F32, a1=i1, b1=b1, k1=k1, out=out, ldo=C)
+        chk()
+        assert not torch.isnan(out).any() and rel(out, ref) < 2e-6
+        img, chk_i = image_like(rows, C)
+        bnd, chk_b = guarded((rows,), torch.float32, DEV, fill=0)
+        lib.linear_planes(rows, C, 1, i0, b0, k0, pk, lib.PL_PLANES, a1=i1, b1=b1, k1=k1, out_image=img, out_image_k=C, out_bound=bnd, relu=True)
+        chk_i(); chk_b()
+        assert rel(lib.planes_to_f32(img, bnd, rows, C), torch.relu(ref)) < 3e-6
+        g1, be = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+        res = torch.randn(rows, C, device=DEV)
+        rb = res.abs().amax(1)
+        o32, chk_o = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+        lib.linear_planes(rows, C, 1, i0, b0, k0, pk, lib.PL_LN, a1=i1, b1=b1, k1=k1, out=o32, ldo=C, out_image=img, out_image_k=C, out_bound=bnd,
+                          gamma=g1, beta=be, resid=res, ldr=C, bound_resid=rb, lnb=lib.ln_bound(g1, be))
+        chk_o(); chk_i()
+        want = res.double() + torch.nn.functional.layer_norm(ref, (C,), g1.double(), be.double())
+        assert rel(o32, want) < 3e-6 and rel(lib.planes_to_f32(img, bnd, rows, C), want) < 3e-6
+    finally:
+        os.environ.pop("DR_PG_M16", None)
