@@ -47,7 +47,7 @@ PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / SPLIT_PRODUCTS
 SPLIT_KERNEL = "pgemm_kernel"
 SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand planes (rows of both operands scaled by exact powers of two into fp16's range; "
               "planes written by the producing kernels, both operands streamed by LDS-DMA)")
-LOOP_PMC = os.path.join(ROOT, "profiles", "r03_pgemm_loop_pmc_v2.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
+LOOP_PMC = os.path.join(ROOT, "profiles", "r04_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -346,6 +346,9 @@ def bench_cfg5(dev, batches=(1, 8)):
         ent = {"ms_per_call": dt * 1e3, "pairs_per_s": P / dt, "ms_per_pair": dt * 1e3 / P, "launch": "one captured HIP graph per call",
                "distinct_scenes": min(P, len(distinct)), "path": "plane images" if P * (N + M) >= 4096 else "f32-input MFMA kernels"}
         if P > 1:
+            two = _time_calls(lambda: eng.run_streams([kw, kw], 2), warm=3, reps=4)
+            ent["two_concurrent_calls"] = {"ms_per_pass": two * 1e3, "pairs_per_s": 2 * P / two,
+                                           "what": "two independent %d-pair calls, one captured graph each, on two HIP streams" % P}
             ref = {k_: v_.clone() for k_, v_ in eng.run_static(slot=0, graph=True, **kw).items()}
             eng16 = DenoiseEngine2D3D(W, steps=steps, max_condition_num=mc, device=dev, attn_f16=True)
             t16 = _time_calls(lambda: eng16.run_static(slot=0, graph=True, **kw), warm=3, reps=4)
@@ -360,9 +363,6 @@ def bench_cfg5(dev, batches=(1, 8)):
                                       "note": "DR_LOOP_ATTN_F16: one fp16 product per contraction in q k^T and P v (BASELINE's 'fp16 MFMA cross-attn'); "
                                               "outside the 1e-4 contract by design; never the default"}
             del eng16
-            two = _time_calls(lambda: eng.run_streams([kw, kw], 2), warm=3, reps=4)
-            ent["two_concurrent_calls"] = {"ms_per_pass": two * 1e3, "pairs_per_s": 2 * P / two,
-                                           "what": "two independent %d-pair calls, one captured graph each, on two HIP streams" % P}
         lib.prof_enable(True)
         eng.run(*args)
         prof = lib.prof_collect()
@@ -717,7 +717,7 @@ def main():
                 # `bench.py --breakdown-only` (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; per launch, averaged like `achieved`)
                 tj = json.load(open(LOOP_PMC))
                 roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/r03_pgemm_loop_pmc_v2.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
+                roof["traffic_source"] = "profiles/r04_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
                 roof["effective_clock_GHz_pmc"] = tj.get("derived", {}).get("effective_clock_GHz")
                 roof["avg_us_per_launch_pmc_run"] = tj.get("avg_us_per_launch_profiled")
