@@ -242,6 +242,37 @@ def test_2d3d_loop_matches_reference_at_cfg5_size(golden):
     np.testing.assert_allclose(torch.stack([r["x0"][0, :16, :16] for r in trace]).numpy(), g["x0_corner"], atol=1e-4)
 
 
+def test_2d3d_loop_matches_reference_at_cfg5_size_with_the_warp_fed_back(golden):
+    """the same size with max_condition_num = 200: every step's Procrustes fit is accepted (cond 6 .. 11) and warps the points of the next
+    step -- the fixture is the REFERENCE's run (oracle/make_golden.py, x_T scaled by 0.3 so that no step's K-th boundary is an exact tie).
+    The K-th boundary gap is still one ulp (K = 2 000 of 2 M entries): the selection is not pinned, what it feeds -- the poses of all ten
+    steps, the state, the read-out -- is, at 1e-4."""
+    N, M, nv, mv, mv_da, steps, mc, seed = 1024, 2048, 1000, 2000, 1900, 10, 200, 51
+    g = golden("2d3d_loop_n1024x2048_s10_mc200_xt03_masked")
+    assert (g["kth_gap_rel"] > 0).all() and (g["cond"] < mc).all()             # no exact tie; every fit is fed back
+    v = synth.VARIANTS["2d3d"]
+    Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
+    W = {k: T(a) for k, a in Wn.items()}
+    pr = synth.make_pair_2d3d(N, M, seed, weights=Wn)
+    q = lambda k: T(pr[k])[None]
+    ms, mt = masks(N, M, nv, mv)
+    mt_da = torch.arange(M)[None] < mv_da
+    trace = []
+    out = orc.denoise_loop_2d3d(W, v, q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"),
+                                ms, mt, mt_da, q("x_T") * float(g["xt_scale"]), steps, mc, trace=trace)
+    cfg5_compact_checks(g, trace[-1]["x0"][0].numpy(), out["conf_matrix_pred"][0].double().numpy(),
+                        torch.stack([r["R_forwd"][0] for r in trace]).numpy(), torch.stack([r["t_forwd"][0] for r in trace]).numpy(),
+                        [float(r["cond"][0]) for r in trace])
+    np.testing.assert_allclose(torch.stack([r["x0"][0, :16, :16] for r in trace]).numpy(), g["x0_corner"], atol=1e-4)
+    # control: the SAME oracle with x_T moved by one float32 ulp.  The top-2 000 of these flat matrices is decided by the last bit, so the
+    # trajectories part at the first step with a sub-3e-6 boundary: this is why no other implementation can be held to the later steps' poses
+    tr2 = []
+    orc.denoise_loop_2d3d(W, v, q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"), q("t_pcd_da"),
+                          ms, mt, mt_da, torch.nextafter(q("x_T") * float(g["xt_scale"]), torch.tensor(10.0)), steps, mc, trace=tr2)
+    dR = [float((a["R_forwd"] - b["R_forwd"]).abs().max()) for a, b in zip(trace, tr2)]
+    assert dR[0] < 1e-4 and max(dR) > 1e-2, dR
+
+
 def kpfcn_inputs(golden):
     """synthetic KPFCN batch + hash weights (+ the reference's kernel points from the fixture) as torch tensors"""
     g = golden("kpfcn_coarse")
