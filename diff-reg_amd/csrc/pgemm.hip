@@ -628,7 +628,8 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #define PG_TABLE_INDEX(i)                                                                                                   \
     int col = min(colw + 16 * (i), C - 4);                                                                                  \
     if (rpad > 0) { const int hq = (int)(((unsigned)col * rmagic) >> 20); col = hq * rlen + min(col - hq * rpad, rlen - 4); } \
-    const int ridx = (col % P.rot_C) >> 1;
+    if (col >= P.rot_C) col %= P.rot_C; /* (rot_C = C in every caller: the division is never reached) */                    \
+    const int ridx = col >> 1;
 #define PG_LOAD_TABLES(rr, tb)                                                                                              \
     {                                                                                                                       \
     if (P.csT) { /* one 16-byte load per piece: (cos_k, sin_k, cos_k+1, sin_k+1) */                                         \
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    if (col < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                    if (wcol0 + 16 * i < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
             return;
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    if (col < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
+                    if (wcol0 + 16 * i < C && !(G.dbg & 4)) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + col) = v[rr][i];
                 }
             }
         }
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    const float4 x = col < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 x = wcol0 + 16 * i < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(park(rr) + 16 * i) = x;
                 }
             }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
                     const int col = colw + 16 * i;
-                    r0[rr][i] = col < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    r0[rr][i] = wcol0 + 16 * i < C ? *reinterpret_cast<const float4*>(rp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NIE; ++i)
-                if (colw + 16 * i < C) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
+                if (wcol0 + 16 * i < C) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
             s = row_sum4(s);
             if (q == 0) s_sum[wcw * 128 + wrow0 + 16 * rr + lrow] = s;
         }
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NIE; ++i)
-                if (colw + 16 * i < C) {
+                if (wcol0 + 16 * i < C) {
                     const float d0 = v[rr][i].x - mean[rr], d1 = v[rr][i].y - mean[rr], d2 = v[rr][i].z - mean[rr], d3 = v[rr][i].w - mean[rr];
                     s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
                 }
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
             for (int i = 0; i < NIE; ++i) {
                 const int col = colw + 16 * i;
-                if (col < C) {
+                if (wcol0 + 16 * i < C) {                        // (C % 16 == 0: a 16-column piece is inside or outside as a whole -- a wave-uniform test)
                     const float4 g4 = *reinterpret_cast<const float4*>(s_gam + col), b4 = *reinterpret_cast<const float4*>(s_bet + col);
                     float4 y;
                     y.x = (v[rr][i].x - mean[rr]) * rstd[rr] * g4.x + b4.x; y.y = (v[rr][i].y - mean[rr]) * rstd[rr] * g4.y + b4.y;
