@@ -120,6 +120,14 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     // (14 float4 per lane) it made the 128-row q|k|v / mlp0 instantiations spill
     const bool has_bias = P.bias != nullptr;
     float* const s_bias = s_sq + NCW * 128 + 2 * BN;
+    float* const s_gam = s_sq + NCW * 128;                           // gamma | beta of the block (PG_LN)
+    float* const s_bet = s_gam + BN;
+    float* const s_cinv = s_bias + BN;                               // 2^-s_c of the block's columns
+    float* const s_bound = s_cinv + BN;                              // [128] bound of the row's output image
+    const bool rot = MODE != PG_LN && ((P.rot_mask >> nb) & 1);
+    const bool per_blk = P.pimg_blk_stride != 0;
+    // (the 16x16x32 loop calls this BEHIND the DMA of its first chunk pair: the loads' latency then passes while the pair is in flight)
+    auto stage_inputs = [&]() __attribute__((always_inline)) {
     if (has_bias) {
         const float* bp = P.bias + (size_t)nb * C;
         for (int c = t; c < BN; c += NTHR) s_bias[c] = c < C ? bp[c] : 0.f;
@@ -128,10 +136,6 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     // the columns' 2^-s_c, gamma | beta, and the bound each row's image is scaled by.  (Round 4: the bound's loads -- row bounds, weight norms,
     // group bounds: a chain of dependent loads per round of rows, each behind the previous round's stores -- were ~10 exposed memory latencies
     // per round in the epilogue.)
-    float* const s_gam = s_sq + NCW * 128;                           // gamma | beta of the block (PG_LN)
-    float* const s_bet = s_gam + BN;
-    float* const s_cinv = s_bias + BN;                               // 2^-s_c of the block's columns
-    float* const s_bound = s_cinv + BN;                              // [128] bound of the row's output image
     {
         const float* cp = P.W.cinv + (size_t)nb * BN;
         for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
@@ -141,8 +145,6 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 s_bet[c] = c < C ? P.beta[c] : 0.f;
             }
     }
-    const bool rot = MODE != PG_LN && ((P.rot_mask >> nb) & 1);
-    const bool per_blk = P.pimg_blk_stride != 0;
     if (t < BM) {
         const int row = min(rb * BM + t, rows - 1);
         const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             s_bound[t] = bound;
         }
     }
+    };
 
     // ---- fragment addresses: a lane reads 16 bytes = 8 k of "its" row; lane half h takes k 8 h .. 8 h + 7
     const int sw = (l31 >> 2) & 3;
@@ -337,14 +340,21 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 
         // ---- prologue: group 1 puts stages 0 .. NST - 2 in flight, group 0 stages 0 .. NST - 3 (it issues stage s + NST - 2 in
         // the first burst of stage s, group 1 stage s + NST - 1 in the second); stage 0 landed
+        // (the epilogue's inputs are fetched behind stage 0's pieces: their latency passes while the stage is in flight, and the wait for
+        // them is the wait for stage 0)
 #pragma unroll
         for (int q2 = 0; q2 < AHEAD; ++q2) {
             const unsigned dstb = lds_base + (unsigned)q2 * STAGE;
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) dma_piece(i, dstb);
             dma_advance();
+            if (q2 == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_inputs();
+                __builtin_amdgcn_sched_barrier(0);
+                PG_VMCNT(0);
+            }
         }
-        if (wl < REMP) PG_VMCNT((AHEAD - 1) * (NFULLP + 1)); else PG_VMCNT((AHEAD - 1) * NFULLP);
         __builtin_amdgcn_s_barrier();
         PG_READ(fa0[0], lds_base + offAh, 0);
         PG_READ(fa0[1], lds_base + offAl, 0);
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             }
 #undef PG_MFMA16
         };
-        // prologue: pair 0 and the first 7 pieces of pair 1 in flight, pair 0 landed
+        // prologue: pair 0 in flight | the epilogue's inputs fetched into LDS behind it | pair 0 landed | the first 7 pieces of pair 1
         if (ISS) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) piece(q);
@@ -497,9 +507,14 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
             for (int q = 0; q < 9; ++q) piece(q);
             advance();
+            __builtin_amdgcn_sched_barrier(0);
+            stage_inputs();
+            __builtin_amdgcn_sched_barrier(0);
+            PG_VMCNT(0);
 #pragma unroll
             for (int q = 0; q < 7; ++q) piece(q);
-            PG_VMCNT(7);
+        } else {
+            stage_inputs();
         }
         __builtin_amdgcn_s_barrier();
         PG_READ(fa[0][0], lds_base + oAh, 0);
