@@ -719,6 +719,10 @@ def main():
                 roof["traffic"] = tj.get("hbm_bytes_per_launch")
                 roof["traffic_source"] = "profiles/r04_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
+                # what a bare MFMA loop of this kernel's shape sustains on random data under the chip's own clock management (tools/mfma_f16_ceiling.hip):
+                # informational -- `peak` stays the nominal figure
+                roof["sustained_bare_loop_TFLOPs"] = {"v_mfma_f32_16x16x32_f16 / 3 products": 1941.7 / 3, "source": "profiles/r04_mfma_f16_sustained_ceiling.txt"}
+                roof["frac_of_sustained_bare_loop"] = roof["achieved"] / (1941.7 / 3)
                 roof["effective_clock_GHz_pmc"] = tj.get("derived", {}).get("effective_clock_GHz")
                 roof["avg_us_per_launch_pmc_run"] = tj.get("avg_us_per_launch_profiled")
                 if roof["traffic"] and tj.get("avg_us_per_launch_profiled"):
