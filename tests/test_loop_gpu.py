@@ -40,8 +40,8 @@ def test_denoiser_and_head_match_golden(variant, golden):
     for tag, (ms, mt) in (("", masks(64, 48)), ("_mask", masks(64, 48, 50, 41))):
         so, to, conf = eng.denoise_match(p["f_s"].to(DEV), p["f_t"].to(DEV), p["p_s"].to(DEV), p["p_t"].to(DEV),
                                          ms.to(DEV), mt.to(DEV))
-        assert np.abs(so[0].cpu().numpy() - g["f_s" + tag]).max() < 5e-4
-        assert np.abs(to[0].cpu().numpy() - g["f_t" + tag]).max() < 5e-4
+        assert np.abs(so[0].cpu().numpy() - g["f_s" + tag]).max() < 1e-4          # (measured: 1.5e-5 on features up to 12.9)
+        assert np.abs(to[0].cpu().numpy() - g["f_t" + tag]).max() < 1e-4
         # conf: 1e-4 against the reference, or -- on the few sharp, ill-conditioned entries -- at least as close to a
         # float64 evaluation as the reference's own float32 run is (see the module docstring)
         hs, ht, pe_s, pe_t = orc.denoiser(W64, v, p["f_s"].double(), p["f_t"].double(), p["p_s"], p["p_t"], ms, mt)
@@ -160,7 +160,7 @@ def test_loop_matches_reference(golden, variant, N, M, nv, mv, steps, mc, seed, 
     Rf, tf = out["R_forwd"][:, 0].cpu().numpy(), out["t_forwd"][:, 0].cpu().numpy()
     assert np.abs(Rf - g["R_forwd"]).max() < 1e-4, np.abs(Rf - g["R_forwd"]).max(axis=(1, 2))
     assert np.abs(tf - g["t_forwd"]).max() < 1e-4, np.abs(tf - g["t_forwd"]).max(axis=(1, 2))
-    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=2e-3)
+    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=1e-4)
     x0 = out["x0"][:, 0].cpu().numpy()
     x0_f64, conf_f64, corner_f64 = f64_evaluation(variant, N, M, nv, mv, steps, mc, seed, corners=True)
     # the 16 x 16 corner of EVERY step's x_start: the same plain-bound-plus-rule as the full matrices (no percentile)
@@ -216,7 +216,7 @@ def test_soft_family_plain_bounds(golden, variant, N, M, nv, mv, steps, mc, seed
     torch.cuda.synchronize()
     Rf, tf = out["R_forwd"][:, 0].cpu().numpy(), out["t_forwd"][:, 0].cpu().numpy()
     assert np.abs(Rf - g["R_forwd"]).max() < 1e-4 and np.abs(tf - g["t_forwd"]).max() < 1e-4
-    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=1e-3)
+    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=1e-4)
     x0 = out["x0"][:, 0].cpu().numpy()
     assert np.abs(x0[:, :16, :16] - g["x0_corner"]).max() <= 1e-4                       # every step
     assert np.abs(x0[-1] - g["x0_last"]).max() <= 1e-4                                  # every entry
