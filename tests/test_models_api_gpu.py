@@ -114,8 +114,11 @@ def test_pipeline_forward_matches_reference(golden, variant, N, M, nv, mv, steps
     out = model(data)
     conf = out["conf_matrix_pred"]
     assert conf.dtype == torch.float64 and conf.shape == (1, N, M)
-    d = np.abs(conf[0].cpu().numpy() - g["conf"])
-    assert (d > 1e-4).mean() <= 1e-3
+    # the loop fixture's rule (tests/test_loop_gpu.py): a plain 1e-4 on every entry but the committed ill-conditioned ones, and on those at
+    # least as close to the float64 evaluation as twice the reference's own float32 run
+    from tests.test_loop_gpu import assert_matrix_parity, exemptions, f64_evaluation
+    _, conf_f64 = f64_evaluation(variant, N, M, nv, mv, steps, mc, seed)
+    assert_matrix_parity(conf[0].cpu().numpy(), g["conf"], conf_f64, "Pipeline.forward conf", exemptions("%s_loop_%s" % (variant, tag), "conf"))
     assert out["R_s2t_pred"].shape == (1, 3, 3) and out["t_s2t_pred"].shape == (1, 3, 1)
     assert torch.equal(out["s_pcd"].cpu(), p["p_s"])
     if variant == "3dmatch":
@@ -186,8 +189,12 @@ def test_pipeline_end_to_end_with_overlay_backbone(golden):
     v = synth.VARIANTS[variant]
     ms, mt = torch.ones(1, ns, dtype=torch.bool), torch.ones(1, nt, dtype=torch.bool)
     ref = orc.denoise_loop(W, v, feats[None, :ns], feats[None, ns:], pts[None, :ns], pts[None, ns:], ms, mt, x_T, steps, mc, variant=variant)
-    d = (conf - ref["conf_matrix_pred"][0]).abs()
-    assert (d > 1e-4).double().mean().item() <= 1e-3, d.max().item()
+    # (no percentile: the plain bound + the ill-conditioning rule against a float64 run of the same oracle chain)
+    from tests.test_loop_gpu import assert_matrix_parity
+    W64 = {k: t.double() for k, t in W.items()}
+    f64 = orc.denoise_loop(W64, v, feats[None, :ns].double(), feats[None, ns:].double(), pts[None, :ns], pts[None, ns:], ms, mt, x_T.double(), steps, mc,
+                           variant=variant)
+    assert_matrix_parity(conf.numpy(), ref["conf_matrix_pred"][0].numpy(), f64["conf_matrix_pred"][0].numpy(), "KPFCN + loop conf")
 
 
 def test_get_match_on_device_equals_reference_rule():
