@@ -9,6 +9,10 @@
 // kernel ever sweeps a row for its maximum and the A operand streams by LDS-DMA exactly like the weights: no VGPR-held
 // requests, no VALU split, no in-order vmcnt chain between A loads and the B image.
 //
+// Two main loops share the epilogue.  Round 4 (M16; the 128-row geometry of <= 448 columns): v_mfma_f32_16x16x32_f16 on chunk PAIRS, 8 waves as
+// 2 (rows) x 4 (columns) of 64 x 112, the weight fragment as the MFMA's first operand so that the accumulators are in the epilogue's layout --
+// see the comment at `run16`.  Rounds 2-3 (the 64-row workgroups, the 256- and 576-column geometries): v_mfma_f32_32x32x16_f16, described next.
+//
 // Geometry: a workgroup is 128 rows x one column block of up to 448 columns (the whole C = 432 row of one nn.Linear), 8 waves
 // as 4 (rows) x 2 (columns), a wave = 32 x 224 = 7 accumulator tiles of v_mfma_f32_32x32x16_f16; one workgroup per CU.
 // A stage = one 16-deep k-chunk = 8 KB of A + 28 KB of W, 36 one-KB DMA instructions dealt over the 8 waves; NST = 4 stages
