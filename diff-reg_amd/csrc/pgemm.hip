@@ -132,55 +132,55 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     const bool per_blk = P.pimg_blk_stride != 0;
     // (the 16x16x32 loop calls this BEHIND the DMA of its first chunk pair: the loads' latency then passes while the pair is in flight)
     auto stage_inputs = [&]() __attribute__((always_inline)) {
-    if (has_bias) {
-        const float* bp = P.bias + (size_t)nb * C;
-        for (int c = t; c < BN; c += NTHR) s_bias[c] = c < C ? bp[c] : 0.f;
-    }
-    // Everything else the epilogue needs from memory that does not depend on the accumulators is fetched HERE, in front of the main loop:
-    // the columns' 2^-s_c, gamma | beta, and the bound each row's image is scaled by.  (Round 4: the bound's loads -- row bounds, weight norms,
-    // group bounds: a chain of dependent loads per round of rows, each behind the previous round's stores -- were ~10 exposed memory latencies
-    // per round in the epilogue.)
-    {
-        const float* cp = P.W.cinv + (size_t)nb * BN;
-        for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
-        if (MODE == PG_LN && P.gamma)
-            for (int c = t; c < BN; c += NTHR) {
-                s_gam[c] = c < C ? P.gamma[c] : 0.f;
-                s_bet[c] = c < C ? P.beta[c] : 0.f;
-            }
-    }
-    if (t < BM) {
-        const int row = min(rb * BM + t, rows - 1);
-        const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
-        const int e0 = scale_exp(b0);
-        int e1 = e0;
-        if (nc1 > 0) e1 = scale_exp(b1);
-        s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
-        s_rinv[t] = pow2i(-e1);
-        if (P.pimg) {
-            float bound;
-            if (MODE == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[row] : 0.f) + (P.lnB ? P.lnB[0] : 0.f);
-            else {
-                // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
-                // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
-                const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + row / P.grp_rows] : fmaxf(b0, b1);
-                // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
-                // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
-                // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
-                float wn_ = P.W.wnorm[nb];
-                if (!per_blk)
-                    for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
-                float bm = 0.f;                                  // |x W^T + b| <= bound(x) ||W|| + max |b|  (same rule for blocks sharing an image)
-                if (P.bias_max) {
-                    bm = P.bias_max[nb];
-                    if (!per_blk)
-                        for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
-                }
-                bound = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
-            }
-            s_bound[t] = bound;
+        if (has_bias) {
+            const float* bp = P.bias + (size_t)nb * C;
+            for (int c = t; c < BN; c += NTHR) s_bias[c] = c < C ? bp[c] : 0.f;
         }
-    }
+        // Everything else the epilogue needs from memory that does not depend on the accumulators is fetched HERE, in front of the main loop:
+        // the columns' 2^-s_c, gamma | beta, and the bound each row's image is scaled by.  (Round 4: the bound's loads -- row bounds, weight norms,
+        // group bounds: a chain of dependent loads per round of rows, each behind the previous round's stores -- were ~10 exposed memory latencies
+        // per round in the epilogue.)
+        {
+            const float* cp = P.W.cinv + (size_t)nb * BN;
+            for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
+            if (MODE == PG_LN && P.gamma)
+                for (int c = t; c < BN; c += NTHR) {
+                    s_gam[c] = c < C ? P.gamma[c] : 0.f;
+                    s_bet[c] = c < C ? P.beta[c] : 0.f;
+                }
+        }
+        if (t < BM) {
+            const int row = min(rb * BM + t, rows - 1);
+            const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
+            const int e0 = scale_exp(b0);
+            int e1 = e0;
+            if (nc1 > 0) e1 = scale_exp(b1);
+            s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
+            s_rinv[t] = pow2i(-e1);
+            if (P.pimg) {
+                float bound;
+                if (MODE == PG_LN) bound = ((P.bnd_res && !P.ln_postadd) ? P.bnd_res[row] : 0.f) + (P.lnB ? P.lnB[0] : 0.f);
+                else {
+                    // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
+                    // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
+                    const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + row / P.grp_rows] : fmaxf(b0, b1);
+                    // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
+                    // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
+                    // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
+                    float wn_ = P.W.wnorm[nb];
+                    if (!per_blk)
+                        for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
+                    float bm = 0.f;                                  // |x W^T + b| <= bound(x) ||W|| + max |b|  (same rule for blocks sharing an image)
+                    if (P.bias_max) {
+                        bm = P.bias_max[nb];
+                        if (!per_blk)
+                            for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
+                    }
+                    bound = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+                }
+                s_bound[t] = bound;
+            }
+        }
     };
 
     // ---- fragment addresses: a lane reads 16 bytes = 8 k of "its" row; lane half h takes k 8 h .. 8 h + 7
