@@ -1218,9 +1218,9 @@ int dr_planes_from_f32_bounded(int rows, int K, const float* x, int ldx, const f
     return launch_planes_from_f32(x, ldx, rows, K, (char*)image, bound, (hipStream_t)stream, bound_in);
 }
 
-int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
-                        const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
-                        void* out_image, float* out_bound, void* stream) {
+static int attention_planes_entry(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                                  const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                                  void* out_image, float* out_bound, int f16_single, void* stream) {
     if (P < 1 || Lq < 1 || Lk < 1 || H < 1 || d < 4 || d % 4 || !q_image || !k_image || !v_image || !q_bound || !k_bound || !v_bound || !out_image ||
         !out_bound) return DR_EINVAL;
     const int dp = (d + 15) / 16 * 16;
@@ -1232,7 +1232,19 @@ int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image
     a.pimg[0] = a.pimg[1] = (char*)out_image; a.p_split = 0x7fffffff; a.p_nct = H * dp / 16; a.p_dp = dp; a.pbnd = out_bound;
     a.qimg[0] = a.qimg[1] = (const char*)q_image; a.kimg[0] = a.kimg[1] = (const char*)k_image; a.vimg[0] = a.vimg[1] = (const char*)v_image;
     a.qbnd = q_bound; a.kgb = k_bound; a.vgb = v_bound;
+    a.f16_single = f16_single;
     return launch_attention(a, (hipStream_t)stream);
+}
+
+int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                        const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                        void* out_image, float* out_bound, void* stream) {
+    return attention_planes_entry(P, Lq, Lk, H, d, q_image, q_bound, k_image, k_bound, v_image, v_bound, q_mask, k_mask, out_image, out_bound, 0, stream);
+}
+int dr_attention_planes_f16(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                            const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                            void* out_image, float* out_bound, void* stream) {
+    return attention_planes_entry(P, Lq, Lk, H, d, q_image, q_bound, k_image, k_bound, v_image, v_bound, q_mask, k_mask, out_image, out_bound, 1, stream);
 }
 
 int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream) {

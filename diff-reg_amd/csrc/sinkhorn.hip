@@ -160,6 +160,33 @@ struct VecIO<double, 4> {
         *reinterpret_cast<double2*>(p + 2) = make_double2((double)v[2], (double)v[3]);
     }
 };
+// fp16 storage (dr_sinkhorn_f16: opt-in, half the HBM bytes of the fp32 tile; the arithmetic stays fp32)
+typedef _Float16 sk_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sk_h2 __attribute__((ext_vector_type(2)));
+template <>
+struct VecIO<_Float16, 4> {
+    static __device__ __forceinline__ void load(const _Float16* p, float (&v)[4], double sh) {
+        const sk_h4 t = *reinterpret_cast<const sk_h4*>(p);
+        const float s = (float)sh;
+        v[0] = (float)t.x - s; v[1] = (float)t.y - s; v[2] = (float)t.z - s; v[3] = (float)t.w - s;
+    }
+    static __device__ __forceinline__ void store(_Float16* p, const float (&v)[4]) {
+        sk_h4 t; t.x = (_Float16)v[0]; t.y = (_Float16)v[1]; t.z = (_Float16)v[2]; t.w = (_Float16)v[3];
+        *reinterpret_cast<sk_h4*>(p) = t;
+    }
+};
+template <>
+struct VecIO<_Float16, 2> {
+    static __device__ __forceinline__ void load(const _Float16* p, float (&v)[2], double sh) {
+        const sk_h2 t = *reinterpret_cast<const sk_h2*>(p);
+        const float s = (float)sh;
+        v[0] = (float)t.x - s; v[1] = (float)t.y - s;
+    }
+    static __device__ __forceinline__ void store(_Float16* p, const float (&v)[2]) {
+        sk_h2 t; t.x = (_Float16)v[0]; t.y = (_Float16)v[1];
+        *reinterpret_cast<sk_h2*>(p) = t;
+    }
+};
 template <>
 struct VecIO<float, 2> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[2], double sh) {
@@ -1670,6 +1697,35 @@ int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift,
     return sinkhorn_dispatch<double>(B, N, M, scores, shift, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
 }
 
+// fp16 tiles in, fp16 confidences out: the register-resident kernel only (tiles up to 256 x 256: BASELINE cfg1 / cfg2)
+int sinkhorn_f16(int B, int N, int M, const void* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score, int iters, int flags,
+                 void* out, hipStream_t st) {
+    if (B < 0 || N < 1 || M < 1 || iters < 1 || !scores || !bin_score || !out) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!reg_path(N, M, flags)) return DR_ENOSUP;
+    SkArgs a;
+    a.scores = scores; a.src_mask = sm; a.tgt_mask = tm; a.bin_score = bin_score;
+    a.out = out; a.ws = nullptr; a.shift = nullptr; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
+    a.spin_limit = g_sk_spin_limit;
+    ProfScope ps(PK_SINKHORN, (double)B * N * M * 4.0, st);
+    const int cpl = (N <= 128 && M <= 128) ? 2 : 4;
+    a.vec_in = (M % cpl == 0) && ((uintptr_t)scores % (2 * cpl) == 0);
+    a.vec_out = (M % cpl == 0) && ((uintptr_t)out % (2 * cpl) == 0);
+    const bool plain = a.vec_in && a.vec_out && !sm && !tm && !(flags & DR_SK_MINSHIFT);
+    if (plain && N == 256 && M == 256) {              // the headline's tile: the per-tile fast kernel (16 waves x 16 rows, 4 columns per lane)
+        hipLaunchKernelGGL((sk_fast_kernel<_Float16, _Float16, 16, 4, false>), dim3(B), dim3(1024), 0, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
+    if (plain && N == 128 && M == 128) {
+        hipLaunchKernelGGL((sk_fast_kernel<_Float16, _Float16, 8, 2, false>), dim3(B), dim3(512), 0, st, a);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
+    if (a.vec_in && a.vec_out) return launch_reg2<_Float16, _Float16, true>(a, st);
+    return launch_reg2<_Float16, _Float16, false>(a, st);
+}
+
 // waits for the stream, reads (and clears) the sticky flag
 int sinkhorn_device_status(hipStream_t st, bool clear) {
     DR_HIP_CHECK(hipStreamSynchronize(st));
@@ -1702,6 +1758,11 @@ int dr_sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* src
                     void* stream) {
     return dr::sinkhorn_dispatch<float>(B, N, M, scores, nullptr, src_mask, tgt_mask, bin_score, iters, flags, out, workspace,
                                         workspace_bytes, stream);
+}
+
+int dr_sinkhorn_f16(int B, int N, int M, const void* scores, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
+                    int iters, int flags, void* out, void* stream) {
+    return dr::sinkhorn_f16(B, N, M, scores, src_mask, tgt_mask, bin_score, iters, flags, out, (hipStream_t)stream);
 }
 
 int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* src_mask, const uint8_t* tgt_mask,

@@ -28,6 +28,7 @@ SIGNATURES = {
     "dr_sinkhorn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dr_sinkhorn_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dr_sinkhorn_f16": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dr_sinkhorn_f64": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
 }
@@ -100,6 +101,7 @@ SIGNATURES.update({
     "dr_planes_from_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_planes_from_f32_bounded": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_attention_planes": (c_int, [c_int] * 5 + [c_void_p] * 10 + [c_void_p]),
+    "dr_attention_planes_f16": (c_int, [c_int] * 5 + [c_void_p] * 10 + [c_void_p]),
     "dr_planes_to_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dr_plane_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -292,7 +294,7 @@ def planes_from_f32_bounded(x, bound_in):
     return img, bnd
 
 
-def attention_planes(q, k, v, H, q_mask=None, k_mask=None):
+def attention_planes(q, k, v, H, q_mask=None, k_mask=None, f16=False):
     """q [P,Lq,C], k, v [P,Lk,C] float32 (rotary already applied) -> softmax(q k^T / sqrt(d)) v per head, [P,Lq,C], through the
     plane-image attention kernel (images built here: head-padded columns, one k / v bound per segment)."""
     ensure_init()
@@ -313,7 +315,7 @@ def attention_planes(q, k, v, H, q_mask=None, k_mask=None):
     vi, vb = planes_from_f32_bounded(pad(v), vb_in)
     oi = torch.zeros(_lib.dr_plane_image_bytes(P * Lq, H * dp), dtype=torch.uint8, device=q.device)
     ob = torch.zeros(P * Lq, device=q.device)
-    check(_lib.dr_attention_planes(P, Lq, Lk, H, d, ptr(qi), ptr(qb), ptr(ki), ptr(kb), ptr(vi), ptr(vb), ptr(mask_u8(q_mask)), ptr(mask_u8(k_mask)),
+    check((_lib.dr_attention_planes_f16 if f16 else _lib.dr_attention_planes)(P, Lq, Lk, H, d, ptr(qi), ptr(qb), ptr(ki), ptr(kb), ptr(vi), ptr(vb), ptr(mask_u8(q_mask)), ptr(mask_u8(k_mask)),
                                    ptr(oi), ptr(ob), stream_of(q)))
     o = planes_to_f32(oi, ob, P * Lq, H * dp).view(P * Lq, H, dp)[:, :, :d]
     return o.reshape(P, Lq, C)
@@ -605,6 +607,20 @@ def mutual_match(conf, thr=0.0, mutual=True, cap=None, want_mask=False):
     fn = _lib.dr_mutual_match_f64 if conf.dtype == torch.float64 else _lib.dr_mutual_match_f32
     check(fn(P, N, M, ptr(conf), float(thr), 1 if mutual else 0, cap, ptr(matches), ptr(mconf), ptr(count), ptr(mask), stream_of(conf)))
     return matches, mconf, count, mask
+
+
+def sinkhorn_f16(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift=False, apply_mask=False, ragged=False):
+    """dr_sinkhorn_f16 (opt-in): [B,N,M] float16 scores -> float16 conf; tiles up to 256 x 256"""
+    ensure_init()
+    assert scores.dim() == 3 and scores.dtype == torch.float16
+    scores = scores.contiguous()
+    B, N, M = scores.shape
+    flags = (SK_MINSHIFT if minshift else 0) | (SK_APPLY_MASK if apply_mask else 0) | (SK_RAGGED if ragged else 0)
+    out = torch.empty(B, N, M, dtype=torch.float16, device=scores.device)
+    bs = bin_score.detach().to(device=scores.device, dtype=torch.float32).reshape(1).contiguous()
+    sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    check(_lib.dr_sinkhorn_f16(B, N, M, ptr(scores), ptr(sm), ptr(tm), ptr(bs), int(iters), flags, ptr(out), stream_of(scores)))
+    return out
 
 
 def sinkhorn(scores, bin_score, iters, src_mask=None, tgt_mask=None, *, minshift=False, apply_mask=False,

@@ -83,6 +83,12 @@ int dr_sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* src
                     const uint8_t* tgt_mask, const float* bin_score, int iters, int flags,
                     float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* OPT-IN reduced precision (SURVEY 8b lists dr_sinkhorn_f16; never used by the loop): the score tiles and the confidences are stored as
+ * IEEE fp16 -- half the bytes of an HBM-bound op -- the iteration itself runs in fp32 registers exactly like dr_sinkhorn_f32.  Tiles of up to
+ * 256 x 256 (the register-resident kernel: BASELINE cfg1 / cfg2 sizes; DR_ENOSUP beyond); flags as dr_sinkhorn_f32 except DR_SK_STRICT /
+ * DR_SK_OUT_LOG.  Outside the 1e-4 contract by construction: an fp16 confidence carries 11 bits. */
+int dr_sinkhorn_f16(int B, int N, int M, const void* scores_f16, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
+                    int iters, int flags, void* out_f16, void* stream);
 int dr_sinkhorn_f64(int B, int N, int M, const double* scores, const uint8_t* src_mask,
                     const uint8_t* tgt_mask, const float* bin_score, int iters, int flags,
                     void* out /* double*, or float* with DR_SK_OUT_F32 */, void* workspace,
@@ -146,6 +152,11 @@ int dr_planes_from_f32_bounded(int rows, int K, const float* x, int ldx, const f
 int dr_attention_planes(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
                         const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
                         void* out_image, float* out_bound, void* stream);
+/* OPT-IN reduced precision: the same op with ONE fp16 product per contraction (the hi planes of q, k, v and of P only) instead of three --
+ * what dr_loop_config.flags & DR_LOOP_ATTN_F16 selects inside the loops.  11-bit operands: outside the 1e-4 contract, never a default. */
+int dr_attention_planes_f16(int P, int Lq, int Lk, int H, int d, const void* q_image, const float* q_bound, const void* k_image,
+                            const float* k_bound, const void* v_image, const float* v_bound, const uint8_t* q_mask, const uint8_t* k_mask,
+                            void* out_image, float* out_bound, void* stream);
 /* image -> fp32 rows (tests) */
 int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, float* out, int ldo, void* stream);
 /* weights W [nblk * C, K] (nn.Linear layout; nblk stacked layers of C output columns each, C <= 448, C % 16 == 0) ->

@@ -173,6 +173,20 @@ def test_attention_on_plane_images(P, Lq, Lk, H, d, masked):
     assert float((o.double() - ref)[keep].abs().max()) < 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("P,Lq,Lk,H,d", [(2, 128, 64, 4, 108), (2, 96, 80, 4, 132), (2, 64, 160, 4, 64)])
+def test_attention_on_plane_images_f16_entry(P, Lq, Lk, H, d):
+    """dr_attention_planes_f16 (opt-in, SURVEY 8b's reduced-precision entry): ONE fp16 product per contraction.  Not the three-product result
+    (the mode is on) and within the 11-bit operands' error of float64 attention: 3e-3 of the largest output."""
+    torch.manual_seed(P + Lq + d)
+    C = H * d
+    q, k, v = torch.randn(P, Lq, C, device=DEV), torch.randn(P, Lk, C, device=DEV), torch.randn(P, Lk, C, device=DEV) * 3
+    o3, o1 = lib.attention_planes(q, k, v, H), lib.attention_planes(q, k, v, H, f16=True)
+    qh, kh, vh = (z.double().view(P, -1, H, d).transpose(1, 2) for z in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / d ** 0.5, -1) @ vh).transpose(1, 2).reshape(P, Lq, C)
+    e3, e1 = float((o3.double() - ref).abs().max()), float((o1.double() - ref).abs().max())
+    assert e3 < 1e-5 * float(ref.abs().max()) and 1e-5 * float(ref.abs().max()) < e1 < 3e-3 * float(ref.abs().max()), (e3, e1)
+
+
 @pytest.mark.parametrize("gain1", [1.0, 1.37, 0.6])
 def test_column_blocks_sharing_one_image_share_one_scale(gain1):
     """ADVICE (round 2, high): mlp0's two column blocks write ONE hidden image with ONE bound per row.  The scale of a row must

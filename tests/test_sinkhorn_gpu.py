@@ -216,6 +216,30 @@ def test_persistent_kernel_equals_per_tile_kernel(B):
         assert rel_err(big[b:b + 1], ref)[1] < 2e-5
 
 
+@pytest.mark.parametrize("N,M,nv,mv", [(256, 256, 256, 256), (128, 128, 100, 77), (96, 80, 70, 61), (255, 253, 201, 77), (5, 7, 5, 7)])
+def test_f16_entry_matches_oracle_on_f16_scores(N, M, nv, mv):
+    """dr_sinkhorn_f16 (opt-in, SURVEY 8b's reduced-precision entry): fp16 score tiles in, fp16 confidences out, the iteration in fp32 -- the
+    oracle on the SAME fp16-rounded scores, to fp16's own rounding of the result (2^-11 relative, 6e-8 absolute in the subnormal range);
+    tiles beyond 256 x 256 are refused."""
+    from diffreg_hip import lib
+    sc, sm, tm = sinkhorn_case(N, M, nv, mv, torch.float32)
+    a = torch.tensor(1.0)
+    raw = T(3.0 * synth.hash_normal(1, N * 1000 + M, (1, N, M))).half()
+    scm = raw.float().masked_fill(~(sm[:, :, None] & tm[:, None, :]), float("-inf"))
+    ref = orc.sinkhorn_log(scm, a, 3, sm, tm).exp()[:, :-1, :-1].double()
+    got = lib.sinkhorn_f16(raw.to(DEV), a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True)
+    assert got.dtype == torch.float16 and got.shape == (1, N, M)
+    err = (got.double().cpu() - ref).abs()
+    assert bool((err <= 6e-4 * ref + 7e-8).all()), float((err / (ref + 1e-7)).max())
+    if nv == N and mv == M:                                     # unmasked: the plain-tile kernels (256 x 256 and 128 x 128 take the fast form)
+        ref2 = orc.sinkhorn_log(raw.float(), a, 3, sm, tm).exp()[:, :-1, :-1].double()
+        got2 = lib.sinkhorn_f16(raw.to(DEV).repeat(3, 1, 1), a.to(DEV), 3)
+        err2 = (got2.double().cpu() - ref2).abs()
+        assert bool((err2 <= 6e-4 * ref2 + 7e-8).all())
+    with pytest.raises(RuntimeError):
+        lib.sinkhorn_f16(torch.zeros(1, 300, 300, dtype=torch.float16, device=DEV), a.to(DEV), 3)
+
+
 def test_bad_arguments():
     from diffreg_hip import lib
     with pytest.raises(RuntimeError):
