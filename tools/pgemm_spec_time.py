@@ -1,5 +1,6 @@
-"""TIMING ONLY (DR_PG_NOEPI=1: every kernel returns behind its main loop): main loops of the plane GEMM at 65 536 rows -- 32x32x16 (8 waves), 16x16x32 (8 waves,
-the issuing waves also compute), 16x16x32 with four producer waves that only feed the LDS-DMA (12 waves, 168 registers)."""
+"""TIMING ONLY (DR_PG_NOEPI=1: every kernel returns behind its main loop): main loops of the plane GEMM at 65 536 rows -- 32x32x16 against 16x16x32.
+(The third arm of profiles/r04_pgemm_16x16x32_and_rejected_experiments.json -- four producer waves beside eight consumers -- was a build of its own and
+is not in the library.)"""
 import os, sys, torch
 os.environ["DR_DIAGNOSTICS"] = "1"; os.environ["DR_PG_HALF"] = "0"; os.environ["DR_PG_NOEPI"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
@@ -34,7 +35,7 @@ def t(f, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 for _ in range(30): shapes["mlp0 (2 blocks)"][0]()
-variants = {"32x32x16": ("0", "0"), "16x16x32": ("1", "0"), "16x16x32 + producers": ("1", "1")}
+variants = {"32x32x16": ("0", "0"), "16x16x32": ("1", "0")}
 for name, (f, kn) in shapes.items():
     res = {}
     for rnd in range(3):
