@@ -293,8 +293,9 @@ def test_vision3d_layer_chain_against_float64(rows, C, row_block):
 
 @pytest.mark.parametrize("row_block", [0], indirect=True)
 @pytest.mark.parametrize("m16", ["1", "0"])
+@pytest.mark.parametrize("rows", [300, 1, 129])
 @pytest.mark.parametrize("k0,k1", [(432, 0), (448, 0), (432, 432), (448, 432), (432, 448), (864, 0), (80, 432), (64, 0)])
-def test_chunk_pairs_and_virtual_chunks(k0, k1, m16, row_block):
+def test_chunk_pairs_and_virtual_chunks(k0, k1, m16, row_block, rows):
     """The 128-row plane GEMM contracts k-chunks in PAIRS (v_mfma_f32_16x16x32_f16, DR_PG_M16=1: the default): segments with an even and an odd
     number of 16-deep chunks, alone and as [A0 | A1] with different row scales (the odd ones end in a virtual zero chunk; the accumulators are
     rescaled at the segment boundary), a segment shorter than five chunks (falls back to the 32x32x16 loop), both loops against float64 --
@@ -302,8 +303,8 @@ def test_chunk_pairs_and_virtual_chunks(k0, k1, m16, row_block):
     import os
     os.environ["DR_PG_M16"] = m16
     try:
-        rows, C = 300, 432
-        torch.manual_seed(k0 + 7 * k1)
+        C = 432
+        torch.manual_seed(k0 + 7 * k1 + rows)
         x0 = torch.randn(rows, k0, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
         x1 = torch.randn(rows, k1, device=DEV) * (torch.rand(rows, 1, device=DEV) * 300 + 1e-3) if k1 else None
         i0, b0 = lib.planes_from_f32(x0)
