@@ -272,8 +272,10 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     const bool cached = kv_cached != nullptr;            // (the plane path keeps the cached K | V as images: kvc_img / kvc_bnd)
     char* const kv_img = kv_store ? pw.kvc_img : pw.qkv_img + pw.qkv_stride;
     float* const kv_bnd = kv_store ? pw.kvc_bnd : pw.qkv_bnd + T;
-    if (!cached) {
-        // bound of the keys' source rows per group (pair x side)
+    // bound of the keys' source rows per group (pair x side): taken inside the projection's own kernel when a group is a whole number of
+    // workgroups (the 480 five-microsecond launches of a 20-step loop were 2 - 4 % of it), by a kernel of its own otherwise
+    const bool grp_inline = X.N % 128 == 0 && X.M % 128 == 0 && env_knob("DR_LOOP_GRP_INLINE", 1) != 0;
+    if (!cached && !grp_inline) {
         for (int side = 1; side <= 2 && rc_ok; ++side)
             if (ys & side) rc_ok = launch_group_max(yin.bnd + r0(side), X.P, side == SIDE_TGT ? X.M : X.N, pw.grp_x + (side == SIDE_TGT ? X.P : 0), st) == DR_OK;
         if (!rc_ok) return DR_ELAUNCH;
@@ -287,7 +289,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.csT = X.pw->csT + (size_t)r0(side) * halfC * 2;
         p.pimg = at(img, pw.side_att, side); p.p_nct = nq; p.pbnd = bnd + r0(side);
         p.pimg_blk_stride = (long long)pw.qkv_stride; p.pbnd_blk_stride = T;
-        p.grp_bnd = pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_TGT ? X.P : 0; p.grp_rows = side == SIDE_TGT ? X.M : X.N;
+        p.grp_bnd = grp_inline ? nullptr : pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_TGT ? X.P : 0; p.grp_rows = side == SIDE_TGT ? X.M : X.N;
     };
     reset();
     if (kv_store) {

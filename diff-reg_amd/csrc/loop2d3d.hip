@@ -241,7 +241,9 @@ static int fusion_layer_planes(const P2Ctx& X, const dr_fusion_layer_weights& W,
     auto for_sides = [&](int mask, auto fn) { for (int side = 1; side <= 2; ++side) if (mask & side) fn(side); };
     int rc = DR_OK;
     // bound of the keys' source rows per group (pair x side): all keys of a group share one scale in the k and v images
-    for (int side = 1; side <= 2 && rc == DR_OK; ++side)
+    // (taken inside the projection's kernel when a group is a whole number of workgroups: pgemm.h)
+    const bool grp_inline = X.N % 128 == 0 && X.M % 128 == 0 && env_knob("DR_LOOP_GRP_INLINE", 1) != 0;
+    for (int side = 1; side <= 2 && rc == DR_OK && !grp_inline; ++side)
         if (ys & side) rc = launch_group_max(yin.bnd + r0(side), X.P, per_pair(side), pw.grp_x + (side == SIDE_PCD ? X.P : 0), st);
     if (rc) return rc;
     // ---- q | k | v = x W^T + b -> three plane images (head h at k = h d), no rotary (vision3d/layers/transformer.py:96-104)
@@ -252,7 +254,7 @@ static int fusion_layer_planes(const P2Ctx& X, const dr_fusion_layer_weights& W,
         p.bias = L.qkv_b + (size_t)b0 * C; p.bias_max = L.qkv_bmax + b0;
         p.pimg = at(pw.qkv_img + (size_t)b0 * pw.qkv_stride, pw.side_C, side); p.p_nct = nC; p.pbnd = pw.qkv_bnd + (size_t)b0 * T + r0(side);
         p.pimg_blk_stride = (long long)pw.qkv_stride; p.pbnd_blk_stride = T;
-        p.grp_bnd = pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_PCD ? X.P : 0; p.grp_rows = per_pair(side);
+        p.grp_bnd = grp_inline ? nullptr : pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_PCD ? X.P : 0; p.grp_rows = per_pair(side);
     };
     reset();
     if (xs == ys && xin.img == yin.img) {

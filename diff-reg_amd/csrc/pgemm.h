@@ -47,6 +47,7 @@ struct PgProblem {
     char* pimg; int p_nct; int p_kc0; float* pbnd;
     long long pimg_blk_stride; long long pbnd_blk_stride;   // != 0: every column block writes its OWN image / bound array (q | k | v)
     // PG_PLANES bound of block nb: bit nb of grp_mask set -> grp_bnd[grp_first + row / grp_rows] instead of the row's own bound
+    // (grp_bnd == nullptr with grp_mask != 0: the kernel takes the group maximum of bnd0 itself -- needs grp_rows % 128 == 0)
     const float* grp_bnd; int grp_mask, grp_first, grp_rows;
     int relu;
     // PG_LN: y = LayerNorm(acc) * gamma + beta (+ resid[row][col]);  bound = (bnd_res ? bnd_res[row] : 0) + *lnB

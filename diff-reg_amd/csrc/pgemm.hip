@@ -149,6 +149,19 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                     s_bet[c] = c < C ? P.beta[c] : 0.f;
                 }
         }
+        // the bound of the row's GROUP (blocks flagged in grp_mask) without a kernel of its own: when a group's rows are a whole number of
+        // workgroups (grp_rows % 128 == 0: the caller then passes grp_bnd = nullptr) the workgroup takes the maximum over its group's rows here
+        float gmax = 0.f;
+        if (MODE != PG_LN && ((P.grp_mask >> nb) & 1) && !P.grp_bnd) {
+            const int gbase = (rb * BM) / P.grp_rows * P.grp_rows;
+            float m = 0.f;
+            for (int i = t; i < P.grp_rows; i += NTHR) m = fmaxf(m, P.bnd0[gbase + i]);
+            m = wave_max(m);
+            if (lane == 0) s_sum[w] = m;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NTHR / 64; ++k) gmax = fmaxf(gmax, s_sum[k]);
+        }
         if (t < BM) {
             const int row = min(rb * BM + t, rows - 1);
             const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
                 else {
                     // |x W^T| <= bound(x) max_c ||W_c||_1 (x sqrt 2 behind the rotary embedding, x |scale|); blocks flagged in grp_mask take
                     // the bound of the row's GROUP (a pair's side) so that all rows of a group share one scale (the attention kernel's K / V)
-                    const float bin = ((P.grp_mask >> nb) & 1) ? P.grp_bnd[P.grp_first + row / P.grp_rows] : fmaxf(b0, b1);
+                    const float bin = ((P.grp_mask >> nb) & 1) ? (P.grp_bnd ? P.grp_bnd[P.grp_first + row / P.grp_rows] : gmax) : fmaxf(b0, b1);
                     // blocks that share ONE image and ONE bound array (mlp0's two column blocks -> hid) must derive the same scale: the bound is
                     // taken from the largest of their weight norms (a per-block bound would scale block 1 by 2^s(bin wnorm[1]) while every
                     // consumer rescales the whole row by the stored 2^-s(bin wnorm[0]): off by a power of two where the two straddle one)
