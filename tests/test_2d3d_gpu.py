@@ -298,21 +298,22 @@ def test_2d3d_tiny_and_odd_shapes(N, M):
     assert float(dc.max()) < 1e-4, float(dc.max())
 
 
-@pytest.mark.parametrize("P", [2, 4])
+@pytest.mark.parametrize("P", [2, 4, 8])
 def test_cfg5_batch_of_pairs_on_the_plane_path(golden, P):
-    """BASELINE configs[4] batched (P pairs of 1024 x 2048 per call = 6144 / 12288 token rows: the size rule selects the plane path by
+    """BASELINE configs[4] batched (P pairs of 1024 x 2048 per call = 6144 / 12288 / 24576 token rows -- 8 pairs is what bench.py times, and from
+    half a chip of 128-row workgroups on the plane GEMM leaves the 64-row form: the size rule selects the plane path by
     itself, the Sinkhorn runs the multi-launch grid form, the top-K the chip-wide selection over P tiles): pair 0 is the reference fixture's
     pair (identity warp) and is held to the reference's own components; every pair to its own B = 1 run through the f32 kernels by a
     plain 1e-4 on every entry of every step's x_start, of conf and of the final state."""
     from tests.test_oracle_golden import cfg5_compact_checks
     N, M, steps, mc = 1024, 2048, 10, 0
     g = golden("2d3d_loop_n1024x2048_s10_mc0_masked")
-    seeds = [51, 52, 53, 54][:P]
+    seeds = [51, 52, 53, 54, 55, 56, 57, 58][:P]
     W, eng, _ = setup(N, M, 51, steps, mc)                      # planes=None: chosen by the size rule
     Wn = synth.make_weights_2d3d(seed=9, head_gain=16.0)
     prs = [synth.make_pair_2d3d(N, M, sd, weights=Wn) for sd in seeds]
     cat = lambda k: torch.stack([T(p[k]) for p in prs]).to(DEV)
-    nv, mv, mda = [1000, 1024, 900, 1011][:P], [2000, 2048, 2048, 1777][:P], [1900, 2048, 2000, 1700][:P]
+    nv, mv, mda = [1000, 1024, 900, 1011, 1024, 777, 1024, 960][:P], [2000, 2048, 2048, 1777, 2048, 2048, 1500, 2048][:P], [1900, 2048, 2000, 1700, 2048, 1999, 1500, 2011][:P]
     ms = torch.stack([torch.arange(N) < n for n in nv]); mt = torch.stack([torch.arange(M) < m for m in mv])
     mt_da = torch.stack([torch.arange(M) < m for m in mda])
     out = eng.run(cat("img_feats"), cat("img_dino"), cat("img_pixels"), cat("pcd_feats"), cat("s_pcd"), cat("t_pcd_da"), cat("x_T"),
@@ -323,7 +324,7 @@ def test_cfg5_batch_of_pairs_on_the_plane_path(golden, P):
     assert np.abs(out["x0"][:, 0, :16, :16].cpu().numpy() - g["x0_corner"]).max() <= 1e-4
     x0_all, conf_all, xf_all = out["x0"].cpu(), out["conf_matrix_pred"].cpu(), out["x_final"].cpu()
     eng1 = setup(N, M, 51, steps, mc, False)[1]
-    for i in range(P):
+    for i in (range(P) if P <= 4 else (0, 3, 5, 7)):             # (8 pairs: four B = 1 runs bound the test's time)
         d = lambda k: T(prs[i][k])[None].to(DEV)
         one = eng1.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"),
                        (ms[i:i + 1].to(DEV), mt[i:i + 1].to(DEV), mt_da[i:i + 1].to(DEV)), trace=True)
