@@ -296,10 +296,16 @@ def bench_cfg3(dev):
     g0, g1 = group(300), group(320)
     one = _time_calls(lambda: eng.run(graph=True, borrow=True, **g0), warm=3, reps=5)
     two = _time_calls(lambda: eng.run_streams([g0, g1], 2), warm=3, reps=5)
+    three = None
+    if os.environ.get("DIFFREG_BENCH_CFG3_STREAMS", "3") == "3":
+        g2 = group(340)
+        three = _time_calls(lambda: eng.run_streams([g0, g1, g2], 3), warm=3, reps=4)
     res = {"workload": "cfg3: 4DMatch N=M=512, C=528 (d_head 132), %d denoise steps, %d pairs per call, max_condition_num=%g" % (steps, P, mc),
            "ms_per_call": one * 1e3, "pairs_per_s": P / one,
            "two_concurrent_calls": {"ms_per_pass": two * 1e3, "pairs_per_s": 2 * P / two,
                                     "what": "two independent 8-pair calls, one captured graph each, on two HIP streams (16 pairs in flight)"}}
+    if three:
+        res["three_concurrent_calls"] = {"ms_per_pass": three * 1e3, "pairs_per_s": 3 * P / three, "what": "three 8-pair calls on three HIP streams (24 pairs in flight)"}
     eng.run(graph=False, borrow=True, **g0)
     torch.cuda.synchronize()
     lib.prof_enable(True)
