@@ -72,7 +72,7 @@ int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream) {
     return DR_OK;
 }
 
-int dr_version(void) { return 100; /* 0.1.0 */ }
+int dr_version(void) { return DR_ABI_VERSION; /* 0.2.0: the header this library was built from */ }
 
 const char* dr_strerror(int code) {
     switch (code) {

@@ -830,6 +830,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     const bool v4d = cfg->variant == DR_VARIANT_4DMATCH;
     if (v4d && !noise) return DR_EINVAL;
     if ((matches == nullptr) != (match_count == nullptr) || (R_final == nullptr) != (t_final == nullptr)) return DR_EINVAL;
+    if (trace && (trace->force_R == nullptr) != (trace->force_t == nullptr)) return DR_EINVAL;
     if (!workspace || workspace_bytes < dr_denoise_loop_workspace_bytes(cfg, P, N, M)) return DR_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Carver c(workspace, workspace_bytes);
@@ -869,6 +870,8 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     const float* fin = nullptr;
     for (int k = 0; k < cfg->steps; ++k) {
         const int tcur = cfg->h_times[k], tnext = cfg->h_times[k + 1];
+        // teacher forcing (parity tests): this step starts from the caller's state, not from the loop's own
+        if (trace && trace->force_x) DR_HIP_CHECK(hipMemcpyAsync(L.x, trace->force_x + (size_t)k * NM, NM * 8, hipMemcpyDeviceToDevice, st));
         // -- x <- x - x.min() (3D only, pipeline.py:239); mask; Sinkhorn; exp; slice; float32 (pipeline.py:293-302)
         const double* shift = nullptr;
         if (!v4d) {
@@ -880,12 +883,23 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
                           DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
         // -- denoising_soft_procrustes (pipeline.py:304)
+        int* tk = nullptr;
+        if (trace && trace->topk_idx) {
+            const size_t Kf = (size_t)(int)((float)(N > M ? N : M) * cfg->sample_rate);
+            tk = trace->topk_idx + (size_t)k * P * Kf;
+            DR_HIP_CHECK(hipMemsetAsync(tk, 0xff, (size_t)P * Kf * 4, st));
+        }
+        if (trace && trace->wconf) DR_HIP_CHECK(hipMemcpyAsync(trace->wconf + (size_t)k * NM, L.wconf, NM * 4, hipMemcpyDeviceToDevice, st));
         rc = launch_procrustes(L.wconf, s_pcd, t_pcd, src_mask, tgt_mask, P, N, M, (v4d || ragged) ? 1 : 0, cfg->sample_rate,
-                               cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
+                               cfg->max_condition_num, L.R, L.t, L.Rf, L.tf, L.cond, L.ok, tk, st, L.pws, L.pws_bytes);
         if (rc) return rc;
         if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
         if (trace && trace->t_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->t_forwd + (size_t)k * P * 3, L.tf, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
         if (trace && trace->cond) DR_HIP_CHECK(hipMemcpyAsync(trace->cond + (size_t)k * P, L.cond, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+        if (trace && trace->force_R) {           // teacher forcing: warp with the caller's pose (the fit above is traced all the same)
+            DR_HIP_CHECK(hipMemcpyAsync(L.Rf, trace->force_R + (size_t)k * P * 9, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
+            DR_HIP_CHECK(hipMemcpyAsync(L.tf, trace->force_t + (size_t)k * P * 3, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
+        }
         // -- position code of the warped source (pipeline.py:306, transformero.py:165)
         rc = fill_pe(*cfg, *w, P, N, M, s_pcd, L.Rf, L.tf, t_pcd, true, false, L.dw, st);
         if (rc) return rc;
@@ -907,6 +921,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         d.sqrt_an = (float)sqrt(an);
         rc = launch_ddim(d, P, st);
         if (rc) return rc;
+        if (trace && trace->x_next) DR_HIP_CHECK(hipMemcpyAsync(trace->x_next + (size_t)k * NM, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
     }
     if (x_final) DR_HIP_CHECK(hipMemcpyAsync(x_final, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
     if (trace && (trace->feats_nopos || trace->feats_pos) && fin) {

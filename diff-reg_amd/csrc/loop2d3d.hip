@@ -356,6 +356,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
     if (masked != (tgt_mask != nullptr) || masked != (tgt_mask_da != nullptr)) return DR_EINVAL;
     if (cfg->steps > 0 && (!x_T || !t_pcd_da || !cfg->h_alphas_cumprod || !cfg->h_times)) return DR_EINVAL;
     if ((matches == nullptr) != (match_count == nullptr)) return DR_EINVAL;
+    if (trace && (trace->force_R == nullptr) != (trace->force_t == nullptr)) return DR_EINVAL;
     if (!workspace || workspace_bytes < dr_denoise_loop_2d3d_workspace_bytes(cfg, P, N, M)) return DR_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Carver2 c(workspace);
@@ -524,16 +525,29 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
     const double* ac = cfg->h_alphas_cumprod;
     for (int k = 0; k < cfg->steps; ++k) {
         const int tcur = cfg->h_times[k], tnext = cfg->h_times[k + 1];
+        // teacher forcing (parity tests): this step starts from the caller's state, not from the loop's own
+        if (trace && trace->force_x) DR_HIP_CHECK(hipMemcpyAsync(L.x, trace->force_x + (size_t)k * NM, NM * 8, hipMemcpyDeviceToDevice, st));
         // warp from the noisy matrix: masks (src, tgt_da), no min-shift (EXP/model.py:830-846)
         rc = sinkhorn_f64(P, N, M, L.x, nullptr, src_mask, tgt_mask_da, w->bin_score, cfg->sk_iters,
                           DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
         if (rc) return rc;
+        int* tk = nullptr;
+        if (trace && trace->topk_idx) {
+            const size_t Kf = (size_t)(int)((float)(N > M ? N : M) * cfg->sample_rate);
+            tk = trace->topk_idx + (size_t)k * P * Kf;
+            DR_HIP_CHECK(hipMemsetAsync(tk, 0xff, (size_t)P * Kf * 4, st));
+        }
+        if (trace && trace->wconf) DR_HIP_CHECK(hipMemcpyAsync(trace->wconf + (size_t)k * NM, L.wconf, NM * 4, hipMemcpyDeviceToDevice, st));
         rc = launch_procrustes(L.wconf, s_pcd, t_pcd_da, src_mask, tgt_mask_da, P, N, M, 1, cfg->sample_rate, cfg->max_condition_num,
-                               L.R, L.t, L.Rf, L.tf, L.cond, L.ok, nullptr, st, L.pws, L.pws_bytes);
+                               L.R, L.t, L.Rf, L.tf, L.cond, L.ok, tk, st, L.pws, L.pws_bytes);
         if (rc) return rc;
         if (trace && trace->R_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->R_forwd + (size_t)k * P * 9, L.Rf, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
         if (trace && trace->t_forwd) DR_HIP_CHECK(hipMemcpyAsync(trace->t_forwd + (size_t)k * P * 3, L.tf, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
         if (trace && trace->cond) DR_HIP_CHECK(hipMemcpyAsync(trace->cond + (size_t)k * P, L.cond, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+        if (trace && trace->force_R) {           // teacher forcing: warp with the caller's pose (the fit above is traced all the same)
+            DR_HIP_CHECK(hipMemcpyAsync(L.Rf, trace->force_R + (size_t)k * P * 9, (size_t)P * 36, hipMemcpyDeviceToDevice, st));
+            DR_HIP_CHECK(hipMemcpyAsync(L.tf, trace->force_t + (size_t)k * P * 3, (size_t)P * 12, hipMemcpyDeviceToDevice, st));
+        }
         rc = evaluate(L.Rf, L.tf);
         if (rc) return rc;
         if (trace && trace->x0) DR_HIP_CHECK(hipMemcpyAsync(trace->x0 + (size_t)k * NM, L.x0, NM * 4, hipMemcpyDeviceToDevice, st));
@@ -548,6 +562,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
         d.sqrt_an = (float)sqrt(an);
         rc = launch_ddim(d, P, st);
         if (rc) return rc;
+        if (trace && trace->x_next) DR_HIP_CHECK(hipMemcpyAsync(trace->x_next + (size_t)k * NM, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
     }
     if (x_final) DR_HIP_CHECK(hipMemcpyAsync(x_final, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
     // read-out: no min-shift, masks (src, tgt) (EXP/model.py:681-694)

@@ -163,11 +163,18 @@ class DenoiseEngine:
     def _enqueue(self, bufs):
         b = bufs
         tr = None
-        if b.get("trace") or "feats_nopos" in b:
+        if b.get("trace") or "feats_nopos" in b or b.get("force"):
             tr = lib.LoopTrace()
         if b.get("trace"):
             tr.x0, tr.R_forwd, tr.t_forwd, tr.cond = (b["tr_x0"].data_ptr(), b["tr_R"].data_ptr(), b["tr_t"].data_ptr(),
                                                       b["tr_cond"].data_ptr())
+        if b.get("trace") == "full":
+            tr.x_next, tr.topk_idx, tr.wconf = b["tr_xn"].data_ptr(), b["tr_topk"].data_ptr(), b["tr_wconf"].data_ptr()
+        f = b.get("force")
+        if f:
+            tr.force_x = f["x"].data_ptr() if f.get("x") is not None else None
+            if f.get("R") is not None:
+                tr.force_R, tr.force_t = f["R"].data_ptr(), f["t"].data_ptr()
         if "feats_nopos" in b:
             tr.feats_nopos, tr.feats_pos = b["feats_nopos"].data_ptr(), b["feats_pos"].data_ptr()
         lib.check(lib.raw().dr_denoise_loop(
@@ -197,12 +204,15 @@ class DenoiseEngine:
                  R_final=A((P, 3, 3)), t_final=A((P, 3, 1)))
         if trace:
             b.update(tr_x0=A((S, P, N, M)), tr_R=A((S, P, 3, 3)), tr_t=A((S, P, 3, 1)), tr_cond=A((S, P), torch.float64))
+        if trace == "full":
+            K = int(float(torch.tensor(float(max(N, M)), dtype=torch.float32) * self.cfg.sample_rate))
+            b.update(tr_xn=A((S, P, N, M), torch.float64), tr_topk=A((S, P, K), torch.int32), tr_wconf=A((S, P, N, M)))
         if side_outputs:
             b.update(feats_nopos=A((P * (N + M), C)), feats_pos=A((P * (N + M), C)))
         return b
 
     def run(self, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask=None, tgt_mask=None, noise=None, trace=False,
-            graph=False, _slot=0, ragged=False, side_outputs=False, borrow=False):
+            graph=False, _slot=0, ragged=False, side_outputs=False, borrow=False, force=None):
         """Run the loop for P pairs.  Returns a dict of device tensors (conf float64, x_final, matches list (3D),
         R_final, t_final, and the per-step trace when asked).  ragged=True (with masks): the masks are the true extents
         of pairs padded to (N, M) and every pair gets the result of its own unpadded run (DR_LOOP_RAGGED).
@@ -229,6 +239,17 @@ class DenoiseEngine:
             self._graphs.move_to_end(key)
         b = ent["b"]
         self._fill(b, src_feats, tgt_feats, s_pcd, t_pcd, x_T, src_mask, tgt_mask, noise)
+        # teacher forcing (parity tests; dr_loop_trace.force_*): x [steps,P,N,M] float64 = the state entering every step, optional
+        # R [steps,P,3,3] / t [steps,P,3,1] float32 = the pose every step warps with.  trace="full" adds x_next / topk_idx / wconf.
+        b["force"] = None
+        if force is not None:
+            if graph:
+                raise RuntimeError("teacher forcing is a test facility of the eager path")
+            S = self.steps
+            fx = force.get("x")
+            b["force"] = dict(x=None if fx is None else fx.to(self.device, torch.float64).reshape(S, P, N, M).contiguous(),
+                              R=None if force.get("R") is None else force["R"].to(self.device, torch.float32).reshape(S, P, 9).contiguous(),
+                              t=None if force.get("R") is None else force["t"].to(self.device, torch.float32).reshape(S, P, 3).contiguous())
         if graph and ent["g"] is None and ent["uses"] >= 1:
             # second visit of this shape: capture (the earlier eager run was the warm-up)
             torch.cuda.synchronize(self.device)
@@ -260,6 +281,8 @@ class DenoiseEngine:
             out["matches_padded"], out["match_count"] = b["matches"], b["match_count"]
         if b["trace"]:
             out.update(x0=b["tr_x0"], R_forwd=b["tr_R"], t_forwd=b["tr_t"], cond=b["tr_cond"])
+        if b["trace"] == "full":
+            out.update(x_next=b["tr_xn"], topk_idx=b["tr_topk"], wconf=b["tr_wconf"])
         if "feats_nopos" in b:
             P, N, M, C = b["P"], b["N"], b["M"], self.C
             for name, t_ in (("nopos", b["feats_nopos"]), ("pos", b["feats_pos"])):
@@ -408,7 +431,7 @@ class DenoiseEngine2D3D:
             self._cfgs[steps] = (cfg, times)
         return self._cfgs[steps][0]
 
-    def _call(self, steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace):
+    def _call(self, steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace, force=None):
         P, M, _ = img_feats.shape
         N = pcd_feats.shape[1]
         cfg = self._cfg(steps)
@@ -430,6 +453,21 @@ class DenoiseEngine2D3D:
                        t_forwd=torch.empty(steps, P, 3, 1, device=dev), cond=torch.empty(steps, P, dtype=torch.float64, device=dev))
             tr = lib.LoopTrace()
             tr.x0, tr.R_forwd, tr.t_forwd, tr.cond = (trb[k].data_ptr() for k in ("x0", "R_forwd", "t_forwd", "cond"))
+            if trace == "full":
+                K = int(float(torch.tensor(float(max(N, M)), dtype=torch.float32) * self._base["sample_rate"]))
+                trb.update(x_next=torch.empty(steps, P, N, M, dtype=torch.float64, device=dev),
+                           topk_idx=torch.empty(steps, P, K, dtype=torch.int32, device=dev), wconf=torch.empty(steps, P, N, M, device=dev))
+                tr.x_next, tr.topk_idx, tr.wconf = (trb[k].data_ptr() for k in ("x_next", "topk_idx", "wconf"))
+        keep = []
+        if force is not None and steps > 0:            # teacher forcing (parity tests; dr_loop_trace.force_*)
+            tr = tr or lib.LoopTrace()
+            if force.get("x") is not None:
+                keep.append(force["x"].to(dev, torch.float64).reshape(steps, P, N, M).contiguous())
+                tr.force_x = keep[-1].data_ptr()
+            if force.get("R") is not None:
+                keep.append(force["R"].to(dev, torch.float32).reshape(steps, P, 9).contiguous())
+                keep.append(force["t"].to(dev, torch.float32).reshape(steps, P, 3).contiguous())
+                tr.force_R, tr.force_t = keep[-2].data_ptr(), keep[-1].data_ptr()
         lib.check(lib.raw().dr_denoise_loop_2d3d(
             ctypes.byref(cfg), ctypes.byref(self.w), P, N, M, lib.ptr(c(img_feats)), lib.ptr(c(img_dino)), lib.ptr(c(img_pixels)),
             lib.ptr(c(pcd_feats)), lib.ptr(c(s_pcd)), lib.ptr(c(t_pcd_da)), lib.ptr(sm), lib.ptr(tm), lib.ptr(tmd), lib.ptr(c(x_T)),
@@ -437,6 +475,8 @@ class DenoiseEngine2D3D:
             ctypes.byref(tr) if tr is not None else None, lib.ptr(self._ws), need, lib.stream_of(img_feats)))
         out = dict(conf_matrix_pred=conf, x_final=xf, matches_padded=matches, match_count=cnt, img_feats=img_out, pcd_feats=pcd_out)
         out.update(trb)
+        if keep:
+            out["_forced_inputs"] = keep          # (alive until the caller drops the result: the call is asynchronous)
         return out
 
     def fuse_and_match(self, img_feats, img_dino, img_pixels, pcd_feats, pcd_points, masks=None):
@@ -444,8 +484,10 @@ class DenoiseEngine2D3D:
         o = self._call(0, img_feats, img_dino, img_pixels, pcd_feats, pcd_points, None, masks, None, False)
         return o["img_feats"], o["pcd_feats"], o["conf_matrix_pred"].float()
 
-    def run(self, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, x_T, masks=None, trace=False):
-        return self._call(self.steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace)
+    def run(self, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, x_T, masks=None, trace=False, force=None):
+        """trace=True: per-step x0 / R_forwd / t_forwd / cond; trace="full" adds x_next / topk_idx / wconf; force = dict(x=[steps,P,N,M],
+        R=[steps,P,3,3], t=[steps,P,3,1]): teacher forcing for the parity tests (dr_loop_trace.force_*)."""
+        return self._call(self.steps, img_feats, img_dino, img_pixels, pcd_feats, s_pcd, t_pcd_da, masks, x_T, trace, force)
 
     # ------------------------------------------------------------------------------------------
     _ARGS = ("img_feats", "img_dino", "img_pixels", "pcd_feats", "s_pcd", "t_pcd_da", "x_T")

@@ -84,8 +84,10 @@ class Loop2D3DConfig(ctypes.Structure):
 
 
 class LoopTrace(ctypes.Structure):
+    """dr_loop_trace: per-step records and (ABI 0.2.0) the teacher-forcing inputs / outputs of the parity tests"""
     _fields_ = [("x0", c_void_p), ("R_forwd", c_void_p), ("t_forwd", c_void_p), ("cond", c_void_p), ("feats_nopos", c_void_p),
-                ("feats_pos", c_void_p)]
+                ("feats_pos", c_void_p), ("force_x", c_void_p), ("force_R", c_void_p), ("force_t", c_void_p), ("x_next", c_void_p),
+                ("topk_idx", c_void_p), ("wconf", c_void_p)]
 
 
 _P = ctypes.POINTER
@@ -209,6 +211,11 @@ def _bind(table):
 
 _bind(SIGNATURES)
 _INIT_DONE = False
+
+ABI_VERSION = 200          # DR_ABI_VERSION of the include/diffreg_hip.h these signatures were written against
+if _lib.dr_version() // 100 != ABI_VERSION // 100:
+    raise ImportError("libdiffreg_hip.so is ABI %d, this binding is written against %d: rebuild (make -C diff-reg_amd/csrc)"
+                      % (_lib.dr_version(), ABI_VERSION))
 
 
 def ensure_init():

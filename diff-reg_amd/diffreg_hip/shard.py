@@ -13,12 +13,18 @@ def shard_pairs(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
+def _group_active():
+    """a process group exists: the collectives below then always run through it -- also with ONE rank (`bench.py --dist-single-rank`,
+    tests/test_rccl_gpu.py: the only way a box with one GPU can push this module through RCCL at all)"""
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_metrics(local_sums, device=None):
     """all_reduce(SUM) of a 1-D float64 vector of per-rank sums; returns the global sums (on every rank)."""
     v = torch.as_tensor(local_sums, dtype=torch.float64)
     if device is not None:
         v = v.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_active():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return v
 
@@ -27,7 +33,7 @@ def max_over_ranks(x, device=None):
     v = torch.tensor([float(x)], dtype=torch.float64)
     if device is not None:
         v = v.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_active():
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
     return float(v.item())
 
@@ -37,7 +43,7 @@ def gather_per_rank(x, device=None):
     v = torch.tensor([float(x)], dtype=torch.float64)
     if device is not None:
         v = v.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_active():
         out = [torch.zeros_like(v) for _ in range(dist.get_world_size())]
         dist.all_gather(out, v)
         return [float(o.item()) for o in out]

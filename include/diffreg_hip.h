@@ -31,6 +31,12 @@ extern "C" {
 #define DR_EWORKSPACE (-4) /* workspace too small                                           */
 #define DR_ETIMEOUT (-5) /* a kernel gave up waiting for another workgroup (dr_device_status) */
 
+/* ABI version of THIS header.  dr_version() returns the library's; a binding must refuse to run when they differ in major or
+ * minor (the Python mirror does, diffreg_hip/lib.py).  History of breaks:
+ *   0.2.0  dr_loop_trace grew the teacher-forcing fields (a 0.1.0 caller's struct is too short); dr_procrustes_f32 and
+ *          dr_top1_union_f32 / _f64 take (workspace, workspace_bytes) in front of `stream` since the last 0.1.0 builds -- a caller
+ *          compiled against the header without them passes its stream in the workspace slot. */
+#define DR_ABI_VERSION 200
 int dr_version(void);                 /* major*10000 + minor*100 + patch */
 const char* dr_strerror(int code);
 const char* dr_last_hip_error(void);  /* text of the last failing HIP call on this thread */
@@ -384,6 +390,22 @@ typedef struct {                /* all optional (NULL to skip); per-step records
      * [P*N + P*M, C] (all src rows, then all tgt rows): src_proj(feats) and its rotary-embedded form (before the 1/sqrt(C)) */
     float* feats_nopos;
     float* feats_pos;
+    /* ---- ABI 0.2.0: teacher forcing, for per-step parity tests (tests/test_teacher_forced_gpu.py).  Every step of the loop is then an
+     * independent evaluation of one pass through pipeline.py:237-256 (EXP/model.py:637-680) on a state the CALLER supplies, so a top-K
+     * near-tie at one step cannot hide the steps behind it.  All optional; a struct zero-filled beyond `feats_pos` behaves like 0.1.0's.
+     * force_x   [steps,P,N,M] float64: the state ENTERING step k is force_x[k] instead of the loop's own (step 0: x_T widened; x_T is ignored).
+     * force_R / force_t [steps,P,9] / [steps,P,3] (both or neither): the warp of step k is this pose instead of the fit's R_forwd, t_forwd
+     *           (the fit still runs and is still traced: R_forwd / t_forwd / cond / topk_idx are the loop's own).
+     * x_next    [steps,P,N,M] float64: the state after step k's update (what the loop would carry into step k + 1).
+     * topk_idx  [steps,P,K] int32, K = int(max(N,M) * sample_rate): flat indices i * M + j of the entries the fit of step k selected, in arrival
+     *           order (a set); slots beyond a pair's own K (mask-length rule) keep -1.
+     * wconf     [steps,P,N,M] float32: the warp confidences of step k, float32(exp(Z)[:N,:M]) of pipeline.py:299-302. */
+    const double* force_x;
+    const float* force_R;
+    const float* force_t;
+    double* x_next;
+    int32_t* topk_idx;
+    float* wconf;
 } dr_loop_trace;
 
 size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, int M);

@@ -50,6 +50,13 @@ def assert_match_list_is_the_references(got, g, conf_err):
     return len(und_r), len(und_c)
 
 
+def ref_match_list_2d3d(g, conf=None):
+    """the 2D-3D fixtures store the reference's match list as match_i / match_j (+ the full conf for the small scenes; the cfg5-size ones are
+    compact, so the caller supplies the matrix the arg-maxima's decidedness is judged on) -> the mapping assert_match_list_is_the_references reads"""
+    mi, mj = np.asarray(g["match_i"]), np.asarray(g["match_j"])
+    return {"match_pred": np.stack([np.zeros_like(mi), mi, mj], 1), "conf": np.asarray(g["conf"] if conf is None else conf)}
+
+
 def masks(N, M, nv=None, mv=None):
     nv = N if nv is None else nv
     mv = M if mv is None else mv

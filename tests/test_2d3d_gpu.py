@@ -10,7 +10,7 @@ import torch
 
 from diffreg_hip import synth
 from oracle import diffreg_oracle as orc
-from tests.helpers import T, masks
+from tests.helpers import T, masks, assert_match_list_is_the_references, ref_match_list_2d3d
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -40,8 +40,8 @@ def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, 
     d = lambda k: q(k).to(DEV)
     # one fusion + matching evaluation on the un-warped points
     f_img, f_pcd, c0 = eng.fuse_and_match(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), dmask)
-    assert np.abs(f_img[0].cpu().numpy() - g["f_img0"]).max() < 2e-4
-    assert np.abs(f_pcd[0].cpu().numpy() - g["f_pcd0"]).max() < 2e-4
+    assert np.abs(f_img[0].cpu().numpy() - g["f_img0"]).max() < 1e-4
+    assert np.abs(f_pcd[0].cpu().numpy() - g["f_pcd0"]).max() < 1e-4
     assert np.abs(c0[0].cpu().numpy() - g["conf0"]).max() < 1e-4
     # the loop
     out = eng.run(d("img_feats"), d("img_dino"), d("img_pixels"), d("pcd_feats"), d("s_pcd"), d("t_pcd_da"), d("x_T"), dmask, trace=True)
@@ -54,9 +54,13 @@ def test_2d3d_against_reference_vectors(golden, N, M, nv, mv, mv_da, steps, mc, 
     assert np.abs(conf - g["conf"]).max() <= 1e-4
     rel = np.abs(conf - g["conf"]) / np.maximum(g["conf"], 1e-9)
     assert rel[g["conf"] > 1e-6].max() < 5e-3
-    # read-out = top-1 union of the library's own conf (bit-exact index work)
+    np.testing.assert_allclose(out["cond"][:, 0].cpu().numpy(), g["cond"], rtol=1e-4)
+    # read-out (vision3d/ops/mutual_topk_select.py:7-60, k = 1, mutual = False): the REFERENCE's list, exactly, up to undecided arg-maxima (the
+    # all-zero rows / columns of the padding masks are exact ties) -- and the top-1 union of the library's own conf (bit-exact index work)
     cnt = int(out["match_count"][0])
-    got = set(map(tuple, out["matches_padded"][0, :cnt, 1:].cpu().tolist()))
+    got3 = set(map(tuple, out["matches_padded"][0, :cnt].cpu().tolist()))
+    assert_match_list_is_the_references(got3, ref_match_list_2d3d(g), float(np.abs(conf - g["conf"]).max()))
+    got = set((i, j) for _, i, j in got3)
     assert got == set(map(tuple, orc.top1_union(out["conf_matrix_pred"][0].cpu())[:, 1:].tolist()))
 
 
@@ -154,6 +158,12 @@ def test_cfg5_identity_warp_against_reference_and_oracle(golden, planes):
     cfg5_compact_checks(g, out["x0"][-1, 0].cpu().numpy(), out["conf_matrix_pred"][0].cpu().numpy(), out["R_forwd"][:, 0].cpu().numpy(),
                         out["t_forwd"][:, 0].cpu().numpy(), out["cond"][:, 0].cpu().tolist())
     assert np.abs(out["x0"][:, 0, :16, :16].cpu().numpy() - g["x0_corner"]).max() <= 1e-4
+    # match_pred against the REFERENCE's list at cfg5's size (the fixture is compact: decidedness of an arg-maximum is judged on the device's
+    # conf, the deviation on the fixture's every-8th-entry sub-matrix)
+    conf_dev = out["conf_matrix_pred"][0].cpu().numpy()
+    cnt = int(out["match_count"][0])
+    got3 = set(map(tuple, out["matches_padded"][0, :cnt].cpu().tolist()))
+    assert_match_list_is_the_references(got3, ref_match_list_2d3d(g, conf_dev), float(np.abs(conf_dev[::8, ::8] - g["conf_sub"]).max()))
     tr = []
     ref = orc.denoise_loop_2d3d(W, synth.VARIANTS["2d3d"], q("img_feats"), q("img_dino"), q("img_pixels"), q("pcd_feats"), q("s_pcd"),
                                 q("t_pcd_da"), ms, mt, mt_da, q("x_T"), steps, mc, trace=tr)
@@ -188,7 +198,7 @@ def test_cfg5_warp_fed_back_against_the_reference(golden, planes):
             break
         np.testing.assert_allclose(out["R_forwd"][k, 0].cpu().numpy(), g["R_forwd"][k], atol=1e-4)
         np.testing.assert_allclose(out["t_forwd"][k, 0].cpu().numpy(), g["t_forwd"][k], atol=1e-4)
-        np.testing.assert_allclose(float(out["cond"][k, 0]), g["cond"][k], rtol=2e-3)
+        np.testing.assert_allclose(float(out["cond"][k, 0]), g["cond"][k], rtol=1e-4 if g["kth_gap_rel"][k] > 1e-5 else 2e-3)
         assert np.abs(out["x0"][k, 0, :16, :16].cpu().numpy() - g["x0_corner"][k]).max() <= 1e-4
         held += 1
     assert held >= 1

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_header():
     from diffreg_hip import lib
     assert sorted(lib.SIGNATURES) == declared_symbols()
-    assert lib.raw().dr_version() >= 100
+    assert lib.raw().dr_version() == lib.ABI_VERSION
     assert lib.raw().dr_strerror(-1) == b"invalid argument"
 
 

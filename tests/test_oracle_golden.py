@@ -199,9 +199,11 @@ def test_2d3d_loop_matches_reference(golden, N, M, nv, mv, mv_da, steps, mc, see
     np.testing.assert_allclose(torch.stack([r["t_forwd"][0] for r in trace]).numpy(), g["t_forwd"], atol=1e-4)
     np.testing.assert_allclose(trace[-1]["x0"][0].numpy(), g["x0_last"], atol=1e-4)
     np.testing.assert_allclose(out["conf_matrix_pred"][0].numpy(), g["conf"], atol=1e-5, rtol=1e-3)
-    got = set(map(tuple, out["match_pred"][:, 1:].tolist()))
-    want = set(zip(g["match_i"].tolist(), g["match_j"].tolist()))
-    assert len(got ^ want) <= 0.05 * len(want)
+    # match_pred against the reference's list (vision3d/ops/mutual_topk_select.py:7-60 with k = 1, no threshold, mutual = False): index work,
+    # compared exactly up to undecided arg-maxima (tests/helpers.py)
+    from tests.helpers import assert_match_list_is_the_references, ref_match_list_2d3d
+    got = set(map(tuple, out["match_pred"].tolist()))
+    assert_match_list_is_the_references(got, ref_match_list_2d3d(g), float(np.abs(out["conf_matrix_pred"][0].numpy() - g["conf"]).max()))
 
 
 def cfg5_compact_checks(g, x0_last, conf, R_forwd, t_forwd, cond, atol_x0=1e-4):
