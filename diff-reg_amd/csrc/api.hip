@@ -81,7 +81,7 @@ const char* dr_strerror(int code) {
         case DR_ELAUNCH: return "HIP call failed";
         case DR_ENOSUP: return "shape not supported by this build";
         case DR_EWORKSPACE: return "workspace missing or too small";
-        case DR_ETIMEOUT: return "a kernel gave up waiting for a workgroup that was not resident (outputs of that call are NaN)";
+        case DR_ETIMEOUT: return "a kernel gave up waiting for a workgroup that was not resident (outputs of that call are unspecified: NaN where the waiting workgroup wrote)";
         default: return "unknown error";
     }
 }

@@ -1378,7 +1378,27 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         if (t == 0) __hip_atomic_store(flagA + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad);
         __syncthreads();
-        // this workgroup's slice: column sums over the G partials; thread = partial (G <= 256 per pass), two float4 groups per
+        // this workgroup's slice: column sums over the G partials
+        if constexpr (RW * RPW >= 32) {
+            // few partials per tile (G <= 32: the batch form, a workgroup owns 32 rows): a HALF-WAVE per float4 group, lane = partial,
+            // NT / 32 groups per round trip, summed by a fixed half-wave butterfly (bit-reproducible), no workgroup barrier inside
+            const int hw = t >> 5, l32 = t & 31;
+            for (int gq = g0 + hw; gq < g1; gq += NT / 32) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (l32 < G) {
+                    sk_v4f y;
+                    const float* pq = P + (size_t)l32 * M4 + 4 * gq;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(y) : "v"(pq) : "memory");
+                    x = make_float4(y.x, y.y, y.z, y.w);
+                }
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) {
+                    x.x += __shfl_xor(x.x, m); x.y += __shfl_xor(x.y, m); x.z += __shfl_xor(x.z, m); x.w += __shfl_xor(x.w, m);
+                }
+                if (l32 == 0) sk_st_sc1(cb + 4 * gq, x);
+            }
+        } else
+        // thread = partial (G <= 256 per pass), two float4 groups per
         // round trip; lanes are summed by the butterfly, the 4 waves in fixed order: bit-reproducible
         for (int gq = g0; gq < g1; gq += 2) {
             float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
@@ -1517,7 +1537,47 @@ static int coop_rows_per_wave(int B, int N, int M, int flags) {
         (long)B * ((N + 2 * SK_COOP_RW - 1) / (2 * SK_COOP_RW)) <= (long)coop_blocks_per_cu(vpl, 2) * n_cu / SK_COOP_SHARE) return 2;
     return 0;
 }
-static bool coop_path(int B, int N, int M, int flags) { return coop_rows_per_wave(B, N, M, flags) != 0; }
+// The BATCH form of the co-resident kernel (round 5; cfg5's 8 x 1024 x 2048 per call): the register files of the chip hold the exponentials of
+// the whole batch.  A wave keeps EIGHT rows (256 registers of E at 2 048 columns), a workgroup is 4 waves -- one per SIMD, one workgroup per CU
+// at ~330 registers -- so 32 rows per CU and 8 192 rows on the chip: 8 tiles of 1 024 rows exactly.  One launch instead of 2 iters + 1, E never
+// touches memory, a tile's column sums cross its 32 workgroups once per iteration (two hops).  Residency: the synchronisation domain is ONE
+// TILE (its N / 32 workgroups, consecutive block indices), not the launch: a launch that fits the chip alone is always safe, and beside other
+// launches (the engine's concurrent calls) every fully resident tile finishes by itself and hands its CUs on, so at most the frontier tile
+// of each launch is ever waiting for CUs -- with the in-order dispatch of a queue that cannot deadlock; the spins stay bounded all the same
+// (DR_ETIMEOUT instead of a hang if the hardware ever dispatched out of order).
+constexpr int SK_BATCH_RW = 4, SK_BATCH_RPW = 8;
+static size_t coop_batch_lds_bytes(int vpl) { return ((size_t)SK_BATCH_RW * (vpl * 256 + 4) + 8 * SK_BATCH_RW + 8) * sizeof(float); }
+// (two instantiations per type pair: 4 or 8 float4 groups per lane and row.  A 6-group one -- 1 025 .. 1 536 columns -- faulted on the device
+//  for M < 1 536 in the first hardware run and was dropped unexplained: such tiles take the 8-group kernel with idle lanes)
+static int coop_batch_vpl(int M) { return M <= 1024 ? 4 : 8; }
+static bool coop_batch_path(int B, int N, int M, int flags) {
+    if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return false;
+    if (M > 2048 || M <= 768 || !env_knob("DR_SK_COOP", 1) || !env_knob("DR_SK_BATCH", 1)) return false;
+    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const long G = (N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW);
+    return G <= 32 && (long)B * G <= n_cu;
+}
+static bool coop_path(int B, int N, int M, int flags) { return coop_rows_per_wave(B, N, M, flags) != 0 || coop_batch_path(B, N, M, flags); }
+
+template <typename TIn, typename TOut>
+static int launch_coop_batch(const SkArgs& a, hipStream_t st) {
+    const int G = (a.N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW), vpl = coop_batch_vpl(a.M);
+    const size_t tf = sk_coop_tile_floats(a.N, a.M);
+    for (int b = 0; b < a.B; ++b)
+        DR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<float*>(a.ws) + (size_t)b * tf + (size_t)(G + 1) * sk_coop_m4(a.M), 0,
+                                    (2 * (size_t)sk_coop_g64(a.N) + 64) * 4, st));
+    const dim3 grid(G, a.B), blk(64 * SK_BATCH_RW);
+    const size_t lds = coop_batch_lds_bytes(vpl);
+#define SK_BATCH_LAUNCH(V)                                                                                                                   \
+    {                                                                                                                                        \
+        if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>), grid, blk, lds, st, a);                               \
+    }
+    if (vpl == 4) SK_BATCH_LAUNCH(4) else SK_BATCH_LAUNCH(8)
+#undef SK_BATCH_LAUNCH
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
 
 template <typename TIn, typename TOut>
 static int launch_coop(const SkArgs& a, hipStream_t st) {
@@ -1668,9 +1728,13 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
     const size_t need = sk_workspace_need(B, N, M, strict64 ? 8 : 4, flags, iters);
     if (!ws || ws_bytes < need) return DR_EWORKSPACE;
     a.vec_in = a.vec_out = 0;
-    if (coop_path(B, N, M, flags)) {
+    if (coop_rows_per_wave(B, N, M, flags) != 0) {
         if (out32) return launch_coop<TIn, float>(a, st);
         return launch_coop<TIn, double>(a, st);
+    }
+    if (coop_batch_path(B, N, M, flags)) {
+        if (out32) return launch_coop_batch<TIn, float>(a, st);
+        return launch_coop_batch<TIn, double>(a, st);
     }
     if (grid_path(N, M, flags)) {
         if (strict64) {

@@ -247,7 +247,8 @@ def check(code):
 
 def device_status(device=None, clear=True):
     """Waits for the current stream of `device` and raises if a kernel reported a device-side failure since the last check
-    (DR_ETIMEOUT: the single-launch Sinkhorn gave up waiting for a workgroup that was not resident; its outputs are NaN).
+    (DR_ETIMEOUT: the single-launch Sinkhorn gave up waiting for a workgroup that was not resident; the outputs of that call are
+    unspecified -- the flag is process-wide and sticky: the first reader with clear=True consumes it).
     Called wherever the host mirrors synchronise anyway (match counts)."""
     st = torch.cuda.current_stream(device).cuda_stream
     check(_lib.dr_device_status(c_void_p(st), 1 if clear else 0))

@@ -44,7 +44,9 @@ const char* dr_last_hip_error(void);  /* text of the last failing HIP call on th
 /* Device-side failures.  Every call above returns when its kernels are ENQUEUED, so a failure that only a running kernel can
  * detect cannot come back as a return value.  There is one such failure: the single-launch Sinkhorn of tiles beyond 256 x 256
  * exchanges column sums between workgroups that must all be resident; its spins are bounded, and a workgroup that gives up
- * writes NaN to every output entry it owns (the failure is visible in the data) and sets a sticky flag on the device.
+ * writes NaN to every output entry it owns and sets a sticky, process-wide flag on the device.  The outputs of such a call are
+ * UNSPECIFIED as a whole: a sibling workgroup that was scheduled late may have summed partials of peers that had moved on and
+ * written finite but wrong values -- the flag, not the data, is the signal; whoever reads it first (with `clear`) consumes it.
  * dr_device_status is the ONE entry point that synchronises: it waits for `stream`, reads the flag (clearing it when `clear`
  * is non-zero) and returns DR_OK or DR_ETIMEOUT.  The host mirrors call it wherever they already synchronise to read a match
  * count.  (The launcher checks residency with the occupancy API and takes the multi-launch form when the launch would not

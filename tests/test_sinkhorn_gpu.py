@@ -88,6 +88,48 @@ def test_batched_large_tiles_coresident(B, N, M, nv, mv, dt):
         assert re_ < 2e-5 and ae < 1e-6, (b, ae, re_)
 
 
+@pytest.mark.parametrize("B,N,M,nv,mv", [(8, 1024, 2048, 1000, 2000), (5, 1000, 1530, 1000, 1530), (7, 1024, 1000, 1024, 990), (3, 997, 2047, 900, 2047),
+                                         (8, 1024, 1280, 1024, 1280), (5, 1024, 1532, 1024, 1532), (16, 512, 800, 512, 800)])
+@pytest.mark.parametrize("dt,out_f32", [("f32", False), ("f64", True), ("f64", False)])
+def test_batch_form_keeps_the_whole_batch_in_registers(B, N, M, nv, mv, dt, out_f32):
+    """The BATCH form of the co-resident Sinkhorn (round 5; cfg5's 8 x 1024 x 2048 per call, real 2D-3D sizes 1 000 x 1 530, odd extents): a wave
+    keeps eight rows of exponentials in registers, a workgroup = 32 rows = one CU, a tile's column sums cross its <= 32 workgroups once per
+    iteration; one launch.  Every tile is held to the oracle on its own scores (different masks per tile), the three type pairs the loops use
+    (head: f32 -> f32; state: f64 -> f32 warp confidences; read-out: f64 -> f64), and two launches give the same bits."""
+    from diffreg_hip import lib
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    a = torch.tensor(1.0)
+    raw = torch.cat([T(3.0 * synth.hash_normal(17 + b, N * 1000 + M, (1, N, M))) for b in range(B)]).to(tdt)
+    sm = torch.arange(N)[None].expand(B, N) < torch.tensor([nv - 3 * b for b in range(B)])[:, None]
+    tm = torch.arange(M)[None].expand(B, M) < torch.tensor([mv - 5 * b for b in range(B)])[:, None]
+    x = raw.to(DEV)
+    from tests.helpers import guarded
+    odt = torch.float32 if (dt == "f32" or out_f32) else torch.float64
+    gout, check = guarded((B, N, M), odt, DEV)                    # the output between two 64 KiB guard bands
+    got = lib.sinkhorn(x, a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True, out_f32=out_f32, out=gout).clone()
+    check()
+    assert got.dtype == odt and got.shape == (B, N, M)
+    again = lib.sinkhorn(x, a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True, out_f32=out_f32)
+    assert torch.equal(got, again)
+    lib.device_status(DEV)
+    for b in sorted(set((0, B // 2, B - 1))):
+        sc = raw[b:b + 1].masked_fill(~(sm[b][None, :, None] & tm[b][None, None, :]), float("-inf"))
+        ref = orc.sinkhorn_log(sc, a, 3, sm[b:b + 1], tm[b:b + 1]).exp()[:, :-1, :-1]
+        ae, re_ = rel_err(got[b:b + 1], ref)
+        assert re_ < 2e-5 and ae < 1e-6, (b, ae, re_)
+    # the multi-launch grid form (the path of batches that do not fit the chip) agrees with it to rounding
+    lib.raw().dr_debug_enable_env(1)
+    import os
+    os.environ["DR_SK_BATCH"] = "0"
+    try:
+        grid = lib.sinkhorn(x, a.to(DEV), 3, sm.to(DEV), tm.to(DEV), apply_mask=True, out_f32=out_f32)
+    finally:
+        os.environ.pop("DR_SK_BATCH")
+        lib.raw().dr_debug_enable_env(1 if os.environ.get("DR_DIAGNOSTICS") == "1" else 0)
+    big = grid.double() > 1e-12
+    assert ((got.double() - grid.double()).abs() / grid.double().clamp_min(1e-30))[big].max().item() < 2e-5
+
+
 def test_minshift_and_batch_of_different_masks():
     from diffreg_hip import lib
     B, N, M = 5, 256, 256

@@ -1,6 +1,6 @@
 """A few launches of the attention layer at a batch that selects the 128-query kernels: target of rocprofv3 --pmc runs."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib, synth
 lib.ensure_init()
 P, L, C, H = int(os.environ.get("P", "64")), 256, 432, 4

@@ -1,7 +1,7 @@
 """Time dr_attention_planes alone (HIP events, images built once) at loop shapes: cfg2 (128 pairs x 2 sides, 256 x 256, d 108), cfg3 (8 pairs,
 512 x 512, d 132), cfg5 self / cross segments (2048 / 1024 keys, d 64).  TFLOP/s = 4 L S C per segment / time (fp32-equivalent)."""
 import json, os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = "cuda:0"

@@ -1,6 +1,6 @@
 """One pair (B = 1, N = M = 256, 20 steps) through the engine: a few graph replays -- the target of rocprofv3 --kernel-trace --stats"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd")); sys.path.insert(0, ROOT)
 import torch
 from diffreg_hip import synth

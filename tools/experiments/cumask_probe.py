@@ -1,7 +1,7 @@
 """Probe (not in the product): hipExtStreamCreateWithCUMask on MI355X -- which mask bit is which XCC / CU, and what the plane GEMM launches cost
 when the chip is split between independent streams (each on its own CUs, de-phased) instead of one stream on all of it."""
 import os, sys, ctypes, collections, json, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

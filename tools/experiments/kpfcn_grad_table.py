@@ -1,7 +1,7 @@
 """per-tensor deviation of the device backbone gradients from the reference backbone's (tests/golden/kpfcn_coarse.npz)"""
 import importlib.util, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "diff-reg_amd"), ROOT):
     sys.path.insert(0, p)
 from diffreg_hip import synth

@@ -1,7 +1,7 @@
 """GPU check + timing of the plane-image GEMM (dr_linear_planes_f32) against an fp64 product.
     python tools/pgemm_check.py [rows]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
 import torch
 from diffreg_hip import lib

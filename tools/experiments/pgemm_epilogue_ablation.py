@@ -2,7 +2,7 @@
 epilogue of each layer GEMM shape costs per launch at 65 536 rows, and which of its memory streams it is.  Results are wrong by construction; only times matter."""
 import os, sys, torch
 os.environ["DR_DIAGNOSTICS"] = "1"; os.environ["DR_PG_HALF"] = "0"
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """One shape of the plane-image GEMM, a few launches: the target of rocprofv3 --pmc / --kernel-trace runs.
    MODE = f32 | ln | mlp0 | mlp2   ROWS (default 32768)   N launches (default 10)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 is not in the library.)"""
 import os, sys, torch
 os.environ["DR_DIAGNOSTICS"] = "1"; os.environ["DR_PG_HALF"] = "0"; os.environ["DR_PG_NOEPI"] = "1"
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

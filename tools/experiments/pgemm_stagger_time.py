@@ -2,7 +2,7 @@
 runs epilogues.  Launch times of the four layer GEMM shapes at 65 536 / 131 072 rows."""
 import os, sys, torch
 os.environ["DR_DIAGNOSTICS"] = "1"; os.environ["DR_PG_HALF"] = "0"
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

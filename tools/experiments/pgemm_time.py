@@ -1,6 +1,6 @@
 """time per launch of the four layer GEMM shapes of the plane path at ROWS rows (HIP events; DR_DIAGNOSTICS=1 DR_PG_HALF=0 selects the 128-row geometry)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

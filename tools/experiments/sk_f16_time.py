@@ -1,6 +1,6 @@
 """dr_sinkhorn_f16 against dr_sinkhorn_f32 at the headline's size (B tiles of 256 x 256, 3 iterations): us per call and algorithmic GB/s (HIP events)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Time the multi-launch (grid) Sinkhorn on batches of large tiles (the batched 2D-3D loop: 8 x 1024 x 2048), vector vs scalar accesses."""
 import json, os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 lib.ensure_init()
 res = []

@@ -2,7 +2,7 @@
 cfg5: 1 x 1024 x 2048 (2D-3D), cfg3: 8 x 512 x 512 (4DMatch), a real 3DMatch pair: 1 x 564 x 629.  Writes gpurun_out/r03_sinkhorn_large_tiles.json."""
 import json, os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diff-reg_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
 from diffreg_hip import lib
 
 dev = "cuda:0"

@@ -1,6 +1,6 @@
 """throughput of k concurrent batches (one graph each) on k HIP streams vs one big batch"""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd")); sys.path.insert(0, ROOT)
 import bench
 dev = torch.device("cuda:0")
