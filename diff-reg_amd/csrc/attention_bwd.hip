@@ -241,12 +241,14 @@ template <int DT, int NW>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     const size_t lds = bwd_lds<DT, NW>(a.d);
     if (lds > 160 * 1024) return DR_ENOSUP;
-    static bool done = false;
-    if (!done) {
+    // raise the dynamic-LDS limit whenever this launch needs more than the largest size set so far for this instantiation (a later call with a
+    // larger head dim inside the same DT bucket needs more than the first one did; as in sinkhorn.hip the attribute follows the need)
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kernel<DT, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kernel<DT, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kernel<DT, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
+        lds_set = lds;
     }
     const dim3 blk(64 * NW), gq((a.L + 31) / 32, a.H, a.B), gk((a.S + 31) / 32, a.H, a.B);
     hipLaunchKernelGGL((attn_bwd_kernel<DT, NW, 0>), gq, blk, lds, st, a);

@@ -297,22 +297,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
     const float* a1 = pA + (size_t)ar * P.lda;
     const float* a2 = pA2 ? pA2 + (size_t)ar * P.lda2 - K1 : a1;
     const float* bw = pW + (size_t)bc * K;
-    // LayerNorm folded into the A2 operand (round 5: the single-pair chain loses its 181 LayerNorm1 launches): the row's statistics from the
-    // producer's per-tile partials, gamma | beta staged in LDS (the reduction buffer is free until the MFMAs are done).  These loads are issued
-    // FIRST, so that the counted wait below does not cover the fragment loads behind them.
-    const bool ln = P.ln_stats != nullptr;
-    const int lnC = K - K1, lnT = (lnC + 31) >> 5;
-    constexpr int LNT_MAX = 18;                                 // <= 576 normalised columns
-    float2 st2[LNT_MAX];
-    float lg0 = 0.f, lg1 = 0.f, lb0 = 0.f, lb1 = 0.f;
-    if (ln) {
-        const float2* sp = reinterpret_cast<const float2*>(P.ln_stats) + (size_t)ar * lnT;
-#pragma unroll
-        for (int q = 0; q < LNT_MAX; ++q) st2[q] = q < lnT ? sp[q] : make_float2(0.f, 0.f);
-        if (t < lnC) { lg0 = P.ln_gamma[t]; lb0 = P.ln_beta[t]; }
-        if (NW * 64 < 576 && t + NW * 64 < lnC) { lg1 = P.ln_gamma[t + NW * 64]; lb1 = P.ln_beta[t + NW * 64]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
     float4 fa[MAXG], fb[MAXG];
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) {
@@ -322,23 +306,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
         fb[i] = *reinterpret_cast<const float4*>(bw + kc);
     }
     __builtin_amdgcn_sched_barrier(0);                          // every load is issued before the first MFMA waits for one
-    float ln_mean = 0.f, ln_rstd = 1.f;
-    if (ln) {
-        if (t < lnC) { red[t] = lg0; red[576 + t] = lb0; }
-        if (NW * 64 < 576 && t + NW * 64 < lnC) { red[t + NW * 64] = lg1; red[576 + t + NW * 64] = lb1; }
-        // Chan: mean = sum n_t mean_t / C, M2 = sum (M2_t + n_t (mean_t - mean)^2); every tile has 32 columns but the last
-        float sm = 0.f;
-#pragma unroll
-        for (int q = 0; q < LNT_MAX; ++q)
-            if (q < lnT) sm += (float)min(32, lnC - 32 * q) * st2[q].x;
-        ln_mean = sm / (float)lnC;
-        float m2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < LNT_MAX; ++q)
-            if (q < lnT) { const float dm = st2[q].x - ln_mean; m2 += st2[q].y + (float)min(32, lnC - 32 * q) * dm * dm; }
-        ln_rstd = 1.0f / sqrtf(m2 / (float)lnC + 1e-5f);
-        __syncthreads();
-    }
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -346,12 +313,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
     for (int i = 0; i < MAXG; ++i) {
         const bool ok = 8 * (w + NW * i) + 4 * h < K;           // groups past the end (and the k tail of the last one) add zeros
         float4 a = fa[i];
-        if (ln && 8 * (w + NW * i) >= K1) {                     // (K1 % 8 == 0 is required of the caller: a group is inside one operand)
-            const int k2 = min(8 * (w + NW * i) + 4 * h, K - 4) - K1;
-            const float4 g4 = *reinterpret_cast<const float4*>(red + k2), b4 = *reinterpret_cast<const float4*>(red + 576 + k2);
-            a.x = (a.x - ln_mean) * ln_rstd * g4.x + b4.x; a.y = (a.y - ln_mean) * ln_rstd * g4.y + b4.y;
-            a.z = (a.z - ln_mean) * ln_rstd * g4.z + b4.z; a.w = (a.w - ln_mean) * ln_rstd * g4.w + b4.w;
-        }
         if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 b = fb[i];
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0], 0, 0, 0);
@@ -360,7 +321,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[1], 0, 0, 0);
     }
     (void)ngroups;
-    if (ln) __syncthreads();                                    // every wave is done with gamma | beta before the buffer takes the partial tiles
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[0][r] + acc[1][r];
     __syncthreads();
@@ -391,20 +351,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
         if (row < rows && col_ok) {
             if (P.addend) v += P.addend[(size_t)row * P.ldo + col];
             outp[(size_t)row * P.ldo + col] = v;
-        }
-        if (P.ln_stats_out) {
-            // the producer half of a folded LayerNorm: (mean, sum of squared deviations) of the row's stored values over this 32-column tile
-            // (a lane half = one row; fixed butterfly order: bit-reproducible)
-            const float nval = (float)min(32, ncols - col0);
-            float sx = col_ok ? v : 0.f;
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) sx += __shfl_xor(sx, m);
-            const float mt = sx / nval;
-            const float dv = col_ok ? v - mt : 0.f;
-            float sq = dv * dv;
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
-            if (l31 == 0 && row < rows) *reinterpret_cast<float2*>(P.ln_stats_out + ((size_t)row * tiles_n + tn) * 2) = make_float2(mt, sq);
         }
     }
 }
@@ -443,39 +389,7 @@ int gemm_configure() {
 static int g_force_cfg = -1;   // tools / tests: force a configuration (0, 1, 2, 9: LDS-staged f32-MFMA tiles; 11, 12: latency form)
 void gemm_force_config(int c) { g_force_cfg = c; }
 
-// 0 = LDS-staged tiles, 8 / 16 = the latency form with that many waves; < 0 = an error code
-static int gemm_pick(const GemmBatch& g);
-
-bool gemm_uses_direct(const GemmBatch& g) { return gemm_pick(g) > 0; }
-
 int launch_gemm(const GemmBatch& g, hipStream_t st) {
-    const int pick = gemm_pick(g);
-    if (pick < 0) return pick;
-    for (int i = 0; i < g.n; ++i) {
-        const GemmProblem& p = g.p[i];
-        if ((p.ln_stats_out || p.ln_stats) && pick == 0) return DR_ENOSUP;       // (callers ask gemm_uses_direct first)
-        if (p.ln_stats && (!p.A2 || !p.ln_gamma || !p.ln_beta || p.K1 % 8 || p.K - p.K1 > 576 || (p.K - p.K1) % 4)) return DR_EINVAL;
-    }
-    if (pick == 8) return launch_direct<8, 7>(g, st);
-    if (pick == 16) return launch_direct<16, 7>(g, st);
-    long nM = 0;
-    for (int i = 0; i < g.n; ++i) {
-        const GemmProblem& p = g.p[i];
-        nM += (long)((p.rows + 63) / 64) * ((p.ncols + 63) / 64) * (p.nbatch > 1 ? p.nbatch : 1);
-    }
-    int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
-                                     // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
-    const int env_cfg = env_knob("DR_GEMM_CFG", -1);   // tools/: tile experiments
-    if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
-    if (g_force_cfg >= 0) cfg = g_force_cfg;
-    if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
-    if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
-    if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
-    if (cfg == 0) return launch_cfg<CFG_SMALL>(g, st);
-    return DR_EINVAL;
-}
-
-static int gemm_pick(const GemmBatch& g) {
     if (g.n < 1 || g.n > 4) return DR_EINVAL;
     long nM = 0;                    // 64 x 64 tiles of the launch
     for (int i = 0; i < g.n; ++i) {
@@ -502,11 +416,20 @@ static int gemm_pick(const GemmBatch& g) {
         static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
         const double t_staged = 5.0 + (double)((nM + n_cu - 1) / n_cu) * 0.0244 * maxK;
         const double t_direct = maxK <= 8 * 8 * 7 ? 2.5 + 0.0145 * (double)n32 : (n32 <= 512 ? 11.0 : 10.0 + 0.026 * (double)n32);
-        if (t_direct <= t_staged || nM < 128) return maxK <= 8 * 8 * 7 ? 8 : 16;
+        if (t_direct <= t_staged || nM < 128) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);
     }
-    if (g_force_cfg == 11) return 8;
-    if (g_force_cfg == 12) return 16;
-    return 0;
+    int cfg = nM >= 128 ? 9 : 0;     // 9 = 64 x 64 tiles with a single LDS buffer (18 KB -> 8 workgroups per CU): best of
+                                     // every f32-MFMA configuration measured on the loop's shapes (tools/gemm_bench.py)
+    const int env_cfg = env_knob("DR_GEMM_CFG", -1);   // tools/: tile experiments
+    if (env_cfg >= 0 && cfg == 9) cfg = env_cfg;
+    if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (cfg == 11) return launch_direct<8, 7>(g, st);
+    if (cfg == 12) return launch_direct<16, 7>(g, st);
+    if (cfg == 9) return launch_cfg<CFG_M1B>(g, st);
+    if (cfg == 2) return launch_cfg<CFG_LARGE>(g, st);
+    if (cfg == 1) return launch_cfg<CFG_MEDIUM>(g, st);
+    if (cfg == 0) return launch_cfg<CFG_SMALL>(g, st);
+    return DR_EINVAL;
 }
 
 }  // namespace dr

@@ -40,14 +40,6 @@ struct GemmProblem {
     // strided batch (f32-MFMA kernels only): instance z = blockIdx.z uses A + z sA, W + z sW, out + z sO (floats)
     int nbatch;         // 0 or 1 = a single instance
     long long sA, sW, sO;
-    // LayerNorm folded across two launches of the latency form (gemm_nt_direct_kernel; gemm_uses_direct tells whether a batch takes it):
-    //   producer: ln_stats_out [rows][ceil(ncols / 32)][2] = (mean, sum of squared deviations) of the stored values over each 32-column tile
-    //   consumer: the A2 operand is LayerNorm(A2) * ln_gamma + ln_beta over its K - K1 columns (eps 1e-5, biased variance), the row statistics
-    //             combined from the producer's per-tile partials (Chan's parallel form: mathematically the two-pass statistics)
-    float* ln_stats_out;
-    const float* ln_stats;
-    const float* ln_gamma;
-    const float* ln_beta;
 };
 
 struct GemmBatch {
@@ -56,7 +48,6 @@ struct GemmBatch {
 };
 
 int launch_gemm(const GemmBatch& g, hipStream_t st);
-bool gemm_uses_direct(const GemmBatch& g);      // launch_gemm would take the latency form (the only one that knows ln_stats_out / ln_stats)
 int gemm_configure();
 void gemm_force_config(int c);
 

@@ -205,35 +205,23 @@ static int layer_call(const dr_layer_weights& W, int C, int H, int P, const floa
     rc = launch_attention(a, st);
     if (rc) return rc;
 
-    // message = norm1(merge(o)); hidden = relu(mlp0(cat[x, message]))
-    // Round 5: when both GEMMs take the latency form (a single pair, a few pairs) LayerNorm1 is NOT a launch: the merge GEMM's epilogue leaves
-    // per-tile (mean, M2) partials of its rows, mlp0 combines them and normalises its second operand while the fragments are in registers
-    // (the statistics live in ws.msg, which the folded form does not need for the message itself).
-    GemmBatch gm, gh;
-    memset(&gm, 0, sizeof(gm));
-    GemmProblem& m = gm.p[0];
+    // message = norm1(merge(o))
+    memset(&g, 0, sizeof(g));
+    GemmProblem& m = g.p[0];
     m.A = ws.att + (size_t)xr0 * C; m.W = W.merge; m.out = ws.mrg + (size_t)xr0 * C;
     m.rows = xrows; m.ncols = C; m.K = C; m.K1 = C; m.lda = C; m.ldo = C; m.epi = EPI_NONE; m.scale = 1.f;
-    gm.n = 1;
-    memset(&gh, 0, sizeof(gh));
-    GemmProblem& h = gh.p[0];
+    g.n = 1;
+    rc = launch_gemm(g, st);
+    if (rc) return rc;
+    rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st);
+    if (rc) return rc;
+    // message = norm2(mlp(cat[x, message]))
+    memset(&g, 0, sizeof(g));
+    GemmProblem& h = g.p[0];
     h.A = xin + (size_t)xr0 * C; h.A2 = ws.msg + (size_t)xr0 * C; h.W = W.mlp0; h.out = ws.hid + (size_t)xr0 * 2 * C;
     h.rows = xrows; h.ncols = 2 * C; h.K = 2 * C; h.K1 = C; h.lda = C; h.lda2 = C; h.ldo = 2 * C; h.epi = EPI_RELU; h.scale = 1.f;
-    gh.n = 1;
-    const int tiles_c = (C + 31) / 32;
-    const bool fold = C % 8 == 0 && C <= 576 && 2 * tiles_c <= C && env_knob("DR_LN1_FOLD", 1) != 0 && gemm_uses_direct(gm) && gemm_uses_direct(gh);
-    if (fold) {
-        float* stats = ws.msg + (size_t)xr0 * C;                   // [xrows][tiles_c][2] <= xrows * C floats
-        m.ln_stats_out = stats;
-        h.A2 = ws.mrg + (size_t)xr0 * C; h.ln_stats = stats; h.ln_gamma = W.norm1_w; h.ln_beta = W.norm1_b;
-    }
-    rc = launch_gemm(gm, st);
-    if (rc) return rc;
-    if (!fold) {
-        rc = launch_layernorm(ws.mrg + (size_t)xr0 * C, C, W.norm1_w, W.norm1_b, nullptr, 0, ws.msg + (size_t)xr0 * C, C, xrows, C, st);
-        if (rc) return rc;
-    }
-    rc = launch_gemm(gh, st);
+    g.n = 1;
+    rc = launch_gemm(g, st);
     if (rc) return rc;
     memset(&g, 0, sizeof(g));
     GemmProblem& o = g.p[0];

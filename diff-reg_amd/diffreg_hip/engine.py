@@ -10,6 +10,7 @@ import math
 
 import numpy as np
 import os
+import threading
 import torch
 
 from . import lib
@@ -34,17 +35,23 @@ def sampling_times(steps, timesteps=1000):
 
 
 _STREAM_POOL = {}
+_STREAM_POOL_LOCK = threading.Lock()
 
 
 def _side_streams(device, n):
     """The side streams of run_streams, shared by every engine of the process: the runtime maps streams onto a handful of hardware queues in
     creation order, so engines that each created their own would end up with streams that share a queue (measured: three concurrent cfg3 calls
-    163 pairs/s behind other engines' streams against 240 with the first three streams of a process)."""
-    key = torch.device(device).index or 0
-    pool = _STREAM_POOL.setdefault(key, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
-    return pool[:n]
+    163 pairs/s behind other engines' streams against 240 with the first three streams of a process).
+    The pool is per DEVICE INDEX (a bare "cuda" means the current device) and guarded by a lock; the streams themselves are shared: run_streams
+    calls issued from different host threads at the same time interleave their work on the same side streams (each call still waits for and is
+    waited on by its own caller's stream, so results are correct; the overlap is then no longer per engine)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _STREAM_POOL_LOCK:
+        pool = _STREAM_POOL.setdefault(key, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=torch.device("cuda", key)))
+        return pool[:n]
 
 
 class DenoiseEngine:
@@ -103,6 +110,8 @@ class DenoiseEngine:
             lib.check(lib.raw().dr_loop_prepack(ctypes.byref(cfg), ctypes.byref(self.w), self._packed.data_ptr(), nb,
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             self.w.prepacked = self._packed.data_ptr()
+            # the pack kernels were enqueued on the stream current at construction; runs may come on other streams (run_streams): order them
+            torch.cuda.current_stream(dev).synchronize()
 
     # ------------------------------------------------------------------------------------------
     GUARD = 64 * 1024          # bytes of 0xA5 on either side of every buffer when guard bands are on (tests)
@@ -300,7 +309,8 @@ class DenoiseEngine:
         The first pass of a group runs eagerly, the second captures its graph, later ones replay it."""
         cur = torch.cuda.current_stream(self.device)
         self._streams = _side_streams(self.device, n_streams)
-        self._skew_cycles = int(float(os.environ.get("DR_STREAM_SKEW_US", "0")) * 2000)
+        # (experiment knob, read only under DR_DIAGNOSTICS=1 like the library's own: a start skew between the streams, in microseconds)
+        self._skew_cycles = int(float(os.environ.get("DR_STREAM_SKEW_US", "0")) * 2000) if os.environ.get("DR_DIAGNOSTICS") == "1" else 0
         self._cache_entries = max(self._cache_entries, len(groups) + 2)        # every group keeps its own slot
         outs = []
         for gi, kw in enumerate(groups):
@@ -418,6 +428,7 @@ class DenoiseEngine2D3D:
             lib.check(lib.raw().dr_loop2d3d_prepack(ctypes.byref(cfg0), ctypes.byref(self.w), self._packed.data_ptr(), nb,
                                                     ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             self.w.prepacked = self._packed.data_ptr()
+            torch.cuda.current_stream(self.device).synchronize()       # (later runs may come on other streams: see DenoiseEngine)
 
     def _cfg(self, steps):
         if steps not in self._cfgs:

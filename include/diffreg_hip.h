@@ -585,7 +585,11 @@ typedef struct {
     const float* src_proj;                   /* denoising_coarse_matching.src_proj.weight [C,C] (Q1)        */
     const float* bin_score;
     const void* prepacked;                   /* dr_loop2d3d_prepack image of THESE weights (device, 256-byte aligned) or NULL: calls that
-                                              * take the plane path then pack them into the workspace every time                      */
+                                              * take the plane path then pack them into the workspace EVERY time -- 7 pack launches, 3 copies
+                                              * and 6 bound kernels per layer, also inside a captured graph (every replay repeats them): pass a
+                                              * prepacked image unless the weights really change between calls.  The image must be complete on
+                                              * the stream of the call: synchronise (or order with an event) after dr_loop2d3d_prepack when the
+                                              * loop runs on another stream                                                            */
 } dr_fusion_weights;
 
 typedef struct {

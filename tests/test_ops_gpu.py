@@ -57,48 +57,6 @@ def test_vol_pe_and_rotary_linear(variant, golden):
     assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("rows_x,rows_y", [(256, 256), (64, 48), (300, 77), (33, 500)])
-def test_layernorm1_folded_into_the_latency_gemms(rows_x, rows_y):
-    """Round 5 (the single-pair chain): where both the merge GEMM and mlp0 take the latency form, LayerNorm1 is not a launch -- the merge
-    GEMM's epilogue leaves per-tile (mean, M2) partials, mlp0 combines them (Chan's parallel form of the two-pass statistics) and normalises
-    its second operand in registers (transformero.py:88-92).  The layer with the fold must equal the layer with the separate LayerNorm launch to
-    float32 rounding, must run one LayerNorm launch instead of two, and must equal the float64 oracle layer as before."""
-    import os
-    from diffreg_hip import lib
-    variant = "3dmatch"
-    v = synth.VARIANTS[variant]
-    C, H = v["C"], v["H"]
-    Wd = weights(variant)
-    pre = "denoising_transformer.layers.1."
-    tens = [Wd[pre + k].to(DEV) for k in lib._LAYER_KEYS]
-    _, p = pair(variant, rows_x, rows_y, 5)
-    pes = orc.vol_pe(p["p_s"], C, v["origin"], v["voxel"]); pet = orc.vol_pe(p["p_t"], C, v["origin"], v["voxel"])
-    cs, ss = [a.to(DEV) for a in half_tables(*pes)]
-    ct, st = [a.to(DEV) for a in half_tables(*pet)]
-    x, y = p["f_s"].to(DEV), p["f_t"].to(DEV)
-    lib.ensure_init()
-    outs, lns = {}, {}
-    lib.raw().dr_debug_enable_env(1)
-    try:
-        for fold in (1, 0):
-            os.environ["DR_LN1_FOLD"] = str(fold)
-            lib.attention_layer(tens, C, H, x, y, cs, ss, ct, st)
-            torch.cuda.synchronize()
-            lib.prof_enable(True)
-            outs[fold] = lib.attention_layer(tens, C, H, x, y, cs, ss, ct, st).cpu()
-            lns[fold] = lib.prof_collect()["layernorm"][0]
-            lib.prof_enable(False)
-    finally:
-        os.environ.pop("DR_LN1_FOLD", None)
-        lib.raw().dr_debug_enable_env(1 if os.environ.get("DR_DIAGNOSTICS") == "1" else 0)
-    assert lns[1] == 1 and lns[0] == 2, lns
-    scale = float(outs[0].abs().max())
-    assert float((outs[1] - outs[0]).abs().max()) <= 4e-6 * scale, (float((outs[1] - outs[0]).abs().max()), scale)
-    W64 = {k: t.double() for k, t in Wd.items()}
-    ref = orc.attention_layer(W64, pre, p["f_s"].double(), p["f_t"].double(), tuple(a.double() for a in pes), tuple(a.double() for a in pet), None, None, H)
-    assert float((outs[1].double() - ref).abs().max()) < 1e-4
-
-
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
 def test_attention_layer(variant, golden):
     from diffreg_hip import lib
