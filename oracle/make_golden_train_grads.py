@@ -1,7 +1,8 @@
 """Mint EVERY parameter gradient of the two training branches by RUNNING THE REFERENCE, in float32 and in float64 (build container only;
 needs /root/reference).
 
-    python oracle/make_golden_train_grads.py          # writes tests/golden/train_backward_params.npz
+    python oracle/make_golden_train_grads.py          # writes tests/golden/train_backward_params.npz       (stress head, HEAD_GAIN 24)
+    python oracle/make_golden_train_grads.py soft     # writes tests/golden/train_backward_params_soft.npz  (HEAD_GAIN_SOFT 3: logits O(10))
 
 oracle/make_golden_train.py stores, for the denoising branch (3D/models/pipeline.py:209-212 + loss.py:160-163) and the coarse branch with the
 motion term (pipeline.py:184-196 + loss.py:97-128), the gradient NORM of every parameter and two weight gradients entry-wise.  This script
@@ -35,8 +36,11 @@ def sub(g):
 
 def main():
     import torch
-    from oracle.make_golden import ref_config, HEAD_GAIN
+    from oracle.make_golden import ref_config, HEAD_GAIN, HEAD_GAIN_SOFT
     from oracle.make_golden_train import LOSS_CFG
+    soft = len(sys.argv) > 1 and sys.argv[1] == "soft"
+    gain = HEAD_GAIN_SOFT if soft else HEAD_GAIN
+    out_path = OUT.replace(".npz", "_soft.npz") if soft else OUT
     sys.modules["open3d"] = MagicMock()
     for m in ("easydict", "tensorboardX", "nibabel", "nibabel.quaternions", "cv2"):
         sys.modules.setdefault(m, MagicMock())
@@ -54,13 +58,35 @@ def main():
     v = synth.VARIANTS["3dmatch"]
     C = v["C"]
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    Wnp = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN))
-    Wnp.update(synth.make_weights_coarse(C, seed=17, head_gain=HEAD_GAIN))
+    Wnp = dict(synth.make_weights(C, seed=7, head_gain=gain))
+    Wnp.update(synth.make_weights_coarse(C, seed=17, head_gain=gain))
     old = np.load(os.path.join(GOLD, "train_backward.npz"))
     fwd = np.load(os.path.join(GOLD, "train_forward.npz"))
     cb = train_case("b1")
     res = {}
+    # The float64 yardstick needs ONE shim: procrustes.py:41 casts R to float32 whatever the inputs are, and the next line then mixes float32 and
+    # float64 in a matmul, raises, and the bare except of :79-84 returns the identity (quirk Q3) -- the coarse branch's positioning layer would
+    # silently stop fitting.  For the float64 run only, the same arithmetic with that cast following the input dtype (the float32 run below is the
+    # unmodified reference; the script asserts that it reproduces train_backward.npz bit for bit).
+    from models.procrustes import SoftProcrustesLayer
+    ref_bwp = SoftProcrustesLayer.batch_weighted_procrustes
+
+    def bwp_dtype_preserving(X, Y, w, eps=0.0001):
+        bsize = X.shape[0]
+        W1 = torch.abs(w).sum(dim=1, keepdim=True)
+        w_norm = w / (W1 + eps)
+        mean_X = (w_norm * X).sum(dim=1, keepdim=True)
+        mean_Y = (w_norm * Y).sum(dim=1, keepdim=True)
+        Sxy = torch.matmul((Y - mean_Y).transpose(1, 2), w_norm * (X - mean_X)).cpu().double()
+        U, D, V = Sxy.svd()
+        condition = D.max(dim=1)[0] / D.min(dim=1)[0]
+        S = torch.eye(3)[None].repeat(bsize, 1, 1).double()
+        S[:, 2:3, 2:3] = (U.det() * V.det()).view(-1, 1, 1)
+        R = torch.matmul(U, torch.matmul(S, V.transpose(1, 2))).to(X.dtype)
+        t = mean_Y.transpose(1, 2) - torch.matmul(R, mean_X.transpose(1, 2))
+        return R, t, condition
     for dt, tag in ((torch.float32, "32"), (torch.float64, "64")):
+        SoftProcrustesLayer.batch_weighted_procrustes = staticmethod(ref_bwp if dt == torch.float32 else bwp_dtype_preserving)
         cfg_d = ref_config("3dmatch", 20, 200.0)
         cfg_d.kpfcn_config["architecture"] = architectures["3dmatch"]
         pipe = Pipeline(cfg_d)
@@ -89,7 +115,7 @@ def main():
             if prm.grad is not None:
                 res["branch_g%s_%s" % (tag, k)] = sub(prm.grad)
                 n_b += 1
-        if tag == "32":      # what this run recomputes must be what train_backward.npz holds
+        if tag == "32" and not soft:      # what this run recomputes must be what train_backward.npz holds
             assert np.array_equal(res["branch_conf32"], old["branch_conf"]) and np.array_equal(res["branch_grad_src32"], old["branch_grad_src"])
             assert np.array_equal(res["branch_g32_layers.0.q_proj.weight"], old["branch_grad_layers.0.q_proj.weight"])
         # ---- coarse branch with the motion term
@@ -116,7 +142,7 @@ def main():
             if prm.grad is not None:
                 res["coarse_g%s_%s" % (tag, k)] = sub(prm.grad)
                 n_c += 1
-        if tag == "32":
+        if tag == "32" and not soft:
             assert np.array_equal(res["coarse_conf32"], old["coarse_conf"]) and np.array_equal(res["coarse_grad_src32"], old["coarse_grad_src"])
         print("dtype", tag, "branch params", n_b, "coarse params", n_c, "loss_d %.6f" % float(loss_d))
     # how far the reference's own float32 backward is from float64, per tensor, relative to the tensor's maximum
@@ -125,10 +151,13 @@ def main():
         a, b = res[k].astype(np.float64), res[k.replace("_g32_", "_g64_")]
         worst = max(worst, float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)))
     print("largest |g32 - g64| / max|g64| over all parameter tensors: %.3e" % worst)
-    # the float32 entries already in train_backward.npz stay there; this file adds the rest
-    keep = {k: a for k, a in res.items() if not k.endswith("conf32") and not k.endswith("src32") and not k.endswith("tgt32") and k != "branch_loss32"}
-    np.savez_compressed(OUT, **keep)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(keep), "arrays")
+    # the float32 conf / input gradients of the stress family are in train_backward.npz already; the soft family's file carries everything
+    if soft:
+        keep = dict(res)
+    else:
+        keep = {k: a for k, a in res.items() if not k.endswith("conf32") and not k.endswith("src32") and not k.endswith("tgt32") and k != "branch_loss32"}
+    np.savez_compressed(out_path, **keep)
+    print("wrote", out_path, os.path.getsize(out_path), "bytes;", len(keep), "arrays")
 
 
 if __name__ == "__main__":

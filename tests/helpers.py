@@ -140,10 +140,11 @@ def guarded(shape, dtype, device, fill=None):
 TRAIN_CASES = {"b1": (1, 96, 80, 50, 137, 200.0), "b2": (2, 64, 64, 60, 640, 200.0)}      # B, N, M, seed, time step, max_condition_num
 
 
-def train_weights():
+def train_weights(family="main"):
     C = synth.VARIANTS["3dmatch"]["C"]
-    w = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN))
-    w.update(synth.make_weights_coarse(C, seed=17, head_gain=HEAD_GAIN))
+    gain = HEAD_GAIN if family == "main" else HEAD_GAIN_SOFT
+    w = dict(synth.make_weights(C, seed=7, head_gain=gain))
+    w.update(synth.make_weights_coarse(C, seed=17, head_gain=gain))
     return {k: T(v) for k, v in w.items()}
 
 

@@ -145,6 +145,49 @@ def test_training_forward_and_loss_against_reference(tag):
 
 
 GB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_backward.npz"))
+# every parameter gradient of the two training branches from the reference's own float32 backward AND from the same modules in float64
+# (oracle/make_golden_train_grads.py: entries [::6, ::6] of matrices, all entries of vectors), for the stress head (HEAD_GAIN 24, the family of
+# train_backward.npz) and for the soft head (HEAD_GAIN_SOFT 3: logits O(10))
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GP = {"main": np.load(os.path.join(_GOLD, "train_backward_params.npz")), "soft": np.load(os.path.join(_GOLD, "train_backward_params_soft.npz"))}
+# The STRESS head (HEAD_GAIN 24: matching logits in the thousands) is held to 4e-2 of the tensor maximum on EVERY entry of all 104 tensors (the
+# old test: 2e-2 on the tensors' NORMS and on two tensors' entries).  Measured (round 5): the device's gradients are up to 2.6e-2 of the tensor
+# maximum from float64 on the denoising branch (layers.4.v_proj.weight: 6.3e-5 against the reference's own 2.2e-6), 4.9e-3 on the coarse branch -- a
+# 1e-4 deviation of a confidence is a percent of the focal loss's gradient at that entry when the matrix is that sharp, and it reaches the early
+# layers amplified.  The SOFT head (logits O(10), same scenes) holds 1e-3 / twice the reference on all 104 tensors: 4.8e-5 of the tensor maximum
+# at worst -- the backward kernels are float32-exact where the problem is conditioned like a trained model's.
+STRESS_REL = 4e-2
+
+
+def assert_gradient_entries(dev, ref32, ref64, what, rel=1e-3):
+    """Every ENTRY of a gradient tensor against the reference's autograd: |dev - ref32| <= rel x the tensor's largest entry (rel = 1e-3; STRESS_REL on
+    the stress head), or at least as close to the float64 backward of the same modules as the reference's own float32 backward is:
+    |dev - ref64| <= max(rel M, 2 max|ref32 - ref64|).  A tensor whose float64 gradient (nearly) vanishes -- bin_score at a stationary point -- is
+    held absolutely.  -> the deviation as a fraction of the tensor maximum."""
+    dev, ref32, ref64 = (np.asarray(a, dtype=np.float64) for a in (dev, ref32, ref64))
+    assert dev.shape == ref32.shape == ref64.shape, (what, dev.shape, ref32.shape)
+    M = float(np.abs(ref64).max())
+    if M < 1e-6:
+        assert float(np.abs(dev - ref64).max()) < 1e-7, (what, "(nearly) vanishing gradient", float(np.abs(dev - ref64).max()))
+        return 0.0
+    e32 = float(np.abs(dev - ref32).max())
+    if e32 <= rel * M:
+        return e32 / M
+    e64, r64 = float(np.abs(dev - ref64).max()), float(np.abs(ref32 - ref64).max())
+    assert e64 <= max(rel * M, 2.0 * r64), (what, "device %.3e from float64, reference %.3e, tensor max %.3e" % (e64, r64, M))
+    return e64 / M
+
+
+def branch_refs(family, pre):
+    """(conf32, conf64, grad_src32, grad_tgt32) of a branch for a fixture family"""
+    g = GP[family]
+    if family == "main":
+        return GB[pre + "_conf"], g[pre + "_conf64"], GB[pre + "_grad_src"], GB[pre + "_grad_tgt"]
+    return g[pre + "_conf32"], g[pre + "_conf64"], g[pre + "_grad_src32"], g[pre + "_grad_tgt32"]
+
+
+def param_sub(g):
+    return (g[::6, ::6] if g.dim() == 2 else g).detach().cpu().numpy()
 
 
 @pytest.mark.parametrize("tag", ["full", "masked", "big"])
@@ -284,7 +327,8 @@ def test_attention_layer_backward_against_reference_autograd():
         assert abs(float(gq.double().norm()) - float(GB["layer_gradnorm_" + k])) <= 1e-3 * float(GB["layer_gradnorm_" + k]), k
 
 
-def test_denoising_branch_backward_end_to_end():
+@pytest.mark.parametrize("family", ["soft", "main"])
+def test_denoising_branch_backward_end_to_end(family):
     """The denoising half of the training loss, differentiable on the device (diffreg_hip.autograd.denoising_branch + focal_loss): six
     GeometryAttentionLayers + the matching head, 62 parameter tensors.  Loss, conf, the gradients of the backbone features and the gradient norm
     of every parameter (+ two weight gradients entry-wise) against torch autograd through the reference's modules."""
@@ -293,7 +337,7 @@ def test_denoising_branch_backward_end_to_end():
     c = train_case("b1")
     model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
     sd = model.state_dict()
-    for k, a in train_weights().items():
+    for k, a in train_weights(family).items():
         sd[k] = a
     model.load_state_dict(sd)
     model = model.to(DEV)
@@ -302,30 +346,35 @@ def test_denoising_branch_backward_end_to_end():
     ft = (c["f_t"] * 0.5).to(DEV).requires_grad_(True)
     warped = torch.from_numpy(G["b1_src_warped"]).to(DEV)
     hat = denoising_branch(model, fs, ft, warped, c["p_t"].to(DEV), c["src_mask"].to(DEV), c["tgt_mask"].to(DEV))
-    d = np.abs(hat.detach().cpu().numpy() - GB["branch_conf"])
-    assert (d > 1e-4).mean() <= 1e-3 and d.max() < 2e-3
+    # conf: the loop tests' rule -- a plain 1e-4 on every entry except where the reference's own float32 value is > 2e-5 from the float64 run
+    from tests.test_loop_gpu import assert_matrix_parity
+    conf32, conf64, gsrc32, gtgt32 = branch_refs(family, "branch")
+    gp, fac = GP[family], (STRESS_REL if family == "main" else 1e-3)
+    assert_matrix_parity(hat.detach().cpu().numpy(), conf32, conf64, "denoising branch conf")
+    if family == "soft":
+        assert np.abs(hat.detach().cpu().numpy() - conf32).max() <= 1e-4          # (plain: nothing is exempt at this scale)
     gt = torch.zeros_like(hat)
     gt[0][c["matches"][0][0].to(DEV), c["matches"][0][1].to(DEV)] = 1
     loss = focal_loss(hat, gt)
     loss.backward()
-    assert abs(float(loss.detach()) - float(GB["branch_loss"])) <= 2e-3 * float(GB["branch_loss"])
-    for got, key in ((fs.grad, "branch_grad_src"), (ft.grad, "branch_grad_tgt")):
-        ref = GB[key]
-        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), (key, np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max())
+    ref_loss = float(GB["branch_loss"]) if family == "main" else float(gp["branch_loss32"])
+    assert abs(float(loss.detach()) - ref_loss) <= (2e-3 if family == "main" else 1e-4) * ref_loss
+    worst = 0.0
+    for got, r32, key in ((fs.grad, gsrc32, "branch_grad_src"), (ft.grad, gtgt32, "branch_grad_tgt")):
+        worst = max(worst, assert_gradient_entries(got.cpu().numpy(), r32, gp[key + "64"], key, fac))
     named = list(model.denoising_transformer.named_parameters()) + [("head." + k, p) for k, p in model.denoising_coarse_matching.named_parameters()]
     checked = 0
     for k, prm in named:
-        key = "branch_gradnorm_" + k
-        if key in GB.files:
+        key = "branch_g32_" + k
+        if key in gp.files:
             assert prm.grad is not None, k
-            ref = float(GB[key])
-            assert abs(float(prm.grad.double().norm()) - ref) <= 2e-2 * ref + 1e-9, (k, float(prm.grad.double().norm()), ref)
+            worst = max(worst, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["branch_g64_" + k], "denoising branch d/d " + k, fac))
+            if family == "main":
+                ref = float(GB["branch_gradnorm_" + k])
+                assert abs(float(prm.grad.double().norm()) - ref) <= 1e-2 * ref + 1e-9, (k, float(prm.grad.double().norm()), ref)
             checked += 1
     assert checked == 62
-    for key, prm in (("branch_grad_layers.0.q_proj.weight", model.denoising_transformer.layers[0].q_proj.weight),
-                     ("branch_grad_layers.5.mlp.2.weight", model.denoising_transformer.layers[5].mlp[2].weight)):
-        ref = GB[key]
-        assert np.abs(prm.grad[::6, ::6].cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), key
+    print("denoising branch (%s head): worst gradient deviation / tensor maximum %.2e" % (family, worst))
 
 
 def test_motion_l1_backward_against_torch():
@@ -343,7 +392,8 @@ def test_motion_l1_backward_against_torch():
     assert (gR - Rp.grad).abs().max().item() < 1e-5 and (gt - tp.grad).abs().max().item() < 1e-5
 
 
-def test_coarse_branch_backward_with_motion_term():
+@pytest.mark.parametrize("family", ["soft", "main"])
+def test_coarse_branch_backward_with_motion_term(family):
     """The non-denoising half of the training loss with the L1 motion term (motion_weight 0.1, as 4DMatch trains): autograd.coarse_branch (four attention
     layers around the positioning layer, whose position code is a constant of the graph as in the reference, + matching head + differentiable
     Procrustes fit) + focal_loss + motion_l1.  Against torch autograd through the reference's modules: 42 parameter tensors."""
@@ -352,7 +402,7 @@ def test_coarse_branch_backward_with_motion_term():
     c = train_case("b1")
     model = Pipeline(ref_like_config("3dmatch", 20, c["mc"]), backbone=StubBackbone())
     sd = model.state_dict()
-    for k, a in train_weights().items():
+    for k, a in train_weights(family).items():
         sd[k] = a
     model.load_state_dict(sd)
     model = model.to(DEV)
@@ -360,9 +410,14 @@ def test_coarse_branch_backward_with_motion_term():
     ft = (c["f_t"] * 0.5).to(DEV).requires_grad_(True)
     ps, pt, sm, tm = c["p_s"].to(DEV), c["p_t"].to(DEV), c["src_mask"].to(DEV), c["tgt_mask"].to(DEV)
     conf, R, t = coarse_branch(model, fs, ft, ps, pt, sm, tm)
-    d = np.abs(conf.detach().cpu().numpy() - GB["coarse_conf"])
-    assert (d > 1e-4).mean() <= 1e-3 and d.max() < 2e-3
-    assert np.abs(R.detach().cpu().numpy() - GB["coarse_R"]).max() < 1e-4 and np.abs(t.detach().cpu().numpy() - GB["coarse_t"]).max() < 1e-4
+    from tests.test_loop_gpu import assert_matrix_parity
+    conf32, conf64, gsrc32, gtgt32 = branch_refs(family, "coarse")
+    gp, fac = GP[family], (STRESS_REL if family == "main" else 1e-3)
+    assert_matrix_parity(conf.detach().cpu().numpy(), conf32, conf64, "coarse branch conf")
+    if family == "main":
+        assert np.abs(R.detach().cpu().numpy() - GB["coarse_R"]).max() < 1e-4 and np.abs(t.detach().cpu().numpy() - GB["coarse_t"]).max() < 1e-4
+    else:
+        assert np.abs(conf.detach().cpu().numpy() - conf32).max() <= 1e-4
     gt = torch.zeros_like(conf)
     gt[0][c["matches"][0][0].to(DEV), c["matches"][0][1].to(DEV)] = 1
     ov = torch.zeros(1, c["N"], dtype=torch.bool, device=DEV)
@@ -371,22 +426,27 @@ def test_coarse_branch_backward_with_motion_term():
     l1 = motion_l1(ps, R, t, c["R_gt"].to(DEV), c["t_gt"].to(DEV), ov)
     loss = focal + 0.1 * l1
     loss.backward()
-    assert abs(float(focal.detach()) - float(GB["coarse_focal"])) <= 2e-3 * float(GB["coarse_focal"])
-    assert abs(float(l1.detach()) - float(GB["coarse_l1"])) <= 1e-3 * float(GB["coarse_l1"])
-    for got, key in ((fs.grad, "coarse_grad_src"), (ft.grad, "coarse_grad_tgt")):
-        ref = GB[key]
-        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), (key, np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max())
+    if family == "main":
+        assert abs(float(focal.detach()) - float(GB["coarse_focal"])) <= 2e-3 * float(GB["coarse_focal"])
+        assert abs(float(l1.detach()) - float(GB["coarse_l1"])) <= 1e-3 * float(GB["coarse_l1"])
+    worst = 0.0
+    for got, r32, key in ((fs.grad, gsrc32, "coarse_grad_src"), (ft.grad, gtgt32, "coarse_grad_tgt")):
+        worst = max(worst, assert_gradient_entries(got.cpu().numpy(), r32, gp[key + "64"], key, fac))
     named = list(model.coarse_transformer.named_parameters()) + [("head." + k, p) for k, p in model.coarse_matching.named_parameters()]
     checked = 0
     for k, prm in named:
-        key = "coarse_gradnorm_" + k
-        if key in GB.files:
-            ref = float(GB[key])
-            assert prm.grad is not None and abs(float(prm.grad.double().norm()) - ref) <= 2e-2 * ref + 1e-9, (k, ref)
+        key = "coarse_g32_" + k
+        if key in gp.files:
+            assert prm.grad is not None, k
+            if family == "main":
+                ref = float(GB["coarse_gradnorm_" + k])
+                assert abs(float(prm.grad.double().norm()) - ref) <= 1e-2 * ref + 1e-9, (k, ref)
+            worst = max(worst, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["coarse_g64_" + k], "coarse branch d/d " + k, fac))
             checked += 1
         else:
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k          # the positioning layer's Matching, tgt_proj (quirk Q1)
     assert checked == 42
+    print("coarse branch (%s head): worst gradient deviation / tensor maximum %.2e" % (family, worst))
 
 
 def test_training_step_on_the_device():
