@@ -1,3 +1,7 @@
+    // NB tile buffers (the DMA of tile kt + NB - 1 is issued when tile kt starts).  Two.  Round 5 measured four at d = 64 (66 KB, counted waits
+    // that leave the two younger tiles' pieces in flight): 141 against 137 us for 8 x 2048 x 2048 -- the prefetch distance is not what bounds the
+    // kernel (profiles/r05_attention_planes_d64_experiments.json); the ring form stays in the loop below for NB > 2.
+    static constexpr int NB = 2;
 // attention.hip -- masked multi-head softmax attention on the f32-input MFMA (exact fp32 products).
 //
 // Replaces  a = einsum(q,k); masked_fill; a / sqrt(d); softmax; o = einsum(a, v)
@@ -9,6 +13,7 @@
 //   O^T = V^T P^T (d on the MFMA rows, queries on the lanes: the softmax rescale stays lane-local
 //                  and P^T is consumed straight from the score registers as the B operand)
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 namespace dr {
@@ -798,15 +803,28 @@ typedef short as16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void a_lds_void;
 typedef __attribute__((address_space(3))) as16x4 a_lds_s4;
 
+// op(own value, the value of the lane 32 away): one v_permlane32_swap instead of a ds_bpermute round trip through the LDS crossbar
+template <typename Op>
+__device__ __forceinline__ float attn_xhalf(float v, Op op) {
+    typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(v);
+    const au32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);       // (low low), (high high): both halves see both values
+    return op(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+
 template <int KS, int NDT>
 struct AttnPlGeom {
     static constexpr int KCH = 2048;                             // a K chunk: 32 keys x 64 B
     static constexpr int VCH = 2048 + 32;                        // a V chunk, shifted by 32 B per chunk: the two 16-lane groups of a
                                                                  // transposed read (features 0..15 / 16..31) then hit disjoint banks
     static constexpr int KIMG = KS * KCH, VIMG = KS * VCH, BUF = KIMG + VIMG;
+    // NB tile buffers: the DMA of tile kt + NB - 1 is issued when tile kt starts.  Round 5 (PMC + three null results): with two
+    // buffers the copy of a tile had ONE tile of arithmetic (~1 us at d = 64) to arrive, an L2 miss under load takes ~2 us, and the d = 64 kernel ran
+    // at exactly that: 2 us per tile whatever its VALU stream did.  Four buffers (66 KB at d = 64: still two workgroups per CU) give it three tiles.
+    static constexpr int NB = KS <= 4 ? 4 : 2;
     static constexpr int OQS = NDT * 32 + 4;
     static constexpr int OBYTES = 4 * 32 * OQS * 4;
-    static constexpr int SMEM = (2 * BUF > OBYTES ? 2 * BUF : OBYTES) + 64;
+    static constexpr int SMEM = (NB * BUF > OBYTES ? NB * BUF : OBYTES) + 64;
 };
 
 __device__ __forceinline__ int attn_scale_exp(float bound) {
@@ -864,17 +882,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kside = kbase >= A.p_split ? 1 : 0, klrow0 = kbase - (kside ? A.p_split : 0);
     const char* const kimg = A.kimg[kside];
     const char* const vimg = A.vimg[kside];
+    // A DMA instruction copies 16 key rows x 64 B of one chunk.  When the segment's first key row is a multiple of 16 inside its image (every
+    // loop of the library: key groups start at multiples of 32) and the tile is complete, those 16 rows are ONE contiguous KB of the image:
+    // the source is a wave-uniform base (SALU arithmetic, SGPR pair) + 16 bytes per lane -- round 5: the per-lane form (row clamp, block index,
+    // 64-bit multiply-adds per lane) was ~12 VALU instructions per DMA instruction, 48 per tile and wave: a fifth of the VALU stream of the
+    // d = 64 instantiation, which is VALU-bound (profiles/r05_attention_planes_d64_pmc.json).  Incomplete tiles and odd segments keep it.
+    const bool seg_aligned = (klrow0 & 15) == 0;
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto stage = [&](int kt, int b) __attribute__((always_inline)) {
+        const bool fast = seg_aligned && kt * 32 + 32 <= Lk;
 #pragma unroll
         for (int i = 0; i < (4 * KS + 3) / 4; ++i) {
             const int ins = w + 4 * i;
             if (ins < 4 * KS) {
                 const bool isv = ins >= 2 * KS;
                 const int j = ins - (isv ? 2 * KS : 0), chunk = j >> 1, half = j & 1;
-                const int key = min(kt * 32 + half * 16 + (lane >> 2), Lk - 1), lrow = klrow0 + key;
-                const char* src = (isv ? vimg : kimg) + (((size_t)(lrow >> 7) * nct + KS * head + chunk) * 128 + (lrow & 127)) * 64 + (lane & 3) * 16;
                 const unsigned dst = lds_base + b * G::BUF + (isv ? G::KIMG + chunk * G::VCH : chunk * G::KCH) + half * 1024;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+                if (fast) {
+                    const int lrow0 = klrow0 + kt * 32 + half * 16;
+                    const char* sbase = (isv ? vimg : kimg) + (((size_t)(lrow0 >> 7) * nct + KS * head + chunk) * 128 + (lrow0 & 127)) * 64;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(sbase) : "memory");
+                } else {
+                    const int key = min(kt * 32 + half * 16 + (lane >> 2), Lk - 1), lrow = klrow0 + key;
+                    const char* src = (isv ? vimg : kimg) + (((size_t)(lrow >> 7) * nct + KS * head + chunk) * 128 + (lrow & 127)) * 64 + (lane & 3) * 16;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+                }
             }
         }
     };
@@ -904,13 +936,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float m_run = -INFINITY, l_run = 0.f;
     const int nkt = (Lk + 31) / 32;
 
-    stage(0, 0);
+    // The Q fragments must have ARRIVED before the loop, and the compiler must know it.  Round 5 (ISA of every instantiation): their 2 KS global
+    // loads were still "pending" in the compiler's vmcnt model when the loop began, so it placed its counted waits at their first uses -- inside
+    // the loop: s_waitcnt vmcnt(2 KS - 1) .. vmcnt(0) down the Q K^T chain of EVERY tile.  vmcnt retires in order and the LDS-DMA of the next tile
+    // (inline asm, invisible to that model) is issued just in front of the chain: each tile's chain waited for the whole prefetch it had just
+    // issued -- the copy of tile kt + 1 never overlapped the arithmetic of tile kt.  Consuming the registers here puts the one wait here.
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(qh[s]), "v"(ql[s]));
+
+    // (the key mask of a tile is fetched one tile AHEAD too, in front of that tile's DMA, and consumed behind the loop's own wait: loaded inside
+    //  the tile, the compiler's wait for it -- vmcnt(0), in order -- again covered the prefetch just issued: cfg3's and every ragged batch's case)
+    constexpr int NB = G::NB;
+    static_assert((4 * KS) % 4 == 0, "every wave issues KS DMA instructions per tile");
+    const bool counted = A.kmask == nullptr;                     // (a mask byte load per tile is a compiler-placed VMEM operation between the DMAs: those
+                                                                 //  calls -- 4DMatch, ragged batches -- keep the drain-all wait and a prefetch distance of one)
+    unsigned mnext = attn_mask_byte(A, kbase, 0, Lk, l31);
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j)
+        if (j < nkt && (counted || j == 0)) stage(j, j);
     for (int kt = 0; kt < nkt; ++kt) {
-        const int b = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // own DMA instructions of tile kt have landed ...
-        __syncthreads();                                         // ... and everybody's; everybody is done with the other buffer
-        if (kt + 1 < nkt) stage(kt + 1, b ^ 1);
-        const unsigned char mbyte = attn_mask_byte(A, kbase, kt * 32, Lk, l31);
+        const int b = kt % NB;
+        // own DMA instructions of tile kt have landed; those of the tiles behind it (KS per tile and wave, issued in order) may still fly
+        if (counted) {
+            const int ahead = min(NB - 2, nkt - 1 - kt);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * KS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" : "+v"(mnext));                          // (the compiler's wait for this tile's mask byte goes here, where it is free)
+        __syncthreads();                                         // ... and everybody's; everybody is done with tile kt - 1's buffer
+        const unsigned char mbyte = (unsigned char)mnext;
+        if (counted) {
+            if (kt + NB - 1 < nkt) stage(kt + NB - 1, (kt + NB - 1) % NB);
+        } else if (kt + 1 < nkt) {
+            mnext = attn_mask_byte(A, kbase, (kt + 1) * 32, Lk, l31);
+            stage(kt + 1, (kt + 1) % NB);
+        }
         const char* kb = lds + b * G::BUF + l31 * 64;
         const char* vb = lds + b * G::BUF + G::KIMG;
         // ---- S^T = K Q^T
@@ -942,7 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (full_tile) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sfac;           // sfac > 0: the maximum commutes with the scale
+            mx = attn_xhalf(mx, [](float x, float y) { return fmaxf(x, y); }) * sfac;   // sfac > 0: the maximum commutes with the scale
             m_new = fmaxf(m_run, mx);
             alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
@@ -962,7 +1025,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 sc[r] = s;
                 mx = fmaxf(mx, s);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = attn_xhalf(mx, [](float x, float y) { return fmaxf(x, y); });
             m_new = fmaxf(m_run, mx);
             if (m_new == -INFINITY) {
 #pragma unroll
@@ -977,7 +1040,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        psum += __shfl_xor(psum, 32);
+        psum = attn_xhalf(psum, [](float x, float y) { return x + y; });
         l_run = l_run * alpha + psum;
         if (__any(m_new != m_run)) {                             // (alpha == 1 exactly in every lane otherwise: exp2(0))
 #pragma unroll
@@ -1028,6 +1091,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wave_lds_fence();
     attn_store_planes(A, ob, G::OQS, qbase + qb + w * 32, Lq - (qb + w * 32), head, d, vb_bound, lane);
 }
+
 
 template <int DG, int NDT>
 static int configure_attn() {
