@@ -770,7 +770,7 @@ def main():
                 # `bench.py --breakdown-only` (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; per launch, averaged like `achieved`)
                 tj = json.load(open(LOOP_PMC))
                 roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/r04_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
+                roof["traffic_source"] = "profiles/r05_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
                 # what a bare MFMA loop of this kernel's shape sustains on random data under the chip's own clock management (tools/mfma_f16_ceiling.hip):
                 # informational -- `peak` stays the nominal figure
