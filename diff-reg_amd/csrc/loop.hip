@@ -160,31 +160,38 @@ struct Family {   // P segments: queries rows q0 + p*Lq (+Lq) attend keys rows k
 static int layer_call(const dr_layer_weights& W, int C, int H, int P, const float* xin, int xr0, int xrows,
                       const float* yin, int yr0, int yrows, const float* cosT, const float* sinT,
                       const uint8_t* tokmask, const Family& f1, const Family* f2, const LayerWs& ws, float* out,
-                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr) {
+                      hipStream_t st, const float* kv_cached = nullptr, float* kv_store = nullptr, const float* xq_in = nullptr,
+                      const float* yk_in = nullptr) {
     // kv_cached: K|V of the source rows were projected earlier ([tokens, 2C], rotary applied to K): skip them.
     // kv_store : project ONLY K|V of the source rows into this buffer and return (used to fill the cache).
+    // xq_in / yk_in: the inputs of the q / k projections where they are not x / y themselves (pe_type 'sinusoidal', transformero.py:50-57:
+    //   q = W_q (x + pe_x), k = W_k (y + pe_y), v = W_v y); cosT == nullptr: no rotary code on q and k (sinusoidal, or the entangled form whose
+    //   layers are called without a position code, transformero.py:246-252)
     const int halfC = C / 2, d = C / H;
+    const bool rotary = cosT != nullptr;
+    const float* const qin = xq_in ? xq_in : xin;
+    const float* const kin = yk_in ? yk_in : yin;
     GemmBatch g;
     memset(&g, 0, sizeof(g));
     auto proj = [&](GemmProblem& p, const float* in, int r0, int rows, const float* Wm, int coloff, bool rot) {
         p.A = in + (size_t)r0 * C; p.A2 = nullptr; p.W = Wm; p.out = ws.qkv + (size_t)r0 * 3 * C + coloff;
         p.rows = rows; p.ncols = C; p.K = C; p.K1 = C; p.lda = C; p.lda2 = 0; p.ldo = 3 * C;
-        p.epi = rot ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
-        p.cosT = cosT + (size_t)r0 * halfC; p.sinT = sinT + (size_t)r0 * halfC;
+        p.epi = (rot && rotary) ? EPI_ROTARY : EPI_NONE; p.rot_C = C; p.scale = 1.f;
+        p.cosT = rotary ? cosT + (size_t)r0 * halfC : nullptr; p.sinT = rotary ? sinT + (size_t)r0 * halfC : nullptr;
     };
     int rc;
     if (kv_store) {
-        proj(g.p[0], yin, yr0, yrows, W.k_proj, 0, true);
+        proj(g.p[0], kin, yr0, yrows, W.k_proj, 0, true);
         proj(g.p[1], yin, yr0, yrows, W.v_proj, 0, false);
         g.p[0].out = kv_store + (size_t)yr0 * 2 * C; g.p[0].ldo = 2 * C;
         g.p[1].out = kv_store + (size_t)yr0 * 2 * C + C; g.p[1].ldo = 2 * C;
         g.n = 2;
         return launch_gemm(g, st);
     }
-    proj(g.p[0], xin, xr0, xrows, W.q_proj, 0, true);
+    proj(g.p[0], qin, xr0, xrows, W.q_proj, 0, true);
     g.n = 1;
     if (!kv_cached) {
-        proj(g.p[1], yin, yr0, yrows, W.k_proj, C, true);
+        proj(g.p[1], kin, yr0, yrows, W.k_proj, C, true);
         proj(g.p[2], yin, yr0, yrows, W.v_proj, 2 * C, false);
         g.n = 3;
     }
@@ -675,6 +682,7 @@ size_t dr_attention_layer_workspace_bytes(int P, int Lx, int Ly, int C) {
     c.take<float>(T * (C / 2));    // cos
     c.take<float>(T * (C / 2));    // sin
     c.take<uint8_t>(T);
+    c.take<float>(T * C);          // q | k inputs of the additive (sinusoidal) form
     return c.off + 256;
 }
 
@@ -682,8 +690,20 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
                            const float* cos_x, const float* sin_x, const float* cos_y, const float* sin_y,
                            const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* workspace,
                            size_t workspace_bytes, void* stream) {
+    if (!cos_x || !sin_x || !cos_y || !sin_y) return DR_EINVAL;
+    return dr_attention_layer_pe_f32(w, C, H, P, Lx, Ly, x, y, nullptr, nullptr, cos_x, sin_x, cos_y, sin_y, x_mask, y_mask, out, workspace,
+                                     workspace_bytes, stream);
+}
+
+int dr_attention_layer_pe_f32(const dr_layer_weights* w, int C, int H, int P, int Lx, int Ly, const float* x, const float* y,
+                              const float* xq, const float* yk, const float* cos_x, const float* sin_x, const float* cos_y, const float* sin_y,
+                              const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     if (!w || !x || !y || !out || P < 1 || Lx < 1 || Ly < 1 || C % H || (C / H) % 4 || C % 4) return DR_EINVAL;
     if ((x_mask == nullptr) != (y_mask == nullptr)) return DR_EINVAL;
+    const bool rotary = cos_x != nullptr;
+    if ((sin_x != nullptr) != rotary || (cos_y != nullptr) != rotary || (sin_y != nullptr) != rotary) return DR_EINVAL;
+    if ((xq == nullptr) != (yk == nullptr) || (xq && rotary)) return DR_EINVAL;   // additive code and rotary code exclude each other (pe_type)
     if (workspace_bytes < dr_attention_layer_workspace_bytes(P, Lx, Ly, C) || !workspace) return DR_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Carver c(workspace, workspace_bytes);
@@ -696,19 +716,27 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
     float* cosT = c.take<float>(T * halfC);
     float* sinT = c.take<float>(T * halfC);
     uint8_t* mask = c.take<uint8_t>(T);
+    float* qk_buf = c.take<float>(T * C);
     DR_HIP_CHECK(hipMemcpyAsync(tok, x, PX * C * 4, hipMemcpyDeviceToDevice, st));
     DR_HIP_CHECK(hipMemcpyAsync(tok + PX * C, y, PY * C * 4, hipMemcpyDeviceToDevice, st));
-    DR_HIP_CHECK(hipMemcpyAsync(cosT, cos_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
-    DR_HIP_CHECK(hipMemcpyAsync(cosT + PX * halfC, cos_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
-    DR_HIP_CHECK(hipMemcpyAsync(sinT, sin_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
-    DR_HIP_CHECK(hipMemcpyAsync(sinT + PX * halfC, sin_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
+    float* qk_tok = nullptr;                       // q | k inputs of the additive form
+    if (rotary) {
+        DR_HIP_CHECK(hipMemcpyAsync(cosT, cos_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(cosT + PX * halfC, cos_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(sinT, sin_x, PX * halfC * 4, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(sinT + PX * halfC, sin_y, PY * halfC * 4, hipMemcpyDeviceToDevice, st));
+    } else if (xq) {
+        qk_tok = qk_buf;
+        DR_HIP_CHECK(hipMemcpyAsync(qk_tok, xq, PX * C * 4, hipMemcpyDeviceToDevice, st));
+        DR_HIP_CHECK(hipMemcpyAsync(qk_tok + PX * C, yk, PY * C * 4, hipMemcpyDeviceToDevice, st));
+    }
     if (x_mask) {
         DR_HIP_CHECK(hipMemcpyAsync(mask, x_mask, PX, hipMemcpyDeviceToDevice, st));
         DR_HIP_CHECK(hipMemcpyAsync(mask + PX, y_mask, PY, hipMemcpyDeviceToDevice, st));
     }
     const Family f{0, Lx, (int)PX, Ly};
-    int rc = layer_call(*w, C, H, P, tok, 0, (int)PX, tok, (int)PX, (int)PY, cosT, sinT, x_mask ? mask : nullptr, f, nullptr, lw,
-                        otok, st);
+    int rc = layer_call(*w, C, H, P, tok, 0, (int)PX, tok, (int)PX, (int)PY, rotary ? cosT : nullptr, rotary ? sinT : nullptr,
+                        x_mask ? mask : nullptr, f, nullptr, lw, otok, st, nullptr, nullptr, qk_tok, qk_tok);
     if (rc) return rc;
     DR_HIP_CHECK(hipMemcpyAsync(out, otok, PX * C * 4, hipMemcpyDeviceToDevice, st));
     return DR_OK;

@@ -627,6 +627,48 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(int rows, int cols, i
         P[(size_t)row * cols + j] = dead ? 0.f : expf(sr[j] * scale - mx) / sum;
     }
 }
+// dual-softmax read-out of Matching.forward (3D/models/matching.py:193-205): conf = softmax over the ROWS (dim 1) of sim / T with the invalid source
+// rows at -inf, times softmax over the COLUMNS (dim 2) with the invalid target columns at -inf.  Column statistics first (one thread per column, rows in
+// order), then one wave per row.
+__global__ __launch_bounds__(256) void dual_softmax_cols_kernel(int N, int M, const float* __restrict__ sim, float T, const uint8_t* __restrict__ sm,
+                                                                float* __restrict__ cmax, float* __restrict__ csum) {
+    const int p = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const float* s = sim + (size_t)p * N * M + j;
+    const uint8_t* m = sm ? sm + (size_t)p * N : nullptr;
+    float mx = -INFINITY;
+    for (int i = 0; i < N; ++i)
+        if (!m || m[i]) mx = fmaxf(mx, s[(size_t)i * M] / T);
+    float sum = 0.f;
+    for (int i = 0; i < N; ++i)
+        if (!m || m[i]) sum += expf(s[(size_t)i * M] / T - mx);
+    cmax[(size_t)p * M + j] = mx;
+    csum[(size_t)p * M + j] = sum;
+}
+__global__ __launch_bounds__(256) void dual_softmax_rows_kernel(int rows, int N, int M, const float* __restrict__ sim, float T, const uint8_t* __restrict__ sm,
+                                                                const uint8_t* __restrict__ tm, const float* __restrict__ cmax,
+                                                                const float* __restrict__ csum, float* __restrict__ conf) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int p = row / N;
+    const bool rv = sm ? sm[row] != 0 : true;
+    const float* sr = sim + (size_t)row * M;
+    const uint8_t* t = tm ? tm + (size_t)p * M : nullptr;
+    float mx = -INFINITY;
+    for (int j = lane; j < M; j += 64)
+        if (!t || t[j]) mx = fmaxf(mx, sr[j] / T);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < M; j += 64)
+        if (!t || t[j]) sum += expf(sr[j] / T - mx);
+    sum = wave_sum(sum);
+    for (int j = lane; j < M; j += 64) {
+        const float x = sr[j] / T;
+        const float a = rv ? expf(x - cmax[(size_t)p * M + j]) / csum[(size_t)p * M + j] : 0.f;
+        const float b = (!t || t[j]) ? expf(x - mx) / sum : 0.f;
+        conf[(size_t)row * M + j] = a * b;
+    }
+}
 // dS = scale P (dP - sum_j dP_j P_j)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int rows, int cols, const float* __restrict__ P, const float* __restrict__ dP, float scale,
                                                           float* __restrict__ dS) {
@@ -673,6 +715,20 @@ int dr_softmax_rows_f32(int B, int H, int L, int S, const float* scores, float s
     const int rows = B * H * L;
     if (rows == 0) return DR_OK;
     hipLaunchKernelGGL(dr::softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, S, L, H, scores, scale, q_mask, k_mask, P);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+int dr_dual_softmax_f32(int P, int N, int M, const float* sim, float temperature, const uint8_t* src_mask, const uint8_t* tgt_mask, float* conf,
+                        float* col_stats, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || !sim || !conf || !col_stats || !(temperature > 0.f) || ((src_mask == nullptr) != (tgt_mask == nullptr))) return DR_EINVAL;
+    if (P == 0) return DR_OK;
+    float* cmax = col_stats;
+    float* csum = col_stats + (size_t)P * M;
+    hipLaunchKernelGGL(dr::dual_softmax_cols_kernel, dim3((M + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, N, M, sim, temperature, src_mask, cmax, csum);
+    DR_LAUNCH_CHECK();
+    const int rows = P * N;
+    hipLaunchKernelGGL(dr::dual_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, N, M, sim, temperature, src_mask, tgt_mask,
+                       cmax, csum, conf);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

@@ -131,6 +131,8 @@ SIGNATURES.update({
     "dr_attention_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dr_attention_layer_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9 +
                                [c_void_p, c_size_t, c_void_p]),
+    "dr_attention_layer_pe_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 11 +
+                                  [c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "dr_device_status": (c_int, [c_void_p, c_int]),
@@ -163,6 +165,7 @@ SIGNATURES.update({
     "dr_attention_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_attention_backward_f32": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 3 + [c_void_p, c_size_t, c_void_p]),
     "dr_softmax_rows_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_dual_softmax_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_softmax_backward_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dr_relu_backward_f32": (c_int, [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_rotary_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
@@ -823,8 +826,9 @@ def layer_weights(tensors):
     return lw
 
 
-def attention_layer(tensors, C, H, x, y, cos_x, sin_x, cos_y, sin_y, x_mask=None, y_mask=None):
-    """x [P,Lx,C] attends y [P,Ly,C] (GeometryAttentionLayer.forward)."""
+def attention_layer(tensors, C, H, x, y, cos_x=None, sin_x=None, cos_y=None, sin_y=None, x_mask=None, y_mask=None, xq=None, yk=None):
+    """x [P,Lx,C] attends y [P,Ly,C] (GeometryAttentionLayer.forward).  Rotary tables given: pe_type 'rotary'.  No tables: no position code inside
+    the layer (entangled form), or -- with xq = x + pe_x, yk = y + pe_y -- pe_type 'sinusoidal' (transformero.py:50-57)."""
     ensure_init()
     P, Lx, _ = x.shape
     Ly = y.shape[1]
@@ -833,10 +837,23 @@ def attention_layer(tensors, C, H, x, y, cos_x, sin_x, cos_y, sin_y, x_mask=None
     wsb = _lib.dr_attention_layer_workspace_bytes(P, Lx, Ly, C)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     xm, ym = mask_u8(x_mask), mask_u8(y_mask)
-    check(_lib.dr_attention_layer_f32(ctypes.byref(lw), C, H, P, Lx, Ly, ptr(x.contiguous()), ptr(y.contiguous()),
-                                      ptr(cos_x.contiguous()), ptr(sin_x.contiguous()), ptr(cos_y.contiguous()),
-                                      ptr(sin_y.contiguous()), ptr(xm), ptr(ym), ptr(out), ptr(ws), wsb, stream_of(x)))
+    cont = lambda a: None if a is None else a.contiguous().float()
+    x, y, xq, yk, cos_x, sin_x, cos_y, sin_y = (cont(a) for a in (x, y, xq, yk, cos_x, sin_x, cos_y, sin_y))
+    check(_lib.dr_attention_layer_pe_f32(ctypes.byref(lw), C, H, P, Lx, Ly, ptr(x), ptr(y), ptr(xq), ptr(yk), ptr(cos_x), ptr(sin_x), ptr(cos_y),
+                                         ptr(sin_y), ptr(xm), ptr(ym), ptr(out), ptr(ws), wsb, stream_of(x)))
     return out
+
+
+def dual_softmax(sim, temperature, src_mask=None, tgt_mask=None):
+    """sim [P,N,M] float32 -> conf = softmax_dim1(sim / T | source rows) * softmax_dim2(sim / T | target columns) (matching.py:193-205)"""
+    ensure_init()
+    sim = sim.contiguous().float()
+    P, N, M = sim.shape
+    conf = torch.empty_like(sim)
+    stats = torch.empty(2 * P * M, dtype=torch.float32, device=sim.device)
+    sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    check(_lib.dr_dual_softmax_f32(P, N, M, ptr(sim), float(temperature), ptr(sm), ptr(tm), ptr(conf), ptr(stats), stream_of(sim)))
+    return conf
 
 
 def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_condition_num, use_mask_len=False,

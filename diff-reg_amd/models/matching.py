@@ -85,24 +85,32 @@ class Matching(nn.Module):
 
     @torch.no_grad()
     def forward(self, src_feats, tgt_feats, src_pe, tgt_pe, src_mask, tgt_mask, data, pe_type="rotary"):
-        if self.match_type != "sinkhorn" or self.entangled or pe_type != "rotary":
-            raise NotImplementedError("accelerated path: match_type='sinkhorn', entangled=False, rotary PE")
         B, N, C = src_feats.shape
         M = tgt_feats.shape[1]
         W = self.src_proj.weight.detach()
-        cs, ss = half_tables(src_pe)
-        ct, st = half_tables(tgt_pe)
         s_np = lib.linear(src_feats.reshape(B * N, C), W)
         t_np = lib.linear(tgt_feats.reshape(B * M, C), W)            # src_proj on both sides (Q1)
         data["src_feats_nopos"], data["tgt_feats_nopos"] = s_np.view(B, N, C), t_np.view(B, M, C)
-        # (the rotary form comes from the GEMM's epilogue: a second pass over the same small projection; inside the denoising
-        #  loop -- dr_denoise_loop -- neither copy is materialised per step)
-        s_rot = lib.linear(src_feats.reshape(B * N, C), W, epilogue=2, cos=cs, sin=ss, rot_C=C).view(B, N, C)
-        t_rot = lib.linear(tgt_feats.reshape(B * M, C), W, epilogue=2, cos=ct, sin=st, rot_C=C).view(B, M, C)
-        data["src_feats"], data["tgt_feats"] = s_rot, t_rot
-        a = s_rot / C ** 0.5
-        b = t_rot / C ** 0.5
+        if self.entangled:                                            # matching.py:181: the features already carry the code
+            s_pos, t_pos = s_np.view(B, N, C), t_np.view(B, M, C)
+        elif pe_type == "rotary":
+            # (the rotary form comes from the GEMM's epilogue: a second pass over the same small projection; inside the denoising
+            #  loop -- dr_denoise_loop -- neither copy is materialised per step)
+            cs, ss = half_tables(src_pe)
+            ct, st = half_tables(tgt_pe)
+            s_pos = lib.linear(src_feats.reshape(B * N, C), W, epilogue=2, cos=cs, sin=ss, rot_C=C).view(B, N, C)
+            t_pos = lib.linear(tgt_feats.reshape(B * M, C), W, epilogue=2, cos=ct, sin=st, rot_C=C).view(B, M, C)
+        elif pe_type == "sinusoidal":                                 # position_encoding.py:43-44: x + pe
+            s_pos, t_pos = s_np.view(B, N, C) + src_pe, t_np.view(B, M, C) + tgt_pe
+        else:
+            raise KeyError(pe_type)
+        data["src_feats"], data["tgt_feats"] = s_pos, t_pos
+        a = s_pos / C ** 0.5
+        b = t_pos / C ** 0.5
         sim = lib.bmm_nt(a, b)                                        # one strided-batch launch over the pairs
-        conf = lib.sinkhorn(sim, self.bin_score, self.skh_iters, src_mask, tgt_mask, apply_mask=src_mask is not None)
+        if self.match_type == "dual_softmax":                         # matching.py:193-205
+            conf = lib.dual_softmax(sim, self.temperature, src_mask, tgt_mask)
+        else:
+            conf = lib.sinkhorn(sim, self.bin_score, self.skh_iters, src_mask, tgt_mask, apply_mask=src_mask is not None)
         coarse_match, _, _ = self.get_match(conf, self.confidence_threshold)
         return conf, coarse_match

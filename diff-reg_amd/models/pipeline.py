@@ -154,6 +154,8 @@ class Pipeline(nn.Module):
         P, N, _ = src_feats.shape
         M = tgt_feats.shape[1]
         dev = src_feats.device
+        if not self._fused_loop_config():
+            return self._eval_loop_on_modules(data, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask)
         eng = self._get_engine(dev)
         S = self.sampling_timesteps
         x_T = data["x_T"] if "x_T" in data else torch.randn(P, N, M, device=dev)          # pipeline.py:224
@@ -191,6 +193,59 @@ class Pipeline(nn.Module):
         data.update({"R_s2t_pred": R, "t_s2t_pred": t})
         return data
 
+    def _fused_loop_config(self):
+        """dr_denoise_loop implements the configuration every shipped yaml selects: rotary code, disentangled, Sinkhorn read-out"""
+        ct = self.config["coarse_transformer"]
+        return ct["pe_type"] == "rotary" and not ct["entangled"] and not self.denoising_coarse_matching.entangled \
+            and self.denoising_coarse_matching.match_type == "sinkhorn"
+
+    def _eval_loop_on_modules(self, data, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask):
+        """The evaluation loop (3D/models/pipeline.py:221-283, 4D/models/pipeline.py:155-197) for the configuration branches no shipped yaml
+        selects (pe_type 'sinusoidal', entangled = True): the same steps, one module call at a time -- every module of this overlay runs on
+        libdiffreg_hip kernels; the DDIM arithmetic is the reference's own lines on device tensors, so the dtype choreography (float64 state from
+        the second step on, quirk Q2) is torch's, not a restatement.  No HIP graph, no batching across steps: this is the compatible path, the
+        fused dr_denoise_loop the fast one.  match_type 'dual_softmax' fails here exactly where the reference fails (no `bin_score`)."""
+        dev = src_feats.device
+        P, N, _ = src_feats.shape
+        M = tgt_feats.shape[1]
+        head = self.denoising_coarse_matching
+        x = (data["x_T"] if "x_T" in data else torch.randn(P, N, M, device=dev)).float().clone()
+        times = list(reversed(torch.linspace(0, self.num_timesteps - 1, steps=self.sampling_timesteps + 1).int().tolist()))
+        for k, (time, time_next) in enumerate(zip(times[:-1], times[1:])):
+            time_cond = torch.full((1,), time, device=dev, dtype=torch.long)
+            if self.variant == "3dmatch":
+                x = x - x.min()
+            src_w, tgt_w = self.get_warped_from_noising_matching(s_pcd, t_pcd, src_mask, tgt_mask, x)
+            s_n, t_n, src_pe, tgt_pe = self.denoising_transformer(src_feats, tgt_feats, src_w, tgt_w, src_mask, tgt_mask, data)
+            x_start, _ = head(s_n, t_n, src_pe, tgt_pe, src_mask, tgt_mask, data, pe_type=self.pe_type)
+            pred_noise = self.predict_noise_from_start(x, time_cond, x_start)
+            alpha, alpha_next = self.alphas_cumprod[time], self.alphas_cumprod[time_next]
+            sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            noise = data["noise"][k].to(x.dtype) if "noise" in data else torch.randn_like(x)
+            x = x_start * alpha_next.sqrt() + c * pred_noise
+            if self.variant == "4dmatch":
+                x = x + sigma * noise
+        if self.variant == "3dmatch":
+            sim = x - x.min()
+            sim.masked_fill_(~(src_mask[..., None] * tgt_mask[:, None]).bool(), float("-inf"))
+            conf = log_optimal_transport(sim, head.bin_score, head.skh_iters, src_mask, tgt_mask).exp()[:, :-1, :-1].contiguous()
+            rows = []
+            for b in range(P):
+                si, ti, _ = mutual_topk_select(conf[b], 1, largest=True, threshold=None, mutual=False)
+                rows.append(torch.stack([torch.full_like(si, b), si, ti], dim=-1))
+            data.update({"conf_matrix_pred": conf, "match_pred": torch.cat(rows, 0)})
+        else:
+            conf = torch.sigmoid(x)
+            data.update({"conf_matrix_pred": conf})
+        if self.strict_reference:
+            R = torch.eye(3, dtype=torch.float64, device=dev)[None].repeat(P, 1, 1)
+            t = torch.zeros(P, 3, 1, dtype=torch.float64, device=dev)
+        else:
+            R, t, _, _, _, _ = self.soft_procrustes(conf.float(), s_pcd, t_pcd, src_mask, tgt_mask)
+        data.update({"R_s2t_pred": R, "t_s2t_pred": t})
+        return data
+
     def _training_forward(self, data, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask):
         """the `if self.training:` block of pipeline.py:182-216, values only: both transformers, both matching heads and the two
         Procrustes fits run on the HIP kernels of the loop; the GT-matrix noising (q_sample on the structured noise, nan_to_num,
@@ -225,6 +280,9 @@ class Pipeline(nn.Module):
         matrix -- are differentiable on the device (diffreg_hip.backbone_autograd, diffreg_hip.autograd).  Writes the keys of pipeline.py:182-216 into `data`; `models.loss.MatchMotionLoss.forward_train`
         turns them into a loss whose .backward() fills the gradients of every parameter the reference's training updates behind the backbone."""
         from diffreg_hip import autograd as dag, lib
+        if not self._fused_loop_config() or self.config["coarse_transformer"]["positioning_type"] != "procrustes":
+            raise NotImplementedError("forward_train: the backward kernels exist for the shipped configuration (rotary code, disentangled, Sinkhorn "
+                                      "read-out, Procrustes positioning); the other branches run value-only through forward()")
         # the overlay backbone (models.backbone.KPFCN) is differentiable under .train() (diffreg_hip/backbone_autograd.py); any other backbone
         # module takes part in the graph as far as its own forward does (a reference-tree KPFCN on torch ops, a stub returning constants)
         coarse_feats = self.backbone(data, phase="coarse")

@@ -44,11 +44,17 @@ class VolumetricPositionEncoding(nn.Module):
 
     def forward(self, XYZ):
         """[B,N,3] -> position code [B,N,C,2] (cos, sin; each angle on two adjacent channels)."""
-        if self.pe_type != "rotary":
-            raise NotImplementedError("only pe_type='rotary' is on the accelerated path (all shipped configs)")
         B, N, _ = XYZ.shape
         cos, sin = self.tables(XYZ)
         C = self.feature_dim
+        if self.pe_type == "sinusoidal":
+            # position_encoding.py:68-69: cat[sin x, cos x, sin y, cos y, sin z, cos z], each C / 6 wide -- the same sinusoid bank
+            # dr_vol_pe_f32 computes for the rotary form (tables = [x | y | z] thirds of C / 6 angles), re-ordered
+            k = C // 6
+            c3, s3 = cos.view(B, N, 3, k), sin.view(B, N, 3, k)
+            return torch.stack([s3, c3], dim=3).reshape(B, N, 6 * k)
+        if self.pe_type != "rotary":
+            raise KeyError(self.pe_type)
         cos = cos.view(B, N, C // 2).repeat_interleave(2, dim=-1)
         sin = sin.view(B, N, C // 2).repeat_interleave(2, dim=-1)
         return torch.stack([cos, sin], dim=-1)

@@ -274,6 +274,16 @@ int dr_attention_layer_f32(const dr_layer_weights* w, int C, int H, int P, int L
                            const float* y, const float* cos_x, const float* sin_x, const float* cos_y,
                            const float* sin_y, const uint8_t* x_mask, const uint8_t* y_mask, float* out,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same layer for the configuration branches no shipped yaml selects (3D/models/transformero.py:50-57, 246-252;
+ * configs/test/3dmatch.yaml:45 "options: ['rotary', 'sinusoidal']", :1 "entangled"):
+ *   cos_x .. sin_y all NULL : no rotary code on q and k -- pe_type 'sinusoidal', or a layer called without position codes (entangled = True);
+ *   xq [P*Lx, C], yk [P*Ly, C] (both or neither; only without rotary tables): the inputs of the q and k projections where they are not x and y --
+ *     the sinusoidal form q = W_q (x + pe_x), k = W_k (y + pe_y), v = W_v y; the residual and the mlp's cat[x, message] keep x.
+ * Same workspace.  dr_attention_layer_f32 is this entry with xq = yk = NULL and all four tables given. */
+int dr_attention_layer_pe_f32(const dr_layer_weights* w, int C, int H, int P, int Lx, int Ly, const float* x, const float* y,
+                              const float* xq, const float* yk, const float* cos_x, const float* sin_x, const float* cos_y,
+                              const float* sin_y, const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* SoftProcrustesLayer.forward (3D/models/procrustes.py:48-93): top-K of conf, weighted Kabsch,
  * fp64 3x3 SVD ON DEVICE (replaces the .cpu().double().svd() of procrustes.py:35-36), gate.
@@ -693,6 +703,11 @@ int dr_attention_backward_f32(int B, int H, int L, int S, int d, const float* q,
                               void* workspace, size_t workspace_bytes, void* stream);
 int dr_softmax_rows_f32(int B, int H, int L, int S, const float* scores, float scale, const uint8_t* q_mask, const uint8_t* k_mask, float* P, void* stream);
 int dr_softmax_backward_f32(int rows, int cols, const float* P, const float* grad_P, float scale, float* grad_scores, void* stream);
+/* The dual-softmax read-out of Matching.forward (3D/models/matching.py:193-205; match_type 'dual_softmax'):
+ *   conf[p][i][j] = softmax_i(sim[p][.][j] / temperature over the valid source rows) * softmax_j(sim[p][i][.] / temperature over the valid target columns),
+ *   0 where either mask is 0; masks uint8 [P,N] / [P,M] or both NULL (the reference's mask-free branch).  col_stats: caller scratch of 2 P M floats. */
+int dr_dual_softmax_f32(int P, int N, int M, const float* sim, float temperature, const uint8_t* src_mask, const uint8_t* tgt_mask, float* conf,
+                        float* col_stats, void* stream);
 int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float* grad_x, void* stream);
 
 /* embed_rotary (position_encoding.py:25-35) on contiguous rows [rows, C]: out = R(theta) x * scale with cos / sin [rows, C/2]; inverse != 0:

@@ -106,6 +106,31 @@ def vol_pe(xyz, C, origin, voxel):
     return torch.cat(cs, -1), torch.cat(sn, -1)
 
 
+def vol_pe_sinusoidal(xyz, C, origin, voxel):
+    """pe_type 'sinusoidal' (3D/models/position_encoding.py:56-69): the same sinusoid bank as cat[sin x, cos x, sin y, cos y, sin z, cos z],
+    each C / 6 wide, ADDED to the features (embed_pos, :43-44)"""
+    vox = (xyz - torch.tensor(origin, dtype=F32).view(1, 1, 3)) / voxel
+    d = C // 3
+    freq = torch.exp(torch.arange(0, d, 2, dtype=F32) * (-math.log(10000.0) / d)).view(1, 1, -1)
+    parts = []
+    for a in range(3):
+        ang = vox[..., a:a + 1] * freq
+        parts += [torch.sin(ang), torch.cos(ang)]
+    return torch.cat(parts, -1)
+
+
+def position_code(cfg, xyz):
+    """the code in the form cfg['pe_type'] uses: (cos, sin) tables for 'rotary' (default), one additive tensor for 'sinusoidal'"""
+    if cfg.get("pe_type", "rotary") == "sinusoidal":
+        return vol_pe_sinusoidal(xyz, cfg["C"], cfg["origin"], cfg["voxel"])
+    return vol_pe(xyz, cfg["C"], cfg["origin"], cfg["voxel"])
+
+
+def embed_pos(x, pe):
+    """VolPE.embed_pos (position_encoding.py:38-46): rotary tables rotate, a sinusoidal code is added"""
+    return rotary(x, *pe) if isinstance(pe, tuple) else x + pe
+
+
 def rotary(x, cos, sin):
     """x*cos + swap(x)*sin with swap(x)[2k] = -x[2k+1], swap(x)[2k+1] = x[2k]."""
     sw = torch.stack([-x[..., 1::2], x[..., 0::2]], dim=-1).reshape(x.shape)
@@ -124,12 +149,15 @@ def attention_layer(W, pre, x, y, pe_x, pe_y, mask_x, mask_y, H):
     B, L, C = x.shape
     S = y.shape[1]
     d = C // H
-    q = x @ W[pre + "q_proj.weight"].T
-    k = y @ W[pre + "k_proj.weight"].T
+    # pe = (cos, sin): rotary, R w x (transformero.py:59-74); pe = tensor: sinusoidal, w (x + p) on q and k only (:50-57);
+    # pe = None: a layer of the entangled form, no code inside (:246-252)
+    add = pe_x is not None and not isinstance(pe_x, tuple)
+    q = ((x + pe_x) if add else x) @ W[pre + "q_proj.weight"].T
+    k = ((y + pe_y) if add else y) @ W[pre + "k_proj.weight"].T
     v = y @ W[pre + "v_proj.weight"].T
-    q = rotary(q, *pe_x).view(B, L, H, d)
-    k = rotary(k, *pe_y).view(B, S, H, d)
-    v = v.view(B, S, H, d)
+    if isinstance(pe_x, tuple):
+        q, k = rotary(q, *pe_x), rotary(k, *pe_y)
+    q, k, v = q.view(B, L, H, d), k.view(B, S, H, d), v.view(B, S, H, d)
     a = torch.einsum("blhd,bshd->blsh", q, k)
     if mask_y is not None:
         a = a.masked_fill(mask_x[:, :, None, None] & ~mask_y[:, None, :, None], float("-inf"))
@@ -145,8 +173,18 @@ def denoiser(W, cfg, f_s, f_t, p_s, p_t, mask_s, mask_t, prefix="denoising_trans
     """six layers self,cross,...; same weights for the src and the tgt call; in a cross layer tgt
     attends to the UPDATED src (quirk Q11)."""
     C, H = cfg["C"], cfg["H"]
-    pe_s = vol_pe(p_s, C, cfg["origin"], cfg["voxel"])
-    pe_t = vol_pe(p_t, C, cfg["origin"], cfg["voxel"])
+    pe_s, pe_t = position_code(cfg, p_s), position_code(cfg, p_t)
+    if cfg.get("entangled", False):          # transformero.py:234-254: the code enters the features once, the layers get none
+        f_s, f_t = embed_pos(f_s, pe_s), embed_pos(f_t, pe_t)
+        for l in range(cfg["n_layers"]):
+            pre = prefix + "layers.%d." % l
+            if l % 2 == 0:
+                f_s = attention_layer(W, pre, f_s, f_s, None, None, mask_s, mask_s, H)
+                f_t = attention_layer(W, pre, f_t, f_t, None, None, mask_t, mask_t, H)
+            else:
+                f_s = attention_layer(W, pre, f_s, f_t, None, None, mask_s, mask_t, H)
+                f_t = attention_layer(W, pre, f_t, f_s, None, None, mask_t, mask_s, H)
+        return f_s, f_t, pe_s, pe_t
     for l in range(cfg["n_layers"]):
         pre = prefix + "layers.%d." % l
         if l % 2 == 0:
@@ -164,8 +202,18 @@ def denoiser(W, cfg, f_s, f_t, p_s, p_t, mask_s, mask_t, prefix="denoising_trans
 def match_head(W, cfg, f_s, f_t, pe_s, pe_t, mask_s, mask_t, prefix="denoising_coarse_matching."):
     C = cfg["C"]
     Wp = W[prefix + "src_proj.weight"]
-    a = rotary(f_s @ Wp.T, *pe_s) / C ** 0.5
-    b = rotary(f_t @ Wp.T, *pe_t) / C ** 0.5
+    a, b = f_s @ Wp.T, f_t @ Wp.T
+    if not cfg.get("entangled", False):      # matching.py:181-183
+        a, b = embed_pos(a, pe_s), embed_pos(b, pe_t)
+    a, b = a / C ** 0.5, b / C ** 0.5
+    if cfg.get("match_type", "sinkhorn") == "dual_softmax":      # matching.py:193-205
+        s1 = torch.einsum("bsc,btc->bst", a, b) / cfg["dsmax_temperature"]
+        if mask_s is None:
+            return torch.softmax(s1, 1) * torch.softmax(s1, 2)
+        s2 = s1.clone()
+        s1 = s1.masked_fill(~mask_s[:, :, None], float("-inf"))
+        s2 = s2.masked_fill(~mask_t[:, None, :], float("-inf"))
+        return torch.softmax(s1, 1) * torch.softmax(s2, 2)
     sim = torch.einsum("bsc,btc->bst", a, b)
     return sinkhorn_conf(sim, W[prefix + "bin_score"], cfg["skh_iters"], mask_s, mask_t)
 

@@ -1,0 +1,201 @@
+"""Mint golden vectors for the configuration branches NO shipped yaml selects, by RUNNING THE REFERENCE (build container only; needs /root/reference):
+
+    python oracle/make_golden_branches.py        # writes tests/golden/3dmatch_branches.npz
+
+  pe_type 'sinusoidal'      3D/models/position_encoding.py:43-44, 68-69; transformero.py:50-57      (configs/test/3dmatch.yaml:45 lists it as an option)
+  entangled = True          transformero.py:234-254; matching.py:181                                (yaml :1)
+  match_type 'dual_softmax' matching.py:113, 193-205                                                (yaml :34)
+  positioning_type 'oracle' / 'randSO3'  transformero.py:202-216, 261-280                           (yaml :44)
+
+Stored: the position code, one GeometryAttentionLayer call per form (with and without masks), the six-layer denoiser + Matching head per form, the
+dual-softmax read-out (masks / no masks), a coarse transformer with the 'oracle' positioning layer, and the reverse-diffusion loop through the
+reference's own Pipeline.forward (stub backbone, injected x_T, as oracle/make_golden.py) for ('sinusoidal', disentangled) and ('rotary', entangled).
+With match_type 'dual_softmax' the reference's Pipeline cannot run at all (pipeline.py:270 / :299 read `denoising_coarse_matching.bin_score`, which
+that branch never creates), so the read-out is pinned at the level of Matching.forward.  Inputs and weights come from diffreg_hip.synth (integer
+hash, the soft head: logits O(10)); only reference OUTPUTS are stored.  4D/models/transformer.py is the same file as 3D/models/transformero.py.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "diff-reg_amd"))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "3dmatch_branches.npz")
+TREE = "/root/reference/Diff-Reg-3dmatch"
+
+FORMS = {"sin": ("sinusoidal", False), "rot_ent": ("rotary", True), "sin_ent": ("sinusoidal", True)}
+
+
+def form_config(ref_config, pe_type, entangled, steps=3, max_cond=200.0, match_type="sinkhorn"):
+    cfg = ref_config("3dmatch", steps, max_cond)
+    ct = cfg.coarse_transformer
+    ct["pe_type"], ct["entangled"] = pe_type, entangled
+    ct["feature_matching"]["entangled"] = entangled
+    cfg.coarse_matching["entangled"] = entangled
+    cfg.coarse_matching["match_type"] = ct["feature_matching"]["match_type"] = match_type
+    return cfg
+
+
+def main():
+    import torch
+    from oracle.make_golden import ref_config, to_attr, HEAD_GAIN_SOFT
+    sys.modules["open3d"] = MagicMock()
+    for m in ("easydict", "tensorboardX", "nibabel", "nibabel.quaternions", "cv2"):
+        sys.modules.setdefault(m, MagicMock())
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    os.chdir(TREE)
+    sys.path.insert(0, TREE)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from diffreg_hip import synth
+    from models.matching import Matching
+    from models.position_encoding import VolumetricPositionEncoding
+    from models.transformero import RepositioningTransformer
+    from models.pipeline import Pipeline
+    from configs.models import architectures
+
+    v = synth.VARIANTS["3dmatch"]
+    C = v["C"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Wnp = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN_SOFT))
+    Wnp.update(synth.make_weights_coarse(C, seed=17, head_gain=HEAD_GAIN_SOFT))
+    sub = lambda pre: {k[len(pre):]: T(a) for k, a in Wnp.items() if k.startswith(pre)}
+    res = {}
+    pair = synth.make_pair(64, 48, C, seed=3)
+    fs, ft = T(pair["src_feats"])[None] * 0.5, T(pair["tgt_feats"])[None] * 0.5
+    ps, pt = T(pair["s_pcd"])[None], T(pair["t_pcd"])[None]
+    sm_full, tm_full = torch.ones(1, 64, dtype=torch.bool), torch.ones(1, 48, dtype=torch.bool)
+    sm_part, tm_part = torch.arange(64)[None] < 50, torch.arange(48)[None] < 41
+
+    # ---- the sinusoidal position code
+    pe_sin = VolumetricPositionEncoding(form_config(ref_config, "sinusoidal", False).coarse_transformer)
+    res["pe_sin"] = pe_sin(ps)[0, :16].numpy()
+
+    with torch.no_grad():
+        for tag, (pe_type, ent) in FORMS.items():
+            cfg = form_config(ref_config, pe_type, ent)
+            ct = to_attr(dict(cfg.coarse_transformer))
+            ct["layer_types"] = list(synth.LAYER_TYPES)
+            den = RepositioningTransformer(ct)
+            den.load_state_dict(sub("denoising_transformer."))
+            head = Matching(cfg.coarse_matching)
+            head.load_state_dict(sub("denoising_coarse_matching."))
+            den.eval(); head.eval()
+            # one layer call in the form this configuration calls it: with codes (disentangled) or without (entangled)
+            pe_mod = VolumetricPositionEncoding(ct)
+            pes, pet = pe_mod(ps), pe_mod(pt)
+            lay = den.layers[1]
+            if ent:
+                res[tag + "_layer_cross_mask"] = lay(fs, ft, None, None, sm_part, tm_part)[0].numpy()
+                res[tag + "_layer_self_full"] = lay(fs, fs, None, None, sm_full, sm_full)[0].numpy()
+            else:
+                res[tag + "_layer_cross_mask"] = lay(fs, ft, pes, pet, sm_part, tm_part)[0].numpy()
+                res[tag + "_layer_self_full"] = lay(fs, fs, pes, pes, sm_full, sm_full)[0].numpy()
+            for mtag, (sm, tm) in (("full", (sm_full, tm_full)), ("mask", (sm_part, tm_part))):
+                d = {}
+                o_s, o_t, pe_s, pe_t = den(fs, ft, ps, pt, sm, tm, d)
+                conf, match = head(o_s, o_t, pe_s, pe_t, sm, tm, d, pe_type=pe_type)
+                res["%s_den_fs_%s" % (tag, mtag)], res["%s_den_ft_%s" % (tag, mtag)] = o_s[0].numpy(), o_t[0].numpy()
+                res["%s_conf_%s" % (tag, mtag)] = conf[0].numpy()
+                res["%s_match_%s" % (tag, mtag)] = match.numpy()
+                res["%s_feats_pos_%s" % (tag, mtag)] = d["src_feats"][0, :8].numpy()
+
+        # ---- dual softmax (rotary, disentangled): Matching.forward only (see the header)
+        cfg = form_config(ref_config, "rotary", False, match_type="dual_softmax")
+        head = Matching(cfg.coarse_matching)
+        sd = sub("denoising_coarse_matching.")
+        sd.pop("bin_score")
+        head.load_state_dict(sd)
+        head.eval()
+        pe_mod = VolumetricPositionEncoding(cfg.coarse_transformer)
+        pes, pet = pe_mod(ps), pe_mod(pt)
+        for mtag, (sm, tm) in (("mask", (sm_part, tm_part)), ("none", (None, None))):
+            d = {}
+            conf, match = head(fs, ft, pes, pet, sm, tm, d, pe_type="rotary")
+            res["dsm_conf_" + mtag], res["dsm_match_" + mtag] = conf[0].numpy(), match.numpy()
+        res["dsm_temperature"] = np.float64(cfg.coarse_matching["dsmax_temperature"])
+
+        # ---- coarse transformer with the ground-truth ('oracle') positioning layer
+        cfg = form_config(ref_config, "rotary", False)
+        ct = to_attr(dict(cfg.coarse_transformer))
+        ct["positioning_type"] = "oracle"
+        cot = RepositioningTransformer(ct)
+        sdc = {k: a for k, a in sub("coarse_transformer.").items() if not k.startswith("layers.2.")}     # the procrustes layer's Matching is not built
+        cot.load_state_dict(sdc)
+        cot.eval()
+        d = {"batched_rot": T(pair["R_gt"])[None].float(), "batched_trn": T(pair["t_gt"])[None].float().view(1, 3, 1)}
+        o_s, o_t, pe_s, pe_t = cot(fs, ft, ps, pt, sm_part, tm_part, d)
+        res["oracle_pos_fs"], res["oracle_pos_ft"] = o_s[0].numpy(), o_t[0].numpy()
+        res["oracle_pos_pe_s"] = pe_s[0, :8].numpy()
+
+        # ---- the 'randSO3' positioning layer's re-posing (transformero.py:261-280; numpy's global generator, seeded here)
+        np.random.seed(5)
+        res["rand_rot_pcd"] = cot.rand_rot_pcd(ps.clone(), sm_part)[0].numpy()
+
+    # ---- the loop through Pipeline.forward for two forms
+    class StubBackbone(torch.nn.Module):
+        feats = None
+
+        def forward(self, data, phase="coarse"):
+            return self.feats
+
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+    for tag in ("sin", "rot_ent"):
+        pe_type, ent = FORMS[tag]
+        N, M, nv, mv, steps, mc, seed = 96, 80, 96, 80, 3, 200.0, 12
+        cfg = form_config(ref_config, pe_type, ent, steps=steps, max_cond=mc)
+        cfg.kpfcn_config["architecture"] = architectures["3dmatch"]
+        model = Pipeline(cfg)
+        model.backbone = StubBackbone()
+        sd = model.state_dict()
+        for k, a in Wnp.items():
+            if k in sd:
+                sd[k] = T(a)
+        model.load_state_dict(sd)
+        model.eval()
+        pr = synth.make_pair(N, M, C, seed=seed)
+        model.backbone.feats = torch.cat([T(pr["src_feats"]), T(pr["tgt_feats"])], 0)
+        pts = torch.cat([T(pr["s_pcd"]), T(pr["t_pcd"])], 0)
+        data = {"points": [None, None, pts, None], "src_mask": torch.arange(N)[None] < nv, "tgt_mask": torch.arange(M)[None] < mv,
+                "src_ind_coarse_split": torch.arange(N), "tgt_ind_coarse_split": torch.arange(M),
+                "src_ind_coarse": torch.arange(N), "tgt_ind_coarse": torch.arange(N, N + M)}
+        x_T = T(pr["x_T"])[None]
+        x0_log, warp_log = [], []
+        orig_head, orig_proc = model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward
+
+        def head_spy(*a, **k):
+            r = orig_head(*a, **k)
+            x0_log.append(r[0].detach().clone())
+            return r
+
+        def proc_spy(*a, **k):
+            r = orig_proc(*a, **k)
+            warp_log.append([z.detach().clone() for z in r])
+            return r
+        model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward = head_spy, proc_spy
+        torch.randn = lambda *a, **k: x_T.clone()
+        torch.randn_like = lambda x, *a, **k: torch.zeros_like(x)          # (the 3D loop draws it and drops it, pipeline.py:254-256)
+        try:
+            with torch.no_grad():
+                out = model(data)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        conf = out["conf_matrix_pred"]
+        res.update({"loop_%s_conf" % tag: conf[0].numpy(), "loop_%s_x0" % tag: torch.stack([z[0] for z in x0_log]).numpy(),
+                    "loop_%s_R_forwd" % tag: torch.stack([w[2][0] for w in warp_log]).numpy(),
+                    "loop_%s_t_forwd" % tag: torch.stack([w[3][0] for w in warp_log]).numpy(),
+                    "loop_%s_cond" % tag: torch.stack([w[4][0] for w in warp_log]).numpy(),
+                    "loop_%s_match_pred" % tag: out["match_pred"].numpy()})
+        res["loop_shape"] = np.array([N, M, steps, seed], dtype=np.int64)
+        c = conf[0].double()
+        print(tag, "conf", conf.dtype, "max %.4f" % float(c.max()), "rowmax mean %.4f" % float(c.max(1)[0].mean()), "cond", res["loop_%s_cond" % tag])
+    np.savez_compressed(OUT, **res)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(res), "arrays")
+
+
+if __name__ == "__main__":
+    main()
