@@ -1,0 +1,10 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+export P=8 CPU=0
+rocprofv3 --kernel-trace --stats -d gpurun_out/r05_prof_cfg5 --output-format csv -- python3 tools/bench_2d3d.py > gpurun_out/r05_prof_cfg5.json 2> gpurun_out/r05_prof_cfg5.err
+python3 tools/trim_stats.py $(ls gpurun_out/r05_prof_cfg5/*/*kernel_stats.csv | head -1) > gpurun_out/r05_cfg5_p8_rocprof_kernel_stats.txt
+rm -rf gpurun_out/r05_prof_cfg5
+rocprofv3 --kernel-trace --stats -d gpurun_out/r05_prof_cfg3 --output-format csv -- python3 tools/bench_cfg3.py > gpurun_out/r05_prof_cfg3.json 2> gpurun_out/r05_prof_cfg3.err
+python3 tools/trim_stats.py $(ls gpurun_out/r05_prof_cfg3/*/*kernel_stats.csv | head -1) > gpurun_out/r05_cfg3_rocprof_kernel_stats.txt
+rm -rf gpurun_out/r05_prof_cfg3
+head -24 gpurun_out/r05_cfg5_p8_rocprof_kernel_stats.txt; head -20 gpurun_out/r05_cfg3_rocprof_kernel_stats.txt
