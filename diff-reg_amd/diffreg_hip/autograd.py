@@ -136,12 +136,28 @@ class _GeometryAttentionLayer(torch.autograd.Function):
     query blocks and dK | dV by key blocks on the f32-input MFMA -- no [B,H,L,S] matrix exists in either direction); LayerNorm / ReLU / rotary
     backward kernels (csrc/train.hip); every projection and its weight gradient on dr_linear_f32."""
 
+    #: True (default): forward and backward are ONE library call each (dr_attention_layer_train_forward_f32 / dr_attention_layer_backward_f32:
+    #: the same kernels launched from C++ -- a step is ~1 900 launches, and driving them from Python cost more host time than the kernels run).
+    #: False: the per-op form below (one library call per kernel), kept as the readable statement of the backward and for A/B tests.
+    fused = True
+
     @staticmethod
     def forward(ctx, x, source, cx, sx, cy, sy, x_mask, source_mask, H, Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2):
         B, L, C = x.shape
         S = source.shape[1]
         d = C // H
         det = lambda t: t.detach().float().contiguous()
+        if _GeometryAttentionLayer.fused:
+            x3, s3 = det(x), det(source)
+            wts = [det(t) for t in (Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2)]
+            tabs = [det(t) for t in (cx, sx, cy, sy)]
+            out, saved = lib.attention_layer_train_forward(wts, C, H, x3, s3, *tabs, x_mask, source_mask)
+            ctx.save_for_backward(x3, s3, saved, *tabs, *wts)
+            ctx.dims = (B, L, S, C, H, d, 1.0 / d ** 0.5)
+            ctx.masks = (x_mask, source_mask)
+            ctx.is_fused = True
+            return out
+        ctx.is_fused = False
         x2, s2 = det(x).reshape(B * L, C), det(source).reshape(B * S, C)
         Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2 = map(det, (Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2))
         cx, sx, cy, sy = map(det, (cx, sx, cy, sy))
@@ -164,6 +180,12 @@ class _GeometryAttentionLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ge):
+        if ctx.is_fused:
+            x3, s3, saved, cx, sx, cy, sy, *wts = ctx.saved_tensors
+            B, L, S, C, H, d, scale = ctx.dims
+            xm, sm_ = ctx.masks
+            gx, gs, gw = lib.attention_layer_backward(wts, C, H, x3, s3, cx, sx, cy, sy, xm, sm_, saved, ge.contiguous().float())
+            return (gx, gs, None, None, None, None, None, None, None, *gw)
         (x2, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, qw, kw, vw, o2, m_pre, st1, cat, h, f_pre, st2) = ctx.saved_tensors
         B, L, S, C, H, d, scale = ctx.dims
         tr = lambda t: t.transpose(-1, -2).contiguous()

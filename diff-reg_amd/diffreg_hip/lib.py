@@ -133,6 +133,10 @@ SIGNATURES.update({
                                [c_void_p, c_size_t, c_void_p]),
     "dr_attention_layer_pe_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 11 +
                                   [c_void_p, c_size_t, c_void_p]),
+    "dr_attention_layer_train_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dr_attention_layer_train_forward_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 10 + [c_size_t, c_void_p]),
+    "dr_attention_layer_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dr_attention_layer_backward_f32": (c_int, [_P(LayerWeights), c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12 + [_P(LayerWeights), c_void_p, c_size_t, c_void_p]),
     "dr_procrustes_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "dr_device_status": (c_int, [c_void_p, c_int]),
@@ -842,6 +846,39 @@ def attention_layer(tensors, C, H, x, y, cos_x=None, sin_x=None, cos_y=None, sin
     check(_lib.dr_attention_layer_pe_f32(ctypes.byref(lw), C, H, P, Lx, Ly, ptr(x), ptr(y), ptr(xq), ptr(yk), ptr(cos_x), ptr(sin_x), ptr(cos_y),
                                          ptr(sin_y), ptr(xm), ptr(ym), ptr(out), ptr(ws), wsb, stream_of(x)))
     return out
+
+
+def attention_layer_train_forward(tensors, C, H, x, y, cos_x, sin_x, cos_y, sin_y, x_mask=None, y_mask=None):
+    """GeometryAttentionLayer.forward keeping what the backward needs: x [B,L,C], y [B,S,C] -> (out [B,L,C], saved: an opaque uint8 tensor)"""
+    ensure_init()
+    B, L, _ = x.shape
+    S = y.shape[1]
+    lw = layer_weights(tensors)
+    out = torch.empty(B, L, C, device=x.device)
+    nb = _lib.dr_attention_layer_train_saved_bytes(B, L, S, C)
+    saved = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    xm, ym = mask_u8(x_mask), mask_u8(y_mask)
+    check(_lib.dr_attention_layer_train_forward_f32(ctypes.byref(lw), C, H, B, L, S, ptr(x), ptr(y), ptr(cos_x), ptr(sin_x), ptr(cos_y), ptr(sin_y),
+                                                    ptr(xm), ptr(ym), ptr(out), ptr(saved), nb, stream_of(x)))
+    return out, saved
+
+
+def attention_layer_backward(tensors, C, H, x, y, cos_x, sin_x, cos_y, sin_y, x_mask, y_mask, saved, grad_out):
+    """-> grad_x [B,L,C], grad_y [B,S,C], the ten parameter gradients in the order of lib._LAYER_KEYS"""
+    ensure_init()
+    B, L, _ = x.shape
+    S = y.shape[1]
+    lw = layer_weights(tensors)
+    grads = [torch.empty_like(t_) for t_ in tensors]
+    gw = layer_weights(grads)
+    gx, gy = torch.empty(B, L, C, device=x.device), torch.empty(B, S, C, device=x.device)
+    wsb = _lib.dr_attention_layer_backward_workspace_bytes(B, H, L, S, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    xm, ym = mask_u8(x_mask), mask_u8(y_mask)
+    check(_lib.dr_attention_layer_backward_f32(ctypes.byref(lw), C, H, B, L, S, ptr(x), ptr(y), ptr(cos_x), ptr(sin_x), ptr(cos_y), ptr(sin_y),
+                                               ptr(xm), ptr(ym), ptr(saved), ptr(grad_out), ptr(gx), ptr(gy), ctypes.byref(gw), ptr(ws), wsb,
+                                               stream_of(x)))
+    return gx, gy, grads
 
 
 def dual_softmax(sim, temperature, src_mask=None, tgt_mask=None):

@@ -285,6 +285,30 @@ int dr_attention_layer_pe_f32(const dr_layer_weights* w, int C, int H, int P, in
                               const float* sin_y, const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* The same layer for TRAINING (what torch autograd records through transformero.py:43-96): the forward that keeps what its
+ * backward needs, and the whole backward, one call each -- every kernel launched inside the library (the per-op entries further down drive the same
+ * kernels one by one).  x [B*L, C], y [B*S, C] contiguous; rotary tables [B*L, C/2] / [B*S, C/2]; masks uint8 [B*L] / [B*S] or both NULL.
+ *   forward : out [B*L, C]; `saved` = caller memory of dr_attention_layer_train_saved_bytes(B, L, S, C): q | k (rotary applied) | v | heads' output |
+ *             merge output | norm1 output | hidden activation | mlp output | (mean, rstd) of both LayerNorms -- opaque to the caller, handed to the backward
+ *   backward: grad_out [B*L, C] -> grad_x [B*L, C], grad_y [B*S, C] (separate buffers also when x == y: the caller adds them) and the ten parameter
+ *             gradients (dr_layer_grads: the layout of dr_layer_weights; overwritten, not accumulated).  Position codes are constants of the graph
+ *             (the reference detaches them, position_encoding.py:83-84).  workspace: dr_attention_layer_backward_workspace_bytes(B, H, L, S, C). */
+typedef struct {
+    float *q_proj, *k_proj, *v_proj, *merge; /* [C,C]          */
+    float *mlp0;                             /* [2C,2C]        */
+    float *mlp2;                             /* [C,2C]         */
+    float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [C]       */
+} dr_layer_grads;
+size_t dr_attention_layer_train_saved_bytes(int B, int L, int S, int C);
+int dr_attention_layer_train_forward_f32(const dr_layer_weights* w, int C, int H, int B, int L, int S, const float* x, const float* y,
+                                         const float* cos_x, const float* sin_x, const float* cos_y, const float* sin_y,
+                                         const uint8_t* x_mask, const uint8_t* y_mask, float* out, void* saved, size_t saved_bytes, void* stream);
+size_t dr_attention_layer_backward_workspace_bytes(int B, int H, int L, int S, int C);
+int dr_attention_layer_backward_f32(const dr_layer_weights* w, int C, int H, int B, int L, int S, const float* x, const float* y,
+                                    const float* cos_x, const float* sin_x, const float* cos_y, const float* sin_y, const uint8_t* x_mask,
+                                    const uint8_t* y_mask, const void* saved, const float* grad_out, float* grad_x, float* grad_y,
+                                    const dr_layer_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* SoftProcrustesLayer.forward (3D/models/procrustes.py:48-93): top-K of conf, weighted Kabsch,
  * fp64 3x3 SVD ON DEVICE (replaces the .cpu().double().svd() of procrustes.py:35-36), gate.
  *   conf [P,N,M] float32; src_pcd [P,N,3]; tgt_pcd [P,M,3]

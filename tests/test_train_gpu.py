@@ -290,7 +290,18 @@ def test_layer_pieces_against_torch():
     assert torch.equal(lib.relu_backward(yv, gv), torch.where(yv > 0, gv, torch.zeros_like(gv)))
 
 
-def test_attention_layer_backward_against_reference_autograd():
+@pytest.fixture(params=["one library call each way", "one call per kernel"])
+def layer_form(request):
+    """the GeometryAttentionLayer's autograd node in its fused form (dr_attention_layer_train_forward_f32 / dr_attention_layer_backward_f32, the
+    default) and in the per-op form it replaces as the default (the same kernels driven from Python)"""
+    from diffreg_hip import autograd as dag
+    before = dag._GeometryAttentionLayer.fused
+    dag._GeometryAttentionLayer.fused = request.param.startswith("one library call")
+    yield request.param
+    dag._GeometryAttentionLayer.fused = before
+
+
+def test_attention_layer_backward_against_reference_autograd(layer_form):
     """diffreg_hip.autograd.geometry_attention_layer on a models.transformero.GeometryAttentionLayer: output = the production forward kernel's
     (dr_attention_layer_f32) and = the reference's; input and parameter gradients = torch autograd through the reference's module (cross attention,
     masks; tests/golden/train_backward.npz: layer_*)"""
