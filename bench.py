@@ -520,8 +520,9 @@ def bench_train_step(dev):
                         % (len(b["points"][0]) - b["stack_lengths"][0][1], b["stack_lengths"][0][1], ns, nt),
             "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "parameters_with_gradients": with_grad, "parameters_total": sum(p.numel() for p in params),
             "backbone_forward_only_ms": fwd * 1e3,
-            "note": "first, unfused backward apart from the attention (flash-style) and the Procrustes adjoint: every projection's two backward products "
-                    "are separate launches of the f32-input MFMA GEMM with explicit transposes; not a tuned path"}
+            "note": "the 20 GeometryAttentionLayer calls of a step run forward-with-saves and backward as ONE library call each (round 5: 28.5 -> 23.4 ms); "
+                    "the backbone's blocks and the matching heads are still driven kernel by kernel from Python; the projections' backward products are "
+                    "f32-input MFMA GEMMs on explicitly transposed operands; not a tuned path"}
 
 
 def other_configs(dev):
