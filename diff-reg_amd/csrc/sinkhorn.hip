@@ -1559,13 +1559,26 @@ static bool coop_batch_path(int B, int N, int M, int flags) {
 }
 static bool coop_path(int B, int N, int M, int flags) { return coop_rows_per_wave(B, N, M, flags) != 0 || coop_batch_path(B, N, M, flags); }
 
+// flags + status of every tile start at zero: they sit behind the G partials and the column sums of the launch's G inside each tile's workspace
+// slice.  ONE launch for the batch (a hipMemsetAsync per tile was 8 x 4.8 us in front of every Sinkhorn of an 8-pair call: 183 memset nodes, 0.9 ms
+// of cfg5's 26 ms graph; 350 nodes in cfg3's)
+__global__ __launch_bounds__(256) void sk_coop_zero_kernel(float* __restrict__ base, size_t stride, int n) {
+    float* p = base + (size_t)blockIdx.x * stride;
+    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0.f;
+}
+static int coop_zero_flags(const SkArgs& a, int G, hipStream_t st) {
+    const size_t tf = sk_coop_tile_floats(a.N, a.M);
+    hipLaunchKernelGGL(sk_coop_zero_kernel, dim3(a.B), dim3(256), 0, st, reinterpret_cast<float*>(a.ws) + (size_t)(G + 1) * sk_coop_m4(a.M), tf,
+                       (int)(2 * (size_t)sk_coop_g64(a.N) + 64));
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
 template <typename TIn, typename TOut>
 static int launch_coop_batch(const SkArgs& a, hipStream_t st) {
     const int G = (a.N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW), vpl = coop_batch_vpl(a.M);
-    const size_t tf = sk_coop_tile_floats(a.N, a.M);
-    for (int b = 0; b < a.B; ++b)
-        DR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<float*>(a.ws) + (size_t)b * tf + (size_t)(G + 1) * sk_coop_m4(a.M), 0,
-                                    (2 * (size_t)sk_coop_g64(a.N) + 64) * 4, st));
+    const int zrc = coop_zero_flags(a, G, st);
+    if (zrc) return zrc;
     const dim3 grid(G, a.B), blk(64 * SK_BATCH_RW);
     const size_t lds = coop_batch_lds_bytes(vpl);
 #define SK_BATCH_LAUNCH(V)                                                                                                                   \
@@ -1584,11 +1597,8 @@ static int launch_coop(const SkArgs& a, hipStream_t st) {
     const int rpw = coop_rows_per_wave(a.B, a.N, a.M, a.flags);
     if (!rpw) return DR_EINVAL;
     const int G = (a.N + SK_COOP_RW * rpw - 1) / (SK_COOP_RW * rpw), vpl = (a.M + 255) / 256;
-    const size_t tf = sk_coop_tile_floats(a.N, a.M);
-    // flags + status of every tile start at zero (they sit behind the G partials and the column sums of THIS launch's G)
-    for (int b = 0; b < a.B; ++b)
-        DR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<float*>(a.ws) + (size_t)b * tf + (size_t)(G + 1) * sk_coop_m4(a.M), 0,
-                                    (2 * (size_t)sk_coop_g64(a.N) + 64) * 4, st));
+    const int zrc = coop_zero_flags(a, G, st);
+    if (zrc) return zrc;
     const dim3 grid(G, a.B), blk(64 * SK_COOP_RW);
 #define SK_COOP_LAUNCH(V, R)                                                                                                 \
     {                                                                                                                        \
