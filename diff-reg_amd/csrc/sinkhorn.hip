@@ -23,6 +23,7 @@
 
 namespace dr {
 
+constexpr int SK_FLAG_XCD_LOCAL = 0x40000;   // internal (launcher -> kernel): batch form with a tile's workgroups on one XCD
 struct SkArgs {
     const void* scores;
     const uint8_t* src_mask;
@@ -1253,7 +1254,19 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     float* s_red = s_col + RW * (Mp + 4);                         // [RW][8]
     __shared__ int s_cnt[2];
     __shared__ int s_bad;                                         // a poll of this workgroup gave up: its outputs become NaN
-    const int tile = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+    int tile = blockIdx.y, g = blockIdx.x;
+    if constexpr (RW * RPW >= 32) {
+        // batch form: workgroup ids are dealt round-robin to the 8 XCDs, so (tile, g) = (id % B, id / B) puts the workgroups of a tile on ONE XCD
+        // when B is a multiple of 8 (cfg5's 8 tiles: tile b = XCD b, its 32 workgroups = that XCD's 32 CUs) and the column-sum exchange of a
+        // tile never leaves that XCD's L2 side of the fabric
+        if (A.flags & SK_FLAG_XCD_LOCAL) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x, B = gridDim.y;
+            tile = lin % B; g = lin / B;
+        }
+        tile = __builtin_amdgcn_readfirstlane(tile);              // (the division runs on the VALU: back to scalar registers, the ids are wave-uniform)
+        g = __builtin_amdgcn_readfirstlane(g);
+    }
     float* wsb = reinterpret_cast<float*>(A.ws) + (size_t)tile * sk_coop_tile_floats(N, M);
     float* P = wsb;                                               // [G][M4]
     float* cb = P + (size_t)G * M4;                               // [M4]
@@ -1345,7 +1358,14 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
             s = wave_sum(s);
             ai[r] = a_zero[r] ? 0.f : mu / (s + ed[r] * bM);
         }
-        // column partials of the workgroup's rows -> P[g] (the dustbin column rides at index M)
+        // column partials of the workgroup's rows -> P[g].  The dustbin column rides at index M: for M < Mp that index lies INSIDE the float4 group of
+        // one of the wave's lanes (whose own value there is 0: column M is no column of E), so that lane carries the dustbin partial in its group --
+        // ed and ai are wave-uniform, every lane can form it.  (Until round 5 lane 0 stored it with a separate scalar LDS write behind the groups:
+        // two stores to the same address from one wave, in an order the compiler was free to change -- a build whose only difference was an unrelated
+        // scalar block in front of the kernel put the scalar store first and every tile with M < 2 048 came out with a zero dustbin column.)
+        float dsum = ed[0] * ai[0];
+#pragma unroll
+        for (int r = 1; r < RPW; ++r) dsum = fmaf(ed[r], ai[r], dsum);
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             float4 cp;
@@ -1355,14 +1375,14 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
                 cp.x = fmaf(E[r][k][0], ai[r], cp.x); cp.y = fmaf(E[r][k][1], ai[r], cp.y);
                 cp.z = fmaf(E[r][k][2], ai[r], cp.z); cp.w = fmaf(E[r][k][3], ai[r], cp.w);
             }
-            *reinterpret_cast<float4*>(s_col + w * (Mp + 4) + 4 * (lane + 64 * k)) = cp;
+            const int jb = 4 * (lane + 64 * k);
+            if (jb == (M & ~3)) {
+                const int c = M & 3;
+                if (c == 0) cp.x = dsum; else if (c == 1) cp.y = dsum; else if (c == 2) cp.z = dsum; else cp.w = dsum;
+            }
+            *reinterpret_cast<float4*>(s_col + w * (Mp + 4) + jb) = cp;
         }
-        if (lane == 0) {                                           // (column M is no column of E: its partial there was 0 or absent)
-            float dsum = ed[0] * ai[0];
-#pragma unroll
-            for (int r = 1; r < RPW; ++r) dsum = fmaf(ed[r], ai[r], dsum);
-            s_col[w * (Mp + 4) + M] = dsum;
-        }
+        if (M >= Mp && lane == 0) s_col[w * (Mp + 4) + M] = dsum;   // M = Mp: the index is in the row's pad, behind every lane's groups
         __syncthreads();
         for (int q4 = t; q4 < NG4; q4 += NT) {
             float4 v = *reinterpret_cast<const float4*>(s_col + 4 * q4);
@@ -1579,12 +1599,14 @@ static int launch_coop_batch(const SkArgs& a, hipStream_t st) {
     const int G = (a.N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW), vpl = coop_batch_vpl(a.M);
     const int zrc = coop_zero_flags(a, G, st);
     if (zrc) return zrc;
+    SkArgs ax = a;
+    if (env_knob("DR_SK_XCD", 1)) ax.flags |= SK_FLAG_XCD_LOCAL;
     const dim3 grid(G, a.B), blk(64 * SK_BATCH_RW);
     const size_t lds = coop_batch_lds_bytes(vpl);
 #define SK_BATCH_LAUNCH(V)                                                                                                                   \
     {                                                                                                                                        \
         if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>), grid, blk, lds, st, a);                               \
+        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>), grid, blk, lds, st, ax);                              \
     }
     if (vpl == 4) SK_BATCH_LAUNCH(4) else SK_BATCH_LAUNCH(8)
 #undef SK_BATCH_LAUNCH
