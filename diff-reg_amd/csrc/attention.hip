@@ -844,16 +844,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* const lds = reinterpret_cast<char*>(smem);
     const unsigned lds_base = (unsigned)(size_t)(a_lds_void*)lds;
 
-    int seg = blockIdx.z, qbase, kbase, Lq, Lk;
+    // workgroup -> (query block, head, segment).  Hardware order: x fastest, ids dealt round-robin to the 8 XCDs -- the query blocks of one
+    // (head, segment), which all stream the SAME K / V tiles, would land on all 8 XCDs and every XCD's L2 would fetch those tiles from memory
+    // (PMC at cfg5's image self-attention: 302 MB per launch = q + o + EIGHT times k | v).  With xcd_groups a chunk of 8 gridDim.x consecutive ids
+    // is dealt so that XCD j takes every query block of the chunk's j-th (head, segment): K / V cross the fabric once.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.xcd_groups) {
+        const int NX = gridDim.x, NY = gridDim.y;
+        const int lin = bx + NX * (by + NY * bz), chunk = lin / (8 * NX), r = lin % (8 * NX), grp = chunk * 8 + (r & 7);
+        bx = r >> 3; by = grp % NY; bz = grp / NY;
+    }
+    int seg = bz, qbase, kbase, Lq, Lk;
     if (seg < A.nseg) {
         qbase = A.q0 + seg * A.qstride; kbase = A.k0 + seg * A.kstride; Lq = A.Lq; Lk = A.Lk;
     } else {
         seg -= A.nseg;
         qbase = A.q0b + seg * A.qstrideb; kbase = A.k0b + seg * A.kstrideb; Lq = A.Lqb; Lk = A.Lkb;
     }
-    const int qb = blockIdx.x * 128;
+    const int qb = bx * 128;
     if (qb >= Lq) return;
-    const int head = blockIdx.y, d = A.d, nct = A.p_nct;
+    const int head = by, d = A.d, nct = A.p_nct;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
 
@@ -1145,8 +1155,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         constexpr int KS = (DG * 8 + 15) / 16;
         if (a.p_dp != 16 * KS || !a.pimg[0]) return DR_EINVAL;
         const size_t plds = AttnPlGeom<KS, NDT>::SMEM;
-        if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true>), fgrid, dim3(256), plds, st, a);
-        else hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, a);
+        AttnArgs ax = a;
+        // (the dealing is a bijection only when the (head, segment) count is a multiple of 8; one query block per group has nothing to share)
+        ax.xcd_groups = ((fgrid.y * fgrid.z) % 8 == 0 && fgrid.x > 1 && env_knob("DR_ATTN_XCD", 1)) ? 1 : 0;
+        if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true>), fgrid, dim3(256), plds, st, ax);
+        else hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, ax);
         DR_LAUNCH_CHECK();
         return DR_OK;
     }

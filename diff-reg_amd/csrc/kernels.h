@@ -81,6 +81,7 @@ struct AttnArgs {
     const char* qimg[2]; const char* kimg[2]; const char* vimg[2];
     const float* qbnd; const float* kgb; const float* vgb;
     int f16_single;       // plane-image form only: ONE fp16 product per contraction (hi planes only) -- the opt-in DR_LOOP_ATTN_F16 mode
+    int xcd_groups;       // plane-image form only (set by the launcher): the query blocks of one (head, segment) run on ONE XCD -- they share its K / V
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int attention_configure();

@@ -23,7 +23,6 @@
 
 namespace dr {
 
-constexpr int SK_FLAG_XCD_LOCAL = 0x40000;   // internal (launcher -> kernel): batch form with a tile's workgroups on one XCD
 struct SkArgs {
     const void* scores;
     const uint8_t* src_mask;
@@ -1254,19 +1253,11 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
     float* s_red = s_col + RW * (Mp + 4);                         // [RW][8]
     __shared__ int s_cnt[2];
     __shared__ int s_bad;                                         // a poll of this workgroup gave up: its outputs become NaN
-    const int t = threadIdx.x, lane = lane_id(), w = wave_id();
-    int tile = blockIdx.y, g = blockIdx.x;
-    if constexpr (RW * RPW >= 32) {
-        // batch form: workgroup ids are dealt round-robin to the 8 XCDs, so (tile, g) = (id % B, id / B) puts the workgroups of a tile on ONE XCD
-        // when B is a multiple of 8 (cfg5's 8 tiles: tile b = XCD b, its 32 workgroups = that XCD's 32 CUs) and the column-sum exchange of a
-        // tile never leaves that XCD's L2 side of the fabric
-        if (A.flags & SK_FLAG_XCD_LOCAL) {
-            const int lin = blockIdx.y * gridDim.x + blockIdx.x, B = gridDim.y;
-            tile = lin % B; g = lin / B;
-        }
-        tile = __builtin_amdgcn_readfirstlane(tile);              // (the division runs on the VALU: back to scalar registers, the ids are wave-uniform)
-        g = __builtin_amdgcn_readfirstlane(g);
-    }
+    // (tile-major workgroup ids are part of the protocol's progress guarantee: a tile needs only ITS workgroups co-resident, ids are dispatched in
+    //  order, so under contention -- a second co-resident launch on another stream -- the lowest unfinished tile always gets the CUs that free up.
+    //  Round 5 tried (tile, g) = (id % B, id / B) to put a tile's workgroups on one XCD: 0-3 % faster alone, and two concurrent 8-tile launches
+    //  then each held half of EVERY tile and spun into their time-outs: 3-16 s per call instead of 42 ms.  Removed.)
+    const int tile = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = lane_id(), w = wave_id();
     float* wsb = reinterpret_cast<float*>(A.ws) + (size_t)tile * sk_coop_tile_floats(N, M);
     float* P = wsb;                                               // [G][M4]
     float* cb = P + (size_t)G * M4;                               // [M4]
@@ -1599,14 +1590,12 @@ static int launch_coop_batch(const SkArgs& a, hipStream_t st) {
     const int G = (a.N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW), vpl = coop_batch_vpl(a.M);
     const int zrc = coop_zero_flags(a, G, st);
     if (zrc) return zrc;
-    SkArgs ax = a;
-    if (env_knob("DR_SK_XCD", 1)) ax.flags |= SK_FLAG_XCD_LOCAL;
     const dim3 grid(G, a.B), blk(64 * SK_BATCH_RW);
     const size_t lds = coop_batch_lds_bytes(vpl);
 #define SK_BATCH_LAUNCH(V)                                                                                                                   \
     {                                                                                                                                        \
         if (lds > 64 * 1024) DR_HIP_CHECK(hipFuncSetAttribute((const void*)sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>), grid, blk, lds, st, ax);                              \
+        hipLaunchKernelGGL((sk_coop_kernel<TIn, TOut, V, SK_BATCH_RW, SK_BATCH_RPW>), grid, blk, lds, st, a);                               \
     }
     if (vpl == 4) SK_BATCH_LAUNCH(4) else SK_BATCH_LAUNCH(8)
 #undef SK_BATCH_LAUNCH

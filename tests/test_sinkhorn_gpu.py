@@ -286,3 +286,31 @@ def test_bad_arguments():
     from diffreg_hip import lib
     with pytest.raises(RuntimeError):
         lib.sinkhorn(torch.zeros(1, 4, 4, device=DEV), torch.tensor(1.0), 0)
+
+
+def test_two_concurrent_batch_form_launches_make_progress():
+    """Two batch-form launches on two streams (the engines' concurrent 8-pair calls): each wants every CU.  A tile needs only ITS 32 workgroups
+    co-resident and workgroup ids are tile-major, so whichever tiles are resident finish and free their CUs -- no launch may hold a part of every
+    tile.  (A round-5 variant dealt ids as (id % B, id / B) for XCD locality: alone 0-3 % faster, two concurrent launches spun into their
+    time-outs, seconds per call.)  Checked: same bits as the launch alone, no time-out flag, and a wall time far below one time-out."""
+    import time
+    from diffreg_hip import lib
+    B, N, M = 8, 1024, 2048
+    a = torch.tensor(1.0, device=DEV)
+    xs = [T(3.0 * synth.hash_normal(31 + s, 5, (B, N, M))).to(DEV) for s in range(2)]
+    alone = [lib.sinkhorn(x, a, 3) for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    outs = [[], []]
+    t0 = time.perf_counter()
+    for rep in range(6):
+        for s in range(2):
+            with torch.cuda.stream(streams[s]):
+                outs[s].append(lib.sinkhorn(xs[s], a, 3))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.device_status(DEV)                                         # raises on DR_ETIMEOUT
+    for s in range(2):
+        for o in outs[s]:
+            assert torch.equal(o, alone[s])
+    assert dt < 0.5, dt                                            # (12 launches of ~0.1 ms; one time-out alone is seconds)

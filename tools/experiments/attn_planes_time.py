@@ -1,4 +1,5 @@
-"""Time dr_attention_planes alone (HIP events, images built once) at loop shapes: cfg2 (128 pairs x 2 sides, 256 x 256, d 108), cfg3 (8 pairs,
+"""(XCD=ab: interleaved A/B of the XCD-aware workgroup dealing, DR_ATTN_XCD = 1 / 0, three rounds, outputs compared bitwise.)
+Time dr_attention_planes alone (HIP events, images built once) at loop shapes: cfg2 (128 pairs x 2 sides, 256 x 256, d 108), cfg3 (8 pairs,
 512 x 512, d 132), cfg5 self / cross segments (2048 / 1024 keys, d 64).  TFLOP/s = 4 L S C per segment / time (fp32-equivalent)."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "diff-reg_amd"))
@@ -28,18 +29,34 @@ for name, P, Lq, Lk, H, d in cases:
     ob = torch.zeros(P * Lq, device=dev)
     run = lambda: lib.check(raw.dr_attention_planes(P, Lq, Lk, H, d, lib.ptr(qi), lib.ptr(qb), lib.ptr(ki), lib.ptr(kb), lib.ptr(vi), lib.ptr(vb), None, None,
                                                     lib.ptr(oi), lib.ptr(ob), lib.stream_of(q)))
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / reps * 1e3
+    def timed():
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
     fl = 4.0 * P * Lq * Lk * H * d
+    if os.environ.get("XCD") == "ab":
+        raw.dr_debug_enable_env(1)
+        t = {"1": [], "0": []}
+        outs = {}
+        for rnd in range(3):
+            for m in ("1", "0"):
+                os.environ["DR_ATTN_XCD"] = m
+                oi.zero_()
+                t[m].append(round(timed(), 1))
+                outs[m] = oi.clone()
+        assert torch.equal(outs["1"], outs["0"]), "the dealing changed the result"
+        res.append(dict(case=name, us_xcd_groups=t["1"], us_plain=t["0"], TFLOPs_xcd=fl / min(t["1"]) / 1e6, TFLOPs_plain=fl / min(t["0"]) / 1e6))
+        print(res[-1], flush=True)
+        continue
+    us = timed()
     res.append(dict(case=name, us_per_launch=us, TFLOPs=fl / us / 1e6, workgroups=P * H * ((Lq + 127) // 128)))
     print(res[-1], flush=True)
 print(json.dumps(res))
