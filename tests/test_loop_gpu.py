@@ -272,14 +272,16 @@ def test_loop_against_oracle_fresh_seed(seed):
         assert_matrix_parity(out["conf_matrix_pred"][0].cpu().numpy(), ref["conf_matrix_pred"][0].numpy(), conf_f64, "conf")
 
 
+@pytest.mark.parametrize("family", ["soft", "main"])
 @pytest.mark.parametrize("variant", ["3dmatch", "4dmatch"])
-def test_ragged_batch_equals_single_pairs(variant):
+def test_ragged_batch_equals_single_pairs(variant, family):
     """Pairs of different sizes in one call: padded to the largest extents and run with
     DR_LOOP_RAGGED, every pair reproduces its own unpadded B = 1 run (conf, final pose, match list) -- which the
-    reference's pad-and-mask batching does not (padded rows / columns keep marginal mass there)."""
+    reference's pad-and-mask batching does not (padded rows / columns keep marginal mass there).  Soft head (the contract):
+    the match LISTS are equal; stress set: flat rows may flip at 1e-7 (<= 1 % of the list)."""
     steps, mc = 4, 200 if variant == "3dmatch" else 40
     sizes = [(96, 80), (128, 128), (57, 121), (128, 40)]
-    eng = engine(variant, steps, mc)
+    eng = engine(variant, steps, mc, family)
     ps = [pair(variant, n, m, 61 + i)[1] for i, (n, m) in enumerate(sizes)]
     noises = [T(synth.step_noise(n, m, 61 + i, steps)).to(DEV) for i, (n, m) in enumerate(sizes)] if variant == "4dmatch" else None
     items = [dict(src_feats=q["f_s"][0].to(DEV), tgt_feats=q["f_t"][0].to(DEV), s_pcd=q["p_s"][0].to(DEV), t_pcd=q["p_t"][0].to(DEV),
@@ -300,6 +302,8 @@ def test_ragged_batch_equals_single_pairs(variant):
         #  to float64 as twice that distance)
         if variant == "3dmatch":
             assert dd.max().item() < 2e-6, (i, dd.max().item())
+        elif family == "soft":
+            assert dd.max().item() <= 1e-4, (i, dd.max().item())            # (plain: nothing is exempt at this scale)
         else:
             _, conf_f64 = f64_evaluation(variant, n, m, n, m, steps, mc, 61 + i)
             assert_matrix_parity(got[i]["conf_matrix_pred"].cpu().numpy(), one["conf_matrix_pred"][0].cpu().numpy(), conf_f64,
@@ -309,7 +313,10 @@ def test_ragged_batch_equals_single_pairs(variant):
         if variant == "3dmatch":
             a = set(map(tuple, got[i]["match_pred"].cpu().tolist()))
             b = set(map(tuple, eng.match_list(one)[0].cpu().tolist()))
-            assert len(a ^ b) <= max(1, len(b) // 100), (i, len(a ^ b), len(b))    # flat rows may flip at 1e-7
+            if family == "soft":
+                assert a == b, (i, len(a ^ b), len(b))
+            else:
+                assert len(a ^ b) <= max(1, len(b) // 100), (i, len(a ^ b), len(b))    # flat rows may flip at 1e-7
 
 
 def test_loop_is_bitwise_reproducible(batch_kernels):
