@@ -417,8 +417,8 @@ def bench_cfg5(dev, batches=(1, 8)):
                                   "attention_planes_kernel<4,2> (d = 64)" if P * (N + M) >= 4096 else "attention_kernel / attention_flash_kernel (f32-input MFMA, d = 64)"))
         if "roofline" in ent and P * (N + M) >= 4096:
             # The same family against the OTHER roof.  At C = 256 a layer call's four plane GEMMs move 16 matrix passes of rows x 256 x 4 B (q | k | v images,
-            # fp32 residual rows + their images, the 512-wide hidden image) for 8 GEMM units of 2 rows 256^2 FLOP: ~32 FLOP/B, a third of the ridge point of the
-            # three-product ceiling (105 FLOP/B) -- the family's nearer roof is HBM.  Algorithmic bytes of the family per call from the layer schedule
+            # fp32 residual rows + their images, the 512-wide hidden image) for 8 GEMM units of 2 rows 256^2 FLOP: ~64 FLOP/B over the family (32 for the lin
+            # launch, 96 for q | k | v), under the ridge point of the three-product ceiling (105 FLOP/B) -- the family's nearer roof is HBM.  Algorithmic bytes of the family per call from the layer schedule
             # (self, cross) x 3 per step; the image half of layer 0 once per call:
             C4 = 256 * 4
             def layer_bytes(R, Ry=None):      # x rows R; key / value rows Ry (None: self attention, the same rows)
