@@ -651,3 +651,45 @@ def test_training_step_updates_the_whole_model(golden):
     assert changed >= 0.9 * len(got), (changed, len(got))      # (a step this small rounds away on the few tensors whose gradient is tiny next to their values)
     assert losses[2] < losses[1] < losses[0], losses
     assert n_params > 40e6, n_params                      # 44.9 M parameters in all: the whole trainable model of the 3DMatch configuration
+
+
+@pytest.mark.parametrize("B,L,S,masked", [(2, 37, 53, True), (1, 130, 61, False), (3, 64, 64, True)])
+def test_fused_layer_call_equals_the_per_kernel_form(B, L, S, masked):
+    """dr_attention_layer_train_forward_f32 / dr_attention_layer_backward_f32 (one library call each way) against the per-kernel form of the same
+    autograd node on shapes the fixtures do not cover -- batches of several pairs, token counts that are no multiple of 4 (the transposed operands
+    are zero-padded to one), cross attention with L != S, with and without masks: output, both input gradients and all ten parameter gradients
+    to 2e-5 of the tensor maximum (same kernels; the launches are batched differently, so GEMM tilings -- summation orders -- may differ)."""
+    from diffreg_hip import autograd as dag
+    from models.position_encoding import VolumetricPositionEncoding
+    from models.transformero import GeometryAttentionLayer
+    C = synth.VARIANTS["3dmatch"]["C"]
+    cfg = ref_like_config("3dmatch", 20, 200.0)
+    pre = "denoising_transformer.layers.1."
+    pe_mod = VolumetricPositionEncoding(cfg.coarse_transformer)
+    from tests.helpers import T
+    x0 = T(synth.hash_normal(5, 11, (B, L, C)).astype(np.float32) * 0.5).to(DEV)
+    y0 = T(synth.hash_normal(5, 12, (B, S, C)).astype(np.float32) * 0.5).to(DEV)
+    px = pe_mod(T(synth.hash_normal(5, 13, (B, L, 3)).astype(np.float32)).to(DEV))
+    py = pe_mod(T(synth.hash_normal(5, 14, (B, S, 3)).astype(np.float32)).to(DEV))
+    xm = (torch.arange(L)[None] < torch.tensor([[L - 3 * b] for b in range(B)])).to(DEV) if masked else None
+    ym = (torch.arange(S)[None] < torch.tensor([[S - 5 * b] for b in range(B)])).to(DEV) if masked else None
+    Rw = T(synth.hash_normal(5, 15, (B, L, C)).astype(np.float32)).to(DEV)
+    res = {}
+    before = dag._GeometryAttentionLayer.fused
+    try:
+        for fused in (True, False):
+            dag._GeometryAttentionLayer.fused = fused
+            layer = GeometryAttentionLayer(cfg.coarse_transformer)
+            layer.load_state_dict({k[len(pre):]: a for k, a in train_weights("soft").items() if k.startswith(pre)})
+            layer = layer.to(DEV)
+            x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+            e = dag.geometry_attention_layer(layer, x, y, px, py, xm, ym)
+            keep = e if xm is None else e * xm[..., None]
+            (keep * Rw).sum().backward()
+            res[fused] = [e.detach(), x.grad, y.grad] + [p_.grad for _, p_ in layer.named_parameters()]
+    finally:
+        dag._GeometryAttentionLayer.fused = before
+    for a, b in zip(res[True], res[False]):
+        if xm is not None and a.shape == (B, L, C):
+            a, b = a * xm[..., None], b * xm[..., None]               # (rows of padded queries carry no contract)
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6)
