@@ -281,19 +281,35 @@ def _families(prof):
     return {k: {"launches": v[0], "ms": v[1], "share": v[1] / tot} for k, v in prof.items() if v[0]}
 
 
-def _mfma_roofline(prof, kernel_split, kernel_attn):
+def _pmc(name):
+    """a committed rocprofv3 --pmc summary of a kernel inside one of the other configurations (tools/pmc_collect.py; tools/experiments/_prof_r05_pmc_cfg.sh)"""
+    f = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "avg_us_per_launch_pmc_run": d.get("avg_us_per_launch_profiled"),
+            "mfma_busy_fraction_of_wall": d.get("derived", {}).get("mfma_busy_fraction_of_wall"),
+            "wave_parked_fraction": d.get("derived", {}).get("wave_parked_fraction"), "source": "profiles/" + name}
+
+
+def _mfma_roofline(prof, kernel_split, kernel_attn, pmc_split=None, pmc_attn=None):
     """roofline objects of the two MFMA families of a profiled call: the plane GEMM against the 3-product fp16 ceiling, attention against
     the ceiling of the pipe it runs on (plane attention: the same 3-product ceiling; the f32-input kernels: the f32 MFMA peak)"""
     out = {}
     c, ms_, work = prof.get("gemm_split", (0, 0.0, 0.0))
     if c:
         ach = work / (ms_ * 1e-3) / 1e12
+        pm = _pmc(pmc_split) if pmc_split else None
         out["roofline"] = {"kernel": kernel_split, "bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_SPLIT_TFLOPS, "avg_us_per_launch": ms_ / c * 1e3, "traffic": None}
+                           "frac": ach / PEAK_SPLIT_TFLOPS, "avg_us_per_launch": ms_ / c * 1e3, "traffic": pm["hbm_bytes_per_launch"] if pm else None}
+        if pm:
+            out["roofline"]["pmc"] = pm
     c, ms_, work = prof.get("attention", (0, 0.0, 0.0))
     if c:
         ach = work / (ms_ * 1e-3) / 1e12
         out["attention"] = {"kernel": kernel_attn, "bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "avg_us_per_launch": ms_ / c * 1e3}
+        if pmc_attn and _pmc(pmc_attn):
+            out["attention"]["pmc"] = _pmc(pmc_attn)
     c, ms_, work = prof.get("gemm", (0, 0.0, 0.0))
     if c:
         ach = work / (ms_ * 1e-3) / 1e12
@@ -350,7 +366,8 @@ def bench_cfg3(dev):
     prof = lib.prof_collect()
     lib.prof_enable(False)
     res["kernel_families"] = _families(prof)
-    res.update(_mfma_roofline(prof, "pgemm_kernel<9,3,*,2> (576-column geometry, 64-row workgroups)", "attention_planes_kernel<9,5> (d = 132)"))
+    res.update(_mfma_roofline(prof, "pgemm_kernel<9,3,*,2> (576-column geometry, 64-row workgroups)", "attention_planes_kernel<9,5> (d = 132)",
+                              "r05_cfg3_pgemm_pmc.json", "r05_cfg3_attention_pmc.json"))
     res["measured_on"] = "one eager 8-pair call (HIP events on the launch stream)"
     # the OPT-IN reduced-precision attention (DR_LOOP_ATTN_F16: one fp16 product per contraction, BASELINE's "bf16 MFMA attention"): rate and deviation
     ref_conf = eng.run(graph=False, **g0)["conf_matrix_pred"].clone()
@@ -414,7 +431,8 @@ def bench_cfg5(dev, batches=(1, 8)):
         lib.prof_enable(False)
         ent["kernel_families"] = _families(prof)
         ent.update(_mfma_roofline(prof, "pgemm_kernel<4,4> (256-column geometry; bias / post-add LayerNorm epilogues)",
-                                  "attention_planes_kernel<4,2> (d = 64)" if P * (N + M) >= 4096 else "attention_kernel / attention_flash_kernel (f32-input MFMA, d = 64)"))
+                                  "attention_planes_kernel<4,2> (d = 64)" if P * (N + M) >= 4096 else "attention_kernel / attention_flash_kernel (f32-input MFMA, d = 64)",
+                                  "r05_cfg5_pgemm_pmc.json" if P * (N + M) >= 4096 else None, "r05_cfg5_attention_pmc.json" if P * (N + M) >= 4096 else None))
         if "roofline" in ent and P * (N + M) >= 4096:
             # The same family against the OTHER roof.  At C = 256 a layer call's four plane GEMMs move 16 matrix passes of rows x 256 x 4 B (q | k | v images,
             # fp32 residual rows + their images, the 512-wide hidden image) for 8 GEMM units of 2 rows 256^2 FLOP: ~64 FLOP/B over the family (32 for the lin
