@@ -1,6 +1,7 @@
 """Mint golden vectors for the configuration branches NO shipped yaml selects, by RUNNING THE REFERENCE (build container only; needs /root/reference):
 
     python oracle/make_golden_branches.py        # writes tests/golden/3dmatch_branches.npz
+    python oracle/make_golden_branches.py 4dmatch   # writes tests/golden/4dmatch_branches.npz (the loop of one form in the 4DMatch tree)
 
   pe_type 'sinusoidal'      3D/models/position_encoding.py:43-44, 68-69; transformero.py:50-57      (configs/test/3dmatch.yaml:45 lists it as an option)
   entangled = True          transformero.py:234-254; matching.py:181                                (yaml :1)
@@ -197,5 +198,93 @@ def main():
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(res), "arrays")
 
 
+def main_4d():
+    """the same module-level loop in the 4DMatch tree (4D/models/pipeline.py:155-197: no min-shift, sigma * xi added, sigmoid read-out, masks):
+    pe_type 'sinusoidal' through the reference's Pipeline.forward -> tests/golden/4dmatch_branches.npz"""
+    import torch
+    from oracle.make_golden import ref_config, HEAD_GAIN_SOFT
+    tree = "/root/reference/Diff-Reg-4dmatch"
+    sys.modules["open3d"] = MagicMock()
+    for m in ("easydict", "tensorboardX", "nibabel", "nibabel.quaternions", "cv2"):
+        sys.modules.setdefault(m, MagicMock())
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    os.chdir(tree)
+    sys.path.insert(0, tree)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from diffreg_hip import synth
+    from models.pipeline import Pipeline
+    from configs.models import architectures
+    v = synth.VARIANTS["4dmatch"]
+    C = v["C"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Wnp = dict(synth.make_weights(C, seed=7, head_gain=HEAD_GAIN_SOFT))
+    N, M, nv, mv, steps, mc, seed = 64, 96, 57, 90, 3, 40.0, 22
+    cfg = ref_config("4dmatch", steps, mc)
+    ct = cfg.coarse_transformer
+    ct["pe_type"] = "sinusoidal"
+    cfg.kpfcn_config["architecture"] = architectures["4dmatch"]
+
+    class StubBackbone(torch.nn.Module):
+        feats = None
+
+        def forward(self, data, phase="coarse"):
+            return self.feats
+    model = Pipeline(cfg)
+    model.backbone = StubBackbone()
+    sd = model.state_dict()
+    for k, a in Wnp.items():
+        if k in sd:
+            sd[k] = T(a)
+    model.load_state_dict(sd)
+    model.eval()
+    pr = synth.make_pair(N, M, C, seed=seed)
+    model.backbone.feats = torch.cat([T(pr["src_feats"]), T(pr["tgt_feats"])], 0)
+    pts = torch.cat([T(pr["s_pcd"]), T(pr["t_pcd"])], 0)
+    data = {"points": [None, None, pts, None], "src_mask": torch.arange(N)[None] < nv, "tgt_mask": torch.arange(M)[None] < mv,
+            "src_ind_coarse_split": torch.arange(N), "tgt_ind_coarse_split": torch.arange(M),
+            "src_ind_coarse": torch.arange(N), "tgt_ind_coarse": torch.arange(N, N + M)}
+    x_T = T(pr["x_T"])[None]
+    noise = T(synth.step_noise(N, M, seed, steps))[:, None]
+    calls = []
+    x0_log, warp_log = [], []
+    orig_head, orig_proc = model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward
+
+    def head_spy(*a, **k):
+        r = orig_head(*a, **k)
+        x0_log.append(r[0].detach().clone())
+        return r
+
+    def proc_spy(*a, **k):
+        r = orig_proc(*a, **k)
+        warp_log.append([z.detach().clone() for z in r])
+        return r
+    model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward = head_spy, proc_spy
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def fake_randn_like(x, *a, **k):
+        n = noise[len(calls)].to(x.dtype)
+        calls.append(1)
+        return n.clone()
+    torch.randn = lambda *a, **k: x_T.clone()
+    torch.randn_like = fake_randn_like
+    try:
+        with torch.no_grad():
+            out = model(data)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    conf = out["conf_matrix_pred"]
+    res = {"loop_sin_conf": conf[0].numpy(), "loop_sin_x0": torch.stack([z[0] for z in x0_log]).numpy(),
+           "loop_sin_R_forwd": torch.stack([w[2][0] for w in warp_log]).numpy(), "loop_sin_t_forwd": torch.stack([w[3][0] for w in warp_log]).numpy(),
+           "loop_sin_cond": torch.stack([w[4][0] for w in warp_log]).numpy(),
+           "loop_shape": np.array([N, M, nv, mv, steps, seed], dtype=np.int64), "loop_mc": np.float64(mc)}
+    outp = os.path.join(ROOT, "tests", "golden", "4dmatch_branches.npz")
+    np.savez_compressed(outp, **res)
+    print("4dmatch sin: conf", conf.dtype, "max %.4f" % float(conf.max()), "cond", res["loop_sin_cond"], "wrote", outp, os.path.getsize(outp), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "4dmatch":
+        main_4d()
+    else:
+        main()

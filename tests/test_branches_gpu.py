@@ -189,3 +189,53 @@ def test_pipeline_evaluation_loop_of_a_form(golden, tag):
     assert match_sets_equal(out["match_pred"], g["loop_%s_match_pred" % tag])
     assert out["R_s2t_pred"].shape == (1, 3, 3)
     print("branch loop %s: worst x_start deviation %.3g, conf %.3g (largest conf %.3g)" % (tag, worst, np.abs(conf[0].cpu().numpy() - ref).max(), ref.max()))
+
+
+def test_pipeline_evaluation_loop_of_a_form_in_the_4d_variant(golden):
+    """the module-level loop's 4DMatch branch (4D/models/pipeline.py:155-197: no min-shift, sigma * xi from data['noise'], sigmoid read-out, masks)
+    with pe_type 'sinusoidal', against the reference's own Pipeline.forward in the 4DMatch tree"""
+    from models.pipeline import Pipeline
+    from oracle.make_golden import HEAD_GAIN_SOFT
+    g = golden("4dmatch_branches")
+    N, M, nv, mv, steps, seed = (int(a) for a in g["loop_shape"])
+    mc = float(g["loop_mc"])
+    v = synth.VARIANTS["4dmatch"]
+    cfg = ref_like_config("4dmatch", steps, mc)
+    cfg.coarse_transformer["pe_type"] = "sinusoidal"
+    model = Pipeline(cfg, backbone=StubBackbone())
+    assert model.variant == "4dmatch" and not model._fused_loop_config()
+    W = {k: T(a) for k, a in synth.make_weights(v["C"], seed=7, head_gain=HEAD_GAIN_SOFT).items()}
+    sd = model.state_dict()
+    sd.update({k: t for k, t in W.items() if k in sd})
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    p = synth.make_pair(N, M, v["C"], seed=seed)
+    feats = torch.cat([T(p["src_feats"]), T(p["tgt_feats"])]).to(DEV)
+    pts = torch.cat([T(p["s_pcd"]), T(p["t_pcd"])]).to(DEV)
+    ms, mt = masks(N, M, nv, mv)
+    data = {"points": [None, None, pts, None], "src_mask": ms.to(DEV), "tgt_mask": mt.to(DEV), "_feats": feats,
+            "src_ind_coarse_split": torch.arange(N, device=DEV), "tgt_ind_coarse_split": torch.arange(M, device=DEV),
+            "src_ind_coarse": torch.arange(N, device=DEV), "tgt_ind_coarse": torch.arange(N, N + M, device=DEV), "x_T": T(p["x_T"])[None].to(DEV),
+            "noise": T(synth.step_noise(N, M, seed, steps))[:, None].to(DEV)}
+    x0_log, warp_log = [], []
+    head_fwd, proc_fwd = model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward
+
+    def head_spy(*a, **k):
+        r = head_fwd(*a, **k)
+        x0_log.append(r[0].detach().clone())
+        return r
+
+    def proc_spy(*a, **k):
+        r = proc_fwd(*a, **k)
+        warp_log.append([z.detach().clone() for z in r])
+        return r
+    model.denoising_coarse_matching.forward, model.denoising_soft_procrustes.forward = head_spy, proc_spy
+    out = model(data)
+    for k in range(steps):
+        assert np.abs(warp_log[k][2][0].cpu().numpy() - g["loop_sin_R_forwd"][k]).max() < 1e-4, k
+        assert np.abs(warp_log[k][3][0].cpu().numpy() - g["loop_sin_t_forwd"][k]).max() < 1e-4, k
+        assert abs(float(warp_log[k][4][0]) - float(g["loop_sin_cond"][k])) < 1e-4 * float(g["loop_sin_cond"][k]), k
+        assert np.abs(x0_log[k][0].cpu().numpy() - g["loop_sin_x0"][k]).max() < 1e-4, k
+    conf = out["conf_matrix_pred"]
+    assert conf.dtype == torch.float64 and np.abs(conf[0].cpu().numpy() - g["loop_sin_conf"]).max() < 1e-4
+    assert "match_pred" not in out                                   # (the 4D tree has no read-out list in Pipeline.forward)

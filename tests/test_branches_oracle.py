@@ -89,3 +89,27 @@ def test_loop_of_a_form_matches_the_reference(golden, tag):
         assert np.abs(trace[k]["x0"][0].numpy() - g["loop_%s_x0" % tag][k]).max() < 1e-5, k
     conf = out["conf_matrix_pred"]
     assert conf.dtype == torch.float64 and np.abs(conf[0].numpy() - g["loop_%s_conf" % tag]).max() < 1e-6
+
+
+def test_4d_loop_of_the_sinusoidal_form_matches_the_reference(golden):
+    """the same branch in the 4DMatch tree (no min-shift, sigma * xi, sigmoid read-out, masks; step 0's fit fails the condition gate -> identity warp)"""
+    g = golden("4dmatch_branches")
+    N, M, nv, mv, steps, seed = (int(a) for a in g["loop_shape"])
+    mc = float(g["loop_mc"])
+    v = synth.VARIANTS["4dmatch"]
+    cfg = dict(v, pe_type="sinusoidal", entangled=False)
+    from diffreg_hip.synth import make_weights
+    from oracle.make_golden import HEAD_GAIN_SOFT
+    W = {k: T(a) for k, a in make_weights(v["C"], seed=7, head_gain=HEAD_GAIN_SOFT).items()}
+    p = synth.make_pair(N, M, v["C"], seed=seed)
+    q = lambda k: T(p[k])[None]
+    ms, mt = masks(N, M, nv, mv)
+    noise = T(synth.step_noise(N, M, seed, steps))[:, None]
+    trace = []
+    out = orc.denoise_loop(W, cfg, q("src_feats"), q("tgt_feats"), q("s_pcd"), q("t_pcd"), ms, mt, q("x_T"), steps, mc, variant="4dmatch", noise=noise,
+                           trace=trace)
+    for k in range(steps):
+        assert np.abs(trace[k]["R_forwd"][0].numpy() - g["loop_sin_R_forwd"][k]).max() < 1e-4, k
+        assert abs(float(trace[k]["cond"][0]) - float(g["loop_sin_cond"][k])) < 1e-4 * float(g["loop_sin_cond"][k]), k
+        assert np.abs(trace[k]["x0"][0].numpy() - g["loop_sin_x0"][k]).max() < 1e-5, k
+    assert np.abs(out["conf_matrix_pred"][0].numpy() - g["loop_sin_conf"]).max() < 1e-5
