@@ -1,7 +1,3 @@
-    // NB tile buffers (the DMA of tile kt + NB - 1 is issued when tile kt starts).  Two.  Round 5 measured four at d = 64 (66 KB, counted waits
-    // that leave the two younger tiles' pieces in flight): 141 against 137 us for 8 x 2048 x 2048 -- the prefetch distance is not what bounds the
-    // kernel (profiles/r05_attention_planes_d64_experiments.json); the ring form stays in the loop below for NB > 2.
-    static constexpr int NB = 2;
 // attention.hip -- masked multi-head softmax attention on the f32-input MFMA (exact fp32 products).
 //
 // Replaces  a = einsum(q,k); masked_fill; a / sqrt(d); softmax; o = einsum(a, v)
@@ -818,10 +814,10 @@ struct AttnPlGeom {
     static constexpr int VCH = 2048 + 32;                        // a V chunk, shifted by 32 B per chunk: the two 16-lane groups of a
                                                                  // transposed read (features 0..15 / 16..31) then hit disjoint banks
     static constexpr int KIMG = KS * KCH, VIMG = KS * VCH, BUF = KIMG + VIMG;
-    // NB tile buffers: the DMA of tile kt + NB - 1 is issued when tile kt starts.  Round 5 (PMC + three null results): with two
-    // buffers the copy of a tile had ONE tile of arithmetic (~1 us at d = 64) to arrive, an L2 miss under load takes ~2 us, and the d = 64 kernel ran
-    // at exactly that: 2 us per tile whatever its VALU stream did.  Four buffers (66 KB at d = 64: still two workgroups per CU) give it three tiles.
-    static constexpr int NB = KS <= 4 ? 4 : 2;
+    // NB tile buffers (the DMA of tile kt + NB - 1 is issued when tile kt starts).  Two.  Round 5 measured four at d = 64 (66 KB, counted waits
+    // that leave the two younger tiles' pieces in flight): 141 against 137 us for 8 x 2048 x 2048 -- the prefetch distance is not what bounds the
+    // kernel (profiles/r05_attention_planes_d64_experiments.json, experiment 4); the ring form stays in the loop below for NB > 2.
+    static constexpr int NB = 2;
     static constexpr int OQS = NDT * 32 + 4;
     static constexpr int OBYTES = 4 * 32 * OQS * 4;
     static constexpr int SMEM = (NB * BUF > OBYTES ? NB * BUF : OBYTES) + 64;

@@ -67,3 +67,26 @@ def test_bench_rank_path_with_the_nccl_branch_forced(capsys, monkeypatch):
     assert r["metric_gather"]["backend"] == "nccl (RCCL)" and r["n_gpus"] == 1
     assert r["metric_gather"]["n_pairs"] == 8.0 and r["metric_gather"]["per_rank_pairs"] == [8]
     assert 0.0 <= r["metric_gather"]["mean_inlier_ratio"] <= 1.0 and r["value"] > 0
+    # the line is the short summary the driver can read; the full record is in the file it names
+    assert len(line) < bench.MAX_LINE_BYTES and r["details"] and os.path.exists(os.path.join(ROOT, r["details"]))
+    assert all(k in r for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "config"))
+
+
+def test_bench_default_shape_line_is_short_and_carries_roofline_and_cpu_baseline(capsys, monkeypatch):
+    """a small run with EVERY block of the default run switched on except the other configurations (32 pairs, 2 timed passes): the printed line
+    stays under the limit and carries `roofline` (HIP-event-timed, with PMC traffic from profiles/) and `cpu_baseline`"""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "32", "--no-other-configs"])
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: bench.__dict__["_cpu_baseline_orig"](*a, budget_s=4.0, **k))
+    bench.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert len(line) < bench.MAX_LINE_BYTES
+    rf = r["roofline"]
+    assert all(k in rf for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us_per_launch", "work_per_launch"))
+    assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1
+    assert all(k in r["cpu_baseline"] for k in ("value", "unit", "cores", "kind", "sample")) and r["cpu_baseline"]["kind"] == "port"
+    assert r["sinkhorn_roofline"]["frac"] > 0.5 and r["single_pair"]["ms_per_pair"] > 0
+    assert r["parity_ok"] is True and r["ir_fmr_parity"]["pairs_within_1e4"] == r["ir_fmr_parity"]["pairs"]
