@@ -586,7 +586,8 @@ def compact_line(result, details_path):
         k for k in mg if k.startswith("sum_")))
     line["conf_checksum"] = result["conf_checksum"]
     line["details"] = details_path
-    return _r(line)
+    # (the contract's own top-level numbers keep full precision -- value x ms_per_step must stay consistent; the nested summaries are rounded)
+    return {k: (_r(v) if isinstance(v, (dict, list)) else v) for k, v in line.items()}
 
 
 class _Attr(dict):

@@ -19,6 +19,17 @@ int env_knob(const char* name, int def) {
     return e ? atoi(e) : def;
 }
 
+int device_cu_count() {
+    static int cache[64];                                          // 0 = not asked yet
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+    if (!cache[d]) {
+        hipDeviceProp_t pr;
+        cache[d] = hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return cache[d];
+}
+
 bool g_prof_on = false;
 struct ProfRec { int kind; double work; hipEvent_t a, b; };
 static std::vector<ProfRec> g_prof;
@@ -72,7 +83,7 @@ int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream) {
     return DR_OK;
 }
 
-int dr_version(void) { return DR_ABI_VERSION; /* 0.2.0: the header this library was built from */ }
+int dr_version(void) { return DR_ABI_VERSION; /* 0.2.1: the header this library was built from */ }
 
 const char* dr_strerror(int code) {
     switch (code) {

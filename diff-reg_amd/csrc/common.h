@@ -14,6 +14,8 @@ void set_hip_error(hipError_t e, const char* where);
 // enables it, so a stray DR_* variable in a deployment's environment cannot change which kernels run.
 int env_knob(const char* name, int def);
 void enable_env_knobs(bool on);
+// compute units of the CURRENT device (cached per device index: a process may drive devices with different CU counts)
+int device_cu_count();
 
 #define DR_HIP_CHECK(expr)                                   \
     do {                                                     \

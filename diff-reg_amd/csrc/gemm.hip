@@ -413,7 +413,7 @@ int launch_gemm(const GemmBatch& g, hipStream_t st) {
         //           half the L2 bytes per output tile
         //   latency form: K <= 448 (8 waves):  2.5 + 0.0145 tiles;   K <= 896 (16 waves, 2 workgroups per CU): 11 up to 512 tiles, then 10 + 0.026 tiles
         // (2D-3D loop, 3 072 x 256 x 256: 13.5 -> 10.8 us per launch; 2 048 x 864 x 864: 55 -> 42; a single pair's 512 or 1 193 rows keep the latency form)
-        static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+        const int n_cu = device_cu_count();
         const double t_staged = 5.0 + (double)((nM + n_cu - 1) / n_cu) * 0.0244 * maxK;
         const double t_direct = maxK <= 8 * 8 * 7 ? 2.5 + 0.0145 * (double)n32 : (n32 <= 512 ? 11.0 : 10.0 + 0.026 * (double)n32);
         if (t_direct <= t_staged || nM < 128) return maxK <= 8 * 8 * 7 ? launch_direct<8, 7>(g, st) : launch_direct<16, 7>(g, st);

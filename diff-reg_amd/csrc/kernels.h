@@ -152,8 +152,11 @@ int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hip
 
 // sinkhorn.hip (internal form of dr_sinkhorn_*: `shift` = per-tile value subtracted first, nullable)
 int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,
-                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st, unsigned* call_status = nullptr);
 int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift, const uint8_t* sm, const uint8_t* tm,
-                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st);
+                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st, unsigned* call_status = nullptr);
+// call_status: the caller's own sticky status word (device, 4 bytes, zero-initialised by the caller): bit 0 = a co-resident Sinkhorn of THIS
+// caller timed out (set beside the process-wide flag of dr_device_status, so that concurrent engines cannot swallow or misattribute a time-out)
+int sinkhorn_call_status(unsigned* word, hipStream_t st, bool clear);
 
 }  // namespace dr

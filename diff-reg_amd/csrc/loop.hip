@@ -558,8 +558,10 @@ struct LoopWs {
     size_t skws_bytes;
     void* pws;
     size_t pws_bytes;
+    unsigned* status;                        // the call's own sticky status word (dr_denoise_loop_status): zeroed when a call starts
     static size_t carve(Carver& c, LoopWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), NM = (size_t)P * N * M;
+        w.status = c.take<unsigned>(4);      // (first: its place does not depend on the configuration)
         DenoiseWs::carve(c, w.dw, cfg, P, N, M);
         w.feat0 = c.take<float>(T * cfg.C);
         if (w.dw.pl.on) w.dw.pl.feat0.f32 = w.feat0;
@@ -810,6 +812,12 @@ size_t dr_denoise_loop_workspace_bytes(const dr_loop_config* cfg, int P, int N, 
     return LoopWs::carve(c, w, *cfg, P, N, M);
 }
 
+int dr_denoise_loop_status(void* workspace, void* stream, int clear) {
+    if (!workspace) return DR_EINVAL;
+    Carver c(workspace, (size_t)-1);
+    return sinkhorn_call_status(c.take<unsigned>(4), (hipStream_t)stream, clear != 0);
+}
+
 int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M, const float* src_feats,
                           const float* tgt_feats, const float* s_pcd_warped, const float* t_pcd, const uint8_t* src_mask,
                           const uint8_t* tgt_mask, float* src_out, float* tgt_out, float* conf, void* workspace,
@@ -823,6 +831,7 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
     Carver c(workspace, workspace_bytes);
     LoopWs L;
     LoopWs::carve(c, L, *cfg, P, N, M);
+    DR_HIP_CHECK(hipMemsetAsync(L.status, 0, 16, st));          // the status of THIS call (one 16-byte fill per call)
     const int C = cfg->C;
     const size_t PN = (size_t)P * N, PM = (size_t)P * M;
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
@@ -842,7 +851,7 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
     if (src_out) DR_HIP_CHECK(hipMemcpyAsync(src_out, fin, PN * C * 4, hipMemcpyDeviceToDevice, st));
     if (tgt_out) DR_HIP_CHECK(hipMemcpyAsync(tgt_out, fin + PN * C, PM * C * 4, hipMemcpyDeviceToDevice, st));
     return sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters,
-                        DR_SK_OUT_CONF | (src_mask ? DR_SK_APPLY_MASK : 0), conf, L.skws, L.skws_bytes, st);
+                        DR_SK_OUT_CONF | (src_mask ? DR_SK_APPLY_MASK : 0), conf, L.skws, L.skws_bytes, st, L.status);
 }
 
 int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, int N, int M, const float* src_feats,
@@ -864,6 +873,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     Carver c(workspace, workspace_bytes);
     LoopWs L;
     LoopWs::carve(c, L, *cfg, P, N, M);
+    DR_HIP_CHECK(hipMemsetAsync(L.status, 0, 16, st));          // the status of THIS call (one 16-byte fill per call)
     const int C = cfg->C;
     const size_t PN = (size_t)P * N, PM = (size_t)P * M, NM = (size_t)P * N * M;
     const uint8_t* tokmask = src_mask ? L.tokmask : nullptr;
@@ -908,7 +918,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
             shift = L.dmin;
         }
         rc = sinkhorn_f64(P, N, M, L.x, shift, src_mask, tgt_mask, w->bin_score, cfg->sk_iters,
-                          DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
+                          DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st, L.status);
         if (rc) return rc;
         // -- denoising_soft_procrustes (pipeline.py:304)
         int* tk = nullptr;
@@ -935,7 +945,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = denoiser_and_sim(*cfg, *w, P, N, M, L.feat0, tokmask, L.dw, &fin, st, true);
         if (rc) return rc;
         rc = sinkhorn_f32(P, N, M, L.dw.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0,
-                          L.skws, L.skws_bytes, st);
+                          L.skws, L.skws_bytes, st, L.status);
         if (rc) return rc;
         if (trace && trace->x0) DR_HIP_CHECK(hipMemcpyAsync(trace->x0 + (size_t)k * NM, L.x0, NM * 4, hipMemcpyDeviceToDevice, st));
         // -- DDIM update (pipeline.py:246-256)
@@ -977,7 +987,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
         rc = launch_pair_min(L.x, P, N * M, L.dmin, st, M, rsm, rtm, P <= 32 ? L.pmin : nullptr);  // pipeline.py:264-272
         if (rc) return rc;
         rc = sinkhorn_f64(P, N, M, L.x, L.dmin, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict,
-                          conf, L.skws, L.skws_bytes, st);
+                          conf, L.skws, L.skws_bytes, st, L.status);
         if (rc) return rc;
         if (matches) {
             // (the steps' x0 tile is free by now; the row-block arg-maxima need < N M floats)

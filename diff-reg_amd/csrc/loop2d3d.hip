@@ -143,8 +143,10 @@ struct F2Ws {
     void* skws; size_t skws_bytes;
     void* pws; size_t pws_bytes;
     Planes2 pl;
+    unsigned* status;                        // the call's own sticky status word (dr_denoise_loop_status): zeroed when a call starts
     static size_t carve(Carver2& c, F2Ws& w, const dr_loop2d3d_config& cfg, int P, int N, int M) {
         const size_t T = (size_t)P * (N + M), C = cfg.C, NM = (size_t)P * N * M, PM = (size_t)P * M, PN = (size_t)P * N;
+        w.status = c.take<unsigned>(4);      // (first, as in the 3D / 4D loop's workspace: dr_denoise_loop_status reads either)
         w.tok0 = c.take<float>(T * C); w.ta = c.take<float>(T * C); w.tb = c.take<float>(T * C);
         w.qkv = c.take<float>(T * 3 * C); w.att = c.take<float>(T * C); w.lin = c.take<float>(T * C);
         w.z = c.take<float>(T * C); w.hid = c.take<float>(T * 2 * C); w.f = c.take<float>(T * C);
@@ -362,6 +364,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
     Carver2 c(workspace);
     F2Ws L;
     F2Ws::carve(c, L, *cfg, P, N, M);
+    DR_HIP_CHECK(hipMemsetAsync(L.status, 0, 16, st));          // the status of THIS call (dr_denoise_loop_status)
     const int C = cfg->C, H = cfg->H, PM = P * M, PN = P * N, T = PM + PN;
     const size_t NM = (size_t)P * N * M;
     const int strict = (cfg->flags & DR_LOOP_STRICT_F64) ? DR_SK_STRICT : 0;
@@ -471,7 +474,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
             r = launch_gemm(gs, st);
             if (r) return r;
             return sinkhorn_f32(P, N, M, L.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0, L.skws,
-                                L.skws_bytes, st);
+                                L.skws_bytes, st, L.status);
         }
         const float* cur = L.tok0;
         float* bufs[2] = {L.ta, L.tb};
@@ -510,7 +513,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
             if (r) return r;
         }
         return sinkhorn_f32(P, N, M, L.sim, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag, L.x0, L.skws,
-                            L.skws_bytes, st);
+                            L.skws_bytes, st, L.status);
     };
     if (cfg->steps == 0) {          // component mode: one evaluation on the points as given
         rc = evaluate(nullptr, nullptr);
@@ -529,7 +532,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
         if (trace && trace->force_x) DR_HIP_CHECK(hipMemcpyAsync(L.x, trace->force_x + (size_t)k * NM, NM * 8, hipMemcpyDeviceToDevice, st));
         // warp from the noisy matrix: masks (src, tgt_da), no min-shift (EXP/model.py:830-846)
         rc = sinkhorn_f64(P, N, M, L.x, nullptr, src_mask, tgt_mask_da, w->bin_score, cfg->sk_iters,
-                          DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st);
+                          DR_SK_OUT_CONF | DR_SK_OUT_F32 | mflag | (k > 0 ? strict : 0), L.wconf, L.skws, L.skws_bytes, st, L.status);
         if (rc) return rc;
         int* tk = nullptr;
         if (trace && trace->topk_idx) {
@@ -567,7 +570,7 @@ int dr_denoise_loop_2d3d(const dr_loop2d3d_config* cfg, const dr_fusion_weights*
     if (x_final) DR_HIP_CHECK(hipMemcpyAsync(x_final, L.x, NM * 8, hipMemcpyDeviceToDevice, st));
     // read-out: no min-shift, masks (src, tgt) (EXP/model.py:681-694)
     rc = sinkhorn_f64(P, N, M, L.x, nullptr, src_mask, tgt_mask, w->bin_score, cfg->sk_iters, DR_SK_OUT_CONF | mflag | strict, conf,
-                      L.skws, L.skws_bytes, st);
+                      L.skws, L.skws_bytes, st, L.status);
     if (rc) return rc;
     // (the steps' x0 tile is free by now; the row-block arg-maxima need < N M floats)
     if (matches) rc = launch_top1_union<double>(conf, P, N, M, (long long*)matches, match_count, st, nullptr, nullptr, L.x0, NM * 4);

@@ -1068,7 +1068,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G9::BN ? G9::NST : G7::NST;
     // 64-row workgroups when the launch would not give every CU a 128-row one (DR_PG_HALF under dr_debug_enable_env: 0 never, 2 always)
     const int half_env = env_knob("DR_PG_HALF", 1);
-    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const int n_cu = device_cu_count();
     long wg128 = 0;
     for (int i = 0; i < g.n; ++i) wg128 += (long)((g.p[i].rows + 127) / 128) * g.p[i].nblk;
     // 64-row workgroups up to HALF a chip of 128-row ones: above that they would run in two rounds, slower than one round of 128-row workgroups on

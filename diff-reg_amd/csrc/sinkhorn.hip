@@ -33,6 +33,7 @@ struct SkArgs {
     const double* shift;   // per-tile value subtracted from the scores on load (nullable)
     int B, N, M, iters, flags, vec_in, vec_out;
     unsigned spin_limit;   // co-resident form: polls a workgroup makes before it gives up (dr_device_status)
+    unsigned* call_status; // nullable: the CALLER's own sticky word (a loop call's workspace): bit 0 is set beside the process-wide flag
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1189,7 +1190,8 @@ static unsigned g_sk_spin_limit = SK_COOP_SPIN;                    // (dr_debug_
 // (no read-modify-write: 256 agent-scope adds to one address serialise at the memory side, ~12 us per hop measured), and the first
 // wave of every workgroup polls the whole flag array, 64 words per instruction, until every word has reached p.  Bounded.
 // (wave-uniform) false = gave up after `limit` polls: the sticky flag and the tile's status word are set, *s_bad (LDS) tells the workgroup
-__device__ __forceinline__ bool sk_wait_flags(const unsigned* flags, int G, unsigned target, unsigned limit, int* status, int* s_bad) {
+__device__ __forceinline__ bool sk_wait_flags(const unsigned* flags, int G, unsigned target, unsigned limit, int* status, int* s_bad,
+                                              unsigned* call_status) {
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     while (true) {
@@ -1198,7 +1200,10 @@ __device__ __forceinline__ bool sk_wait_flags(const unsigned* flags, int G, unsi
         if (__all(ok)) return true;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > limit) {
-            if (lane == 0) { *status = 1; *s_bad = 1; atomicOr(&g_sk_status, 1u); }
+            if (lane == 0) {
+                *status = 1; *s_bad = 1; atomicOr(&g_sk_status, 1u);
+                if (call_status) atomicOr(call_status, 1u);
+            }
             return false;
         }
     }
@@ -1387,7 +1392,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                          // every store of the workgroup has left
         if (t == 0) __hip_atomic_store(flagA + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad);
+        if (w == 0) sk_wait_flags(flagA, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad, A.call_status);
         __syncthreads();
         // this workgroup's slice: column sums over the G partials
         if constexpr (RW * RPW >= 32) {
@@ -1441,7 +1446,7 @@ __global__ __launch_bounds__(64 * RW) void sk_coop_kernel(SkArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_store(flagB + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == 0) sk_wait_flags(flagB, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad);
+        if (w == 0) sk_wait_flags(flagB, G, (unsigned)(it + 1), A.spin_limit, status, &s_bad, A.call_status);
         __syncthreads();
         // the M + 1 column sums -> LDS (two float4 groups per thread per round trip), then b_j = nu / (cb_j + a_N), b_M likewise;
         // a_N of the NEXT pass from the new b
@@ -1540,7 +1545,7 @@ static int coop_blocks_per_cu(int vpl, int rpw) {
 static int coop_rows_per_wave(int B, int N, int M, int flags) {
     if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return 0;
     if (M > 2048 || !env_knob("DR_SK_COOP", 1)) return 0;
-    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const int n_cu = device_cu_count();
     const int vpl = (M + 255) / 256;
     // residency as the runtime reports it for the instantiation that would run, shared with SK_COOP_SHARE - 1 other launches
     if ((long)B * sk_coop_g(N) <= (long)coop_blocks_per_cu(vpl, 1) * n_cu / SK_COOP_SHARE) return 1;
@@ -1564,7 +1569,7 @@ static int coop_batch_vpl(int M) { return M <= 1024 ? 4 : 8; }
 static bool coop_batch_path(int B, int N, int M, int flags) {
     if (flags & (DR_SK_MINSHIFT | DR_SK_STRICT | DR_SK_OUT_LOG)) return false;
     if (M > 2048 || M <= 768 || !env_knob("DR_SK_COOP", 1) || !env_knob("DR_SK_BATCH", 1)) return false;
-    static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const int n_cu = device_cu_count();
     const long G = (N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW);
     return G <= 32 && (long)B * G <= n_cu;
 }
@@ -1588,6 +1593,9 @@ static int coop_zero_flags(const SkArgs& a, int G, hipStream_t st) {
 template <typename TIn, typename TOut>
 static int launch_coop_batch(const SkArgs& a, hipStream_t st) {
     const int G = (a.N + SK_BATCH_RW * SK_BATCH_RPW - 1) / (SK_BATCH_RW * SK_BATCH_RPW), vpl = coop_batch_vpl(a.M);
+    // the kernel's half-wave column-sum reduction (RW * RPW >= 32) reads ONE partial per lane of a half-wave: more than 32 partials would be dropped
+    static_assert(SK_BATCH_RW * SK_BATCH_RPW >= 32, "the batch form is the instantiation with the half-wave reduction");
+    if (G > 32) return DR_EINVAL;
     const int zrc = coop_zero_flags(a, G, st);
     if (zrc) return zrc;
     const dim3 grid(G, a.B), blk(64 * SK_BATCH_RW);
@@ -1608,6 +1616,7 @@ static int launch_coop(const SkArgs& a, hipStream_t st) {
     const int rpw = coop_rows_per_wave(a.B, a.N, a.M, a.flags);
     if (!rpw) return DR_EINVAL;
     const int G = (a.N + SK_COOP_RW * rpw - 1) / (SK_COOP_RW * rpw), vpl = (a.M + 255) / 256;
+    static_assert(SK_COOP_RW * 2 < 32, "an instantiation of >= 32 rows per workgroup takes the half-wave reduction: it then needs the G <= 32 guard of the batch form");
     const int zrc = coop_zero_flags(a, G, st);
     if (zrc) return zrc;
     const dim3 grid(G, a.B), blk(64 * SK_COOP_RW);
@@ -1723,7 +1732,7 @@ static size_t sk_workspace_need(int B, int N, int M, int esz, int flags, int ite
 template <typename TIn>
 static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const double* shift, const uint8_t* src_mask,
                              const uint8_t* tgt_mask, const float* bin_score, int iters, int flags, void* out, void* ws,
-                             size_t ws_bytes, void* stream) {
+                             size_t ws_bytes, void* stream, unsigned* call_status = nullptr) {
     if (B < 0 || N < 1 || M < 1 || iters < 1 || !scores || !bin_score || !out) return DR_EINVAL;
     if (B == 0) return DR_OK;
     constexpr bool in64 = sizeof(TIn) == 8;
@@ -1731,7 +1740,7 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
     SkArgs a;
     a.scores = scores; a.src_mask = src_mask; a.tgt_mask = tgt_mask; a.bin_score = bin_score;
     a.out = out; a.ws = ws; a.shift = shift; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
-    a.spin_limit = g_sk_spin_limit;
+    a.spin_limit = g_sk_spin_limit; a.call_status = call_status;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: read the score tile once, write the conf tile once
     ProfScope ps(PK_SINKHORN, (double)B * N * M * (sizeof(TIn) + (out32 ? 4.0 : 8.0)), st);
@@ -1774,12 +1783,12 @@ static int sinkhorn_dispatch(int B, int N, int M, const TIn* scores, const doubl
 }
 
 int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,
-                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
-    return sinkhorn_dispatch<float>(B, N, M, scores, nullptr, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
+                 int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st, unsigned* call_status) {
+    return sinkhorn_dispatch<float>(B, N, M, scores, nullptr, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st, call_status);
 }
 int sinkhorn_f64(int B, int N, int M, const double* scores, const double* shift, const uint8_t* sm, const uint8_t* tm,
-                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st) {
-    return sinkhorn_dispatch<double>(B, N, M, scores, shift, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st);
+                 const float* bin_score, int iters, int flags, void* out, void* ws, size_t ws_bytes, hipStream_t st, unsigned* call_status) {
+    return sinkhorn_dispatch<double>(B, N, M, scores, shift, sm, tm, bin_score, iters, flags, out, ws, ws_bytes, st, call_status);
 }
 
 // fp16 tiles in, fp16 confidences out: the register-resident kernel only (tiles up to 256 x 256: BASELINE cfg1 / cfg2)
@@ -1791,7 +1800,7 @@ int sinkhorn_f16(int B, int N, int M, const void* scores, const uint8_t* sm, con
     SkArgs a;
     a.scores = scores; a.src_mask = sm; a.tgt_mask = tm; a.bin_score = bin_score;
     a.out = out; a.ws = nullptr; a.shift = nullptr; a.B = B; a.N = N; a.M = M; a.iters = iters; a.flags = flags;
-    a.spin_limit = g_sk_spin_limit;
+    a.spin_limit = g_sk_spin_limit; a.call_status = nullptr;
     ProfScope ps(PK_SINKHORN, (double)B * N * M * 4.0, st);
     const int cpl = (N <= 128 && M <= 128) ? 2 : 4;
     a.vec_in = (M % cpl == 0) && ((uintptr_t)scores % (2 * cpl) == 0);
@@ -1820,6 +1829,15 @@ int sinkhorn_device_status(hipStream_t st, bool clear) {
         const unsigned z = 0;
         DR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_status), &z, sizeof(z)));
     }
+    return (h & 1u) ? DR_ETIMEOUT : DR_OK;
+}
+
+// waits for the stream, reads (and clears) a caller's own sticky word (the loops' per-workspace status)
+int sinkhorn_call_status(unsigned* word, hipStream_t st, bool clear) {
+    DR_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned h = 0;
+    DR_HIP_CHECK(hipMemcpy(&h, word, sizeof(h), hipMemcpyDeviceToHost));
+    if (h && clear) DR_HIP_CHECK(hipMemset(word, 0, sizeof(h)));
     return (h & 1u) ? DR_ETIMEOUT : DR_OK;
 }
 

@@ -37,14 +37,18 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TrBatch G) {
 struct Transposer {
     TrBatch g;
     int tiles;
-    Transposer() { memset(&g, 0, sizeof(g)); tiles = 0; }
+    bool overflow;                                                        // an add() beyond the batch's 12 slots: launch() then fails instead of overrunning the struct
+    static constexpr int CAP = (int)(sizeof(TrBatch::p) / sizeof(TrProblem));
+    Transposer() { memset(&g, 0, sizeof(g)); tiles = 0; overflow = false; }
     void add(const float* src, int rows, int cols, int ld_src, float* dst, int ld_dst, int w_dst = -1) {
+        if (g.n >= CAP) { overflow = true; return; }
         TrProblem& p = g.p[g.n++];
         p.src = src; p.dst = dst; p.rows = rows; p.cols = cols; p.ld_src = ld_src; p.ld_dst = ld_dst; p.w_dst = w_dst < 0 ? ld_dst : w_dst;
         p.tile0 = tiles; p.tiles_c = (cols + 31) / 32;
         tiles += ((p.w_dst + 31) / 32) * p.tiles_c;                       // (the pad entries of a destination row are covered too)
     }
     int launch(hipStream_t st) {
+        if (overflow) return DR_EINVAL;
         if (g.n == 0) return DR_OK;
         hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, st, g);
         DR_LAUNCH_CHECK();
@@ -206,7 +210,10 @@ int dr_attention_layer_backward_f32(const dr_layer_weights* w, int C, int H, int
     T.add(x, R, C, C, T_cat, R4);                      // cat[x, m]^T = [x^T ; m^T]
     T.add(sv.m, R, C, C, T_cat + (size_t)C * R4, R4);
     T.add(sv.o, R, C, C, T_o, R4);
-    T.add(y, Q, C, C, T_y, Q4);
+    // self-attention calls (y is x): y^T is x^T, already the first C rows of cat^T
+    const bool y_is_x = y == x && Q == R;
+    if (y_is_x) T_y = T_cat;
+    else T.add(y, Q, C, C, T_y, Q4);
     rc = T.launch(st);
     if (rc) return rc;
     // ---- norm2 -> mlp.2 -> ReLU -> mlp.0

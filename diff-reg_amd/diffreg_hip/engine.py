@@ -38,6 +38,21 @@ _STREAM_POOL = {}
 _STREAM_POOL_LOCK = threading.Lock()
 
 
+class _CallStatus:
+    """Handle on the status word of the workspace a loop call ran on (dr_denoise_loop_status).  Travels in the result dict as `_status`;
+    .check() waits for the current stream and raises if THAT call's co-resident Sinkhorn timed out -- per workspace, so concurrent batches /
+    engines are told apart (the process-wide dr_device_status flag cannot).  clone() returns the handle itself (result dicts are cloned key by key)."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def check(self, clear=True):
+        lib.loop_status(self.ws, clear)
+
+    def clone(self):
+        return self
+
+
 def _side_streams(device, n):
     """The side streams of run_streams, shared by every engine of the process: the runtime maps streams onto a handful of hardware queues in
     creation order, so engines that each created their own would end up with streams that share a queue (measured: three concurrent cfg3 calls
@@ -285,7 +300,7 @@ class DenoiseEngine:
             b["noise"].copy_(noise)
 
     def _collect(self, b):
-        out = dict(conf_matrix_pred=b["conf"], x_final=b["x_final"], R_final=b["R_final"], t_final=b["t_final"])
+        out = dict(conf_matrix_pred=b["conf"], x_final=b["x_final"], R_final=b["R_final"], t_final=b["t_final"], _status=_CallStatus(b["ws"]))
         if b["matches"] is not None:
             out["matches_padded"], out["match_count"] = b["matches"], b["match_count"]
         if b["trace"]:
@@ -349,7 +364,8 @@ class DenoiseEngine:
         out = self.run(fs, ft, ps, pt, xT, sm, tm, noise=nz, graph=graph, ragged=True, borrow=True)
         res = []
         cnt = out["match_count"].cpu().tolist() if "match_count" in out else None
-        lib.device_status(self.device)          # (the count read above synchronised already)
+        out["_status"].check()                  # this call's own status word ...
+        lib.device_status(self.device)          # ... and the process-wide flag (the count read above synchronised already)
         for i in range(P):
             r = dict(conf_matrix_pred=out["conf_matrix_pred"][i, :Ns[i], :Ms[i]].clone(), R_final=out["R_final"][i].clone(),
                      t_final=out["t_final"][i].clone())
@@ -362,6 +378,8 @@ class DenoiseEngine:
     def match_list(out):
         """[K_p,3] int64 tensors (one host sync; raises if a kernel of the run reported a device-side failure)."""
         cnt = out["match_count"].cpu().tolist()
+        if "_status" in out:
+            out["_status"].check()              # the status word of the workspace THIS call ran on
         lib.device_status(out["match_count"].device)
         return [out["matches_padded"][p, :cnt[p]] for p in range(len(cnt))]
 
@@ -484,7 +502,8 @@ class DenoiseEngine2D3D:
             lib.ptr(c(pcd_feats)), lib.ptr(c(s_pcd)), lib.ptr(c(t_pcd_da)), lib.ptr(sm), lib.ptr(tm), lib.ptr(tmd), lib.ptr(c(x_T)),
             lib.ptr(conf), lib.ptr(xf), lib.ptr(matches), lib.ptr(cnt), lib.ptr(img_out), lib.ptr(pcd_out),
             ctypes.byref(tr) if tr is not None else None, lib.ptr(self._ws), need, lib.stream_of(img_feats)))
-        out = dict(conf_matrix_pred=conf, x_final=xf, matches_padded=matches, match_count=cnt, img_feats=img_out, pcd_feats=pcd_out)
+        out = dict(conf_matrix_pred=conf, x_final=xf, matches_padded=matches, match_count=cnt, img_feats=img_out, pcd_feats=pcd_out,
+                   _status=_CallStatus(self._ws))
         out.update(trb)
         if keep:
             out["_forced_inputs"] = keep          # (alive until the caller drops the result: the call is asynchronous)
@@ -555,7 +574,7 @@ class DenoiseEngine2D3D:
         else:
             self._enqueue_slot(e)
         e["uses"] += 1
-        return dict(conf_matrix_pred=e["conf"], x_final=e["xf"], matches_padded=e["matches"], match_count=e["cnt"])
+        return dict(conf_matrix_pred=e["conf"], x_final=e["xf"], matches_padded=e["matches"], match_count=e["cnt"], _status=_CallStatus(e["ws"]))
 
     def run_streams(self, groups, n_streams=2):
         """Several independent batches of pairs concurrently (DenoiseEngine.run_streams for the 2D-3D loop): one captured graph per batch,

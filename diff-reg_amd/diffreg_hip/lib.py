@@ -140,6 +140,7 @@ SIGNATURES.update({
     "dr_procrustes_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dr_procrustes_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_float, c_float] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "dr_device_status": (c_int, [c_void_p, c_int]),
+    "dr_denoise_loop_status": (c_int, [c_void_p, c_void_p, c_int]),
     "dr_procrustes_backward_f32": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 9),
     "dr_debug_sinkhorn_spin_limit": (None, [ctypes.c_uint]),
     "dr_debug_enable_env": (None, [c_int]),
@@ -219,7 +220,7 @@ def _bind(table):
 _bind(SIGNATURES)
 _INIT_DONE = False
 
-ABI_VERSION = 200          # DR_ABI_VERSION of the include/diffreg_hip.h these signatures were written against
+ABI_VERSION = 201          # DR_ABI_VERSION of the include/diffreg_hip.h these signatures were written against
 if _lib.dr_version() // 100 != ABI_VERSION // 100:
     raise ImportError("libdiffreg_hip.so is ABI %d, this binding is written against %d: rebuild (make -C diff-reg_amd/csrc)"
                       % (_lib.dr_version(), ABI_VERSION))
@@ -250,6 +251,14 @@ def check(code):
         if code == -2:
             msg += ": " + _lib.dr_last_hip_error().decode()
         raise RuntimeError("libdiffreg_hip: %s (%d)" % (msg, code))
+
+
+def loop_status(workspace, clear=True):
+    """dr_denoise_loop_status: waits for the current stream of the workspace's device and raises if the LAST loop call that ran on this
+    workspace reported a device-side failure (DR_ETIMEOUT of a co-resident Sinkhorn launch).  The word belongs to the workspace, so
+    concurrent engines / concurrent batches of one engine (one workspace each) are told apart."""
+    st = torch.cuda.current_stream(workspace.device).cuda_stream
+    check(_lib.dr_denoise_loop_status(ptr(workspace), c_void_p(st), 1 if clear else 0))
 
 
 def device_status(device=None, clear=True):

@@ -36,7 +36,7 @@ extern "C" {
  *   0.2.0  dr_loop_trace grew the teacher-forcing fields (a 0.1.0 caller's struct is too short); dr_procrustes_f32 and
  *          dr_top1_union_f32 / _f64 take (workspace, workspace_bytes) in front of `stream` since the last 0.1.0 builds -- a caller
  *          compiled against the header without them passes its stream in the workspace slot. */
-#define DR_ABI_VERSION 200
+#define DR_ABI_VERSION 201
 int dr_version(void);                 /* major*10000 + minor*100 + patch */
 const char* dr_strerror(int code);
 const char* dr_last_hip_error(void);  /* text of the last failing HIP call on this thread */
@@ -460,6 +460,12 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
                     double* conf, double* x_final, int64_t* matches, int32_t* match_count, float* R_final,
                     float* t_final, const dr_loop_trace* trace, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* The status of the LAST call that ran on `workspace` (dr_denoise_loop, dr_denoiser_match_f32, dr_denoise_loop_2d3d): waits for `stream`,
+ * reads the workspace's own sticky word (zeroed when a call starts; clears it when `clear`) -> DR_OK, or DR_ETIMEOUT when a co-resident
+ * Sinkhorn launch OF THAT CALL gave up waiting for another workgroup (its outputs then hold NaN).  Unlike dr_device_status this word
+ * belongs to one workspace: concurrent engines (one workspace per stream) cannot swallow or misattribute each other's time-outs. */
+int dr_denoise_loop_status(void* workspace, void* stream, int clear);
 
 /* RepositioningTransformer.forward for layer types self/cross (3D/models/transformero.py:151-233)
  * + Matching.forward (3D/models/matching.py:164-219) on already-warped points, for P pairs:

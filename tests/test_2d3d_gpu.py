@@ -86,7 +86,7 @@ def kth_boundary_gap(conf, ms, mt_da):
 
 
 @pytest.mark.parametrize("planes", [False, True])
-def test_cfg5_1024x2048_10_steps(planes):
+def test_cfg5_free_running_parity_until_the_first_tied_step_then_invariants(planes):
     """BASELINE configs[4] at its stated size: N = 1024 point nodes x M = 2048 image patches (tiles beyond the register-resident
     Sinkhorn / Procrustes paths), 10 denoise steps, warp active, padding masks on both sides and a different (non-trivial)
     tgt_mask_da for the warp, against the oracle step by step: the -inf persistence of masked entries (quirk Q8), the fp64 state
@@ -183,7 +183,7 @@ def test_cfg5_warp_fed_back_against_the_reference(golden, planes):
     reference's run is below 3e-6 -- with these synthetic weights the matrices are flat, the top-2 000 of 2 M nearly equal confidences is
     decided by the last bit of the Sinkhorn in front of it, and the fit of such a set moves R by up to 0.14 (tests/test_oracle_golden.py
     shows the same for the oracle against ITSELF with x_T moved by one ulp).  Step 0's boundary is 2e-5 wide: its pose, cond and x_start
-    are the reference's; the later steps are held to the structural invariants of test_cfg5_1024x2048_10_steps."""
+    are the reference's; the later steps are held to the structural invariants of test_cfg5_free_running_parity_until_the_first_tied_step_then_invariants."""
     N, M, steps, mc = 1024, 2048, 10, 200
     g = golden("2d3d_loop_n1024x2048_s10_mc200_xt03_masked")
     W, eng, q = setup(N, M, 51, steps, mc, planes)

@@ -239,3 +239,33 @@ def test_pipeline_evaluation_loop_of_a_form_in_the_4d_variant(golden):
     conf = out["conf_matrix_pred"]
     assert conf.dtype == torch.float64 and np.abs(conf[0].cpu().numpy() - g["loop_sin_conf"]).max() < 1e-4
     assert "match_pred" not in out                                   # (the 4D tree has no read-out list in Pipeline.forward)
+
+
+def test_module_loop_pairs_of_a_batch_do_not_see_each_other():
+    """the module-level loop on a batch of two different pairs = the two pairs run alone: the 3DMatch min-shift is taken per PAIR (the reference only
+    ever holds a 1 x N x M state, 3D/models/pipeline.py:238; with the learned bin score the Sinkhorn result is not shift-invariant, so a batch-wide
+    minimum would make a pair's result depend on its neighbours)"""
+    from models.pipeline import Pipeline
+    N, M, steps = 96, 80, 3
+    cfg = form_config("sin", steps=steps)
+    model = Pipeline(cfg, backbone=StubBackbone())
+    W = train_weights("soft")
+    sd = model.state_dict()
+    sd.update({k: t for k, t in W.items() if k in sd})
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    C = synth.VARIANTS["3dmatch"]["C"]
+    prs = [synth.make_pair(N, M, C, seed=410 + i) for i in range(2)]
+    prs[1]["x_T"] = prs[1]["x_T"] - 3.0                      # the second pair's state sits lower: a batch-wide minimum would shift the first pair by ~3
+    st = lambda k, sel: torch.from_numpy(np.stack([prs[i][k] for i in sel])).to(DEV)
+
+    def run(sel):
+        ms, mt = torch.ones(len(sel), N, dtype=torch.bool, device=DEV), torch.ones(len(sel), M, dtype=torch.bool, device=DEV)
+        data = {"x_T": st("x_T", sel)}
+        with torch.no_grad():
+            model._eval_loop_on_modules(data, st("src_feats", sel), st("tgt_feats", sel), st("s_pcd", sel), st("t_pcd", sel), ms, mt)
+        return data["conf_matrix_pred"]
+    both, alone = run([0, 1]), [run([0]), run([1])]
+    for i in range(2):
+        err = float((both[i] - alone[i][0]).abs().max())
+        assert err < 1e-5 * float(alone[i][0].max()), (i, err, float(alone[i][0].max()))

@@ -187,3 +187,45 @@ def test_procrustes_and_readout_take_caller_workspaces():
     for p in range(P):
         have = set(map(tuple, got[p][:, 1:].cpu().tolist()))
         assert all((i, int(rows[p, i])) in have for i in range(N))
+
+
+def test_loop_timeouts_are_attributed_to_the_call_that_had_them():
+    """dr_denoise_loop_status: every loop call zeroes, and a timed-out co-resident Sinkhorn of that call sets, a status word in the call's OWN
+    workspace.  Two engines: A's loop runs with the spin bound at one poll (times out), B's afterwards with the normal bound -- A's handle
+    raises, B's does not (the process-wide dr_device_status flag is set by A and cannot tell them apart), and a clean re-run of A clears A's word."""
+    from bench import make_engine, make_inputs
+    from diffreg_hip import lib
+    r = lib.raw()
+    N = M = 384                                      # beyond the register-resident tiles: the loop's Sinkhorn calls take the co-resident form
+    _, eng_a = make_engine("3dmatch", 2, 200.0, DEV)
+    _, eng_b = make_engine("3dmatch", 2, 200.0, DEV)
+    _, inp = make_inputs("3dmatch", 1, N, M, 8100, DEV)
+    args = (inp["f_s"], inp["f_t"], inp["p_s"], inp["p_t"], inp["x_T"])
+    r.dr_device_status(lib.stream_of(inp["x_T"]), 1)
+    good = eng_b.run(*args, graph=False)
+    good["_status"].check()
+    try:
+        timed_out = False
+        for _ in range(20):
+            r.dr_debug_sinkhorn_spin_limit(1)
+            out_a = eng_a.run(*args, graph=False, borrow=True)
+            torch.cuda.synchronize()
+            r.dr_debug_sinkhorn_spin_limit(0)
+            out_b = eng_b.run(*args, graph=False, borrow=True)
+            torch.cuda.synchronize()
+            if r.dr_denoise_loop_status(lib.ptr(out_a["_status"].ws), lib.stream_of(inp["x_T"]), 0) == ETIMEOUT:
+                assert r.dr_device_status(lib.stream_of(inp["x_T"]), 0) == ETIMEOUT            # the process-wide flag: set, no owner
+                out_b["_status"].check()                                                       # B's call was clean ...
+                assert torch.equal(out_b["conf_matrix_pred"], good["conf_matrix_pred"])
+                with pytest.raises(RuntimeError, match="gave up waiting"):
+                    out_a["_status"].check()                                                   # ... A's was not; the check clears A's word
+                assert r.dr_denoise_loop_status(lib.ptr(out_a["_status"].ws), lib.stream_of(inp["x_T"]), 0) == OK
+                timed_out = True
+                break
+        assert timed_out
+    finally:
+        r.dr_debug_sinkhorn_spin_limit(0)
+        r.dr_device_status(lib.stream_of(inp["x_T"]), 1)
+    again = eng_a.run(*args, graph=False)
+    again["_status"].check()
+    assert torch.equal(again["conf_matrix_pred"], good["conf_matrix_pred"])
