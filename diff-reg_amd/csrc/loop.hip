@@ -123,6 +123,8 @@ struct PlanesWs {
     size_t qkv_stride;                       // bytes from the q image to the k image (= to the next: v)
     size_t side_C, side_att, side_hid;      // byte offset of the tgt part inside an image of K = C / H dp / 2C
     void* own_pack;                         // packed weights inside the workspace (used when the caller passed none)
+    // KSPLIT exchange of the LayerNorm launches (pgemm.h): partial sums + arrival flags (zeroed by planes_begin), the launches counted since then
+    float* xk_buf; unsigned* xk_flags; mutable unsigned xk_epoch; unsigned* status;
     static size_t img_bytes(int PN, int PM, int K) { return plane_image_bytes(PN, K) + plane_image_bytes(PM, K); }
     static void carve(Carver& c, PlanesWs& w, const dr_loop_config& cfg, int P, int N, int M) {
         const int C = cfg.C, PN = P * N, PM = P * M, T = PN + PM;
@@ -147,6 +149,11 @@ struct PlanesWs {
         w.grp_x = c.take<float>(2 * (size_t)P);
         w.csT = c.take<float>((size_t)T * C);
         w.own_pack = c.take<char>(Prepack::carve(nullptr, cfg, nullptr));
+        // (only launches of at most half a chip of 64-row workgroups are split: 128 row blocks on 256 CUs)
+        const bool xk = (T + 63) / 64 + 2 <= PG_XK_MAX_RB;
+        w.xk_buf = xk ? c.take<float>(pgemm_xk_buf_bytes(pgemm_bn(C)) / 4) : nullptr;
+        w.xk_flags = xk ? c.take<unsigned>(pgemm_xk_flag_bytes() / 4) : nullptr;
+        w.xk_epoch = 0; w.status = nullptr;
     }
 };
 
@@ -270,6 +277,13 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     auto reset = [&]() { memset(&g, 0, sizeof(g)); };
     auto add = [&]() -> PgProblem& { return g.p[g.n++]; };
     auto for_sides = [&](int mask, auto fn) { for (int side = 1; side <= 2; ++side) if (mask & side) fn(side); };
+    // KSPLIT exchange region of a LayerNorm problem (launch_pgemm decides whether the launch is split): the tgt side's row blocks behind the src side's
+    auto xk = [&](PgProblem& p, int side) {
+        if (!pw.xk_buf) return;
+        const size_t rb0 = side == SIDE_TGT ? (size_t)(PN + 63) / 64 : 0;
+        p.xk_buf = pw.xk_buf + rb0 * (pgemm_xk_buf_bytes(pgemm_bn(C)) / 4 / PG_XK_MAX_RB); p.xk_flags = pw.xk_flags + rb0 * 2;
+        p.xk_epoch = pw.xk_epoch + 1; p.xk_status = pw.status;
+    };
     int rc;
     bool rc_ok = true;
 
@@ -343,7 +357,9 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.W = L.merge; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN; p.k_alg = C;
         p.gamma = W.norm1_w; p.beta = W.norm1_b; p.lnB = L.lnB1;
         p.pimg = at(pw.msg_img, pw.side_C, side); p.p_nct = nC; p.pbnd = pw.msg_bnd + r0(side);
+        xk(p, side);
     });
+    ++pw.xk_epoch;
     rc = launch_pgemm(g, st);
     if (rc) return rc;
     // ---- hidden = relu(mlp0([x | message])) -> plane image
@@ -367,7 +383,9 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.resid = xin.f32 + (size_t)r0(side) * C; p.ldr = C; p.bnd_res = xin.bnd + r0(side);
         p.out = out.f32 + (size_t)r0(side) * C; p.ldo = C;
         p.pimg = at(out.img, pw.side_C, side); p.p_nct = nC; p.pbnd = out.bnd + r0(side);
+        xk(p, side);
     });
+    ++pw.xk_epoch;
     return launch_pgemm(g, st);
 }
 
@@ -603,6 +621,10 @@ static int planes_begin(const dr_loop_config& cfg, const dr_loop_weights& w, int
     Prepack::carve(buf, cfg, &pp);
     ws.pp = &pp;
     const int C = cfg.C, PN = P * N, PM = P * M;
+    if (ws.pl.xk_flags) {
+        DR_HIP_CHECK(hipMemsetAsync(ws.pl.xk_flags, 0, pgemm_xk_flag_bytes(), st));
+        ws.pl.xk_epoch = 0;
+    }
     int rc = launch_planes_from_f32(ws.pl.feat0.f32, C, PN, C, ws.pl.feat0.img, ws.pl.feat0.bnd, st);
     if (rc == DR_OK) rc = launch_planes_from_f32(ws.pl.feat0.f32 + (size_t)PN * C, C, PM, C, ws.pl.feat0.img + ws.pl.side_C, ws.pl.feat0.bnd + PN, st);
     return rc;
@@ -832,6 +854,7 @@ int dr_denoiser_match_f32(const dr_loop_config* cfg, const dr_loop_weights* w, i
     LoopWs L;
     LoopWs::carve(c, L, *cfg, P, N, M);
     DR_HIP_CHECK(hipMemsetAsync(L.status, 0, 16, st));          // the status of THIS call (one 16-byte fill per call)
+    L.dw.pl.status = L.status;
     const int C = cfg->C;
     const size_t PN = (size_t)P * N, PM = (size_t)P * M;
     DR_HIP_CHECK(hipMemcpyAsync(L.feat0, src_feats, PN * C * 4, hipMemcpyDeviceToDevice, st));
@@ -874,6 +897,7 @@ int dr_denoise_loop(const dr_loop_config* cfg, const dr_loop_weights* w, int P, 
     LoopWs L;
     LoopWs::carve(c, L, *cfg, P, N, M);
     DR_HIP_CHECK(hipMemsetAsync(L.status, 0, 16, st));          // the status of THIS call (one 16-byte fill per call)
+    L.dw.pl.status = L.status;
     const int C = cfg->C;
     const size_t PN = (size_t)P * N, PM = (size_t)P * M, NM = (size_t)P * N * M;
     const uint8_t* tokmask = src_mask ? L.tokmask : nullptr;

@@ -57,7 +57,16 @@ struct PgProblem {
     // nn.Linear bias (all modes): acc + bias[nb * C + col] before rotary / ReLU / LayerNorm; bias_max[nb] >= max |bias| of block nb
     // (added to the bound a PG_PLANES image is scaled by)
     const float* bias; const float* bias_max;
+    // PG_LN launches of 64-row workgroups that would leave half the chip idle (launch_pgemm decides: `ksplit`): the k range of a row block is
+    // SPLIT over two workgroups (ids 8 apart: the same XCD), each keeps 16 of a wave's 32 rows and hands the other 16 rows' partial sums to
+    // its partner through xk_buf [row block][destination half][4 waves][TNW][2][64 lanes] float4 (sc1 accesses); xk_flags [row block][2] holds
+    // the epoch of the last launch whose half has been written (zeroed by the owner of the workspace before the first launch; xk_epoch counts
+    // the launches that use the buffer since then).  xk_status: the caller's sticky status word (bit 1 = a partner did not arrive; nullable).
+    float* xk_buf; unsigned* xk_flags; unsigned xk_epoch; unsigned* xk_status; int ksplit;
 };
+constexpr int PG_XK_MAX_RB = 160;                                  // row blocks (of 64 rows) a split launch can have: xk_buf / xk_flags are sized for it
+inline size_t pgemm_xk_buf_bytes(int bn) { return (size_t)PG_XK_MAX_RB * 2 * 4 * (bn / 64) * 2 * 64 * 16; }
+inline size_t pgemm_xk_flag_bytes() { return (size_t)PG_XK_MAX_RB * 2 * sizeof(unsigned); }
 struct PgBatch { PgProblem p[3]; int n; int dbg; };   // dbg (debug knob DR_PG_NOEPI): 1 = return behind the main loop (timing builds)
 
 bool pgemm_shape_ok(int C);                      // column-block widths the kernel is built for

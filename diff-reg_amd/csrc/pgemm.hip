@@ -104,13 +104,21 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
 
     const PgProblem& P = G.p[blockIdx.y];
-    const int rows = P.rows, C = P.C, nblk = P.nblk, nc0 = P.nc0, nc1 = P.A1 ? P.nc1 : 0, nst = nc0 + nc1;
+    // KSPLIT (64-row LayerNorm launches that would leave half the chip idle; launch_pgemm sets P.ksplit): the k range of a row block is split
+    // over TWO workgroups -- dealt like two column blocks, ids 8 apart: the same XCD -- which exchange half of their partial sums behind the
+    // main loop and each finish 16 of a wave's 32 rows (see the exchange in front of the epilogue)
+    constexpr bool KS_OK = !M16 && WMN == 2 && MODE == PG_LN;
+    const bool ksplit = KS_OK && P.ksplit != 0;
+    const int rows = P.rows, C = P.C, nblk = ksplit ? 2 : P.nblk, nc1 = P.A1 ? P.nc1 : 0;
     const int rbs = (rows + BM - 1) / BM;                       // BM-row blocks; block rb = rows rb BM .. of the 128-row image block rb BM / 128
     // workgroup id -> (row block, column block), XCD-aware: ids are dealt round-robin to the 8 XCDs, so the column blocks of a
     // row block get ids 8 apart: they share an L2 and the A rows cross the fabric once
     const int grp = blockIdx.x / (8 * nblk), rem = blockIdx.x % (8 * nblk);
-    const int rb = grp * 8 + (rem & 7), nb = rem >> 3;
+    const int rb = grp * 8 + (rem & 7), khalf = ksplit ? (rem >> 3) : 0, nb = ksplit ? 0 : (rem >> 3);
     if (rb >= rbs) return;
+    // this workgroup's k-chunks: all of them, or (KSPLIT: one segment only) the first / second half
+    const int kbeg = khalf ? (P.nc0 + 1) / 2 : 0;
+    const int nc0 = ksplit ? (khalf ? P.nc0 - kbeg : (P.nc0 + 1) / 2) : P.nc0, nst = nc0 + nc1;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w % WMN, wn = w / WMN;
     const int rb128 = (rb * BM) >> 7, sub = (rb * BM) & 127;      // image block and first row inside it (0 / 64)
@@ -248,8 +256,8 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         // issued in the SGPR-base + VGPR-offset + immediate form: per piece an s_mov to M0 and the load, nothing else
         const int st0 = GRP ? wl * (WB_CNT / WMN) + min(wl, WB_CNT % WMN) : WB_CNT + wl * (NW0 / WMN) + min(wl, NW0 % WMN);
         const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * wl * 1024;
-        const char* ga = P.A0 + (size_t)rb128 * nc0 * GG::A_IMG + sub * 64;   // A block of stage ti (wave-uniform)
-        const char* gb = P.W.img + (size_t)nb * nst * GG::B_ST;      // weight block of stage ti
+        const char* ga = P.A0 + ((size_t)rb128 * P.nc0 + kbeg) * GG::A_IMG + sub * 64;   // A block of stage ti (wave-uniform)
+        const char* gb = P.W.img + ((size_t)nb * (P.nc0 + nc1) + kbeg) * GG::B_ST;       // weight block of stage ti
         const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb128 * nc1 * GG::A_IMG + sub * 64 : nullptr;
         int ti = 0;                                                  // next stage this wave issues
         // (the instruction's immediate offset is added to the global address AND to the LDS address M0 + 16 lane)
@@ -569,6 +577,62 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     }
     __syncthreads();                                             // every wave is done with the ring: the epilogue reuses it
 
+    // ---- KSPLIT: the two workgroups of a row block swap half of their partial sums.  A wave's 32 rows are two rounds of 16 (accumulator
+    // registers 0..7 / 8..15 of every tile): workgroup `khalf` KEEPS round khalf and gives the other round to its partner, as raw lane
+    // registers (the partner's wave w, same lane, holds the same (row, column): identical tiling), 16 bytes per lane and store, sc1 both ways.
+    // own + partner's is one fp32 addition whichever side does it: the result does not depend on which workgroup finishes a row.
+    int keep = -1;                                               // the round this workgroup finishes (-1: both)
+    if constexpr (KS_OK) {
+        if (ksplit) {
+            keep = khalf;
+            const int give = 1 - khalf;
+            int* const s_bad = reinterpret_cast<int*>(s_sum);   // (LDS word, free until the LayerNorm partials)
+            if (t == 0) *s_bad = 0;
+            float* const xsend = P.xk_buf + ((((size_t)rb * 2 + give) * 4 + w) * TNW * 2) * 256 + lane * 4;
+            const float* const xrecv = P.xk_buf + ((((size_t)rb * 2 + khalf) * 4 + w) * TNW * 2) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const f32x4 x = {acc[j][8 * give + 4 * q2], acc[j][8 * give + 4 * q2 + 1], acc[j][8 * give + 4 * q2 + 2], acc[j][8 * give + 4 * q2 + 3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(xsend + (j * 2 + q2) * 256), "v"(x) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // every store of the workgroup has left
+            unsigned* const fl = P.xk_flags + (size_t)rb * 2;
+            if (t == 0) __hip_atomic_store(fl + khalf, P.xk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 0) {                                        // bounded: a partner that never arrives poisons the rows and raises the status word
+                unsigned spins = 0;
+                while (__hip_atomic_load(fl + give, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.xk_epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        if (lane == 0) { *s_bad = 1; if (P.xk_status) atomicOr(P.xk_status, 2u); }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const bool bad = *s_bad != 0;
+            f32x4 y[TNW][2];
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(y[j][q2]) : "v"(xrecv + (j * 2 + q2) * 256) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float poison = bad ? __uint_as_float(0x7fc00000u) : 0.f;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][8 * khalf + 4 * q2 + e] += y[j][q2][e] + poison;
+            __syncthreads();                                     // (s_bad lives in s_sum: read by everybody before the LayerNorm partials overwrite it)
+        }
+    }
+    auto skip = [&](int rr) __attribute__((always_inline)) { return KS_OK && keep >= 0 && rr != keep; };
+
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // The MFMA result has a lane's 16 values in 16 different rows.  Each wave transposes its 32 x 224 strip in two rounds of
     // 16 rows through a private [16][EP_S] float region; afterwards lane (lr = lane / 4, q = lane % 4) owns the float4s
@@ -756,9 +820,9 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         }
     } else {
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) transpose_round(rr, v[rr]);
+        for (int rr = 0; rr < NR; ++rr) if (!skip(rr)) transpose_round(rr, v[rr]);      // (KSPLIT: only the round this workgroup finishes)
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) add_bias(v[rr]);
+        for (int rr = 0; rr < NR; ++rr) if (!skip(rr)) add_bias(v[rr]);
     }
 
     if (mode == PG_LN) {
@@ -773,6 +837,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         if (res && !(G.dbg & 16)) {
 #pragma unroll
             for (int rr = NRR; rr < NR; ++rr) {
+                if (skip(rr)) continue;
                 const float* rp = res + (size_t)min(grow[rr], rows - 1) * P.ldr;
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
@@ -783,6 +848,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             }
 #pragma unroll
             for (int rr = 0; rr < NRR; ++rr) {
+                if (skip(rr)) continue;
                 const float* rp = res + (size_t)min(grow[rr], rows - 1) * P.ldr;
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
@@ -797,6 +863,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
             for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
                 for (int i = 0; i < NIE; ++i) {
+                    if (skip(rr)) continue;
                     const float4 r4 = rr < NRR ? r0[rr < NRR ? rr : 0][i] : *reinterpret_cast<const float4*>(park(rr) + 16 * i);
                     v[rr][i].x += r4.x; v[rr][i].y += r4.y; v[rr][i].z += r4.z; v[rr][i].w += r4.w;
                 }
@@ -804,6 +871,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         float mean[NR], rstd[NR];
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
+            if (skip(rr)) continue;
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NIE; ++i)
@@ -814,6 +882,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
+            if (skip(rr)) continue;
             const int rl = wrow0 + 16 * rr + lrow;
             float tot = s_sum[rl];
 #pragma unroll
@@ -832,6 +901,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
+            if (skip(rr)) continue;
             const int rl = wrow0 + 16 * rr + lrow;
             float tot = s_sq[rl];
 #pragma unroll
@@ -862,6 +932,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
     // q and q ^ 1 hold the two halves of one hi unit and of one lo unit (16 bytes each); the even lane stores the hi unit, the odd one the lo unit.
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
+        if (skip(rr)) continue;
         const bool rok = grow[rr] < rows;
         const float bound = s_bound[wrow0 + 16 * rr + lrow];
         if (P.pbnd && rok && (nb == 0 || per_blk) && wcw == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
@@ -1075,11 +1146,22 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     // some of the CUs (cfg5 at 8 pairs: 192 of them, 28.4 -> 27.6 ms per call; DR_PG_HALF_PCT: the threshold in percent of the CU count)
     const bool half = bn == G9::BN || half_env == 2 || (half_env == 1 && wg128 * 100 < (long)n_cu * env_knob("DR_PG_HALF_PCT", 51));
     const int bm = half ? 64 : 128;
+    // KSPLIT (see the kernel): a LayerNorm launch of 64-row workgroups that fills at most half the chip, every problem one k segment of at least
+    // two ring depths and with an exchange buffer: two workgroups per row block, each half the k range and half the epilogue
+    bool ksplit = half && g.p[0].mode == PG_LN && env_knob("DR_PG_KSPLIT", 1) != 0;
+    long wg64 = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const PgProblem& p = g.p[i];
+        const long rb64 = (p.rows + 63) / 64;
+        ksplit = ksplit && p.xk_buf && p.xk_flags && p.nblk == 1 && !p.A1 && p.nc0 / 2 >= nst_min && rb64 <= PG_XK_MAX_RB;
+        wg64 += rb64;
+    }
+    ksplit = ksplit && 2 * wg64 <= (long)n_cu;
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
         if (!pgemm_shape_ok(p.C) || pgemm_bn(p.C) != bn || p.rows < 1 || p.nblk < 1 || p.nc0 < 1 || p.nc0 + (p.A1 ? p.nc1 : 0) < nst_min) return DR_ENOSUP;
         if (p.W.nct != p.nc0 + (p.A1 ? p.nc1 : 0)) return DR_EINVAL;
-        const int tl = ((p.rows + bm - 1) / bm + 7) / 8 * 8 * p.nblk;
+        const int tl = ((p.rows + bm - 1) / bm + 7) / 8 * 8 * (ksplit ? 2 : p.nblk);
         maxt = tl > maxt ? tl : maxt;
         flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
@@ -1090,6 +1172,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     const dim3 grid(maxt, g.n);
     PgBatch gd = g;
     gd.dbg = env_knob("DR_PG_NOEPI", 0);
+    for (int i = 0; i < g.n; ++i) gd.p[i].ksplit = ksplit ? 1 : 0;
     if (bn == G9::BN) pg_launch<9, 3, 2>(mode, grid, st, gd);
     else if (bn == G4::BN) { if (half) pg_launch<4, 4, 2>(mode, grid, st, gd); else pg_launch<4, 4, 4>(mode, grid, st, gd); }
     else {

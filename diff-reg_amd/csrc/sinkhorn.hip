@@ -1838,7 +1838,7 @@ int sinkhorn_call_status(unsigned* word, hipStream_t st, bool clear) {
     unsigned h = 0;
     DR_HIP_CHECK(hipMemcpy(&h, word, sizeof(h), hipMemcpyDeviceToHost));
     if (h && clear) DR_HIP_CHECK(hipMemset(word, 0, sizeof(h)));
-    return (h & 1u) ? DR_ETIMEOUT : DR_OK;
+    return (h & 3u) ? DR_ETIMEOUT : DR_OK;      // bit 0: a co-resident Sinkhorn; bit 1: the k-split exchange of a LayerNorm GEMM (pgemm.h)
 }
 
 }  // namespace dr
