@@ -59,6 +59,7 @@ struct Prepack {
         const int dp = (cfg.C / cfg.H + 15) / 16 * 16;                 // the head-padded q | k | v block must fit the column block too
         return pgemm_shape_ok(cfg.H * dp) && pgemm_bn(cfg.H * dp) == pgemm_bn(cfg.C) && (dp == 64 || dp == 112 || dp == 144);
     }
+    static bool wide_layout(const dr_loop_config& cfg) { return pgemm_bn(cfg.C) > 448 && env_knob("DR_PG_WIDE", 1) != 0; }
     // lays the images out in `buf` (nullptr: size only) and returns the byte count
     static size_t carve(void* buf, const dr_loop_config& cfg, Prepack* pp) {
         Carver c(buf, (size_t)-1);
@@ -68,16 +69,23 @@ struct Prepack {
             char* p = c.take<char>(pgemm_weight_bytes(C, nblk, nct));
             if (pp && buf) pgemm_weight_view(p, C, nblk, nct, v);
         };
+        // the launches without LayerNorm of the 576-column geometry (4DMatch) run on the wide-wave kernel: their weights in its layout
+        const bool wide = wide_layout(cfg);
+        auto takew = [&](int nblk, int nct, PgW* v) {
+            if (!wide) return take(nblk, nct, v);
+            char* p = c.take<char>(pgemm16w_weight_bytes(nblk, nct));
+            if (pp && buf) pgemm16w_weight_view(p, nblk, nct, v);
+        };
         for (int l = 0; l < cfg.n_layers; ++l) {
             PrepackLayer* L = pp ? &pp->L[l] : nullptr;
-            take(3, nC, L ? &L->qkv : nullptr);            // (C' = H dp output columns per block: same image size, C' <= BN)
+            takew(3, nC, L ? &L->qkv : nullptr);           // (C' = H dp output columns per block: same image size, C' <= BN)
             take(1, cfg.H * dp / 16, L ? &L->merge : nullptr);
-            take(2, 2 * nC, L ? &L->mlp0 : nullptr);
+            takew(2, 2 * nC, L ? &L->mlp0 : nullptr);
             take(1, 2 * nC, L ? &L->mlp2 : nullptr);
             float* b = c.take<float>(2);
             if (L && buf) { L->lnB1 = b; L->lnB2 = b + 1; }
         }
-        take(1, nC, pp ? &pp->head : nullptr);
+        takew(1, nC, pp ? &pp->head : nullptr);
         return c.off + 256;
     }
     static int fill(void* buf, const dr_loop_config& cfg, const dr_loop_weights& W, hipStream_t st) {
@@ -91,18 +99,23 @@ struct Prepack {
             const PrepackLayer& L = pp.L[l];
             // q | k | v: output columns padded per head (d -> dp) so that the images the GEMM writes start every head at a k-chunk
             const int Cq = cfg.H * pp.dp;
-            int rc = pgemm_pack_weights_block(w.q_proj, Cq, C, C, C, L.qkv, 0, st, d, pp.dp);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.k_proj, Cq, C, C, C, L.qkv, 1, st, d, pp.dp);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.v_proj, Cq, C, C, C, L.qkv, 2, st, d, pp.dp);
+            auto packw = [&](const float* Wm, int Cc, int K, int plen, int ppad, const PgW& v, int nb, int olen = 0, int opad = 0) {
+                return v.sub == 2 ? pgemm16w_pack_weights_block(Wm, Cc, K, plen, ppad, v, nb, st, olen, opad)
+                                  : pgemm_pack_weights_block(Wm, Cc, K, plen, ppad, v, nb, st, olen, opad);
+            };
+            int rc = packw(w.q_proj, Cq, C, C, C, L.qkv, 0, d, pp.dp);
+            if (rc == DR_OK) rc = packw(w.k_proj, Cq, C, C, C, L.qkv, 1, d, pp.dp);
+            if (rc == DR_OK) rc = packw(w.v_proj, Cq, C, C, C, L.qkv, 2, d, pp.dp);
             if (rc == DR_OK) rc = pgemm_pack_weights_block(w.merge, C, C, d, pp.dp, L.merge, 0, st);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0, C, 2 * C, 2 * C, 2 * C, L.mlp0, 0, st);
-            if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp0 + (size_t)C * 2 * C, C, 2 * C, 2 * C, 2 * C, L.mlp0, 1, st);
+            if (rc == DR_OK) rc = packw(w.mlp0, C, 2 * C, 2 * C, 2 * C, L.mlp0, 0);
+            if (rc == DR_OK) rc = packw(w.mlp0 + (size_t)C * 2 * C, C, 2 * C, 2 * C, 2 * C, L.mlp0, 1);
             if (rc == DR_OK) rc = pgemm_pack_weights_block(w.mlp2, C, 2 * C, 2 * C, 2 * C, L.mlp2, 0, st);
             if (rc == DR_OK) rc = launch_ln_bound(w.norm1_w, w.norm1_b, C, (float*)L.lnB1, st);
             if (rc == DR_OK) rc = launch_ln_bound(w.norm2_w, w.norm2_b, C, (float*)L.lnB2, st);
             if (rc) return rc;
         }
-        return pgemm_pack_weights_block(W.src_proj, C, C, C, C, pp.head, 0, st);
+        return pp.head.sub == 2 ? pgemm16w_pack_weights_block(W.src_proj, C, C, C, C, pp.head, 0, st)
+                                : pgemm_pack_weights_block(W.src_proj, C, C, C, C, pp.head, 0, st);
     }
 };
 
@@ -261,6 +274,7 @@ struct PlCtx {
 };
 static PgW pgw_blocks(const PgW& v, int b0, int C) {
     PgW r = v;
+    if (v.sub == 2) { r.img += (size_t)b0 * v.nct * 576 * 64; r.cinv += (size_t)b0 * 576; r.wnorm += b0; return r; }   // (two sub-blocks of 288 rows per block)
     r.img += (size_t)b0 * v.nct * pgemm_bn(C) * 64; r.cinv += (size_t)b0 * pgemm_bn(C); r.wnorm += b0;
     return r;
 }

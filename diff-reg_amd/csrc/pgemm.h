@@ -25,6 +25,8 @@ struct PgW {
     const float* cinv;   // [nblk][BN]  2^-s_c of every output column
     const float* wnorm;  // [nblk]      max_c sum_k |W[c][k]|  (output bound = input bound * wnorm)
     int nct;             // 16-deep k-chunks of the image (= those of the A operand)
+    int sub;             // 0: one block = BN weight rows.  2: the WIDE-WAVE layout (pgemm16w_kernel): a logical block of up to 576 columns is two
+                         //    sub-blocks of 288 weight rows, img [nblk][2][nct][288][64 B]; cinv [nblk][576] and wnorm [nblk] stay logical
 };
 
 enum { PG_F32 = 0, PG_PLANES = 1, PG_LN = 2 };
@@ -82,6 +84,12 @@ void pgemm_weight_view(void* buf, int C, int nblk, int nct, PgW* view);
 int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st);
 int pgemm_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st, int out_len = 0,
                              int out_pad = 0);
+// the same for the wide-wave layout (PgW::sub = 2; C <= 576 columns per logical block; launches without LayerNorm only)
+bool pgemm16w_shape_ok(int C);
+size_t pgemm16w_weight_bytes(int nblk, int nct);
+void pgemm16w_weight_view(void* buf, int nblk, int nct, PgW* view);
+int pgemm16w_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& view, int nb, hipStream_t st, int out_len = 0,
+                                int out_pad = 0);
 int launch_group_max(const float* bnd, int ngroups, int grp_rows, float* out, hipStream_t st);
 
 // fp32 rows -> plane image with bound[row] = max |x[row][:]| (the external features entering the first layer)

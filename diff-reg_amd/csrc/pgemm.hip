@@ -969,6 +969,350 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The WIDE-WAVE geometry (round 6; the 576-column blocks of 4DMatch, C = 528 / 4 heads padded to 144): 128 rows x 288 columns per workgroup,
+// FOUR waves as 2 (rows) x 2 (columns) of 64 x 144 = 4 x 9 tiles of v_mfma_f32_16x16x32_f16, ONE wave per SIMD (144 accumulator + 72 weight-
+// fragment registers).  Why: the 64-row workgroups of the 576-column kernel stage 4 KB of A + 36 KB of weights per 16-deep k-chunk and run at
+// what a CU can take in (50-56 GB/s measured: merge / mlp0 / qkv main loops at 0.71-0.85 us per chunk against 0.36 us of MFMA time); a 128 x 288
+// tile has the same area and stages 8 + 18 KB.  A logical column block of up to 576 columns is TWO physical sub-blocks of 288 weight rows
+// (PgW::sub = 2: image [nblk][2][nct][288 rows][64 B]; cinv / wnorm stay logical), dealt like column blocks.  The main loop is run16's (chunk
+// pairs, a 4-slot ring, one barrier per pair, weight fragments loaded once per pair), every wave issuing its share of the pair's 52 DMA pieces
+// (13-14 per wave) in the read-free gaps of pass 3 and in pass 0.  Epilogues: PG_F32 and PG_PLANES (the launches without LayerNorm: q | k | v,
+// mlp0, the matching head's projection); the accumulators are in the epilogue's layout as in the 16x16x32 form above.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PgGeomW {
+    static constexpr int NJ = 9, BNW = 144, BN = 288, LBN = 576, BM = 128, NTHR = 256, A_ST = BM * 64, B_ST = BN * 64, STAGE = A_ST + B_ST, NST = 4;
+    static constexpr int RING = NST * STAGE;
+    // + fac[128], rinv[128], red[16], bias[BN], cinv[BN], bound[128]
+    static constexpr int SMEM = RING + (128 + 128 + 16 + BN + BN + 128) * 4;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pgemm16w_kernel(PgBatch G) {
+    using GG = PgGeomW;
+    constexpr int NJ = GG::NJ, BN = GG::BN, STAGE = GG::STAGE, A_ST = GG::A_ST, BM = GG::BM, NTHR = GG::NTHR, NST = GG::NST, NG = 3 * NJ;
+    static_assert(MODE == PG_F32 || MODE == PG_PLANES, "the wide-wave geometry has no LayerNorm epilogue");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+
+    const PgProblem& P = G.p[blockIdx.y];
+    const int rows = P.rows, C = P.C, nblk = P.nblk, nc0 = P.nc0, nc1 = P.A1 ? P.nc1 : 0, nst = nc0 + nc1;
+    const int rbs = (rows + BM - 1) / BM, nb2 = 2 * nblk;
+    const int grp = blockIdx.x / (8 * nb2), rem = blockIdx.x % (8 * nb2);
+    const int rb = grp * 8 + (rem & 7), pb = rem >> 3, nb = pb >> 1, csub = (pb & 1) * BN;
+    if (rb >= rbs || csub >= C) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wn = w & 1, wm2 = w >> 1;
+
+    float* const s_fac = reinterpret_cast<float*>(lds + GG::RING);
+    float* const s_rinv = s_fac + 128;
+    float* const s_red = s_rinv + 128;
+    float* const s_bias = s_red + 16;
+    float* const s_cinv = s_bias + BN;
+    float* const s_bound = s_cinv + BN;
+    const bool has_bias = P.bias != nullptr;
+    const bool rot = (P.rot_mask >> nb) & 1;
+    const bool per_blk = P.pimg_blk_stride != 0;
+    auto stage_inputs = [&]() __attribute__((always_inline)) {
+        if (has_bias) {
+            const float* bp = P.bias + (size_t)nb * C + csub;
+            for (int c = t; c < BN; c += NTHR) s_bias[c] = csub + c < C ? bp[c] : 0.f;
+        }
+        {
+            const float* cp = P.W.cinv + (size_t)nb * GG::LBN + csub;
+            for (int c = t; c < BN; c += NTHR) s_cinv[c] = cp[c];
+        }
+        float gmax = 0.f;
+        if (((P.grp_mask >> nb) & 1) && !P.grp_bnd) {
+            const int gbase = (rb * BM) / P.grp_rows * P.grp_rows;
+            float m = 0.f;
+            for (int i = t; i < P.grp_rows; i += NTHR) m = fmaxf(m, P.bnd0[gbase + i]);
+            m = wave_max(m);
+            if (lane == 0) s_red[w] = m;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NTHR / 64; ++k) gmax = fmaxf(gmax, s_red[k]);
+        }
+        if (t < BM) {
+            const int row = min(rb * BM + t, rows - 1);
+            const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
+            const int e0 = scale_exp(b0);
+            int e1 = e0;
+            if (nc1 > 0) e1 = scale_exp(b1);
+            s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
+            s_rinv[t] = pow2i(-e1);
+            if (P.pimg) {
+                // (the bound rules of pgemm_kernel, word for word: both kernels must scale a row of one image alike)
+                const float bin = ((P.grp_mask >> nb) & 1) ? (P.grp_bnd ? P.grp_bnd[P.grp_first + row / P.grp_rows] : gmax) : fmaxf(b0, b1);
+                float wn_ = P.W.wnorm[nb];
+                if (!per_blk)
+                    for (int b2 = 0; b2 < nblk; ++b2) wn_ = fmaxf(wn_, P.W.wnorm[b2]);
+                float bm = 0.f;
+                if (P.bias_max) {
+                    bm = P.bias_max[nb];
+                    if (!per_blk)
+                        for (int b2 = 0; b2 < nblk; ++b2) bm = fmaxf(bm, P.bias_max[b2]);
+                }
+                s_bound[t] = (bin * wn_ + bm) * (rot ? 1.41421366f : 1.f) * fabsf(P.scale);
+            }
+        }
+    };
+
+    // ---- main loop (see run16): lane group g = lane / 16 reads unit (g >> 1) of chunk c + (g & 1)
+    const int l15 = lane & 15, g = lane >> 4, cs = g & 1, uh = g >> 1, sw16 = (l15 >> 2) & 3;
+    const unsigned oAh = cs * STAGE + (wm2 * 64 + l15) * 64 + ((uh ^ sw16) << 4), oAl = cs * STAGE + (wm2 * 64 + l15) * 64 + (((2 + uh) ^ sw16) << 4);
+    const unsigned oBh = cs * STAGE + A_ST + (wn * 144 + l15) * 64 + ((uh ^ sw16) << 4), oBl = cs * STAGE + A_ST + (wn * 144 + l15) * 64 + (((2 + uh) ^ sw16) << 4);
+    f32x4 c16[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) c16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 fb[NJ][2], fa[2][2];
+    const int nv0 = (nc0 + 1) & ~1, nvt = nv0 + ((nc1 + 1) & ~1), npair = nvt >> 1;
+    const int z0 = (nc0 & 1) ? nv0 - 1 : -1, z1 = (nc1 & 1) ? nvt - 1 : -1;
+    // DMA pieces of a chunk: 8 of A (two per wave) + 18 of weights (waves 0, 1: five, waves 2, 3: four, contiguous)
+    const int npw = w < 2 ? 5 : 4, st0 = w < 2 ? w * 5 : 10 + (w - 2) * 4;
+    const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * w * 1024;
+    const char* ga = P.A0 + (size_t)rb * nc0 * GG::A_ST;
+    const char* gb = P.W.img + (size_t)(nb * 2 + (pb & 1)) * nst * GG::B_ST;
+    const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * GG::A_ST : nullptr;
+    int ti = 0, tr = 0;
+    auto piece = [&](int q) __attribute__((always_inline)) {            // q = 0 .. 6 of chunk ti
+        if (ti == z0 || ti == z1) return;
+        const unsigned dstb = lds_base + (unsigned)(ti % NST) * STAGE;
+        const unsigned m0w = dstb + A_ST + st0 * 1024;
+        const int pw = q - 2;
+        const unsigned hop = (unsigned)(pw >> 2) * 4096;
+        if (q < 2) PG_DMA(dstb + 2 * w * 1024, voffA, ga, q * 1024);
+        else if (pw < npw) PG_DMA(m0w + hop, voffW + hop, gb, (pw & 3) * 1024);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (ti != z0 && ti != z1) {
+            ++tr;
+            gb += GG::B_ST;
+            ga = (tr == nc0) ? ga1 : ga + GG::A_ST;
+        }
+        ++ti;
+    };
+    auto stage = [&](int p, auto steady_t) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_t)::value;
+        const unsigned zm = ((2 * p + 1 == z0 || 2 * p + 1 == z1) && cs) ? 0u : ~0u;
+        const unsigned sb = lds_base + (unsigned)(p & 1) * 2 * STAGE, sbn = lds_base + (unsigned)((p + 1) & 1) * 2 * STAGE;
+        const bool has_next = STEADY || p + 1 < npair;
+        if (2 * p == nv0 && nc1 > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = s_fac[wm2 * 64 + 16 * i + l15];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) c16[i][j] *= f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto gap = [&](int m) __attribute__((always_inline)) {
+            const int pass = m / NG, gi = m % NG;
+            if (pass < 3) {
+                if (gi == 0) PG_READ(fa[(pass + 1) & 1][0], sb + oAh, (pass + 1) * 1024);
+                if (gi == 1) PG_READ(fa[(pass + 1) & 1][1], sb + oAl, (pass + 1) * 1024);
+            } else if (has_next) {
+                if (gi == 0) PG_READ(fa[0][0], sbn + oAh, 0);
+                if (gi == 1) PG_READ(fa[0][1], sbn + oAl, 0);
+                if (gi >= 1 && gi <= NJ) PG_READ(fb[gi - 1][1], sbn + oBl, (gi - 1) * 1024);
+                if (gi >= 2 * NJ + 1 && gi <= NG - 1) PG_READ(fb[gi - 2 * NJ - 1][0], sbn + oBh, (gi - 2 * NJ - 1) * 1024);
+                if (gi == NG - 1) PG_READ(fb[NJ - 1][0], sbn + oBh, (NJ - 1) * 1024);
+            }
+            // DMA: the first chunk of pair p + 2 in the read-free gaps of pass 3 (its slot is free behind the barrier), the second chunk of
+            // pair p + 1 in pass 0 (every third gap)
+            if (pass == 3 && gi >= NJ + 1 && gi <= NJ + 7) {
+                if (STEADY || ti < nvt) {
+                    piece(gi - NJ - 1);
+                    if (gi == NJ + 7) advance();
+                }
+            }
+            if (pass == 0 && gi % 3 == 2 && gi <= 20) {
+                if (STEADY || ti < nvt) {
+                    piece(gi / 3);
+                    if (gi == 20) advance();
+                }
+            }
+            if (pass == 2 && gi == NG - 5) {                         // the pair's barrier: pair p + 1 has landed, pair p's slots are free behind it
+                if (has_next) PG_VMCNT(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        };
+#define PG_MFMA16W(X, Y, m)                                                             \
+    c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Y, X, c16[i][j], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    gap(m);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 a_h = fa[i & 1][0] & zm, a_l = fa[i & 1][1] & zm;
+            const f16x8 ah = __builtin_bit_cast(f16x8, a_h), al = __builtin_bit_cast(f16x8, a_l);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { PG_MFMA16W(ah, __builtin_bit_cast(f16x8, fb[j][1]), NG * i + j) }
+            if (i == 0) { asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { PG_MFMA16W(al, __builtin_bit_cast(f16x8, fb[j][0]), NG * i + NJ + j) }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { PG_MFMA16W(ah, __builtin_bit_cast(f16x8, fb[j][0]), NG * i + 2 * NJ + j) }
+        }
+#undef PG_MFMA16W
+    };
+    // prologue: pair 0 in flight | the epilogue's inputs staged behind it | pair 0 landed | the first chunk of pair 1
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) piece(q);
+        advance();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_inputs();
+    __builtin_amdgcn_sched_barrier(0);
+    PG_VMCNT(0);
+    if (ti < nvt) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) piece(q);
+        advance();
+    }
+    __builtin_amdgcn_s_barrier();
+    PG_READ(fa[0][0], lds_base + oAh, 0);
+    PG_READ(fa[0][1], lds_base + oAl, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) PG_READ(fb[j][1], lds_base + oBl, j * 1024);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) PG_READ(fb[j][0], lds_base + oBh, j * 1024);
+    {
+        int p = 0;
+        for (; p < npair - 2; ++p) stage(p, std::true_type{});
+        for (; p < npair; ++p) stage(p, std::false_type{});
+    }
+    if (G.dbg & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) keep += c16[i][j][0] + c16[i][j][1] + c16[i][j][2] + c16[i][j][3];
+        if (keep == 123.456f && P.out) P.out[0] = keep;
+        return;
+    }
+    __syncthreads();
+
+    // ---- epilogue: lane (l15, g) holds columns 4 g .. 4 g + 3 of row l15 of every 16 x 16 tile: row lr = l15, float4 q = g of piece i = tile column
+    const int lr = l15, q = g;
+    constexpr int NR = 4, NIE = NJ;
+    const int wloc = wn * 144, wcol0 = csub + wloc, wrow0 = wm2 * 64;      // the wave's first column inside the sub-block / the logical block
+    const int colw = wcol0 + 4 * q;
+    int grow[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) grow[rr] = rb * BM + wrow0 + 16 * rr + lr;
+    float4 v[NR][NIE];
+    auto scale_round = [&](int rr, float4 (&dst)[NIE]) __attribute__((always_inline)) {
+        const float rinv = s_rinv[wrow0 + 16 * rr + lr];
+#pragma unroll
+        for (int i = 0; i < NIE; ++i) {
+            const float4 c4 = *reinterpret_cast<const float4*>(s_cinv + wloc + 16 * i + 4 * q);
+            const f32x4 a = c16[rr][i];
+            dst[i] = make_float4(a[0] * c4.x * rinv, a[1] * c4.y * rinv, a[2] * c4.z * rinv, a[3] * c4.w * rinv);
+        }
+    };
+    const int halfC = P.rot_C >> 1, rpad = P.rot_piece_pad, rlen = P.rot_piece_len;
+    const unsigned rmagic = rpad > 0 ? ((1u << 20) + rpad - 1) / rpad : 0u;
+    const float scale = P.scale;
+    auto load_tables = [&](int rr, float4 (&tb)[NIE]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIE; ++i) {
+            int col = min(colw + 16 * i, C - 4);
+            if (rpad > 0) { const int hq = (int)(((unsigned)col * rmagic) >> 20); col = hq * rlen + min(col - hq * rpad, rlen - 4); }
+            if (col >= P.rot_C) col %= P.rot_C;
+            const int ridx = col >> 1;
+            if (P.csT) {
+                const float4 cs4 = *reinterpret_cast<const float4*>(P.csT + (size_t)min(grow[rr], rows - 1) * halfC * 2 + 2 * ridx);
+                tb[i] = make_float4(cs4.x, cs4.z, cs4.y, cs4.w);
+            } else {
+                const float2 c = *reinterpret_cast<const float2*>(P.cosT + (size_t)min(grow[rr], rows - 1) * halfC + ridx);
+                const float2 sn = *reinterpret_cast<const float2*>(P.sinT + (size_t)min(grow[rr], rows - 1) * halfC + ridx);
+                tb[i] = make_float4(c.x, c.y, sn.x, sn.y);
+            }
+        }
+    };
+    auto finish_round = [&](int rr, const float4 (&tb)[NIE]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIE; ++i) {
+            float4 x = v[rr][i];
+            if (has_bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(s_bias + wloc + 4 * q + 16 * i);
+                x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+            }
+            if (rot) {
+                const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+                x.x = __fadd_rn(__fmul_rn(x0, tb[i].x), __fmul_rn(-x1, tb[i].z));
+                x.y = __fadd_rn(__fmul_rn(x1, tb[i].x), __fmul_rn(x0, tb[i].z));
+                x.z = __fadd_rn(__fmul_rn(x2, tb[i].y), __fmul_rn(-x3, tb[i].w));
+                x.w = __fadd_rn(__fmul_rn(x3, tb[i].y), __fmul_rn(x2, tb[i].w));
+            }
+            x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+            if (MODE == PG_PLANES && P.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+            v[rr][i] = x;
+        }
+    };
+    {
+        // every rotary table load precedes the wave's first store (vmcnt retires in order): tables of two rounds in flight at a time
+        float4 tb0[NIE], tb1[NIE];
+        if (rot) { load_tables(0, tb0); load_tables(1, tb1); }
+        scale_round(0, v[0]);
+        scale_round(1, v[1]);
+        finish_round(0, tb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rot) load_tables(2, tb0);
+        finish_round(1, tb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rot) load_tables(3, tb1);
+        scale_round(2, v[2]);
+        scale_round(3, v[3]);
+        finish_round(2, tb0);
+        finish_round(3, tb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == PG_F32 || P.out) {
+        float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            if (grow[rr] >= rows) continue;
+#pragma unroll
+            for (int i = 0; i < NIE; ++i)
+                if (wcol0 + 16 * i < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + colw + 16 * i) = v[rr][i];
+        }
+    }
+    if (MODE == PG_F32 || !P.pimg) return;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const bool rok = grow[rr] < rows;
+        const float bound = s_bound[wrow0 + 16 * rr + lr];
+        if (P.pbnd && rok && (nb == 0 || per_blk) && wcol0 == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
+        const float sc = pow2i(scale_exp(bound));
+        const int rl = wrow0 + 16 * rr + lr, swz = (rl >> 2) & 3;
+        char* const rowp = P.pimg + (size_t)nb * P.pimg_blk_stride +
+                           (((size_t)rb * P.p_nct + P.p_kc0 + (per_blk ? 0 : nb * (C >> 4)) + (wcol0 >> 4)) * 128 + rl) * 64;
+        const unsigned uhi = (unsigned)(((q >> 1) ^ swz) << 4), ulo = (unsigned)(((2 + (q >> 1)) ^ swz) << 4);
+        const bool odd = q & 1;
+#pragma unroll
+        for (int i = 0; i < NIE; ++i) {
+            if (wcol0 + 16 * i >= C) continue;
+            unsigned h0, l0, h1, l1;
+            split2(v[rr][i].x * sc, v[rr][i].y * sc, h0, l0);
+            split2(v[rr][i].z * sc, v[rr][i].w * sc, h1, l1);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 e0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false), e1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+            const u32x4 U = {e0.x, e1.x, e0.y, e1.y};
+            if (rok) __builtin_nontemporal_store(U, reinterpret_cast<u32x4*>(rowp + (size_t)i * 8192 + (odd ? ulo : uhi)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weights: per output column c the scale 2^s_c and the L1 norm; then the image
 // ---------------------------------------------------------------------------------------------------------------------
 // (olen, opad): the image's row c' is row (c' / opad) olen + c' % opad of the block (zero where c' % opad >= olen): output
@@ -1016,6 +1360,32 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const float* __restrict__ 
     uint4 hi, lo;
     split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y); split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
     char* d = img + (((size_t)nb * nct + kc) * BN + c) * 64;
+    const int swz = (c >> 2) & 3;
+    *reinterpret_cast<uint4*>(d + ((half ^ swz) << 4)) = hi;
+    *reinterpret_cast<uint4*>(d + (((2 + half) ^ swz) << 4)) = lo;
+}
+
+// the wide-wave layout: physical block pb = 2 nb + half-block, row c of it = column (pb & 1) * 288 + c of logical block nb
+__global__ __launch_bounds__(256) void pg_pack16w_kernel(const float* __restrict__ W, int nblk, int C, int K, int nct, int piece_len, int piece_pad,
+                                                         const float* __restrict__ cinv, char* __restrict__ img, int olen, int opad, int rows_src) {
+    constexpr int SB = PgGeomW::BN, LBN = PgGeomW::LBN;
+    const size_t n = (size_t)nblk * 2 * nct * SB * 2, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int half = (int)(idx & 1);
+    size_t rest = idx >> 1;
+    const int c = (int)(rest % SB); rest /= SB;
+    const int kc = (int)(rest % nct), pb = (int)(rest / nct), nb = pb >> 1, cl = (pb & 1) * SB + c;
+    const int sr = pg_src_row(cl, C, olen, opad, rows_src);
+    const float sc = sr >= 0 ? 1.0f / cinv[nb * LBN + cl] : 0.f;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kp = kc * 16 + half * 8 + e, piece = kp / piece_pad, off = kp % piece_pad, k = piece * piece_len + off;
+        x[e] = (sr >= 0 && off < piece_len && k < K) ? W[(size_t)(nb * rows_src + sr) * K + k] * sc : 0.f;
+    }
+    uint4 hi, lo;
+    split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y); split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
+    char* d = img + (((size_t)pb * nct + kc) * SB + c) * 64;
     const int swz = (c >> 2) & 3;
     *reinterpret_cast<uint4*>(d + ((half ^ swz) << 4)) = hi;
     *reinterpret_cast<uint4*>(d + (((2 + half) ^ swz) << 4)) = lo;
@@ -1121,6 +1491,10 @@ int pgemm_configure() {
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_F32>();
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_PLANES>();
     if (rc == DR_OK) rc = configure_mode<9, 3, PG_LN>();
+    if (rc == DR_OK) {
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm16w_kernel<PG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeomW::SMEM));
+        DR_HIP_CHECK(hipFuncSetAttribute((const void*)pgemm16w_kernel<PG_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PgGeomW::SMEM));
+    }
     return rc;
 }
 
@@ -1132,8 +1506,35 @@ static void pg_launch(int mode, dim3 grid, hipStream_t st, const PgBatch& g) {
     else hipLaunchKernelGGL((pgemm_kernel<TNW, NST, PG_LN, WMN>), grid, dim3(GG::NTHR), GG::SMEM, st, g);
 }
 
+// the wide-wave geometry (weights in the PgW::sub = 2 layout): 128-row workgroups, two sub-blocks per logical column block
+static int launch_pgemm16w(const PgBatch& g, hipStream_t st) {
+    int maxt = 0;
+    double flops = 0;
+    const int mode = g.p[0].mode;
+    if (mode != PG_F32 && mode != PG_PLANES) return DR_ENOSUP;
+    for (int i = 0; i < g.n; ++i) {
+        const PgProblem& p = g.p[i];
+        const int nst = p.nc0 + (p.A1 ? p.nc1 : 0);
+        // (a virtual chunk's slot must have held real weight planes before: segments of >= 5 chunks, as in the 16x16x32 form of pgemm_kernel)
+        if (p.W.sub != 2 || !pgemm16w_shape_ok(p.C) || p.rows < 1 || p.nblk < 1 || p.nc0 < 5 || (p.A1 && p.nc1 < 5) || p.mode != mode) return DR_ENOSUP;
+        if (p.W.nct != nst) return DR_EINVAL;
+        const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk * 2;
+        maxt = tl > maxt ? tl : maxt;
+        flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
+    }
+    ProfScope ps(PK_GEMM_SPLIT, flops, st);
+    PgBatch gd = g;
+    gd.dbg = env_knob("DR_PG_NOEPI", 0);
+    const dim3 grid(maxt, g.n);
+    if (mode == PG_F32) hipLaunchKernelGGL((pgemm16w_kernel<PG_F32>), grid, dim3(PgGeomW::NTHR), PgGeomW::SMEM, st, gd);
+    else hipLaunchKernelGGL((pgemm16w_kernel<PG_PLANES>), grid, dim3(PgGeomW::NTHR), PgGeomW::SMEM, st, gd);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+
 int launch_pgemm(const PgBatch& g, hipStream_t st) {
     if (g.n < 1 || g.n > 3) return DR_EINVAL;
+    if (g.p[0].W.sub == 2) return launch_pgemm16w(g, st);
     int maxt = 0;
     double flops = 0;
     const int bn = pgemm_bn(g.p[0].C), nst_min = bn == G9::BN ? G9::NST : G7::NST;
@@ -1203,6 +1604,40 @@ void pgemm_weight_view(void* buf, int C, int nblk, int nct, PgW* v) {
     v->cinv = reinterpret_cast<const float*>(p + (size_t)nblk * nct * pg_bst(C));
     v->wnorm = v->cinv + (size_t)nblk * pgemm_bn(C);
     v->nct = nct;
+    v->sub = 0;
+}
+
+bool pgemm16w_shape_ok(int C) { return C > 0 && C % 16 == 0 && C <= PgGeomW::LBN; }
+size_t pgemm16w_weight_bytes(int nblk, int nct) {
+    size_t b = (size_t)nblk * 2 * nct * PgGeomW::B_ST + (size_t)nblk * PgGeomW::LBN * 4 + (size_t)nblk * 4;
+    return (b + 255) & ~(size_t)255;
+}
+void pgemm16w_weight_view(void* buf, int nblk, int nct, PgW* v) {
+    char* p = (char*)buf;
+    v->img = p;
+    v->cinv = reinterpret_cast<const float*>(p + (size_t)nblk * 2 * nct * PgGeomW::B_ST);
+    v->wnorm = v->cinv + (size_t)nblk * PgGeomW::LBN;
+    v->nct = nct;
+    v->sub = 2;
+}
+int pgemm16w_pack_weights_block(const float* W, int C, int K, int piece_len, int piece_pad, const PgW& v, int nb, hipStream_t st, int out_len,
+                                int out_pad) {
+    const int olen = out_len > 0 ? out_len : C, opad = out_pad > 0 ? out_pad : C, rows_src = out_len > 0 ? C / opad * olen : C;
+    if (!pgemm16w_shape_ok(C) || v.sub != 2 || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
+    const int nct = (K + piece_len - 1) / piece_len * piece_pad / 16;
+    if (nct != v.nct) return DR_EINVAL;
+    constexpr int LBN = PgGeomW::LBN;
+    float* cinv = (float*)v.cinv + (size_t)nb * LBN;
+    float* wnorm = (float*)v.wnorm + nb;
+    char* img = (char*)v.img + (size_t)nb * 2 * nct * PgGeomW::B_ST;
+    DR_HIP_CHECK(hipMemsetAsync(wnorm, 0, 4, st));
+    hipLaunchKernelGGL(pg_wscale_kernel, dim3((LBN + 3) / 4), dim3(256), 0, st, W, 1, C, K, LBN, cinv, wnorm, olen, opad, rows_src);
+    DR_LAUNCH_CHECK();
+    const size_t n = (size_t)2 * nct * PgGeomW::BN * 2;
+    hipLaunchKernelGGL(pg_pack16w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, 1, C, K, nct, piece_len, piece_pad,
+                       (const float*)cinv, img, olen, opad, rows_src);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
 }
 int pgemm_pack_weights(const float* W, int nblk, int C, int K, int piece_len, int piece_pad, void* buf, hipStream_t st) {
     if (!pgemm_shape_ok(C) || piece_pad % 16 || piece_len > piece_pad || piece_len < 1) return DR_EINVAL;
@@ -1360,6 +1795,23 @@ int dr_pack_weight_planes_f32(int nblk, int C, int K, int piece_len, int piece_p
     return pgemm_pack_weights(W, nblk, C, K, piece_len, piece_pad, packed, (hipStream_t)stream);
 }
 
+size_t dr_plane_weight_bytes_wide(int nblk, int C, int K, int piece_len, int piece_pad) {
+    if (nblk < 1 || !pgemm16w_shape_ok(C) || K < 1 || piece_len < 1 || piece_pad < piece_len || piece_pad % 16) return 0;
+    return pgemm16w_weight_bytes(nblk, plane_nct(K, piece_len, piece_pad));
+}
+
+int dr_pack_weight_planes_wide_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream) {
+    if (nblk < 1 || K < 1 || !W || !packed || ((uintptr_t)packed & 15) || !pgemm16w_shape_ok(C) || piece_len < 1 || piece_pad < piece_len || piece_pad % 16)
+        return DR_EINVAL;
+    PgW v;
+    pgemm16w_weight_view(packed, nblk, plane_nct(K, piece_len, piece_pad), &v);
+    for (int nb = 0; nb < nblk; ++nb) {
+        const int rc = pgemm16w_pack_weights_block(W + (size_t)nb * C * K, C, K, piece_len, piece_pad, v, nb, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return DR_OK;
+}
+
 int dr_ln_bound_f32(int C, const float* gamma, const float* beta, float* out, void* stream) {
     if (C < 1 || !gamma || !beta || !out) return DR_EINVAL;
     return launch_ln_bound(gamma, beta, C, out, (hipStream_t)stream);
@@ -1378,7 +1830,12 @@ int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
     PgProblem& p = g.p[0];
     p.A0 = (const char*)a->a0; p.bnd0 = a->bound0; p.nc0 = a->k0 / 16;
     p.A1 = (const char*)a->a1; p.bnd1 = a->bound1; p.nc1 = a->a1 ? a->k1 / 16 : 0;
-    pgemm_weight_view((void*)a->packed, a->C, a->nblk, p.nc0 + p.nc1, &p.W);
+    if (a->weight_layout == DR_PL_LAYOUT_WIDE) {
+        if (a->mode == PG_LN || !pgemm16w_shape_ok(a->C)) return DR_EINVAL;
+        pgemm16w_weight_view((void*)a->packed, a->nblk, p.nc0 + p.nc1, &p.W);
+    } else if (a->weight_layout == DR_PL_LAYOUT_BLOCK) {
+        pgemm_weight_view((void*)a->packed, a->C, a->nblk, p.nc0 + p.nc1, &p.W);
+    } else return DR_EINVAL;
     p.nblk = a->nblk; p.rows = a->rows; p.C = a->C; p.mode = a->mode;
     p.out = a->out; p.ldo = a->ldo; p.blk_stride = a->blk_stride;
     p.cosT = a->cos_t; p.sinT = a->sin_t; p.rot_mask = a->rot_mask; p.rot_C = a->rot_C > 0 ? a->rot_C : a->C; p.scale = a->scale;

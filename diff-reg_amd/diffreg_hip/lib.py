@@ -74,7 +74,7 @@ class PlanesLinear(ctypes.Structure):
                 ("out_image", c_void_p), ("out_image_k", c_int), ("out_k0", c_int), ("out_bound", c_void_p),
                 ("relu", c_int),
                 ("gamma", c_void_p), ("beta", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("bound_resid", c_void_p),
-                ("ln_bound", c_void_p), ("bias", c_void_p), ("bias_max", c_void_p), ("ln_postadd", c_int)]
+                ("ln_bound", c_void_p), ("bias", c_void_p), ("bias_max", c_void_p), ("ln_postadd", c_int), ("weight_layout", c_int)]
 
 
 class Loop2D3DConfig(ctypes.Structure):
@@ -107,6 +107,8 @@ SIGNATURES.update({
     "dr_planes_to_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dr_plane_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dr_plane_weight_bytes_wide": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dr_pack_weight_planes_wide_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_ln_bound_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_planes_f32": (c_int, [ctypes.POINTER(PlanesLinear), c_void_p]),
     "dr_bias_max_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -351,18 +353,18 @@ def planes_to_f32(img, bnd, rows, K):
     return out
 
 
-def pack_weight_planes(W, nblk, C, piece_len=None, piece_pad=None):
-    """W [nblk * C, K] -> packed image (uint8 tensor)"""
+def pack_weight_planes(W, nblk, C, piece_len=None, piece_pad=None, wide=False):
+    """W [nblk * C, K] -> packed image (uint8 tensor); wide: the wide-wave layout (dr_pack_weight_planes_wide_f32; pass wide=True to linear_planes too)"""
     ensure_init()
     W = W.contiguous()
     K = W.shape[1]
     piece_len = piece_len or K
     piece_pad = piece_pad or K
-    nbytes = _lib.dr_plane_weight_bytes(nblk, C, K, piece_len, piece_pad)
+    nbytes = (_lib.dr_plane_weight_bytes_wide if wide else _lib.dr_plane_weight_bytes)(nblk, C, K, piece_len, piece_pad)
     if nbytes == 0:
         raise RuntimeError("unsupported plane weight shape")
     buf = torch.zeros(nbytes, dtype=torch.uint8, device=W.device)
-    check(_lib.dr_pack_weight_planes_f32(nblk, C, K, piece_len, piece_pad, ptr(W), ptr(buf), stream_of(W)))
+    check((_lib.dr_pack_weight_planes_wide_f32 if wide else _lib.dr_pack_weight_planes_f32)(nblk, C, K, piece_len, piece_pad, ptr(W), ptr(buf), stream_of(W)))
     return buf
 
 
@@ -374,7 +376,7 @@ def ln_bound(gamma, beta):
 
 def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, k1=0, out=None, ldo=0, blk_stride=0, cos_t=None,
                   sin_t=None, rot_mask=0, rot_C=0, scale=1.0, out_image=None, out_image_k=0, out_k0=0, out_bound=None, relu=False,
-                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None, bias=None, ln_postadd=False):
+                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None, bias=None, ln_postadd=False, wide=False):
     """dr_linear_planes_f32; bias [nblk * C]: its per-block maxima are computed here (dr_bias_max_f32)"""
     a = PlanesLinear()
     a.rows, a.C, a.nblk = rows, C, nblk
@@ -393,6 +395,7 @@ def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, 
         bmax = torch.empty(nblk, device=bias.device)
         check(_lib.dr_bias_max_f32(nblk, C, ptr(bias), ptr(bmax), stream_of(a0)))
     a.bias, a.bias_max, a.ln_postadd = dp(bias), dp(bmax), 1 if ln_postadd else 0
+    a.weight_layout = 1 if wide else 0
     check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
 
 

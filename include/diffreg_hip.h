@@ -173,6 +173,11 @@ int dr_planes_to_f32(int rows, int K, const void* image, const float* bound, flo
  * the identity; (d, round_up(d, 16)) for the merge projection behind the attention kernel's head-padded image. */
 size_t dr_plane_weight_bytes(int nblk, int C, int K, int piece_len, int piece_pad);
 int dr_pack_weight_planes_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream);
+/* The same weights in the WIDE-WAVE layout (round 6; C <= 576, C % 16 == 0): every block of C output columns as two sub-blocks of 288 weight
+ * rows -- what the 128 x 288 workgroups of the DR_PL_F32 / DR_PL_PLANES launches of the 576-column geometry stream (4DMatch: C = 528, heads padded
+ * to 144).  Pass the buffer with dr_planes_linear.weight_layout = DR_PL_LAYOUT_WIDE; DR_PL_LN launches take the block layout only. */
+size_t dr_plane_weight_bytes_wide(int nblk, int C, int K, int piece_len, int piece_pad);
+int dr_pack_weight_planes_wide_f32(int nblk, int C, int K, int piece_len, int piece_pad, const float* W, void* packed, void* stream);
 /* *out = (sqrt(C) max|gamma| + max|beta|): upper bound of |LayerNorm(.) gamma + beta| (device scalar) */
 int dr_ln_bound_f32(int C, const float* gamma, const float* beta, float* out, void* stream);
 
@@ -197,7 +202,10 @@ typedef struct {
      *                      1 = y = LayerNorm(acc + resid) gamma + beta (the vision3d layer, vision3d/layers/transformer.py:188-196, 262-271) */
     int ln_postadd;
     /* DR_PL_PLANES: `out` (optional) also receives the block as fp32 rows (ldo, blk_stride as in DR_PL_F32) */
+    int weight_layout;             /* DR_PL_LAYOUT_*: how `packed` was packed (ABI 0.2.1)                                */
 } dr_planes_linear;
+#define DR_PL_LAYOUT_BLOCK 0   /* dr_pack_weight_planes_f32                                                           */
+#define DR_PL_LAYOUT_WIDE 1    /* dr_pack_weight_planes_wide_f32 (DR_PL_F32 / DR_PL_PLANES only)                      */
 int dr_linear_planes_f32(const dr_planes_linear* args, void* stream);
 /* out[b] = max |bias[b n .. b n + n - 1]| (1 + 1e-4), b < nblk */
 int dr_bias_max_f32(int nblk, int n, const float* bias, float* out, void* stream);

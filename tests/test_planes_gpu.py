@@ -334,3 +334,53 @@ def test_chunk_pairs_and_virtual_chunks(k0, k1, m16, row_block, rows):
         assert rel(o32, want) < 3e-6 and rel(lib.planes_to_f32(img, bnd, rows, C), want) < 3e-6
     finally:
         os.environ.pop("DR_PG_M16", None)
+
+
+@pytest.mark.parametrize("rows", [1, 129, 300, 1000])
+@pytest.mark.parametrize("C", [528, 576, 320, 464])
+def test_wide_wave_kernel_against_float64_and_the_block_layout(rows, C):
+    """The 128 x 288 wide-wave geometry (pgemm16w_kernel; weights packed by dr_pack_weight_planes_wide_f32, dr_planes_linear.weight_layout = WIDE) on
+    the launches it serves: q | k | v with the rotary code into three fp32 blocks (DR_PL_F32; the per-block head-padded images of the loop are held
+    to the reference by the 4DMatch loop fixtures), mlp0 on a two-segment operand [x | msg] + bias + ReLU into one image shared by two column blocks.  Against float64 products,
+    and against the block-layout kernel's images entry for entry (the same arithmetic up to the fp32 summation order of a k-chunk pair)."""
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 5 + 0.01)
+    img, bnd = lib.planes_from_f32(x)
+    W = torch.randn(3 * C, C, device=DEV) / C ** 0.5
+    ang = torch.rand(rows, C // 2, device=DEV) * 6.28
+    cosT, sinT = ang.cos().contiguous(), ang.sin().contiguous()
+    ref = x.double() @ W.double().t()
+
+    def rot(z):
+        e, o = z[:, 0::2], z[:, 1::2]
+        return torch.stack([e * cosT.double() - o * sinT.double(), o * cosT.double() + e * sinT.double()], -1).reshape(z.shape)
+    want = torch.stack([rot(ref[:, :C]), rot(ref[:, C:2 * C]), ref[:, 2 * C:]]) * 0.5
+    outs = {}
+    for wide in (False, True):
+        pk = lib.pack_weight_planes(W, 3, C, wide=wide)
+        out, chk = guarded((3, rows, C), torch.float32, DEV, fill=float("nan"))
+        lib.linear_planes(rows, C, 3, img, bnd, C, pk, lib.PL_F32, out=out, ldo=C, blk_stride=rows * C, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C, scale=0.5,
+                          wide=wide)
+        chk()
+        assert not torch.isnan(out).any() and rel(out, want) < 2e-6, wide
+        outs[wide] = out
+    assert rel(outs[True], outs[False].double()) < 1e-6
+    # ---- mlp0: [x | msg] (two segments with different row scales) + bias + ReLU -> ONE image of 2 C columns written by two column blocks
+    msg = torch.randn(rows, C, device=DEV) * 0.03
+    mimg, mb = lib.planes_from_f32(msg)
+    W0 = torch.randn(2 * C, 2 * C, device=DEV) / (2 * C) ** 0.5
+    bias = torch.randn(2 * C, device=DEV) * 0.2
+    want0 = torch.relu(torch.cat([x, msg], 1).double() @ W0.double().t() + bias.double())
+    hs = {}
+    for wide in (False, True):
+        h_img, chk_i = image_like(rows, 2 * C)
+        h_b, chk_b = guarded((rows,), torch.float32, DEV, fill=0)
+        o32, chk_o = guarded((rows, 2 * C), torch.float32, DEV, fill=float("nan"))
+        lib.linear_planes(rows, C, 2, img, bnd, C, lib.pack_weight_planes(W0, 2, C, wide=wide), lib.PL_PLANES, a1=mimg, b1=mb, k1=C, out_image=h_img,
+                          out_image_k=2 * C, out_bound=h_b, relu=True, bias=bias, out=o32, ldo=2 * C, blk_stride=C, wide=wide)
+        chk_i(); chk_b(); chk_o()
+        back = lib.planes_to_f32(h_img, h_b, rows, 2 * C)
+        assert rel(back, want0) < 2e-6 and rel(o32, want0) < 2e-6, wide
+        hs[wide] = (back, h_b.clone())
+    assert torch.equal(hs[True][1], hs[False][1])               # the same bounds: both kernels scale a row of one image alike
+    assert rel(hs[True][0], hs[False][0].double()) < 1e-6

@@ -9,6 +9,7 @@ dev = torch.device("cuda:0")
 C, H, d, dp = 528, 4, 132, 144
 Cq = H * dp
 KNOB, KVALS = os.environ.get("KNOB", ""), os.environ.get("KVALS", "0,1").split(",")
+WIDE = os.environ.get("WIDE", "0") == "1"        # q | k | v and mlp0 on the wide-wave kernel (128 x 288 workgroups)
 for rows in [int(r) for r in os.environ.get("ROWS", "8192").split(",")]:
     x = torch.randn(rows, C, device=dev)
     img, bnd = lib.planes_from_f32(x)
@@ -21,15 +22,15 @@ for rows in [int(r) for r in os.environ.get("ROWS", "8192").split(",")]:
     h_img = torch.zeros(lib._lib.dr_plane_image_bytes(rows, 2 * C), dtype=torch.uint8, device=dev); h_b = torch.zeros(rows, device=dev)
     xr = torch.randn(rows, C, device=dev)
     ang = torch.rand(rows, C // 2, device=dev); cosT, sinT = ang.cos().contiguous(), ang.sin().contiguous()
-    pk3 = lib.pack_weight_planes(torch.randn(3 * Cq, C, device=dev) / C ** 0.5, 3, Cq)
+    pk3 = lib.pack_weight_planes(torch.randn(3 * Cq, C, device=dev) / C ** 0.5, 3, Cq, wide=WIDE)
     pk1 = lib.pack_weight_planes(torch.randn(C, Cq, device=dev) / C ** 0.5, 1, C)
-    pk0 = lib.pack_weight_planes(torch.randn(2 * C, 2 * C, device=dev) / (2 * C) ** 0.5, 2, C)
+    pk0 = lib.pack_weight_planes(torch.randn(2 * C, 2 * C, device=dev) / (2 * C) ** 0.5, 2, C, wide=WIDE)
     pk2 = lib.pack_weight_planes(torch.randn(C, 2 * C, device=dev) / (2 * C) ** 0.5, 1, C)
     o3 = torch.empty(rows, 3 * Cq, device=dev)
     shapes = {
-        "qkv f32+rot": (lambda: lib.linear_planes(rows, Cq, 3, img, bnd, C, pk3, lib.PL_F32, out=o3, ldo=3 * Cq, blk_stride=Cq, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C), 3 * C * C),
+        "qkv f32+rot": (lambda: lib.linear_planes(rows, Cq, 3, img, bnd, C, pk3, lib.PL_F32, out=o3, ldo=3 * Cq, blk_stride=Cq, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C, wide=WIDE), 3 * C * C),
         "merge+LN": (lambda: lib.linear_planes(rows, C, 1, att_img, att_b, Cq, pk1, lib.PL_LN, out_image=o_img, out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, lnb=lnb), C * C),
-        "mlp0": (lambda: lib.linear_planes(rows, C, 2, img, bnd, C, pk0, lib.PL_PLANES, a1=msg_img, b1=msg_b, k1=C, out_image=h_img, out_image_k=2 * C, out_bound=h_b, relu=True), 4 * C * C),
+        "mlp0": (lambda: lib.linear_planes(rows, C, 2, img, bnd, C, pk0, lib.PL_PLANES, a1=msg_img, b1=msg_b, k1=C, out_image=h_img, out_image_k=2 * C, out_bound=h_b, relu=True, wide=WIDE), 4 * C * C),
         "mlp2+LN+res": (lambda: lib.linear_planes(rows, C, 1, h_img, h_b, 2 * C, pk2, lib.PL_LN, out=o32, ldo=C, out_image=o_img, out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, resid=xr, ldr=C, bound_resid=bnd, lnb=lnb), 2 * C * C)}
     def t(f, n=20):
         for _ in range(4): f()
