@@ -486,6 +486,25 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
             which ^= 1;
         }
         *final_feats = cur->f32;
+        if (env_knob("DR_HEAD_F32", 0)) {
+            // (experiment: the head's projection on the f32-input MFMA GEMM, 24-bit operands, from the fp32 rows of the last layer)
+            GemmBatch gf;
+            memset(&gf, 0, sizeof(gf));
+            GemmProblem& pf = gf.p[0];
+            pf.A = cur->f32; pf.W = w.src_proj; pf.out = ws.proj; pf.rows = T; pf.ncols = C; pf.K = C; pf.K1 = C; pf.lda = C; pf.ldo = C;
+            pf.epi = EPI_ROTARY; pf.rot_C = C; pf.cosT = ws.cosT; pf.sinT = ws.sinT; pf.scale = 1.0f / sqrtf((float)C);
+            gf.n = 1;
+            int rcf = launch_gemm(gf, st);
+            if (rcf) return rcf;
+            GemmBatch gs;
+            memset(&gs, 0, sizeof(gs));
+            GemmProblem& q = gs.p[0];
+            q.A = ws.proj; q.W = ws.proj + (size_t)PN * C; q.out = ws.sim;
+            q.rows = N; q.ncols = M; q.K = C; q.K1 = C; q.lda = C; q.ldo = M; q.epi = EPI_NONE; q.scale = 1.f;
+            q.nbatch = P; q.sA = (long long)N * C; q.sW = (long long)M * C; q.sO = (long long)N * M;
+            gs.n = 1;
+            return launch_gemm(gs, st);
+        }
         // matching head: src_proj on BOTH sides (quirk Q1), rotary, / sqrt(C)
         PgBatch g;
         memset(&g, 0, sizeof(g));

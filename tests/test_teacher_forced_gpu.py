@@ -88,11 +88,14 @@ def ddim_expected(x_in, x0, t, tn, shift_min, first):
 
 
 # stress_tile_parity: how much further from float64 than the reference's own float32 run the device may be on the STRESS head's worst tile.
-# Measured over the 20 steps x 128 slots of the bench seeds (round 5, MI355X): 832 of the 2 560 step evaluations miss the plain 1e-4 somewhere,
+# Measured over the 20 steps x 128 slots of the bench seeds (MI355X): 832 of the 2 560 step evaluations miss the plain 1e-4 somewhere,
 # 512 of those pass the entry-wise exemption rule, 320 need the tile rule; there the device is at most 2.5e-4 from float64 and at most 6.6 x the
-# reference's distance (6 entries per tile beyond 1e-4 of the reference at worst).  The plane path multiplies 22-bit operands (fp16 hi + lo)
-# where torch's float32 matmul multiplies 24-bit ones: at matching logits in the thousands that is ~1e-7 of the logit scale, i.e. up to a few
-# 1e-4 of x_start.  The same kernels hold the SOFT head (logits O(10)) to 5.5e-6 on every entry of every step.
+# reference's distance (6 entries per tile beyond 1e-4 of the reference at worst).
+# What this is NOT (round 6, profiles/r06_stress_head_tile_rule_cause.json): an artefact of the plane path's 22-bit operands.  With the head's
+# projection on 24-bit operands (DR_HEAD_F32=1) 304 tiles still need the rule; with EVERY layer GEMM and the attention on the f32-input MFMA
+# kernels (exact fp32 products, DR_PLANES=0) 407 tiles need it, at the same worst distances (2.4e-4, 4.5 x).  At matching logits in the
+# thousands one float32 ulp of a logit is ~1e-4 of x_start: any two correct fp32 evaluations of the denoiser (another summation order, another
+# BLAS) differ by a few 1e-4 on the sharp entries.  The same kernels hold the SOFT head (logits O(10)) to 5.5e-6 on every entry of every step.
 TILE_FACTOR = 8.0
 TILE_ABS_CAP = 5e-4
 
