@@ -821,6 +821,10 @@ struct AttnPlGeom {
     static constexpr int OQS = NDT * 32 + 4;
     static constexpr int OBYTES = 4 * 32 * OQS * 4;
     static constexpr int SMEM = (NB * BUF > OBYTES ? NB * BUF : OBYTES) + 64;
+    // KG = 2 (two key groups of four waves, see the kernel): every group its own tile buffers; the merge region [4 waves][NDT 16 + 2][64 lanes] floats
+    static constexpr int MBYTES = 4 * (NDT * 16 + 2) * 64 * 4;
+    static constexpr int SMEM2_ = 2 * NB * BUF > OBYTES ? 2 * NB * BUF : OBYTES;
+    static constexpr int SMEM2 = (SMEM2_ > MBYTES ? SMEM2_ : MBYTES) + 64;
 };
 
 __device__ __forceinline__ int attn_scale_exp(float bound) {
@@ -833,8 +837,11 @@ __device__ __forceinline__ int attn_scale_exp(float bound) {
 //  at every cfg5 shape: profiles/r04_attention_planes_softmax_trims.json)
 // F16 (opt-in, DR_LOOP_ATTN_F16): ONE fp16 product per contraction -- the hi planes of q, k, v and of P only -- instead of the three that make an
 // fp32-grade product: what BASELINE's cfg3 / cfg5 wording ("bf16 / fp16 MFMA attention") literally asks for.  11-bit operands: not the default.
-template <int KS, int NDT, bool F16 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_planes_kernel(AttnArgs A) {
+// KG = 2 (round 6; launches of at most one workgroup per CU -- cfg3: 16 segments x 4 heads x 4 query blocks = 256 -- ran ONE wave per SIMD,
+// MFMA busy 0.12): EIGHT waves, two key groups of four; group g takes the key tiles g, g + 2, .. of the same 128 queries with its own tile
+// buffers and its own running softmax; the groups are merged through LDS at the end (m = max, rescale, add) by group 0, which writes the output.
+template <int KS, int NDT, bool F16 = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_planes_kernel(AttnArgs A) {
     using G = AttnPlGeom<KS, NDT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -861,7 +868,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (qb >= Lq) return;
     const int head = by, d = A.d, nct = A.p_nct;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, l31 = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wall = __builtin_amdgcn_readfirstlane(t >> 6), w = wall & 3, kg = wall >> 2;      // query wave, key group (0 when KG = 1)
+    const unsigned grp_lds = (unsigned)kg * G::NB * G::BUF;          // the group's tile buffers
 
     // ---- scales: one per query row, one per key group (uniform over the segment's keys)
     const float kb_bound = A.kgb[kbase], vb_bound = A.vgb[kbase];   // (every key row of a group carries the group's bound)
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ins < 4 * KS) {
                 const bool isv = ins >= 2 * KS;
                 const int j = ins - (isv ? 2 * KS : 0), chunk = j >> 1, half = j & 1;
-                const unsigned dst = lds_base + b * G::BUF + (isv ? G::KIMG + chunk * G::VCH : chunk * G::KCH) + half * 1024;
+                const unsigned dst = lds_base + grp_lds + b * G::BUF + (isv ? G::KIMG + chunk * G::VCH : chunk * G::KCH) + half * 1024;
                 if (fast) {
                     const int lrow0 = klrow0 + kt * 32 + half * 16;
                     const char* sbase = (isv ? vimg : kimg) + (((size_t)(lrow0 >> 7) * nct + KS * head + chunk) * 128 + (lrow0 & 127)) * 64;
@@ -940,7 +948,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int nkt = (Lk + 31) / 32;
+    const int nkt_all = (Lk + 31) / 32;
+    // this group's tiles: absolute tile kg + KG i, i < nkt; the loop runs nkt_max rounds in every group (the barriers are the workgroup's)
+    const int nkt = (nkt_all - kg + KG - 1) / KG, nkt_max = (nkt_all + KG - 1) / KG;
+    auto tile_of = [&](int i) { return kg + KG * i; };
 
     // The Q fragments must have ARRIVED before the loop, and the compiler must know it.  Round 5 (ISA of every instantiation): their 2 KS global
     // loads were still "pending" in the compiler's vmcnt model when the loop began, so it placed its counted waits at their first uses -- inside
@@ -956,15 +967,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert((4 * KS) % 4 == 0, "every wave issues KS DMA instructions per tile");
     const bool counted = A.kmask == nullptr;                     // (a mask byte load per tile is a compiler-placed VMEM operation between the DMAs: those
                                                                  //  calls -- 4DMatch, ragged batches -- keep the drain-all wait and a prefetch distance of one)
-    unsigned mnext = attn_mask_byte(A, kbase, 0, Lk, l31);
+    unsigned mnext = attn_mask_byte(A, kbase, tile_of(0) * 32, Lk, l31);
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j)
-        if (j < nkt && (counted || j == 0)) stage(j, j);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int b = kt % NB;
+        if (j < nkt && (counted || j == 0)) stage(tile_of(j), j);
+    for (int kti = 0; kti < nkt_max; ++kti) {
+        const int b = kti % NB, kt = tile_of(kti);
+        if (KG > 1 && kti >= nkt) {                              // (the other group has one tile more: keep its barrier company)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
         // own DMA instructions of tile kt have landed; those of the tiles behind it (KS per tile and wave, issued in order) may still fly
         if (counted) {
-            const int ahead = min(NB - 2, nkt - 1 - kt);
+            const int ahead = min(NB - 2, nkt - 1 - kti);
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * KS) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -975,13 +991,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                         // ... and everybody's; everybody is done with tile kt - 1's buffer
         const unsigned char mbyte = (unsigned char)mnext;
         if (counted) {
-            if (kt + NB - 1 < nkt) stage(kt + NB - 1, (kt + NB - 1) % NB);
-        } else if (kt + 1 < nkt) {
-            mnext = attn_mask_byte(A, kbase, (kt + 1) * 32, Lk, l31);
-            stage(kt + 1, (kt + 1) % NB);
+            if (kti + NB - 1 < nkt) stage(tile_of(kti + NB - 1), (kti + NB - 1) % NB);
+        } else if (kti + 1 < nkt) {
+            mnext = attn_mask_byte(A, kbase, tile_of(kti + 1) * 32, Lk, l31);
+            stage(tile_of(kti + 1), (kti + 1) % NB);
         }
-        const char* kb = lds + b * G::BUF + l31 * 64;
-        const char* vb = lds + b * G::BUF + G::KIMG;
+        const char* kb = lds + grp_lds + b * G::BUF + l31 * 64;
+        const char* vb = lds + grp_lds + b * G::BUF + G::KIMG;
         // ---- S^T = K Q^T
         f32x16 sc;
 #pragma unroll
@@ -1067,7 +1083,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const ah16x8 p_h = __builtin_bit_cast(ah16x8, phv), p_l = __builtin_bit_cast(ah16x8, plv);
 #pragma unroll
             for (int i = 0; i < NDT; ++i) {
-                const unsigned base = lds_base + b * G::BUF + G::KIMG + vchunk[i];
+                const unsigned base = lds_base + grp_lds + b * G::BUF + G::KIMG + vchunk[i];
                 auto tr = [&](unsigned off) {
                     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s4*)(size_t)(base + off));
                 };
@@ -1086,6 +1102,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         (void)vb;
     }
     __syncthreads();
+
+    if constexpr (KG > 1) {
+        // ---- merge of the two key groups: group 1 parks (m, l, acc) of its queries, group 0 folds them into its own (lane-wise: both groups
+        // hold the same queries in the same lanes)
+        float* const mr = smem + (size_t)w * (NDT * 16 + 2) * 64 + lane;
+        if (kg == 1) {
+            mr[0] = m_run; mr[64] = l_run;
+#pragma unroll
+            for (int i = 0; i < NDT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mr[(2 + 16 * i + r) * 64] = acc[i][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            const float m1 = mr[0], l1 = mr[64];
+            const float m = fmaxf(m_run, m1);
+            const float a0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+            l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+            for (int i = 0; i < NDT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + mr[(2 + 16 * i + r) * 64] * a1;
+        }
+        __syncthreads();                                         // every wave of group 0 has read: the region is free for the output staging
+        if (kg == 1) return;                                     // (no workgroup barrier behind this point)
+    }
 
     // ---- out[q][f] = O^T[f][q] 2^-sv / l, through LDS, then the plane image of the merge projection's operand
     float* ob = smem + w * 32 * G::OQS;
@@ -1116,6 +1158,10 @@ static int configure_attn() {
                                      (int)AttnPlGeom<KS, NDT>::SMEM));
     DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)AttnPlGeom<KS, NDT>::SMEM));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)AttnPlGeom<KS, NDT>::SMEM2));
+    DR_HIP_CHECK(hipFuncSetAttribute((const void*)attention_planes_kernel<KS, NDT, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)AttnPlGeom<KS, NDT>::SMEM2));
 
     return DR_OK;
 }
@@ -1154,7 +1200,17 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         AttnArgs ax = a;
         // (the dealing is a bijection only when the (head, segment) count is a multiple of 8; one query block per group has nothing to share)
         ax.xcd_groups = ((fgrid.y * fgrid.z) % 8 == 0 && fgrid.x > 1 && env_knob("DR_ATTN_XCD", 1)) ? 1 : 0;
-        if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true>), fgrid, dim3(256), plds, st, ax);
+        // at most one workgroup per CU and at least four key tiles: two key groups per workgroup (eight waves, two per SIMD).  OPT-IN (diagnostics
+        // knob DR_ATTN_KG2=1): measured -2.3 % on cfg3's 8-pair call (53.6 -> 52.4 ms), every soft-family bound a plain 1e-4 as before, but the other
+        // summation order moves one sharp stress-family entry of test_cfg3_4dmatch_512_batch8_20_steps across its 2 x rule
+        // (profiles/r06_cfg3_experiments.json) -- not worth a changed bound
+        const int minLk = a.nseg2 > 0 && a.Lkb < a.Lk ? a.Lkb : a.Lk;
+        const bool kg2 = (long)fgrid.x * fgrid.y * fgrid.z <= (long)device_cu_count() && minLk >= 128 && env_knob("DR_ATTN_KG2", 0) != 0;
+        if (kg2) {
+            const size_t plds2 = AttnPlGeom<KS, NDT>::SMEM2;
+            if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true, 2>), fgrid, dim3(512), plds2, st, ax);
+            else hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, false, 2>), fgrid, dim3(512), plds2, st, ax);
+        } else if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true>), fgrid, dim3(256), plds, st, ax);
         else hipLaunchKernelGGL((attention_planes_kernel<KS, NDT>), fgrid, dim3(256), plds, st, ax);
         DR_LAUNCH_CHECK();
         return DR_OK;
