@@ -669,6 +669,77 @@ __global__ __launch_bounds__(256) void dual_softmax_rows_kernel(int rows, int N,
         conf[(size_t)row * M + j] = a * b;
     }
 }
+// ---- backward of the dual-softmax read-out.  x = sim / T, A = softmax over the valid rows of a column, B = softmax over the valid columns of a row,
+// conf = A B, u = grad_conf conf:  d loss / d x = 2 u - A colsum(u) - B rowsum(u)  (the two softmax adjoints; masked entries have A = 0 or B = 0 and
+// receive exactly what torch's masked_fill_ lets through: nothing).  Row pass (statistics + rowsum), column pass (colsum, rows in order), final row pass.
+__global__ __launch_bounds__(256) void dsm_bwd_rows_kernel(int rows, int N, int M, const float* __restrict__ sim, float T, const uint8_t* __restrict__ sm,
+                                                           const uint8_t* __restrict__ tm, const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                           const float* __restrict__ g, float* __restrict__ rmax, float* __restrict__ rsum,
+                                                           float* __restrict__ rs) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int p = row / N;
+    const bool rv = sm ? sm[row] != 0 : true;
+    const float* sr = sim + (size_t)row * M;
+    const uint8_t* t = tm ? tm + (size_t)p * M : nullptr;
+    float mx = -INFINITY;
+    for (int j = lane; j < M; j += 64)
+        if (!t || t[j]) mx = fmaxf(mx, sr[j] / T);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < M; j += 64)
+        if (!t || t[j]) sum += expf(sr[j] / T - mx);
+    sum = wave_sum(sum);
+    float u = 0.f;
+    for (int j = lane; j < M; j += 64) {
+        const float x = sr[j] / T;
+        const float a = rv ? expf(x - cmax[(size_t)p * M + j]) / csum[(size_t)p * M + j] : 0.f;
+        const float b = (!t || t[j]) ? expf(x - mx) / sum : 0.f;
+        u += g[(size_t)row * M + j] * (a * b);
+    }
+    u = wave_sum(u);
+    if (lane == 0) { rmax[row] = mx; rsum[row] = sum; rs[row] = u; }
+}
+__global__ __launch_bounds__(256) void dsm_bwd_cols_kernel(int N, int M, const float* __restrict__ sim, float T, const uint8_t* __restrict__ sm,
+                                                           const uint8_t* __restrict__ tm, const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                           const float* __restrict__ rmax, const float* __restrict__ rsum, const float* __restrict__ g,
+                                                           float* __restrict__ cs) {
+    const int p = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const float* s = sim + (size_t)p * N * M + j;
+    const float* gg = g + (size_t)p * N * M + j;
+    const uint8_t* m = sm ? sm + (size_t)p * N : nullptr;
+    const bool cv = tm ? tm[(size_t)p * M + j] != 0 : true;
+    const float cm = cmax[(size_t)p * M + j], cq = csum[(size_t)p * M + j];
+    float acc = 0.f;
+    if (cv)
+        for (int i = 0; i < N; ++i) {
+            if (m && !m[i]) continue;
+            const float x = s[(size_t)i * M] / T;
+            const float a = expf(x - cm) / cq, b = expf(x - rmax[(size_t)p * N + i]) / rsum[(size_t)p * N + i];
+            acc += gg[(size_t)i * M] * (a * b);
+        }
+    cs[(size_t)p * M + j] = acc;
+}
+__global__ __launch_bounds__(256) void dsm_bwd_final_kernel(int rows, int N, int M, const float* __restrict__ sim, float T, const uint8_t* __restrict__ sm,
+                                                            const uint8_t* __restrict__ tm, const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                            const float* __restrict__ rmax, const float* __restrict__ rsum, const float* __restrict__ rs,
+                                                            const float* __restrict__ cs, const float* __restrict__ g, float* __restrict__ gsim) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int p = row / N;
+    const bool rv = sm ? sm[row] != 0 : true;
+    const float* sr = sim + (size_t)row * M;
+    const uint8_t* t = tm ? tm + (size_t)p * M : nullptr;
+    const float mx = rmax[row], sum = rsum[row], r = rs[row];
+    for (int j = lane; j < M; j += 64) {
+        const float x = sr[j] / T;
+        const float a = rv ? expf(x - cmax[(size_t)p * M + j]) / csum[(size_t)p * M + j] : 0.f;
+        const float b = (!t || t[j]) ? expf(x - mx) / sum : 0.f;
+        const float u = g[(size_t)row * M + j] * (a * b);
+        gsim[(size_t)row * M + j] = (2.f * u - a * cs[(size_t)p * M + j] - b * r) / T;
+    }
+}
 // dS = scale P (dP - sum_j dP_j P_j)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int rows, int cols, const float* __restrict__ P, const float* __restrict__ dP, float scale,
                                                           float* __restrict__ dS) {
@@ -729,6 +800,29 @@ int dr_dual_softmax_f32(int P, int N, int M, const float* sim, float temperature
     const int rows = P * N;
     hipLaunchKernelGGL(dr::dual_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, N, M, sim, temperature, src_mask, tgt_mask,
                        cmax, csum, conf);
+    DR_LAUNCH_CHECK();
+    return DR_OK;
+}
+size_t dr_dual_softmax_backward_workspace_bytes(int P, int N, int M) { return (P > 0 && N > 0 && M > 0) ? (size_t)P * 3 * ((size_t)N + M) * sizeof(float) : 0; }
+int dr_dual_softmax_backward_f32(int P, int N, int M, const float* sim, float temperature, const uint8_t* src_mask, const uint8_t* tgt_mask,
+                                 const float* grad_conf, float* grad_sim, void* workspace, size_t workspace_bytes, void* stream) {
+    if (P < 0 || N < 1 || M < 1 || !sim || !grad_conf || !grad_sim || !(temperature > 0.f) || ((src_mask == nullptr) != (tgt_mask == nullptr))) return DR_EINVAL;
+    if (P == 0) return DR_OK;
+    if (!workspace || workspace_bytes < dr_dual_softmax_backward_workspace_bytes(P, N, M)) return DR_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* cmax = (float*)workspace;
+    float *csum = cmax + (size_t)P * M, *cs = csum + (size_t)P * M, *rmax = cs + (size_t)P * M, *rsum = rmax + (size_t)P * N, *rs = rsum + (size_t)P * N;
+    const int rows = P * N;
+    hipLaunchKernelGGL(dr::dual_softmax_cols_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, N, M, sim, temperature, src_mask, cmax, csum);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::dsm_bwd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, N, M, sim, temperature, src_mask, tgt_mask, cmax, csum, grad_conf, rmax,
+                       rsum, rs);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::dsm_bwd_cols_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, N, M, sim, temperature, src_mask, tgt_mask, cmax, csum, rmax, rsum,
+                       grad_conf, cs);
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::dsm_bwd_final_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, N, M, sim, temperature, src_mask, tgt_mask, cmax, csum, rmax, rsum, rs,
+                       cs, grad_conf, grad_sim);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

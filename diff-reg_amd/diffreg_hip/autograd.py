@@ -34,15 +34,16 @@ class _SinkhornConf(torch.autograd.Function):
 
 class _FocalLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, conf, conf_gt, alpha, gamma, pos_w, neg_w):
+    def forward(ctx, conf, conf_gt, alpha, gamma, pos_w, neg_w, match_type="sinkhorn"):
         ctx.save_for_backward(conf.detach(), conf_gt)
-        ctx.hp = (alpha, gamma, pos_w, neg_w)
-        return lib.focal_loss(conf.detach(), conf_gt, None, alpha, gamma, pos_w, neg_w, "sinkhorn")
+        # the dual-softmax form (loss.py:301-307) is the positive term alone: the sinkhorn form's backward with neg_w = 0
+        ctx.hp = (alpha, gamma, pos_w, neg_w if match_type == "sinkhorn" else 0.0)
+        return lib.focal_loss(conf.detach(), conf_gt, None, alpha, gamma, pos_w, neg_w, match_type)
 
     @staticmethod
     def backward(ctx, grad_loss):
         conf, conf_gt = ctx.saved_tensors
-        return lib.focal_loss_backward(conf, conf_gt, *ctx.hp) * grad_loss, None, None, None, None, None
+        return lib.focal_loss_backward(conf, conf_gt, *ctx.hp) * grad_loss, None, None, None, None, None, None
 
 
 class _MatchingHead(torch.autograd.Function):
@@ -280,30 +281,245 @@ def motion_l1(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow=None):
     return _MotionL1.apply(s_pcd, R_pred, t_pred, R_gt, t_gt, overlap_mask, flow)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The configuration branches no shipped yaml selects (pe_type 'sinusoidal', entangled = True, match_type 'dual_softmax'), differentiable: the
+# per-kernel form of the layer / head above with the position code entering where that branch puts it.  Same kernels, one library call each;
+# gradients pinned to the reference's autograd by tests/test_train_branches_gpu.py (oracle/make_golden_train_branches.py).
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+class _Rotary(torch.autograd.Function):
+    """embed_rotary (position_encoding.py:25-35) on [B,N,C] features with half tables: the entangled rotary form rotates the features ONCE in front of
+    the layers (transformero.py:238-239); backward = the transposed rotation"""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        B, N, C = x.shape
+        ctx.save_for_backward(cos, sin)
+        return lib.rotary(x.detach().float().reshape(B * N, C).contiguous(), cos, sin).view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        B, N, C = g.shape
+        return lib.rotary(g.contiguous().float().reshape(B * N, C), cos, sin, inverse=True).view(B, N, C), None, None
+
+
+class _GeometryAttentionLayerG(torch.autograd.Function):
+    """GeometryAttentionLayer.forward in the forms of transformero.py:50-57 / 246-252: q = W_q (x + x_add), k = W_k (source + s_add), v = W_v source
+    (x_add / s_add: the sinusoidal code, or None), the rotary code on q and k only when tables are given (None: the entangled forms call the layers
+    without a code).  The per-kernel backward of _GeometryAttentionLayer with those inputs."""
+
+    @staticmethod
+    def forward(ctx, x, source, x_add, s_add, cx, sx, cy, sy, x_mask, source_mask, H, Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2):
+        B, L, C = x.shape
+        S = source.shape[1]
+        d = C // H
+        det = lambda t: t.detach().float().contiguous()
+        x2, s2 = det(x).reshape(B * L, C), det(source).reshape(B * S, C)
+        qin = x2 if x_add is None else x2 + det(x_add).reshape(B * L, C)
+        kin = s2 if s_add is None else s2 + det(s_add).reshape(B * S, C)
+        Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2 = map(det, (Wq, Wk, Wv, Wm, W0, W2, g1, b1, g2, b2))
+        rot = cx is not None
+        qw, kw = lib.linear(qin, Wq), lib.linear(kin, Wk)
+        if rot:
+            cx, sx, cy, sy = map(det, (cx, sx, cy, sy))
+            qw, kw = lib.rotary(qw, cx, sx), lib.rotary(kw, cy, sy)
+        vw = lib.linear(s2, Wv)
+        o2 = lib.attention(qw.view(B, L, C), kw.view(B, S, C), vw.view(B, S, C), H, x_mask, source_mask).view(B * L, C)
+        m_pre = lib.linear(o2, Wm)
+        m, st1 = lib.layernorm(m_pre, g1, b1)
+        cat = torch.cat([x2, m], 1)
+        h = lib.linear(cat, W0, epilogue=1)
+        f_pre = lib.linear(h, W2)
+        f, st2 = lib.layernorm(f_pre, g2, b2)
+        tabs = (cx, sx, cy, sy) if rot else tuple(torch.empty(0, device=x2.device) for _ in range(4))
+        ctx.save_for_backward(qin, kin, s2, *tabs, Wq, Wk, Wv, Wm, W0, W2, g1, g2, qw, kw, vw, o2, m_pre, st1, cat, h, f_pre, st2)
+        ctx.dims = (B, L, S, C, H, rot)
+        ctx.masks = (x_mask, source_mask)
+        return (x2 + f).view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, ge):
+        (qin, kin, s2, cx, sx, cy, sy, Wq, Wk, Wv, Wm, W0, W2, g1, g2, qw, kw, vw, o2, m_pre, st1, cat, h, f_pre, st2) = ctx.saved_tensors
+        B, L, S, C, H, rot = ctx.dims
+        tr = lambda t: t.transpose(-1, -2).contiguous()
+        ge = ge.contiguous().float().reshape(B * L, C)
+        g_fpre, gg2, gb2 = lib.layernorm_backward(f_pre, g2, st2, ge)
+        g_h = lib.relu_backward(h, _mm(g_fpre, tr(W2)))
+        gW2 = _mm(tr(g_fpre), tr(h))
+        g_cat = _mm(g_h, tr(W0))
+        gW0 = _mm(tr(g_h), tr(cat))
+        g_x = ge + g_cat[:, :C]
+        g_mpre, gg1, gb1 = lib.layernorm_backward(m_pre, g1, st1, g_cat[:, C:].contiguous())
+        g_o2 = _mm(g_mpre, tr(Wm))
+        gWm = _mm(tr(g_mpre), tr(o2))
+        xm, sm_ = ctx.masks
+        g_qw, g_kw, g_vw = lib.attention_backward(qw.view(B, L, C), kw.view(B, S, C), vw.view(B, S, C), o2.view(B, L, C), g_o2.view(B, L, C), H, xm, sm_)
+        g_qw, g_kw, g_vw = g_qw.view(B * L, C), g_kw.view(B * S, C), g_vw.view(B * S, C)
+        g_qpre = lib.rotary(g_qw, cx, sx, inverse=True) if rot else g_qw.contiguous()
+        g_kpre = lib.rotary(g_kw, cy, sy, inverse=True) if rot else g_kw.contiguous()
+        g_x = g_x + _mm(g_qpre, tr(Wq))
+        g_s = _mm(g_kpre, tr(Wk)) + _mm(g_vw, tr(Wv))
+        gWq, gWk, gWv = _mm(tr(g_qpre), tr(qin)), _mm(tr(g_kpre), tr(kin)), _mm(tr(g_vw), tr(s2))
+        # (the position codes -- x_add / s_add and the tables -- are constants of the graph: position_encoding.py:83-84 detaches them)
+        return (g_x.view(B, L, C), g_s.view(B, S, C), None, None, None, None, None, None, None, None, None, gWq, gWk, gWv, gWm, gW0, gW2, gg1, gb1, gg2, gb2)
+
+
+def geometry_attention_layer_form(layer, x, source, x_pe, source_pe, x_mask=None, source_mask=None):
+    """differentiable GeometryAttentionLayer.forward in the form the module's own pe_type selects; x_pe / source_pe = None: the call of the entangled
+    forms (no code inside the layer).  The shipped form (rotary code given) takes the fused library call of geometry_attention_layer."""
+    pe_type = getattr(layer, "pe_type", "rotary")
+    if pe_type == "rotary" and x_pe is not None:
+        return geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask, source_mask)
+    p = dict(layer.named_parameters())
+    w = [p[k] for k in _LAYER_KEYS]
+    if x_pe is None:
+        return _GeometryAttentionLayerG.apply(x, source, None, None, None, None, None, None, x_mask, source_mask, layer.nhead, *w)
+    if pe_type == "sinusoidal":
+        return _GeometryAttentionLayerG.apply(x, source, x_pe, source_pe, None, None, None, None, x_mask, source_mask, layer.nhead, *w)
+    raise KeyError(pe_type)
+
+
+class _MatchingHeadG(torch.autograd.Function):
+    """Matching.forward (3D/models/matching.py:164-216) in every form: src_proj on both sides (quirk Q1); the position code by `embed` -- 'rotary'
+    (tables), 'add' (the sinusoidal code, position_encoding.py:43-44) or 'none' (entangled, matching.py:181); / sqrt(C); similarity; the read-out:
+    Sinkhorn (bin_score) or dual softmax (temperature).  Backward: the read-out's kernel, then the similarity / code / projection transposes."""
+
+    @staticmethod
+    def forward(ctx, src_feats, tgt_feats, weight, bin_score, embed, pe_a, pe_b, pe_c, pe_d, src_mask, tgt_mask, readout, iters, temperature):
+        B, N, C = src_feats.shape
+        M = tgt_feats.shape[1]
+        sf, tf, W = src_feats.detach().float().contiguous(), tgt_feats.detach().float().contiguous(), weight.detach().float().contiguous()
+        spre, tpre = lib.linear(sf.reshape(B * N, C), W), lib.linear(tf.reshape(B * M, C), W)
+        sc = 1.0 / C ** 0.5
+        if embed == "rotary":
+            cs, ss, ct, st = (t_.detach().float().contiguous() for t_ in (pe_a, pe_b, pe_c, pe_d))
+            a, b = lib.rotary(spre, cs, ss, scale=sc).view(B, N, C), lib.rotary(tpre, ct, st, scale=sc).view(B, M, C)
+        else:
+            cs = ss = ct = st = torch.empty(0, device=sf.device)
+            if embed == "add":
+                spre, tpre = spre + pe_a.detach().float().reshape(B * N, C), tpre + pe_b.detach().float().reshape(B * M, C)
+            a, b = (spre * sc).view(B, N, C), (tpre * sc).view(B, M, C)
+        sim = lib.bmm_nt(a, b)
+        if readout == "dual_softmax":
+            conf = lib.dual_softmax(sim, temperature, src_mask, tgt_mask)
+            bs = torch.empty(0, device=sf.device)
+        else:
+            if src_mask is not None:
+                sim = sim.masked_fill(~(src_mask[:, :, None] & tgt_mask[:, None, :]), float("-inf"))
+            bs = bin_score.detach()
+            conf = lib.sinkhorn(sim, bs.float().reshape(1), iters, src_mask, tgt_mask)
+        ctx.save_for_backward(sf, tf, W, a, b, sim, bs, cs, ss, ct, st)
+        ctx.cfg = (embed, readout, iters, temperature, bin_score is not None)
+        ctx.masks = (src_mask, tgt_mask)
+        return conf
+
+    @staticmethod
+    def backward(ctx, grad_conf):
+        sf, tf, W, a, b, sim, bs, cs, ss, ct, st = ctx.saved_tensors
+        embed, readout, iters, temperature, has_bin = ctx.cfg
+        sm, tm = ctx.masks
+        B, N, C = sf.shape
+        M = tf.shape[1]
+        ga = None
+        if readout == "dual_softmax":
+            gs = lib.dual_softmax_backward(sim, temperature, sm, tm, grad_conf)
+        else:
+            if sm is None:
+                sm = torch.ones(B, N, dtype=torch.bool, device=sf.device)
+                tm = torch.ones(B, M, dtype=torch.bool, device=sf.device)
+            gs, ga = lib.sinkhorn_backward(sim, bs, iters, sm, tm, grad_conf)
+            ga = ga.reshape(bs.shape).to(bs.dtype)
+        tr = lambda x: x.transpose(-1, -2).contiguous()
+        g_a = lib.bmm_nt(gs, tr(b))
+        g_b = lib.bmm_nt(tr(gs), tr(a))
+        sc = 1.0 / C ** 0.5
+        if embed == "rotary":
+            g_sp = lib.rotary(g_a.reshape(B * N, C), cs, ss, inverse=True, scale=sc)
+            g_tp = lib.rotary(g_b.reshape(B * M, C), ct, st, inverse=True, scale=sc)
+        else:
+            g_sp, g_tp = (g_a * sc).reshape(B * N, C).contiguous(), (g_b * sc).reshape(B * M, C).contiguous()
+        Wt = tr(W)
+        g_src, g_tgt = lib.linear(g_sp, Wt).view(B, N, C), lib.linear(g_tp, Wt).view(B, M, C)
+        g_W = _mm(tr(g_sp), tr(sf.reshape(B * N, C))) + _mm(tr(g_tp), tr(tf.reshape(B * M, C)))
+        return g_src, g_tgt, g_W, (ga if has_bin else None), None, None, None, None, None, None, None, None, None, None
+
+
+def matching_head_form(m, src_feats, tgt_feats, src_pe, tgt_pe, src_mask, tgt_mask, pe_type):
+    """differentiable models.matching.Matching.forward for the module `m` in the form its configuration selects (entangled, pe_type, match_type)"""
+    readout = m.match_type
+    bin_score = m.bin_score if readout == "sinkhorn" else None
+    iters = int(getattr(m, "skh_iters", 0) or 0)
+    temperature = float(getattr(m, "temperature", 1.0) or 1.0)
+    W = m.src_proj.weight
+    if m.entangled:
+        return _MatchingHeadG.apply(src_feats, tgt_feats, W, bin_score, "none", None, None, None, None, src_mask, tgt_mask, readout, iters, temperature)
+    if pe_type == "rotary":
+        if readout == "sinkhorn":
+            return matching_head(src_feats, tgt_feats, W, bin_score, src_pe, tgt_pe, src_mask, tgt_mask, iters)          # the shipped form
+        cs, ss = _tables(src_pe)
+        ct, st = _tables(tgt_pe)
+        return _MatchingHeadG.apply(src_feats, tgt_feats, W, bin_score, "rotary", cs, ss, ct, st, src_mask, tgt_mask, readout, iters, temperature)
+    if pe_type == "sinusoidal":
+        return _MatchingHeadG.apply(src_feats, tgt_feats, W, bin_score, "add", src_pe, tgt_pe, None, None, src_mask, tgt_mask, readout, iters, temperature)
+    raise KeyError(pe_type)
+
+
+def _embed_features(pe_type, feats, pe):
+    """VolPE.embed_pos on the features (the entangled forms, transformero.py:238-239), differentiable in the features"""
+    if pe_type == "rotary":
+        c, s_ = _tables(pe)
+        return _Rotary.apply(feats, c, s_)
+    if pe_type == "sinusoidal":
+        return feats + pe
+    raise KeyError(pe_type)
+
+
+def _layers_of(tr, s, t, src_pe, tgt_pe, src_mask, tgt_mask, positioning=None):
+    """the self / cross layers of a RepositioningTransformer in the form its configuration selects (transformero.py:170-254), differentiable:
+    disentangled -- every layer call receives the codes (rotary tables / the sinusoidal code); entangled -- the code is put into the features once
+    and the layers are called without one (positioning layers are skipped there, transformero.py:252).  positioning(s, t, src_pe, tgt_pe) ->
+    the new source code of a positioning layer (disentangled forms), or None where the transformer must not contain one."""
+    ent = bool(tr.entangled)
+    if ent:
+        s, t = _embed_features(tr.pe_type, s, src_pe), _embed_features(tr.pe_type, t, tgt_pe)
+    code = (lambda pe_: None) if ent else (lambda pe_: pe_)
+    for layer, name in zip(tr.layers, tr.layer_types):
+        if name == "self":
+            s = geometry_attention_layer_form(layer, s, s, code(src_pe), code(src_pe), src_mask, src_mask)
+            t = geometry_attention_layer_form(layer, t, t, code(tgt_pe), code(tgt_pe), tgt_mask, tgt_mask)
+        elif name == "cross":
+            s = geometry_attention_layer_form(layer, s, t, code(src_pe), code(tgt_pe), src_mask, tgt_mask)
+            t = geometry_attention_layer_form(layer, t, s, code(tgt_pe), code(src_pe), tgt_mask, src_mask)          # the updated src (quirk Q11)
+        elif ent:
+            continue
+        elif positioning is not None:
+            src_pe = positioning(layer, s, t, src_pe, tgt_pe)
+        else:
+            raise NotImplementedError("positioning layers (Procrustes inside the transformer) have no backward")
+    return s, t, src_pe, tgt_pe
+
+
 def coarse_branch(pipeline, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask):
     """The non-denoising half of the training forward, differentiable (3D/models/pipeline.py:184-196): coarse_transformer -- self, cross, the
     positioning layer (its Matching + Procrustes fit re-pose the source for the position code, which the reference DETACHES,
     position_encoding.py:83-84: a constant of the graph), self, cross -- then coarse_matching and the final soft_procrustes
-    -> (conf_matrix_pred, R_s2t_pred, t_s2t_pred); (R, t) back-propagate into conf_matrix_pred (the L1 motion term of 4DMatch's training)."""
+    -> (conf_matrix_pred, R_s2t_pred, t_s2t_pred); (R, t) back-propagate into conf_matrix_pred (the L1 motion term of 4DMatch's training).
+    Every configuration form (pe_type, entangled, match_type); positioning_type 'procrustes' (the others re-pose with data the training graph does
+    not carry here)."""
     tr = pipeline.coarse_transformer
     pe = tr.positional_encoding
     with torch.no_grad():
         src_pe, tgt_pe = pe(s_pcd), pe(t_pcd)
-    s, t = src_feats, tgt_feats
-    for layer, name in zip(tr.layers, tr.layer_types):
-        if name == "self":
-            s = geometry_attention_layer(layer, s, s, src_pe, src_pe, src_mask, src_mask)
-            t = geometry_attention_layer(layer, t, t, tgt_pe, tgt_pe, tgt_mask, tgt_mask)
-        elif name == "cross":
-            s = geometry_attention_layer(layer, s, t, src_pe, tgt_pe, src_mask, tgt_mask)
-            t = geometry_attention_layer(layer, t, s, tgt_pe, src_pe, tgt_mask, src_mask)
-        else:                                                       # positioning (transformero.py:183-203): no gradient leaves it
-            with torch.no_grad():
-                conf, _ = layer[0](s.detach(), t.detach(), src_pe, tgt_pe, src_mask, tgt_mask, {}, pe_type=tr.pe_type)
-                _, _, Rf, tf, _, _ = layer[1](conf, s_pcd, t_pcd, src_mask, tgt_mask)
-                src_pe = pe((torch.matmul(Rf, s_pcd.transpose(1, 2)) + tf).transpose(1, 2))
-    m = pipeline.coarse_matching
-    conf = matching_head(s, t, m.src_proj.weight, m.bin_score, src_pe, tgt_pe, src_mask, tgt_mask, m.skh_iters)
+
+    def positioning(layer, s, t, spe, tpe):                          # (transformero.py:183-203): no gradient leaves it
+        if tr.positioning_type != "procrustes":
+            raise NotImplementedError("forward_train: positioning_type %r" % tr.positioning_type)
+        with torch.no_grad():
+            conf, _ = layer[0](s.detach(), t.detach(), spe, tpe, src_mask, tgt_mask, {}, pe_type=tr.pe_type)
+            _, _, Rf, tf, _, _ = layer[1](conf, s_pcd, t_pcd, src_mask, tgt_mask)
+            return pe((torch.matmul(Rf, s_pcd.transpose(1, 2)) + tf).transpose(1, 2))
+    s, t, src_pe, tgt_pe = _layers_of(tr, src_feats, tgt_feats, src_pe, tgt_pe, src_mask, tgt_mask, positioning)
+    conf = matching_head_form(pipeline.coarse_matching, s, t, src_pe, tgt_pe, src_mask, tgt_mask, tr.pe_type)
     R, tt, _, _, _, _ = procrustes_fit(pipeline.soft_procrustes, conf, s_pcd, t_pcd, src_mask, tgt_mask)
     return conf, R, tt
 
@@ -312,21 +528,12 @@ def denoising_branch(pipeline, src_feats, tgt_feats, src_pcd_wrapped, tgt_pcd_wr
     """The denoising half of the training forward, differentiable (3D/models/pipeline.py:209-212): denoising_transformer (six self / cross
     GeometryAttentionLayers on the position code of the warped source) + denoising_coarse_matching -> conf_matrix_gt_hat.  Gradients reach every
     parameter of the two modules and the backbone features; the warped points (from the noised ground-truth matrix: no parameters) are constants,
-    exactly as in the reference's graph."""
+    exactly as in the reference's graph.  Every configuration form (pe_type, entangled, match_type)."""
     tr = pipeline.denoising_transformer
-    src_pe, tgt_pe = tr.positional_encoding(src_pcd_wrapped), tr.positional_encoding(tgt_pcd_wrapped)
-    s, t = src_feats, tgt_feats
-    for layer, name in zip(tr.layers, tr.layer_types):
-        if name == "self":
-            s = geometry_attention_layer(layer, s, s, src_pe, src_pe, src_mask, src_mask)
-            t = geometry_attention_layer(layer, t, t, tgt_pe, tgt_pe, tgt_mask, tgt_mask)
-        elif name == "cross":
-            s = geometry_attention_layer(layer, s, t, src_pe, tgt_pe, src_mask, tgt_mask)
-            t = geometry_attention_layer(layer, t, s, tgt_pe, src_pe, tgt_mask, src_mask)          # the updated src (quirk Q11)
-        else:
-            raise NotImplementedError("positioning layers (Procrustes inside the transformer) have no backward")
-    m = pipeline.denoising_coarse_matching
-    return matching_head(s, t, m.src_proj.weight, m.bin_score, src_pe, tgt_pe, src_mask, tgt_mask, m.skh_iters)
+    with torch.no_grad():
+        src_pe, tgt_pe = tr.positional_encoding(src_pcd_wrapped), tr.positional_encoding(tgt_pcd_wrapped)
+    s, t, src_pe, tgt_pe = _layers_of(tr, src_feats, tgt_feats, src_pe, tgt_pe, src_mask, tgt_mask)
+    return matching_head_form(pipeline.denoising_coarse_matching, s, t, src_pe, tgt_pe, src_mask, tgt_mask, tr.pe_type)
 
 
 def matching_head(src_feats, tgt_feats, weight, bin_score, src_pe, tgt_pe, src_mask, tgt_mask, iters):
@@ -342,6 +549,6 @@ def sinkhorn_conf(scores, bin_score, iters, src_mask=None, tgt_mask=None):
     return _SinkhornConf.apply(scores, bin_score, int(iters), src_mask, tgt_mask)
 
 
-def focal_loss(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0):
-    """differentiable compute_correspondence_loss, sinkhorn form (3D/models/loss.py:273-314)"""
-    return _FocalLoss.apply(conf, conf_gt, float(alpha), float(gamma), float(pos_w), float(neg_w))
+def focal_loss(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0, match_type="sinkhorn"):
+    """differentiable compute_correspondence_loss (3D/models/loss.py:273-314): the sinkhorn form, or the dual-softmax form (positive term only)"""
+    return _FocalLoss.apply(conf, conf_gt, float(alpha), float(gamma), float(pos_w), float(neg_w), match_type)

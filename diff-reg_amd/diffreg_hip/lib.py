@@ -173,6 +173,8 @@ SIGNATURES.update({
     "dr_attention_backward_f32": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 3 + [c_void_p, c_size_t, c_void_p]),
     "dr_softmax_rows_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_dual_softmax_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dr_dual_softmax_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dr_dual_softmax_backward_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dr_softmax_backward_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dr_relu_backward_f32": (c_int, [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_rotary_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
@@ -903,6 +905,19 @@ def dual_softmax(sim, temperature, src_mask=None, tgt_mask=None):
     sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
     check(_lib.dr_dual_softmax_f32(P, N, M, ptr(sim), float(temperature), ptr(sm), ptr(tm), ptr(conf), ptr(stats), stream_of(sim)))
     return conf
+
+
+def dual_softmax_backward(sim, temperature, src_mask, tgt_mask, grad_conf):
+    """d loss / d sim of conf = dual_softmax(sim, temperature, masks) given d loss / d conf (dr_dual_softmax_backward_f32)"""
+    ensure_init()
+    sim, grad_conf = sim.contiguous().float(), grad_conf.contiguous().float()
+    P, N, M = sim.shape
+    gs = torch.empty_like(sim)
+    nb = _lib.dr_dual_softmax_backward_workspace_bytes(P, N, M)
+    ws = torch.empty(nb, dtype=torch.uint8, device=sim.device)
+    sm, tm = mask_u8(src_mask), mask_u8(tgt_mask)
+    check(_lib.dr_dual_softmax_backward_f32(P, N, M, ptr(sim), float(temperature), ptr(sm), ptr(tm), ptr(grad_conf), ptr(gs), ptr(ws), nb, stream_of(sim)))
+    return gs
 
 
 def procrustes(conf, src_pcd, tgt_pcd, src_mask, tgt_mask, sample_rate, max_condition_num, use_mask_len=False,

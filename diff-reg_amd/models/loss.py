@@ -81,18 +81,17 @@ class MatchMotionLoss(nn.Module):
         return loss + loss_matrix_gt_hat
 
     def forward_train(self, data):
-        """ge_coarse_loss WITH a graph on the outputs of Pipeline.forward_train (sinkhorn match type): focal(conf_matrix_pred) * match_weight
+        """ge_coarse_loss WITH a graph on the outputs of Pipeline.forward_train (either match type: the dual-softmax form of the focal term is its
+        positive part, loss.py:301-307): focal(conf_matrix_pred) * match_weight
         [+ motion_weight * L1(R, t) when recall > 0.01] + focal(conf_matrix_gt_hat), each term a device kernel with its backward kernel."""
         from diffreg_hip import autograd as dag
-        if self.match_type != "sinkhorn":
-            raise NotImplementedError("differentiable loss: match_type='sinkhorn' (all shipped configs)")
         conf = data["conf_matrix_pred"]
         P, N, M = conf.shape
         dev = conf.device
         rows = self._match_rows(data["coarse_matches"], dev)
         conf_gt = lib.match_matrix(rows, P, N, M)
         hp = (self.focal_alpha, self.focal_gamma, self.pos_w, self.neg_w)
-        focal_coarse = dag.focal_loss(conf, conf_gt, *hp)
+        focal_coarse = dag.focal_loss(conf, conf_gt, *hp, match_type=self.match_type)
         recall, precision = self.compute_match_recall(conf_gt, data["coarse_match_pred"])
         loss_info = {"focal_coarse": focal_coarse.detach(), "recall_coarse": recall, "precision_coarse": precision}
         loss = self.mat_w * focal_coarse
@@ -105,7 +104,7 @@ class MatchMotionLoss(nn.Module):
                 for i, cflow in enumerate(data["coarse_flow"]):
                     flow[i][: len(cflow)] = cflow
             loss = loss + self.mot_w * dag.motion_l1(data["s_pcd"], data["R_s2t_pred"], data["t_s2t_pred"], data["batched_rot"], data["batched_trn"], ov, flow)
-        hat_loss = dag.focal_loss(data["conf_matrix_gt_hat"], conf_gt, *hp)
+        hat_loss = dag.focal_loss(data["conf_matrix_gt_hat"], conf_gt, *hp, match_type=self.match_type)
         loss_info.update({"loss_matrix_gt_hat": hat_loss.detach(), "loss": loss + hat_loss})
         return loss_info
 

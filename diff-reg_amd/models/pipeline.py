@@ -280,9 +280,10 @@ class Pipeline(nn.Module):
         matrix -- are differentiable on the device (diffreg_hip.backbone_autograd, diffreg_hip.autograd).  Writes the keys of pipeline.py:182-216 into `data`; `models.loss.MatchMotionLoss.forward_train`
         turns them into a loss whose .backward() fills the gradients of every parameter the reference's training updates behind the backbone."""
         from diffreg_hip import autograd as dag, lib
-        if not self._fused_loop_config() or self.config["coarse_transformer"]["positioning_type"] != "procrustes":
-            raise NotImplementedError("forward_train: the backward kernels exist for the shipped configuration (rotary code, disentangled, Sinkhorn "
-                                      "read-out, Procrustes positioning); the other branches run value-only through forward()")
+        # every form of pe_type / entangled runs (diffreg_hip.autograd: the per-kernel layer and head with the code where that branch puts it);
+        # match_type 'dual_softmax' fails below exactly where the reference's Pipeline fails (pipeline.py:299 reads bin_score, which that branch never
+        # creates) -- its two graphs are differentiable at the module level (autograd.coarse_branch / denoising_branch); a positioning_type other than
+        # 'procrustes' in a disentangled coarse transformer raises NotImplementedError in coarse_branch
         # the overlay backbone (models.backbone.KPFCN) is differentiable under .train() (diffreg_hip/backbone_autograd.py); any other backbone
         # module takes part in the graph as far as its own forward does (a reference-tree KPFCN on torch ops, a stub returning constants)
         coarse_feats = self.backbone(data, phase="coarse")

@@ -746,6 +746,11 @@ int dr_softmax_backward_f32(int rows, int cols, const float* P, const float* gra
  *   0 where either mask is 0; masks uint8 [P,N] / [P,M] or both NULL (the reference's mask-free branch).  col_stats: caller scratch of 2 P M floats. */
 int dr_dual_softmax_f32(int P, int N, int M, const float* sim, float temperature, const uint8_t* src_mask, const uint8_t* tgt_mask, float* conf,
                         float* col_stats, void* stream);
+/* its backward (ABI 0.2.1): grad_sim = d loss / d sim given grad_conf = d loss / d conf -- the two softmax adjoints; entries under a mask receive 0, as
+ * the reference's masked_fill_ lets nothing through.  workspace: dr_dual_softmax_backward_workspace_bytes (column / row statistics and sums). */
+size_t dr_dual_softmax_backward_workspace_bytes(int P, int N, int M);
+int dr_dual_softmax_backward_f32(int P, int N, int M, const float* sim, float temperature, const uint8_t* src_mask, const uint8_t* tgt_mask,
+                                 const float* grad_conf, float* grad_sim, void* workspace, size_t workspace_bytes, void* stream);
 int dr_relu_backward_f32(long long n, const float* y, const float* grad_y, float* grad_x, void* stream);
 
 /* embed_rotary (position_encoding.py:25-35) on contiguous rows [rows, C]: out = R(theta) x * scale with cos / sin [rows, C/2]; inverse != 0:

@@ -161,6 +161,18 @@ def train_case(tag):
                 src_mask=torch.ones(B, N, dtype=torch.bool), tgt_mask=torch.ones(B, M, dtype=torch.bool))
 
 
+def train_branch_case(N, M, seed):
+    """the case of the non-default training forms (oracle/make_golden_train_branches.py): one synthetic pair, the denoising branch's warped source =
+    the source under the ground-truth pose (float32 torch arithmetic on the host, identical in the minting script and in the test)"""
+    C = synth.VARIANTS["3dmatch"]["C"]
+    p = synth.make_pair(N, M, C, seed=seed)
+    R, t = T(p["R_gt"]).float()[None], T(p["t_gt"]).float().view(1, 3, 1)
+    p_s = T(p["s_pcd"])[None]
+    return dict(B=1, N=N, M=M, mc=200.0, f_s=T(p["src_feats"])[None], f_t=T(p["tgt_feats"])[None], p_s=p_s, p_t=T(p["t_pcd"])[None],
+                warped=(torch.matmul(R, p_s.transpose(1, 2)) + t).transpose(1, 2).contiguous(), matches=[T(p["gt_matches"]).t().contiguous()],
+                R_gt=R, t_gt=t, src_mask=torch.ones(1, N, dtype=torch.bool), tgt_mask=torch.ones(1, M, dtype=torch.bool))
+
+
 def focal_case():
     """inputs of the stand-alone compute_correspondence_loss / compute_match_recall vectors"""
     P, N, M = 2, 40, 56

@@ -113,3 +113,41 @@ def test_4d_loop_of_the_sinusoidal_form_matches_the_reference(golden):
         assert abs(float(trace[k]["cond"][0]) - float(g["loop_sin_cond"][k])) < 1e-4 * float(g["loop_sin_cond"][k]), k
         assert np.abs(trace[k]["x0"][0].numpy() - g["loop_sin_x0"][k]).max() < 1e-5, k
     assert np.abs(out["conf_matrix_pred"][0].numpy() - g["loop_sin_conf"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("form", ["sin", "rot_ent", "sin_ent", "dsm"])
+def test_training_gradients_of_a_form_oracle_autograd_against_reference(golden, form):
+    """The denoising-branch training graph of a non-default form (oracle.denoiser + match_head + train_oracle.focal_loss, float64 weights, torch
+    autograd) against the reference's own float32 backward (oracle/make_golden_train_branches.py): loss, conf, feature gradients and a parameter
+    gradient of every layer.  This is the link that pins what the GPU tests of the same vectors compare the device with; the case is off every
+    ReLU kink by 5e-6 (see the minting script), so the float64 restatement and the float32 reference are on the same side of all of them."""
+    from oracle import train_oracle as tro
+    from tests.helpers import train_branch_case
+    g = golden("train_backward_branches")
+    c = train_branch_case(40, 32, 70)
+    scale = float(g[form + "_feat_scale"])
+    pe_type, ent, mtype = {"sin": ("sinusoidal", False, "sinkhorn"), "rot_ent": ("rotary", True, "sinkhorn"), "sin_ent": ("sinusoidal", True, "sinkhorn"),
+                           "dsm": ("rotary", False, "dual_softmax")}[form]
+    v = dict(synth.VARIANTS["3dmatch"], pe_type=pe_type, entangled=ent, match_type=mtype, dsmax_temperature=float(g["dsm_temperature"]))
+    W = {k: a.double().clone().requires_grad_(True) for k, a in soft_weights().items() if k.startswith("denoising_")}
+    fs = (c["f_s"] * scale).double().requires_grad_(True)
+    ft = (c["f_t"] * scale).double().requires_grad_(True)
+    hs, ht, pe_s, pe_t = orc.denoiser(W, v, fs, ft, c["warped"], c["p_t"], c["src_mask"], c["tgt_mask"])
+    hat = orc.match_head(W, v, hs, ht, pe_s, pe_t, c["src_mask"], c["tgt_mask"])
+    gt = torch.zeros_like(hat)
+    gt[0][c["matches"][0][0], c["matches"][0][1]] = 1
+    loss = tro.focal_loss(hat, gt, match_type=mtype)
+    loss.backward()
+    pre = form + "_branch_"
+    assert abs(float(loss) - float(g[pre + "loss32"])) <= 1e-4 * float(g[pre + "loss32"])
+    assert np.abs(hat.detach().numpy() - g[pre + "conf32"]).max() <= 1e-5
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(fs.grad[0, ::3, ::4].numpy(), g[pre + "grad_src32"]) < 1e-3 and rel(ft.grad[0, ::3, ::4].numpy(), g[pre + "grad_tgt32"]) < 1e-3
+    st = int(g["stride"])
+    for l in range(6):
+        for name in ("q_proj.weight", "mlp.0.weight", "norm2.bias"):
+            got = W["denoising_transformer.layers.%d.%s" % (l, name)].grad
+            got = (got[::st, ::st] if got.dim() == 2 else got).numpy()
+            assert rel(got, g["%sg32_layers.%d.%s" % (pre, l, name)]) < 1e-3, (l, name)
+    got = W["denoising_coarse_matching.src_proj.weight"].grad[::st, ::st].numpy()
+    assert rel(got, g[pre + "g32_head.src_proj.weight"]) < 1e-3
