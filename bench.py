@@ -279,6 +279,50 @@ def stress_head_parity(variant, N, M, steps, mc, seeds, device):
     return ir_fmr_parity(eng, variant, N, M, kept, device, HEAD_GAIN_STRESS)
 
 
+def pgemm_per_op(dev, rows, C=432, reps=10):
+    """The four launches of one GeometryAttentionLayer call of the headline's batch (rows = token rows of one batch, C = 432) on their own: whole-launch
+    time (HIP events) and fraction of the three-product ceiling per op -- where the family's average comes from (q | k | v and mlp0
+    end in a plane-image epilogue, merge and mlp2 in the LayerNorm one)."""
+    from diffreg_hip import lib
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    x = rnd(rows, C)
+    img, bnd = lib.planes_from_f32(x)
+    msg_img, msg_b = lib.planes_from_f32(rnd(rows, C))
+    hid_img, hid_b = lib.planes_from_f32(rnd(rows, 2 * C))
+    g1, b1 = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    lnb = lib.ln_bound(g1, b1)
+    o_img = torch.zeros_like(img); o_b = torch.zeros(rows, device=dev); o32 = torch.empty(rows, C, device=dev)
+    h_img = torch.zeros_like(hid_img); h_b = torch.zeros(rows, device=dev)
+    nbytes = lib.raw().dr_plane_image_bytes(rows, C)
+    q_img = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    ang = torch.rand(rows, C // 2, device=dev); cosT, sinT = ang.cos().contiguous(), ang.sin().contiguous()
+    pk3 = lib.pack_weight_planes(rnd(3 * C, C) / C ** 0.5, 3, C)
+    pk1 = lib.pack_weight_planes(rnd(C, C) / C ** 0.5, 1, C)
+    pk0 = lib.pack_weight_planes(rnd(2 * C, 2 * C) / (2 * C) ** 0.5, 2, C)
+    pk2 = lib.pack_weight_planes(rnd(C, 2 * C) / (2 * C) ** 0.5, 1, C)
+    o3 = torch.empty(rows, 3 * C, device=dev)
+    ops = {
+        "q|k|v (fp32 rows + rotary; the loop writes plane images)": (lambda: lib.linear_planes(rows, C, 3, img, bnd, C, pk3, lib.PL_F32, out=o3, ldo=3 * C, blk_stride=C, cos_t=cosT, sin_t=sinT, rot_mask=3, rot_C=C), 3 * C * C),
+        "merge + LayerNorm": (lambda: lib.linear_planes(rows, C, 1, img, bnd, C, pk1, lib.PL_LN, out_image=o_img, out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, lnb=lnb), C * C),
+        "mlp0 + ReLU": (lambda: lib.linear_planes(rows, C, 2, img, bnd, C, pk0, lib.PL_PLANES, a1=msg_img, b1=msg_b, k1=C, out_image=h_img, out_image_k=2 * C, out_bound=h_b, relu=True), 4 * C * C),
+        "mlp2 + LayerNorm + residual": (lambda: lib.linear_planes(rows, C, 1, hid_img, hid_b, 2 * C, pk2, lib.PL_LN, out=o32, ldo=C, out_image=o_img, out_image_k=C, out_bound=o_b, gamma=g1, beta=b1, resid=x, ldr=C, bound_resid=bnd, lnb=lnb), 2 * C * C)}
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, (fn, kn) in ops.items():
+        for _ in range(3):
+            fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        tf = 2.0 * rows * kn / us / 1e6
+        out[name] = {"us_per_launch": us, "TFLOPs": tf, "frac": tf / PEAK_SPLIT_TFLOPS}
+    return {"rows": rows, "C": C, "ops": out, "measured": "stand-alone launches of the four shapes through dr_linear_planes_f32 (HIP events, %d launches each)" % reps}
+
+
 def _families(prof):
     tot = sum(v[1] for v in prof.values()) or 1.0
     return {k: {"launches": v[0], "ms": v[1], "share": v[1] / tot} for k, v in prof.items() if v[0]}
@@ -369,8 +413,8 @@ def bench_cfg3(dev):
     prof = lib.prof_collect()
     lib.prof_enable(False)
     res["kernel_families"] = _families(prof)
-    res.update(_mfma_roofline(prof, "pgemm_kernel<9,3,*,2> (576-column geometry, 64-row workgroups)", "attention_planes_kernel<9,5> (d = 132)",
-                              "r05_cfg3_pgemm_pmc.json", "r05_cfg3_attention_pmc.json"))
+    res.update(_mfma_roofline(prof, "pgemm16w_kernel (128 x 288 wide-wave workgroups) + pgemm_kernel<9,3,LN,2> (64-row, k-split)", "attention_planes_kernel<9,5> (d = 132)",
+                              "r06_cfg3_pgemm_pmc.json", "r06_cfg3_attention_pmc.json"))
     res["measured_on"] = "one eager 8-pair call (HIP events on the launch stream)"
     # the OPT-IN reduced-precision attention (DR_LOOP_ATTN_F16: one fp16 product per contraction, BASELINE's "bf16 MFMA attention"): rate and deviation
     ref_conf = eng.run(graph=False, **g0)["conf_matrix_pred"].clone()
@@ -540,7 +584,7 @@ def compact_line(result, details_path):
         if "mfma_busy_fraction_of_wall_pmc" in rf:
             line["roofline"]["mfma_busy"] = rf["mfma_busy_fraction_of_wall_pmc"]
         if "per_op" in rf:
-            line["roofline"]["per_op_frac"] = {k: v["frac"] for k, v in rf["per_op"].items()}
+            line["roofline"]["per_op_frac"] = {k.split(" ")[0]: v["frac"] for k, v in rf["per_op"].items()}
     if "sinkhorn_roofline" in result:
         line["sinkhorn_roofline"] = _pick(result["sinkhorn_roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch",
                                                                          "tiles_per_launch", "device_copy_same_bytes_GBps"))
@@ -929,6 +973,13 @@ def main():
                             "the kernel computes each fp32 product as " + SPLIT_TEXT + " accumulated in fp32 "
                             "(fp32-level accuracy: tests/test_planes_gpu.py holds every op of the chain to float64 products)")
             roof["measured_on"] = "eager launches of one batch of %d pairs (HIP events on the launch stream)" % per[0]
+            if dom == "gemm_split" and not args.breakdown_only:
+                try:
+                    po = pgemm_per_op(dev, per[0] * (N + M))
+                    roof["per_op"] = po["ops"]
+                    roof["per_op_measured"] = po["measured"] + "; rows = %d" % po["rows"]
+                except Exception as e:                  # (a diagnostic block must not take the line down)
+                    roof["per_op_error"] = "%s: %s" % (type(e).__name__, e)
             result["roofline"] = roof
             result["kernel_families"] = fam
         if sk_roof is not None:
