@@ -49,7 +49,7 @@ PEAK_SPLIT_TFLOPS = PEAK_MFMA_BF16_TFLOPS / SPLIT_PRODUCTS
 SPLIT_KERNEL = "pgemm_kernel"
 SPLIT_TEXT = ("three fp16 MFMA products of hi/lo operand planes (rows of both operands scaled by exact powers of two into fp16's range; "
               "planes written by the producing kernels, both operands streamed by LDS-DMA)")
-LOOP_PMC = os.path.join(ROOT, "profiles", "r05_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
+LOOP_PMC = os.path.join(ROOT, "profiles", "r06_pgemm_loop_pmc.json")   # rocprofv3 --pmc passes over the loop's own launches (tools/pmc_collect.py)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 METRIC = "scene-pairs/sec @ 20 denoise steps (N=M=256); IR/FMR parity vs ref"
 
@@ -954,7 +954,7 @@ def main():
                 # `bench.py --breakdown-only` (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; per launch, averaged like `achieved`)
                 tj = json.load(open(LOOP_PMC))
                 roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/r05_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
+                roof["traffic_source"] = "profiles/r06_pgemm_loop_pmc.json (%s; %d launches)" % (tj.get("command"), tj.get("launches_seen", 0))
                 roof["mfma_busy_fraction_of_wall_pmc"] = tj.get("derived", {}).get("mfma_busy_fraction_of_wall")
                 # what a bare MFMA loop of this kernel's shape sustains on random data under the chip's own clock management (tools/mfma_f16_ceiling.hip):
                 # informational -- `peak` stays the nominal figure

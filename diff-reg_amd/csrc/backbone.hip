@@ -20,7 +20,7 @@ constexpr int KP_MAXK = 16, KP_MAXH = 64;
 template <int CPL>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int H, int Cin, int K, const float* __restrict__ q_pts,
                                                             const float* __restrict__ s_pts, const long long* __restrict__ nb,
-                                                            const float* __restrict__ x, const float* __restrict__ kp, float extent,
+                                                            const float* __restrict__ x, const float* __restrict__ kp, float extent, int mode,
                                                             float* __restrict__ wf, int ldw) {
     __shared__ __attribute__((aligned(16))) float s_w[4][KP_MAXH * KP_MAXK];     // influences [h][k] of the wave's query
     __shared__ int s_idx[4][KP_MAXH];
@@ -35,13 +35,21 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int 
         // the shadow point sits at +1e6 on every axis (blocks.py:288): its influence is 0
         const float nx = (shadow ? 1e6f : s_pts[id * 3]) - qx, ny = (shadow ? 1e6f : s_pts[id * 3 + 1]) - qy,
                     nz = (shadow ? 1e6f : s_pts[id * 3 + 2]) - qz;
+        float d2[KP_MAXK];
+        int kmin = 0;                                               // the neighbour's nearest kernel point (first minimum, as torch.argmin)
 #pragma unroll
         for (int k = 0; k < KP_MAXK; ++k) {
-            float wv = 0.f;
+            d2[k] = INFINITY;
             if (k < K) {
                 const float dx = nx - kp[k * 3], dy = ny - kp[k * 3 + 1], dz = nz - kp[k * 3 + 2];
-                wv = fmaxf(1.f - sqrtf(dx * dx + dy * dy + dz * dz) / extent, 0.f);       // 'linear' influence (blocks.py:349)
+                d2[k] = dx * dx + dy * dy + dz * dz;
+                if (d2[k] < d2[kmin]) kmin = k;
             }
+        }
+#pragma unroll
+        for (int k = 0; k < KP_MAXK; ++k) {
+            float wv = k < K ? kp_influence(mode, d2[k], extent) : 0.f;         // 'linear' in every shipped configuration (blocks.py:309-312)
+            if ((mode & KP_CLOSEST) && k != kmin) wv = 0.f;
             s_w[w][lane * KP_MAXK + k] = wv;
         }
     }
@@ -89,14 +97,15 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(int Nq, int Ns, int 
 }
 
 int launch_kpconv_gather(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const long long* nb,
-                         const float* x, const float* kp, float extent, float* wf, int ldw, hipStream_t st) {
+                         const float* x, const float* kp, float extent, float* wf, int ldw, hipStream_t st, int mode) {
     if (Nq <= 0) return DR_OK;
+    if ((mode & 3) == 3 || (mode & ~7)) return DR_EINVAL;
     if (K > KP_MAXK || H > KP_MAXH || H < 1 || Cin < 1 || Cin > 512 || ldw < K * Cin) return DR_ENOSUP;
     const dim3 grid((Nq + 3) / 4), blk(256);
-    if (Cin <= 64) hipLaunchKernelGGL(kpconv_gather_kernel<1>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
-    else if (Cin <= 128) hipLaunchKernelGGL(kpconv_gather_kernel<2>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
-    else if (Cin <= 256) hipLaunchKernelGGL(kpconv_gather_kernel<4>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
-    else hipLaunchKernelGGL(kpconv_gather_kernel<8>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, wf, ldw);
+    if (Cin <= 64) hipLaunchKernelGGL(kpconv_gather_kernel<1>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, mode, wf, ldw);
+    else if (Cin <= 128) hipLaunchKernelGGL(kpconv_gather_kernel<2>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, mode, wf, ldw);
+    else if (Cin <= 256) hipLaunchKernelGGL(kpconv_gather_kernel<4>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, mode, wf, ldw);
+    else hipLaunchKernelGGL(kpconv_gather_kernel<8>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, mode, wf, ldw);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
@@ -218,11 +227,17 @@ using namespace dr;
 
 extern "C" {
 
+int dr_kpconv_gather_mode_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
+                              const float* x, const float* kernel_points, float extent, int influence, int closest, float* weighted,
+                              int ld_weighted, void* stream) {
+    if (Nq < 0 || Ns < 1 || !q_pts || !s_pts || !neighb_inds || !x || !kernel_points || !weighted || extent <= 0.f || influence < 0 || influence > 2)
+        return DR_EINVAL;
+    return launch_kpconv_gather(Nq, Ns, H, Cin, K, q_pts, s_pts, (const long long*)neighb_inds, x, kernel_points, extent, weighted,
+                                ld_weighted, (hipStream_t)stream, influence | (closest ? KP_CLOSEST : 0));
+}
 int dr_kpconv_gather_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
                          const float* x, const float* kernel_points, float extent, float* weighted, int ld_weighted, void* stream) {
-    if (Nq < 0 || Ns < 1 || !q_pts || !s_pts || !neighb_inds || !x || !kernel_points || !weighted || extent <= 0.f) return DR_EINVAL;
-    return launch_kpconv_gather(Nq, Ns, H, Cin, K, q_pts, s_pts, (const long long*)neighb_inds, x, kernel_points, extent, weighted,
-                                ld_weighted, (hipStream_t)stream);
+    return dr_kpconv_gather_mode_f32(Nq, Ns, H, Cin, K, q_pts, s_pts, neighb_inds, x, kernel_points, extent, DR_KP_LINEAR, 0, weighted, ld_weighted, stream);
 }
 
 size_t dr_col_stats_workspace_bytes(int N, int C) { return (N > 0 && C > 0) ? col_stats_workspace_bytes(N, C) : 0; }

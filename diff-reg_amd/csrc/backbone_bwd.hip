@@ -17,7 +17,7 @@ constexpr int KPB_MAXK = 16, KPB_MAXH = 64;
 template <int CPL>
 __global__ __launch_bounds__(256) void kpconv_gather_backward_kernel(int Nq, int Ns, int H, int Cin, int K, const float* __restrict__ q_pts,
                                                                      const float* __restrict__ s_pts, const long long* __restrict__ nb,
-                                                                     const float* __restrict__ x, const float* __restrict__ kp, float extent,
+                                                                     const float* __restrict__ x, const float* __restrict__ kp, float extent, int mode,
                                                                      const float* __restrict__ gwf, int ldw, float* __restrict__ gx) {
     __shared__ __attribute__((aligned(16))) float s_w[4][KPB_MAXH * KPB_MAXK];
     __shared__ int s_idx[4][KPB_MAXH];
@@ -31,13 +31,21 @@ __global__ __launch_bounds__(256) void kpconv_gather_backward_kernel(int Nq, int
         s_idx[w][lane] = shadow ? -1 : (int)id;
         const float nx = (shadow ? 1e6f : s_pts[id * 3]) - qx, ny = (shadow ? 1e6f : s_pts[id * 3 + 1]) - qy,
                     nz = (shadow ? 1e6f : s_pts[id * 3 + 2]) - qz;
+        float d2[KPB_MAXK];
+        int kmin = 0;                                               // the neighbour's nearest kernel point (first minimum, as torch.argmin)
 #pragma unroll
         for (int k = 0; k < KPB_MAXK; ++k) {
-            float wv = 0.f;
+            d2[k] = INFINITY;
             if (k < K) {
                 const float dx = nx - kp[k * 3], dy = ny - kp[k * 3 + 1], dz = nz - kp[k * 3 + 2];
-                wv = fmaxf(1.f - sqrtf(dx * dx + dy * dy + dz * dz) / extent, 0.f);
+                d2[k] = dx * dx + dy * dy + dz * dz;
+                if (d2[k] < d2[kmin]) kmin = k;
             }
+        }
+#pragma unroll
+        for (int k = 0; k < KPB_MAXK; ++k) {
+            float wv = k < K ? kp_influence(mode, d2[k], extent) : 0.f;         // 'linear' in every shipped configuration (blocks.py:309-312)
+            if ((mode & KP_CLOSEST) && k != kmin) wv = 0.f;
             s_w[w][lane * KPB_MAXK + k] = wv;
         }
     }
@@ -87,12 +95,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_backward_kernel(int Nq, int
 }
 
 int launch_kpconv_gather_backward(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const long long* nb,
-                                  const float* x, const float* kp, float extent, const float* gwf, int ldw, float* gx, hipStream_t st) {
+                                  const float* x, const float* kp, float extent, const float* gwf, int ldw, float* gx, hipStream_t st, int mode) {
     if (Ns > 0) DR_HIP_CHECK(hipMemsetAsync(gx, 0, (size_t)Ns * Cin * sizeof(float), st));
     if (Nq <= 0) return DR_OK;
     if (K > KPB_MAXK || H > KPB_MAXH || H < 1 || Cin < 1 || Cin > 512 || ldw < K * Cin) return DR_ENOSUP;
     const dim3 grid((Nq + 3) / 4), blk(256);
-#define KPB_LAUNCH(C_) hipLaunchKernelGGL(kpconv_gather_backward_kernel<C_>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, gwf, ldw, gx)
+#define KPB_LAUNCH(C_) hipLaunchKernelGGL(kpconv_gather_backward_kernel<C_>, grid, blk, 0, st, Nq, Ns, H, Cin, K, q_pts, s_pts, nb, x, kp, extent, mode, gwf, ldw, gx)
     if (Cin <= 64) KPB_LAUNCH(1);
     else if (Cin <= 128) KPB_LAUNCH(2);
     else if (Cin <= 256) KPB_LAUNCH(4);
@@ -225,12 +233,19 @@ using namespace dr;
 
 extern "C" {
 
+int dr_kpconv_gather_backward_mode_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
+                                       const float* x, const float* kernel_points, float extent, int influence, int closest,
+                                       const float* grad_weighted, int ld_weighted, float* grad_x, void* stream) {
+    if (Nq < 0 || Ns < 1 || !q_pts || !s_pts || !neighb_inds || !x || !kernel_points || !grad_weighted || !grad_x || extent <= 0.f || influence < 0 ||
+        influence > 2) return DR_EINVAL;
+    return launch_kpconv_gather_backward(Nq, Ns, H, Cin, K, q_pts, s_pts, (const long long*)neighb_inds, x, kernel_points, extent, grad_weighted,
+                                         ld_weighted, grad_x, (hipStream_t)stream, influence | (closest ? KP_CLOSEST : 0));
+}
 int dr_kpconv_gather_backward_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
                                   const float* x, const float* kernel_points, float extent, const float* grad_weighted, int ld_weighted,
                                   float* grad_x, void* stream) {
-    if (Nq < 0 || Ns < 1 || !q_pts || !s_pts || !neighb_inds || !x || !kernel_points || !grad_weighted || !grad_x || extent <= 0.f) return DR_EINVAL;
-    return launch_kpconv_gather_backward(Nq, Ns, H, Cin, K, q_pts, s_pts, (const long long*)neighb_inds, x, kernel_points, extent, grad_weighted,
-                                         ld_weighted, grad_x, (hipStream_t)stream);
+    return dr_kpconv_gather_backward_mode_f32(Nq, Ns, H, Cin, K, q_pts, s_pts, neighb_inds, x, kernel_points, extent, DR_KP_LINEAR, 0, grad_weighted,
+                                              ld_weighted, grad_x, stream);
 }
 
 size_t dr_norm_backward_workspace_bytes(int N, int C) { return (N > 0 && C > 0) ? norm_backward_workspace_bytes(N, C) : 0; }

@@ -150,6 +150,17 @@ int launch_top1_union(const T* conf, int P, int N, int M, long long* out, int* c
 // collate.hip: in-place bitonic sort of (key, value) pairs ascending by (key, value); n_pad = a power of two (pad keys ~0ull sort last)
 int launch_bitonic_sort(unsigned long long* keys, unsigned* vals, int n_pad, hipStream_t st);
 
+// KPConv influence of a kernel point at squared distance d2 (blocks.py:304-321): mode & 3 = 0 'constant', 1 'linear', 2 'gaussian'
+// (radius_gaussian with sigma = 0.3 extent, blocks.py:36-44); bit 2 of mode = aggregation 'closest' (applied by the caller: only the nearest
+// kernel point of a neighbour keeps its influence, blocks.py:324-326)
+enum { KP_CONSTANT = 0, KP_LINEAR = 1, KP_GAUSSIAN = 2, KP_CLOSEST = 4 };
+__device__ __forceinline__ float kp_influence(int mode, float d2, float extent) {
+    const int inf = mode & 3;
+    if (inf == KP_LINEAR) return fmaxf(1.f - sqrtf(d2) / extent, 0.f);
+    if (inf == KP_GAUSSIAN) { const float sig = extent * 0.3f; return expf(-d2 / (2.f * sig * sig + 1e-9f)); }
+    return 1.f;
+}
+
 // sinkhorn.hip (internal form of dr_sinkhorn_*: `shift` = per-tile value subtracted first, nullable)
 int sinkhorn_f32(int B, int N, int M, const float* scores, const uint8_t* sm, const uint8_t* tm, const float* bin_score,
                  int iters, int flags, float* out, void* ws, size_t ws_bytes, hipStream_t st, unsigned* call_status = nullptr);

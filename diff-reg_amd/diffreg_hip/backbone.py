@@ -34,14 +34,24 @@ class KPFCNEngine:
                 self.w2[k] = w2.contiguous()
         self.coarse_w = sd["coarse_out.weight"][:, :, 0].contiguous()
 
+        self.influence, self.aggregation = self.cfg.get("KP_influence", "linear"), self.cfg.get("aggregation_mode", "sum")
+        self.use_bn = bool(self.cfg.get("use_batch_norm", True))
+
     # ---- blocks -------------------------------------------------------------------------------------------------
     def _kpconv(self, pre, q, s, idx, x, extent):
-        wf = lib.kpconv_gather(q, s, idx, x, self.sd[pre + "KPConv.kernel_points"], extent)
+        wf = lib.kpconv_gather(q, s, idx, x, self.sd[pre + "KPConv.kernel_points"], extent, self.influence, self.aggregation)
         return lib.linear_ex(wf, self.w2[pre + "KPConv.weights"])
 
-    def _unary(self, x, W, relu=True):
-        y = lib.linear_ex(x, W)
-        return lib.norm_apply(y, lib.col_stats(y), activate=relu)
+    def _stats(self, y, bias_key):
+        """the (mean, rstd) a BatchNormBlock applies: the column statistics of the InstanceNorm1d, or -- use_batch_norm = False: x + bias,
+        blocks.py:445-446 -- (-bias, 1): (y - mean) rstd is then y + bias exactly"""
+        if self.use_bn:
+            return lib.col_stats(y)
+        return (-self.sd[bias_key]).contiguous(), torch.ones_like(self.sd[bias_key])
+
+    def _unary(self, x, pre, relu=True):
+        y = lib.linear_ex(x, self.sd[pre + "mlp.weight"])
+        return lib.norm_apply(y, self._stats(y, pre + "batch_norm.bias"), activate=relu)
 
     @torch.no_grad()
     def forward(self, batch):
@@ -69,22 +79,22 @@ class KPFCNEngine:
             q, s, idx = (pts[layer + 1], pts[layer], pools[layer]) if strided else (pts[layer], pts[layer], nb[layer])
             if block == "simple":
                 y = self._kpconv(pre, q, s, idx, x, extent)
-                x = lib.norm_apply(y, lib.col_stats(y))
+                x = lib.norm_apply(y, self._stats(y, pre + "batch_norm.bias"))
             else:
                 feats = x
-                y = self._unary(feats, sd[pre + "unary1.mlp.weight"]) if (pre + "unary1.mlp.weight") in sd else feats
+                y = self._unary(feats, pre + "unary1.") if (pre + "unary1.mlp.weight") in sd else feats
                 y = self._kpconv(pre, q, s, idx, y, extent)
-                y = lib.norm_apply(y, lib.col_stats(y))
+                y = lib.norm_apply(y, self._stats(y, pre + "batch_norm_conv.bias"))
                 y = lib.linear_ex(y, sd[pre + "unary2.mlp.weight"])                      # unary2: norm only (no_relu)
                 sc = lib.gather_pool(feats, idx) if strided else feats
                 if (pre + "unary_shortcut.mlp.weight") in sd:
                     sc = lib.linear_ex(sc, sd[pre + "unary_shortcut.mlp.weight"])
-                    x = lib.norm_apply(y, lib.col_stats(y), sc, lib.col_stats(sc))       # lrelu(norm(y) + norm(sc))
+                    x = lib.norm_apply(y, self._stats(y, pre + "unary2.batch_norm.bias"), sc, self._stats(sc, pre + "unary_shortcut.batch_norm.bias"))       # lrelu(norm(y) + norm(sc))
                 else:
-                    x = lib.norm_apply(y, lib.col_stats(y), sc, None)                    # lrelu(norm(y) + feats)
+                    x = lib.norm_apply(y, self._stats(y, pre + "unary2.batch_norm.bias"), sc, None)                    # lrelu(norm(y) + feats)
             if "pool" in block or "strided" in block:
                 layer += 1; r *= 2; out_dim *= 2
         x = lib.gather_pool(x, ups[layer - 1], first_only=True)                          # nearest upsample
         x = torch.cat([x, skip_x.pop()], 1)
-        x = self._unary(x, sd["decoder_blocks.1.mlp.weight"])
+        x = self._unary(x, "decoder_blocks.1.")
         return lib.linear_ex(x, self.coarse_w, bias=sd["coarse_out.bias"])

@@ -46,16 +46,44 @@ class _Linear(torch.autograd.Function):
 
 class _KPGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, q, s, idx, kp, extent):
+    def forward(ctx, x, q, s, idx, kp, extent, influence="linear", aggregation="sum"):
         xd = x.detach().float().contiguous()
         ctx.save_for_backward(xd, q, s, idx, kp)
-        ctx.extent = extent
-        return lib.kpconv_gather(q, s, idx, xd, kp, extent)
+        ctx.cfg = (extent, influence, aggregation)
+        return lib.kpconv_gather(q, s, idx, xd, kp, extent, influence, aggregation)
 
     @staticmethod
     def backward(ctx, g):
         x, q, s, idx, kp = ctx.saved_tensors
-        return lib.kpconv_gather_backward(q, s, idx, x, kp, ctx.extent, g.contiguous().float()), None, None, None, None, None
+        extent, influence, aggregation = ctx.cfg
+        return lib.kpconv_gather_backward(q, s, idx, x, kp, extent, g.contiguous().float(), influence, aggregation), None, None, None, None, None, None, None
+
+
+class _BiasAct(torch.autograd.Function):
+    """act( (a + bias_a) + [(b + bias_b) | b | 0] ): the BatchNormBlock of use_batch_norm = False (a bias per channel, blocks.py:445-446) + LeakyReLU(0.1)
+    + the residual sum.  Forward = dr_norm_apply_f32 with (mean, rstd) = (-bias, 1); backward: the LeakyReLU's slope read off the output's sign (torch
+    element-wise glue) and column sums for the biases."""
+
+    @staticmethod
+    def forward(ctx, a, bias_a, b, bias_b, activate):
+        ad = a.detach().float().contiguous()
+        bd = b.detach().float().contiguous() if b is not None else None
+        one = torch.ones_like(bias_a.detach())
+        sb = ((-bias_b.detach()).contiguous(), one) if bias_b is not None else None
+        out = lib.norm_apply(ad, ((-bias_a.detach()).contiguous(), one), bd, sb, activate=activate)
+        ctx.save_for_backward(out)
+        ctx.cfg = (b is not None, bias_b is not None, activate)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        has_b, has_bb, act = ctx.cfg
+        g = g.contiguous().float()
+        if act:
+            g = torch.where(out > 0, g, g * 0.1)
+        gs = g.sum(0)
+        return g, gs, (g if has_b else None), (gs if has_bb else None), None
 
 
 class _Norm(torch.autograd.Function):
@@ -119,9 +147,17 @@ def kpfcn_coarse(module, batch, arch=None, cfg=None):
     r = cfg["first_subsampling_dl"] * cfg["conv_radius"]
     skips, skip_x = [], []
 
+    influence, aggregation, use_bn = cfg.get("KP_influence", "linear"), cfg.get("aggregation_mode", "sum"), bool(cfg.get("use_batch_norm", True))
+
     def kpconv(pre, q, s, idx, y, extent):
-        wf = _KPGather.apply(y, q, s, idx, P[pre + "KPConv.kernel_points"].detach().float().contiguous(), extent)
+        wf = _KPGather.apply(y, q, s, idx, P[pre + "KPConv.kernel_points"].detach().float().contiguous(), extent, influence, aggregation)
         return _Linear.apply(wf, _w2(P[pre + "KPConv.weights"]), None)
+
+    def norm(a, key_a, b=None, key_b=None, norm_b=False):
+        """the BatchNormBlock(s) + LeakyReLU + residual sum of a block: InstanceNorm statistics, or the bias form of use_batch_norm = False"""
+        if use_bn:
+            return _Norm.apply(a, b, norm_b, True)
+        return _BiasAct.apply(a, P[key_a], b, P[key_b] if (b is not None and norm_b) else None, True)
 
     for bi, block in enumerate(arch):
         if any(t in block for t in ("pool", "strided", "upsample", "global")):
@@ -135,23 +171,23 @@ def kpfcn_coarse(module, batch, arch=None, cfg=None):
         strided = "strided" in block
         q, s, idx = (pts[layer + 1], pts[layer], pools[layer]) if strided else (pts[layer], pts[layer], nb[layer])
         if block == "simple":
-            x = _Norm.apply(kpconv(pre, q, s, idx, x, extent), None, False, True)
+            x = norm(kpconv(pre, q, s, idx, x, extent), pre + "batch_norm.bias")
         else:
             feats = x
             y = feats
             if (pre + "unary1.mlp.weight") in P:
-                y = _Norm.apply(_Linear.apply(feats, P[pre + "unary1.mlp.weight"], None), None, False, True)
-            y = _Norm.apply(kpconv(pre, q, s, idx, y, extent), None, False, True)
+                y = norm(_Linear.apply(feats, P[pre + "unary1.mlp.weight"], None), pre + "unary1.batch_norm.bias")
+            y = norm(kpconv(pre, q, s, idx, y, extent), pre + "batch_norm_conv.bias")
             y = _Linear.apply(y, P[pre + "unary2.mlp.weight"], None)                       # unary2: norm only (no_relu)
             sc = _Pool.apply(feats, idx, False) if strided else feats
             if (pre + "unary_shortcut.mlp.weight") in P:
                 sc = _Linear.apply(sc, P[pre + "unary_shortcut.mlp.weight"], None)
-                x = _Norm.apply(y, sc, True, True)                                           # lrelu(norm(y) + norm(sc))
+                x = norm(y, pre + "unary2.batch_norm.bias", sc, pre + "unary_shortcut.batch_norm.bias", True)   # lrelu(norm(y) + norm(sc))
             else:
-                x = _Norm.apply(y, sc, False, True)                                          # lrelu(norm(y) + feats)
+                x = norm(y, pre + "unary2.batch_norm.bias", sc, None, False)                 # lrelu(norm(y) + feats)
         if "pool" in block or "strided" in block:
             layer += 1; r *= 2
     x = _Pool.apply(x, ups[layer - 1], True)                                                 # nearest upsample
     x = torch.cat([x, skip_x.pop()], 1)
-    x = _Norm.apply(_Linear.apply(x, P["decoder_blocks.1.mlp.weight"], None), None, False, True)
+    x = norm(_Linear.apply(x, P["decoder_blocks.1.mlp.weight"], None), "decoder_blocks.1.batch_norm.bias")
     return _Linear.apply(x, P["coarse_out.weight"][:, :, 0], P["coarse_out.bias"])

@@ -119,6 +119,10 @@ SIGNATURES.update({
     "dr_linear_ex_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dr_kpconv_gather_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_void_p]),
+    "dr_kpconv_gather_mode_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                          c_int, c_int, c_void_p, c_int, c_void_p]),
+    "dr_kpconv_gather_backward_mode_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                   c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "dr_col_stats_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dr_col_stats_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dr_norm_apply_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
@@ -747,16 +751,19 @@ def linear_ex(x, W, bias=None, epilogue=0, scale=1.0, K=None):
     return out
 
 
-def kpconv_gather(q_pts, s_pts, neighb_inds, x, kernel_points, extent):
-    """-> weighted features [Nq, ceil4(K*Cin)] (see dr_kpconv_gather_f32)"""
+KP_INFLUENCE = {"constant": 0, "linear": 1, "gaussian": 2}
+
+
+def kpconv_gather(q_pts, s_pts, neighb_inds, x, kernel_points, extent, influence="linear", aggregation="sum"):
+    """-> weighted features [Nq, ceil4(K*Cin)] (see dr_kpconv_gather_mode_f32; KP_influence / aggregation_mode of blocks.py:304-326)"""
     ensure_init()
     Nq, H = neighb_inds.shape
     K, Cin = kernel_points.shape[0], x.shape[1]
     ld = (K * Cin + 3) // 4 * 4
     out = torch.empty(Nq, ld, device=x.device)
-    check(_lib.dr_kpconv_gather_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()),
-                                    ptr(neighb_inds.contiguous()), ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent),
-                                    ptr(out), ld, stream_of(x)))
+    check(_lib.dr_kpconv_gather_mode_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()),
+                                         ptr(neighb_inds.contiguous()), ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent),
+                                         KP_INFLUENCE[influence], {"sum": 0, "closest": 1}[aggregation], ptr(out), ld, stream_of(x)))
     return out
 
 
@@ -793,15 +800,17 @@ def gather_pool(x, inds, first_only=False):
     return out
 
 
-def kpconv_gather_backward(q_pts, s_pts, neighb_inds, x, kernel_points, extent, grad_weighted):
+def kpconv_gather_backward(q_pts, s_pts, neighb_inds, x, kernel_points, extent, grad_weighted, influence="linear", aggregation="sum"):
     """d loss / d x [Ns, Cin] of kpconv_gather (grad_weighted [Nq, ceil4(K*Cin)])"""
     ensure_init()
     Nq, H = neighb_inds.shape
     K, Cin = kernel_points.shape[0], x.shape[1]
     gw = grad_weighted.contiguous()
     gx = torch.empty_like(x)
-    check(_lib.dr_kpconv_gather_backward_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()), ptr(neighb_inds.contiguous()),
-                                             ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent), ptr(gw), gw.shape[1], ptr(gx), stream_of(x)))
+    check(_lib.dr_kpconv_gather_backward_mode_f32(Nq, s_pts.shape[0], H, Cin, K, ptr(q_pts.contiguous()), ptr(s_pts.contiguous()),
+                                                  ptr(neighb_inds.contiguous()), ptr(x.contiguous()), ptr(kernel_points.contiguous()), float(extent),
+                                                  KP_INFLUENCE[influence], {"sum": 0, "closest": 1}[aggregation], ptr(gw), gw.shape[1], ptr(gx),
+                                                  stream_of(x)))
     return gx
 
 

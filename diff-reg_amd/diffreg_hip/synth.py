@@ -417,3 +417,9 @@ def deform_targets(pair, coarse_flow, dtype=np.float32):
     s = pair["s_pcd"].astype(np.float64) + coarse_flow.astype(np.float64)
     tp[gt[:, 1]] = s[gt[:, 0]] @ pair["R_gt"].T + pair["t_gt"]
     return tp.astype(dtype)
+
+
+def make_kpfcn_bn_biases(keys_shapes, seed=5):
+    """the `bias` parameters of the BatchNormBlocks of a KPFCN built with use_batch_norm = False (3D/models/blocks.py:430-446), hash-generated:
+    keys_shapes = [(state-dict key, shape)], in sorted key order"""
+    return {k: (hash_uniform(seed, 7000 + i, tuple(shape)) * 0.2).astype(np.float32) for i, (k, shape) in enumerate(sorted(keys_shapes))}

@@ -24,25 +24,37 @@ class KPConv(nn.Module):                        # parameters of 3D/models/blocks
         self.kernel_points = nn.Parameter(torch.zeros(K, 3), requires_grad=False)
 
 
-class UnaryBlock(nn.Module):                    # blocks.py:455-484 (its BatchNormBlock is an InstanceNorm1d without parameters)
-    def __init__(self, cin, cout):
+class BiasBlock(nn.Module):                     # BatchNormBlock with use_bn = False: a bias per channel (blocks.py:430-446); with use_bn it is an
+    def __init__(self, dim):                    # InstanceNorm1d without parameters and this module is not created
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class UnaryBlock(nn.Module):                    # blocks.py:455-484
+    def __init__(self, cin, cout, use_bn=True):
         super().__init__()
         self.mlp = nn.Linear(cin, cout, bias=False)
+        if not use_bn:
+            self.batch_norm = BiasBlock(cout)
 
 
 class SimpleBlock(nn.Module):                   # blocks.py:518-572
-    def __init__(self, K, cin, cout):
+    def __init__(self, K, cin, cout, use_bn=True):
         super().__init__()
         self.KPConv = KPConv(K, cin, cout // 2)
+        if not use_bn:
+            self.batch_norm = BiasBlock(cout // 2)
 
 
 class ResnetBottleneckBlock(nn.Module):         # blocks.py:575-660
-    def __init__(self, K, cin, cout):
+    def __init__(self, K, cin, cout, use_bn=True):
         super().__init__()
-        self.unary1 = UnaryBlock(cin, cout // 4) if cin != cout // 4 else nn.Identity()
+        self.unary1 = UnaryBlock(cin, cout // 4, use_bn) if cin != cout // 4 else nn.Identity()
         self.KPConv = KPConv(K, cout // 4, cout // 4)
-        self.unary2 = UnaryBlock(cout // 4, cout)
-        self.unary_shortcut = UnaryBlock(cin, cout) if cin != cout else nn.Identity()
+        if not use_bn:
+            self.batch_norm_conv = BiasBlock(cout // 4)
+        self.unary2 = UnaryBlock(cout // 4, cout, use_bn)
+        self.unary_shortcut = UnaryBlock(cin, cout, use_bn) if cin != cout else nn.Identity()
 
 
 class NearestUpsampleBlock(nn.Module):          # blocks.py:676-691 (no parameters)
@@ -58,11 +70,14 @@ class KPFCN(nn.Module):
         self.cfg = dict(num_layers=_get(config, "num_layers"), in_points_dim=3, first_feats_dim=_get(config, "first_feats_dim"),
                         first_subsampling_dl=_get(config, "first_subsampling_dl"), in_feats_dim=_get(config, "in_feats_dim"),
                         conv_radius=_get(config, "conv_radius"), num_kernel_points=K, KP_extent=_get(config, "KP_extent"),
-                        coarse_feature_dim=_get(config, "coarse_feature_dim"))
-        if _get(config, "KP_influence") != "linear" or _get(config, "aggregation_mode") != "sum" or _get(config, "deformable") \
-                or not _get(config, "use_batch_norm"):
-            raise NotImplementedError("only the shipped KPFCN configuration (linear influence, sum aggregation, rigid kernels, "
-                                      "use_batch_norm) is accelerated")
+                        coarse_feature_dim=_get(config, "coarse_feature_dim"), KP_influence=_get(config, "KP_influence"),
+                        aggregation_mode=_get(config, "aggregation_mode"), use_batch_norm=bool(_get(config, "use_batch_norm")))
+        if self.cfg["KP_influence"] not in ("constant", "linear", "gaussian") or self.cfg["aggregation_mode"] not in ("sum", "closest"):
+            raise ValueError("KP_influence / aggregation_mode: %r / %r" % (self.cfg["KP_influence"], self.cfg["aggregation_mode"]))   # (blocks.py:321, 329)
+        if _get(config, "deformable") or any("deformable" in b for b in arch):
+            raise NotImplementedError("deformable KPConv (offset convolutions + their regulariser, blocks.py:214-286) is not accelerated: no shipped "
+                                      "configuration selects it")
+        use_bn = self.cfg["use_batch_norm"]
         # ---- the reference's construction order (backbone.py:13-112), parameters only --------------------------------
         layer, in_dim, out_dim = 0, _get(config, "in_feats_dim"), _get(config, "first_feats_dim")
         self.encoder_blocks = nn.ModuleList()
@@ -73,7 +88,7 @@ class KPFCN(nn.Module):
             if "upsample" in block:
                 start = bi
                 break
-            self.encoder_blocks.append(SimpleBlock(K, in_dim, out_dim) if "simple" in block else ResnetBottleneckBlock(K, in_dim, out_dim))
+            self.encoder_blocks.append(SimpleBlock(K, in_dim, out_dim, use_bn) if "simple" in block else ResnetBottleneckBlock(K, in_dim, out_dim, use_bn))
             in_dim = out_dim // 2 if "simple" in block else out_dim
             if "pool" in block or "strided" in block:
                 layer += 1; out_dim *= 2
@@ -84,7 +99,7 @@ class KPFCN(nn.Module):
         for di, block in enumerate(arch[start:]):
             if di > 0 and "upsample" in arch[start + di - 1]:
                 in_dim += skip_dims[layer]
-            self.decoder_blocks.append(NearestUpsampleBlock() if "upsample" in block else UnaryBlock(in_dim, out_dim))
+            self.decoder_blocks.append(NearestUpsampleBlock() if "upsample" in block else UnaryBlock(in_dim, out_dim, use_bn))
             in_dim = out_dim
             if "upsample" in block:
                 layer -= 1; out_dim //= 2

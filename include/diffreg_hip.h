@@ -237,6 +237,15 @@ int dr_linear_ex_f32(int rows, int ncols, int K, const float* x, int lda, const 
 int dr_kpconv_gather_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts,
                          const int64_t* neighb_inds, const float* x, const float* kernel_points, float extent,
                          float* weighted, int ld_weighted, void* stream);
+/* the same with the options of KPConv no shipped yaml selects (blocks.py:304-326; ABI 0.2.1): influence DR_KP_CONSTANT (every neighbour weighs 1),
+ * DR_KP_LINEAR (dr_kpconv_gather_f32) or DR_KP_GAUSSIAN (exp(-d^2 / (2 (0.3 extent)^2 + 1e-9))); closest != 0 = aggregation_mode 'closest': a
+ * neighbour contributes through its nearest kernel point only (first minimum, as torch.argmin). */
+#define DR_KP_CONSTANT 0
+#define DR_KP_LINEAR 1
+#define DR_KP_GAUSSIAN 2
+int dr_kpconv_gather_mode_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
+                              const float* x, const float* kernel_points, float extent, int influence, int closest, float* weighted,
+                              int ld_weighted, void* stream);
 size_t dr_col_stats_workspace_bytes(int N, int C);
 int dr_col_stats_f32(int N, int C, const float* x, int ldx, float* mean, float* rstd, void* workspace,
                      size_t workspace_bytes, void* stream);
@@ -255,6 +264,9 @@ int dr_gather_pool_f32(int n2, int H, int ld_inds, int d, const float* x, int n1
 int dr_kpconv_gather_backward_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
                                   const float* x, const float* kernel_points, float extent, const float* grad_weighted, int ld_weighted,
                                   float* grad_x, void* stream);
+int dr_kpconv_gather_backward_mode_f32(int Nq, int Ns, int H, int Cin, int K, const float* q_pts, const float* s_pts, const int64_t* neighb_inds,
+                                       const float* x, const float* kernel_points, float extent, int influence, int closest,
+                                       const float* grad_weighted, int ld_weighted, float* grad_x, void* stream);
 size_t dr_norm_backward_workspace_bytes(int N, int C);
 int dr_norm_backward_f32(int N, int C, const float* grad_out, int ldg, const float* out, int ldo, const float* a, int lda, const float* mean_a,
                          const float* rstd_a, const float* b, int ldb, const float* mean_b, const float* rstd_b, float leaky_slope, int activate,
