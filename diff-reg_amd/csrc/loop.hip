@@ -278,6 +278,17 @@ static PgW pgw_blocks(const PgW& v, int b0, int C) {
     r.img += (size_t)b0 * v.nct * pgemm_bn(C) * 64; r.cinv += (size_t)b0 * pgemm_bn(C); r.wnorm += b0;
     return r;
 }
+// exchange region of a problem whose launch may split its k range over two workgroups (pgemm.h: xk_buf).  The buffer holds PG_XK_MAX_RB units --
+// one per 64-row block of a LayerNorm launch / per 128 x 288 tile of a wide-wave launch; the problems of a launch take consecutive regions
+// (`next`: units handed out so far in this launch); the caller advances pw.xk_epoch once per launch that got regions.
+static void xk_assign(const PlanesWs& pw, int C, PgProblem& p, size_t& next, size_t units) {
+    if (!pw.xk_buf || next + units > (size_t)PG_XK_MAX_RB) return;
+    p.xk_buf = pw.xk_buf + next * (pgemm_xk_buf_bytes(pgemm_bn(C)) / 4 / PG_XK_MAX_RB); p.xk_flags = pw.xk_flags + next * 2; p.xk_cap = (int)units;
+    p.xk_epoch = pw.xk_epoch + 1; p.xk_status = pw.status;
+    next += units;
+}
+static size_t xk_wide_units(const PgProblem& p) { return (size_t)(p.rows + 127) / 128 * p.nblk * 2; }
+
 static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, const Tok& xin, int xs, const Tok& yin, int ys,
                              const Tok& out, const Family& f1, const Family* f2, hipStream_t st, const float* kv_cached = nullptr,
                              float* kv_store = nullptr) {
@@ -288,16 +299,12 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
     auto nrows = [&](int side) { return side == SIDE_TGT ? PM : PN; };
     auto at = [&](char* img, size_t side_off, int side) { return img + (side == SIDE_TGT ? side_off : 0); };
     PgBatch g;
-    auto reset = [&]() { memset(&g, 0, sizeof(g)); };
+    size_t xk_next = 0;                   // exchange units handed to the problems of the launch being assembled
+    auto reset = [&]() { memset(&g, 0, sizeof(g)); xk_next = 0; };
     auto add = [&]() -> PgProblem& { return g.p[g.n++]; };
     auto for_sides = [&](int mask, auto fn) { for (int side = 1; side <= 2; ++side) if (mask & side) fn(side); };
     // KSPLIT exchange region of a LayerNorm problem (launch_pgemm decides whether the launch is split): the tgt side's row blocks behind the src side's
-    auto xk = [&](PgProblem& p, int side) {
-        if (!pw.xk_buf) return;
-        const size_t rb0 = side == SIDE_TGT ? (size_t)(PN + 63) / 64 : 0;
-        p.xk_buf = pw.xk_buf + rb0 * (pgemm_xk_buf_bytes(pgemm_bn(C)) / 4 / PG_XK_MAX_RB); p.xk_flags = pw.xk_flags + rb0 * 2;
-        p.xk_epoch = pw.xk_epoch + 1; p.xk_status = pw.status;
-    };
+    auto xk = [&](PgProblem& p, size_t units) { xk_assign(pw, C, p, xk_next, units); };
     int rc;
     bool rc_ok = true;
 
@@ -325,10 +332,12 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.pimg = at(img, pw.side_att, side); p.p_nct = nq; p.pbnd = bnd + r0(side);
         p.pimg_blk_stride = (long long)pw.qkv_stride; p.pbnd_blk_stride = T;
         p.grp_bnd = grp_inline ? nullptr : pw.grp_x; p.grp_mask = grpm; p.grp_first = side == SIDE_TGT ? X.P : 0; p.grp_rows = side == SIDE_TGT ? X.M : X.N;
+        if (p.W.sub == 2) xk(p, xk_wide_units(p));
     };
     reset();
     if (kv_store) {
         for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_img, kv_bnd, 1, 3); });
+        ++pw.xk_epoch;
         return launch_pgemm(g, st);
     }
     const bool self = xs == ys && xin.img == yin.img && !cached;
@@ -338,6 +347,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         for_sides(xs, [&](int side) { proj(xin, side, 0, 1, pw.qkv_img, pw.qkv_bnd, 1, 0); });
         if (!cached) for_sides(ys, [&](int side) { proj(yin, side, 1, 2, kv_img, kv_bnd, 1, 3); });
     }
+    ++pw.xk_epoch;
     rc = launch_pgemm(g, st);
     if (rc) return rc;
 
@@ -371,7 +381,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.W = L.merge; p.nblk = 1; p.rows = nrows(side); p.C = C; p.mode = PG_LN; p.k_alg = C;
         p.gamma = W.norm1_w; p.beta = W.norm1_b; p.lnB = L.lnB1;
         p.pimg = at(pw.msg_img, pw.side_C, side); p.p_nct = nC; p.pbnd = pw.msg_bnd + r0(side);
-        xk(p, side);
+        xk(p, (size_t)(p.rows + 63) / 64);
     });
     ++pw.xk_epoch;
     rc = launch_pgemm(g, st);
@@ -384,7 +394,9 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.A1 = at(pw.msg_img, pw.side_C, side); p.bnd1 = pw.msg_bnd + r0(side); p.nc1 = nC;
         p.W = L.mlp0; p.nblk = 2; p.rows = nrows(side); p.C = C; p.mode = PG_PLANES; p.relu = 1; p.scale = 1.f;
         p.pimg = at(pw.hid_img, pw.side_hid, side); p.p_nct = 2 * nC; p.pbnd = pw.hid_bnd + r0(side);
+        if (p.W.sub == 2) xk(p, xk_wide_units(p));
     });
+    ++pw.xk_epoch;
     rc = launch_pgemm(g, st);
     if (rc) return rc;
     // ---- out = x + norm2(mlp2(hidden)) -> fp32 rows (the residual stream) + plane image (the next GEMMs' operand)
@@ -397,7 +409,7 @@ static int layer_call_planes(const PlCtx& X, const dr_layer_weights& W, int l, c
         p.resid = xin.f32 + (size_t)r0(side) * C; p.ldr = C; p.bnd_res = xin.bnd + r0(side);
         p.out = out.f32 + (size_t)r0(side) * C; p.ldo = C;
         p.pimg = at(out.img, pw.side_C, side); p.p_nct = nC; p.pbnd = out.bnd + r0(side);
-        xk(p, side);
+        xk(p, (size_t)(p.rows + 63) / 64);
     });
     ++pw.xk_epoch;
     return launch_pgemm(g, st);
@@ -508,6 +520,7 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
         // matching head: src_proj on BOTH sides (quirk Q1), rotary, / sqrt(C)
         PgBatch g;
         memset(&g, 0, sizeof(g));
+        size_t xk_next = 0;
         for (int side = 1; side <= 2; ++side) {
             PgProblem& p = g.p[g.n++];
             const int r0 = side == SIDE_TGT ? PN : 0;
@@ -516,7 +529,9 @@ static int denoiser_and_sim(const dr_loop_config& cfg, const dr_loop_weights& w,
             p.out = ws.proj + (size_t)r0 * C; p.ldo = C; p.blk_stride = 0; p.rot_mask = 1; p.rot_C = C; p.scale = 1.0f / sqrtf((float)C);
             p.cosT = ws.cosT + (size_t)r0 * (C / 2); p.sinT = ws.sinT + (size_t)r0 * (C / 2);
             p.csT = ws.pl.csT + (size_t)r0 * C;
+            if (p.W.sub == 2) xk_assign(ws.pl, C, p, xk_next, xk_wide_units(p));
         }
+        ++ws.pl.xk_epoch;
         int rc = launch_pgemm(g, st);
         if (rc) return rc;
         GemmBatch gs;

@@ -61,10 +61,12 @@ struct PgProblem {
     const float* bias; const float* bias_max;
     // PG_LN launches of 64-row workgroups that would leave half the chip idle (launch_pgemm decides: `ksplit`): the k range of a row block is
     // SPLIT over two workgroups (ids 8 apart: the same XCD), each keeps 16 of a wave's 32 rows and hands the other 16 rows' partial sums to
-    // its partner through xk_buf [row block][destination half][4 waves][TNW][2][64 lanes] float4 (sc1 accesses); xk_flags [row block][2] holds
+    // its partner through xk_buf [tile][destination half][4 waves][9][2][64 lanes] float4 (sc1 accesses; the wide-wave kernel splits its 128 x 288 tiles the
+    // same way: two of a wave's four rounds); xk_flags [tile][2] holds
     // the epoch of the last launch whose half has been written (zeroed by the owner of the workspace before the first launch; xk_epoch counts
     // the launches that use the buffer since then).  xk_status: the caller's sticky status word (bit 1 = a partner did not arrive; nullable).
     float* xk_buf; unsigned* xk_flags; unsigned xk_epoch; unsigned* xk_status; int ksplit;
+    int xk_cap;                         // exchange units (one per split tile: 64-row block / 128 x 288 tile) this problem's xk_buf / xk_flags hold
 };
 constexpr int PG_XK_MAX_RB = 160;                                  // row blocks (of 64 rows) a split launch can have: xk_buf / xk_flags are sized for it
 inline size_t pgemm_xk_buf_bytes(int bn) { return (size_t)PG_XK_MAX_RB * 2 * 4 * (bn / 64) * 2 * 64 * 16; }

@@ -996,11 +996,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
 
     const PgProblem& P = G.p[blockIdx.y];
-    const int rows = P.rows, C = P.C, nblk = P.nblk, nc0 = P.nc0, nc1 = P.A1 ? P.nc1 : 0, nst = nc0 + nc1;
-    const int rbs = (rows + BM - 1) / BM, nb2 = 2 * nblk;
+    // KSPLIT (launches of at most half a chip of tiles: cfg3's one-sided mlp0): a tile's k range is split over TWO workgroups, ids 8 apart (one XCD) --
+    // a two-segment operand by segment ([x | msg]: workgroup 0 contracts x, workgroup 1 msg), a one-segment operand at an even chunk -- which swap two of a
+    // wave's four rounds of partial sums behind the main loop (see pgemm_kernel's KSPLIT) and each run half of the epilogue
+    const bool ksplit = P.ksplit != 0;
+    const int rows = P.rows, C = P.C, nblk = P.nblk, nc0f = P.nc0, nc1f = P.A1 ? P.nc1 : 0, nstf = nc0f + nc1f;
+    const int rbs = (rows + BM - 1) / BM, nb2 = 2 * nblk * (ksplit ? 2 : 1);
     const int grp = blockIdx.x / (8 * nb2), rem = blockIdx.x % (8 * nb2);
-    const int rb = grp * 8 + (rem & 7), pb = rem >> 3, nb = pb >> 1, csub = (pb & 1) * BN;
+    const int rb = grp * 8 + (rem & 7), tix = rem >> 3, khalf = ksplit ? (tix & 1) : 0, pb = ksplit ? (tix >> 1) : tix, nb = pb >> 1, csub = (pb & 1) * BN;
     if (rb >= rbs || csub >= C) return;
+    // this workgroup's chunks: [c_first, c_first + nc0) of the weight image, from A image `Aimg` (a_chunks chunks per row block) starting at chunk a_first
+    int nc0 = nc0f, nc1 = nc1f, c_first = 0, a_first = 0, a_chunks = nc0f;
+    const char* Aimg = P.A0;
+    bool to_seg1_scale = false;                                 // the accumulators of segment 0 are brought to segment 1's row scale behind the loop
+    if (ksplit) {
+        if (nc1f > 0) {
+            nc1 = 0;
+            if (khalf == 0) to_seg1_scale = true;
+            else { Aimg = P.A1; a_chunks = nc1f; c_first = nc0f; nc0 = nc1f; }
+        } else {
+            const int kb = (nc0f / 2) & ~1;
+            if (khalf == 0) nc0 = kb;
+            else { a_first = c_first = kb; nc0 = nc0f - kb; }
+        }
+    }
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), wn = w & 1, wm2 = w >> 1;
 
@@ -1035,10 +1054,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (t < BM) {
             const int row = min(rb * BM + t, rows - 1);
-            const float b0 = P.bnd0[row], b1 = nc1 > 0 ? P.bnd1[row] : 0.f;
+            const float b0 = P.bnd0[row], b1 = nc1f > 0 ? P.bnd1[row] : 0.f;
             const int e0 = scale_exp(b0);
             int e1 = e0;
-            if (nc1 > 0) e1 = scale_exp(b1);
+            if (nc1f > 0) e1 = scale_exp(b1);
             s_fac[t] = pow2i(min(max(e1 - e0, -120), 120));
             s_rinv[t] = pow2i(-e1);
             if (P.pimg) {
@@ -1073,8 +1092,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // DMA pieces of a chunk: 8 of A (two per wave) + 18 of weights (waves 0, 1: five, waves 2, 3: four, contiguous)
     const int npw = w < 2 ? 5 : 4, st0 = w < 2 ? w * 5 : 10 + (w - 2) * 4;
     const unsigned voffW = lane * 16 + st0 * 1024, voffA = lane * 16 + 2 * w * 1024;
-    const char* ga = P.A0 + (size_t)rb * nc0 * GG::A_ST;
-    const char* gb = P.W.img + (size_t)(nb * 2 + (pb & 1)) * nst * GG::B_ST;
+    const char* ga = Aimg + ((size_t)rb * a_chunks + a_first) * GG::A_ST;
+    const char* gb = P.W.img + ((size_t)(nb * 2 + (pb & 1)) * nstf + c_first) * GG::B_ST;
     const char* const ga1 = nc1 > 0 ? P.A1 + (size_t)rb * nc1 * GG::A_ST : nullptr;
     int ti = 0, tr = 0;
     auto piece = [&](int q) __attribute__((always_inline)) {            // q = 0 .. 6 of chunk ti
@@ -1200,6 +1219,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
+    // ---- KSPLIT: bring a segment-0 partial to segment 1's row scale, then swap rounds: workgroup `khalf` keeps rounds 2 khalf, 2 khalf + 1 of every
+    // wave and gives the other two to its partner (raw lane registers: identical tiling), sc1 both ways, epoch flags, bounded spin
+    if (ksplit) {
+        if (to_seg1_scale) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = s_fac[wm2 * 64 + 16 * i + l15];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) c16[i][j] *= f;
+            }
+        }
+        const int give = 1 - khalf;
+        int* const s_bad = reinterpret_cast<int*>(s_red);
+        if (t == 0) *s_bad = 0;
+        const size_t tile = (size_t)rb * (2 * nblk) + pb;
+        float* const xsend = P.xk_buf + (((tile * 2 + give) * 4 + w) * NJ * 2) * 256 + lane * 4;
+        const float* const xrecv = P.xk_buf + (((tile * 2 + khalf) * 4 + w) * NJ * 2) * 256 + lane * 4;
+        // (register arrays: constant indices only -- one copy of the loop per half)
+        auto send = [&](auto GV) __attribute__((always_inline)) {
+            constexpr int g0 = 2 * decltype(GV)::value;
+            float* const xs = xsend;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const f32x4 x = c16[g0 + r2][j];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(xs + (j * 2 + r2) * 256), "v"(x) : "memory");
+                }
+        };
+        if (give == 0) send(std::integral_constant<int, 0>{}); else send(std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const fl = P.xk_flags + tile * 2;
+        if (t == 0) __hip_atomic_store(fl + khalf, P.xk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(fl + give, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.xk_epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) { *s_bad = 1; if (P.xk_status) atomicOr(P.xk_status, 2u); }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const float poison = *s_bad != 0 ? __uint_as_float(0x7fc00000u) : 0.f;
+        auto recv = [&](auto KV) __attribute__((always_inline)) {
+            constexpr int k0 = 2 * decltype(KV)::value;
+            const float* const xr = xrecv;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    f32x4 y;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(y) : "v"(xr + (j * 2 + r2) * 256) : "memory");
+                    c16[k0 + r2][j] += y + poison;
+                }
+        };
+        if (khalf == 0) recv(std::integral_constant<int, 0>{}); else recv(std::integral_constant<int, 1>{});
+        __syncthreads();
+    }
+    auto skip = [&](int rr) __attribute__((always_inline)) { return ksplit && (rr >> 1) != khalf; };
+
     // ---- epilogue: lane (l15, g) holds columns 4 g .. 4 g + 3 of row l15 of every 16 x 16 tile: row lr = l15, float4 q = g of piece i = tile column
     const int lr = l15, q = g;
     constexpr int NR = 4, NIE = NJ;
@@ -1258,7 +1340,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             v[rr][i] = x;
         }
     };
-    {
+    if (ksplit) {
+        // (half of the rounds: the pair this workgroup keeps)
+        float4 tb0[NIE], tb1[NIE];
+        const int r0 = 2 * khalf;
+        if (khalf == 0) {
+            if (rot) { load_tables(0, tb0); load_tables(1, tb1); }
+            scale_round(0, v[0]); scale_round(1, v[1]);
+            finish_round(0, tb0); finish_round(1, tb1);
+        } else {
+            if (rot) { load_tables(2, tb0); load_tables(3, tb1); }
+            scale_round(2, v[2]); scale_round(3, v[3]);
+            finish_round(2, tb0); finish_round(3, tb1);
+        }
+        (void)r0;
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
         // every rotary table load precedes the wave's first store (vmcnt retires in order): tables of two rounds in flight at a time
         float4 tb0[NIE], tb1[NIE];
         if (rot) { load_tables(0, tb0); load_tables(1, tb1); }
@@ -1280,7 +1377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float* __restrict__ outp = P.out + (size_t)nb * P.blk_stride;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
-            if (grow[rr] >= rows) continue;
+            if (grow[rr] >= rows || skip(rr)) continue;
 #pragma unroll
             for (int i = 0; i < NIE; ++i)
                 if (wcol0 + 16 * i < C) *reinterpret_cast<float4*>(outp + (size_t)grow[rr] * P.ldo + colw + 16 * i) = v[rr][i];
@@ -1289,6 +1386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (MODE == PG_F32 || !P.pimg) return;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
+        if (skip(rr)) continue;
         const bool rok = grow[rr] < rows;
         const float bound = s_bound[wrow0 + 16 * rr + lr];
         if (P.pbnd && rok && (nb == 0 || per_blk) && wcol0 == 0 && q == 0) P.pbnd[(size_t)nb * P.pbnd_blk_stride + grow[rr]] = bound;
@@ -1512,19 +1610,30 @@ static int launch_pgemm16w(const PgBatch& g, hipStream_t st) {
     double flops = 0;
     const int mode = g.p[0].mode;
     if (mode != PG_F32 && mode != PG_PLANES) return DR_ENOSUP;
+    // KSPLIT: at most half a chip of tiles, every problem with an exchange region large enough and halves of >= 5 chunks (>= 6: the split chunk is even)
+    bool ksplit = env_knob("DR_PG_KSPLIT", 1) != 0 && env_knob("DR_PG_KSPLITW", 1) != 0;
+    long tiles = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const PgProblem& p = g.p[i];
+        const long tl_ = (long)((p.rows + 127) / 128) * p.nblk * 2;
+        ksplit = ksplit && p.xk_buf && p.xk_flags && tl_ <= p.xk_cap && (p.A1 ? (p.nc0 >= 5 && p.nc1 >= 5) : p.nc0 >= 12);
+        tiles += tl_;
+    }
+    ksplit = ksplit && 2 * tiles <= (long)device_cu_count();
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
         const int nst = p.nc0 + (p.A1 ? p.nc1 : 0);
         // (a virtual chunk's slot must have held real weight planes before: segments of >= 5 chunks, as in the 16x16x32 form of pgemm_kernel)
         if (p.W.sub != 2 || !pgemm16w_shape_ok(p.C) || p.rows < 1 || p.nblk < 1 || p.nc0 < 5 || (p.A1 && p.nc1 < 5) || p.mode != mode) return DR_ENOSUP;
         if (p.W.nct != nst) return DR_EINVAL;
-        const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk * 2;
+        const int tl = ((p.rows + 127) / 128 + 7) / 8 * 8 * p.nblk * 2 * (ksplit ? 2 : 1);
         maxt = tl > maxt ? tl : maxt;
         flops += 2.0 * p.rows * p.C * p.nblk * (p.k_alg > 0 ? (double)p.k_alg : 16.0 * p.W.nct);
     }
     ProfScope ps(PK_GEMM_SPLIT, flops, st);
     PgBatch gd = g;
     gd.dbg = env_knob("DR_PG_NOEPI", 0);
+    for (int i = 0; i < g.n; ++i) gd.p[i].ksplit = ksplit ? 1 : 0;
     const dim3 grid(maxt, g.n);
     if (mode == PG_F32) hipLaunchKernelGGL((pgemm16w_kernel<PG_F32>), grid, dim3(PgGeomW::NTHR), PgGeomW::SMEM, st, gd);
     else hipLaunchKernelGGL((pgemm16w_kernel<PG_PLANES>), grid, dim3(PgGeomW::NTHR), PgGeomW::SMEM, st, gd);
@@ -1554,7 +1663,7 @@ int launch_pgemm(const PgBatch& g, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) {
         const PgProblem& p = g.p[i];
         const long rb64 = (p.rows + 63) / 64;
-        ksplit = ksplit && p.xk_buf && p.xk_flags && p.nblk == 1 && !p.A1 && p.nc0 / 2 >= nst_min && rb64 <= PG_XK_MAX_RB;
+        ksplit = ksplit && p.xk_buf && p.xk_flags && p.nblk == 1 && !p.A1 && p.nc0 / 2 >= nst_min && rb64 <= p.xk_cap;
         wg64 += rb64;
     }
     ksplit = ksplit && 2 * wg64 <= (long)n_cu;

@@ -618,3 +618,30 @@ def test_opt_in_f16_attention_is_a_bounded_deviation(golden):
     assert 1e-7 < dx <= 0.15 and dR <= 2e-2, (dx, dR)                   # different arithmetic (the mode is on), close results
     ir = [orc.inlier_ratio(e.match_list(o)[0].cpu(), p["p_s"], p["p_t"], raw["R_gt"], raw["t_gt"]) for e, o in ((e0, a), (e1, b))]
     assert abs(ir[0] - ir[1]) <= 0.1 and ir[0] > 0.2, ir
+
+
+def test_k_split_launches_agree_with_unsplit_launches(monkeypatch):
+    """launches of at most half a chip of workgroups split a tile's k range over two workgroups that swap partial sums (pgemm.h: xk_buf; the
+    LayerNorm launches and the 128 x 288 tiles of the wide-wave kernel, C = 528).  Same mathematics in another summation order: the loop with the
+    split switched off (diagnostics knob) gives the same first-step x_start to fp32 rounding and the same poses to the 1e-4 contract, the call's
+    status word stays 0, and the two runs are NOT bitwise equal (the split did run)."""
+    from diffreg_hip import lib
+    variant, N, M, steps, mc = "4dmatch", 256, 256, 3, 40
+    ps, kw = _stack_pairs(variant, N, M, [31, 32])
+    eng = engine(variant, steps, mc, family="soft", planes=True)
+    noise = torch.from_numpy(np.stack([synth.step_noise(N, M, sd, steps) for sd in (31, 32)], 1)).to(DEV)
+    run = lambda: eng.run(kw["src_feats"], kw["tgt_feats"], kw["s_pcd"], kw["t_pcd"], kw["x_T"], noise=noise, trace=True, graph=False)
+    lib.ensure_init()
+    lib.raw().dr_debug_enable_env(1)
+    try:
+        monkeypatch.setenv("DR_PG_KSPLIT", "0")
+        off = {k: v.clone() for k, v in run().items()}     # (the result tensors are the engine's buffers: the next call rewrites them)
+        monkeypatch.setenv("DR_PG_KSPLIT", "1")
+        on = run()
+    finally:
+        lib.raw().dr_debug_enable_env(0)
+    on["_status"].check()                   # raises if a partner never arrived (bit 1 of the call's status word)
+    d0 = (on["x0"][0] - off["x0"][0]).abs().max().item()
+    assert 0.0 < d0 < 2e-5, d0
+    assert (on["R_forwd"] - off["R_forwd"]).abs().max().item() < 1e-4 and (on["t_forwd"] - off["t_forwd"]).abs().max().item() < 1e-4
+    assert (on["conf_matrix_pred"] - off["conf_matrix_pred"]).abs().max().item() < 1e-4
