@@ -3,6 +3,10 @@ needs /root/reference).
 
     python oracle/make_golden_train_grads.py          # writes tests/golden/train_backward_params.npz       (stress head, HEAD_GAIN 24)
     python oracle/make_golden_train_grads.py soft     # writes tests/golden/train_backward_params_soft.npz  (HEAD_GAIN_SOFT 3: logits O(10))
+    python oracle/make_golden_train_grads.py upstream # writes tests/golden/train_backward_upstream.npz: the stress head's run once more (checked equal to
+                                                      # the params file), storing d loss / d (the denoising transformer's two outputs) in float32 / float64:
+                                                      # the gradient the six layers receive from the head (tests: the layers' backward held to 1e-3 on the
+                                                      # stress head too when it starts from the reference's upstream gradient)
 
 oracle/make_golden_train.py stores, for the denoising branch (3D/models/pipeline.py:209-212 + loss.py:160-163) and the coarse branch with the
 motion term (pipeline.py:184-196 + loss.py:97-128), the gradient NORM of every parameter and two weight gradients entry-wise.  This script
@@ -39,6 +43,7 @@ def main():
     from oracle.make_golden import ref_config, HEAD_GAIN, HEAD_GAIN_SOFT
     from oracle.make_golden_train import LOSS_CFG
     soft = len(sys.argv) > 1 and sys.argv[1] == "soft"
+    upstream = len(sys.argv) > 1 and sys.argv[1] == "upstream"
     gain = HEAD_GAIN_SOFT if soft else HEAD_GAIN
     out_path = OUT.replace(".npz", "_soft.npz") if soft else OUT
     sys.modules["open3d"] = MagicMock()
@@ -63,7 +68,7 @@ def main():
     old = np.load(os.path.join(GOLD, "train_backward.npz"))
     fwd = np.load(os.path.join(GOLD, "train_forward.npz"))
     cb = train_case("b1")
-    res = {}
+    res, up = {}, {}
     # The float64 yardstick needs ONE shim: procrustes.py:41 casts R to float32 whatever the inputs are, and the next line then mixes float32 and
     # float64 in a matmul, raises, and the bare except of :79-84 returns the identity (quirk Q3) -- the coarse branch's positioning layer would
     # silently stop fitting.  For the float64 run only, the same arithmetic with that cast following the input dtype (the float32 run below is the
@@ -103,6 +108,7 @@ def main():
         p_t, p_s = cb["p_t"].to(dt), cb["p_s"].to(dt)
         with torch.enable_grad():
             s_n, t_n, pe_s, pe_t = pipe.denoising_transformer(fs_d, ft_d, warped, p_t, cb["src_mask"], cb["tgt_mask"], {})
+            s_n.retain_grad(); t_n.retain_grad()
             hat, _ = pipe.denoising_coarse_matching(s_n, t_n, pe_s, pe_t, cb["src_mask"], cb["tgt_mask"], {}, pe_type="rotary")
             gt_d = torch.zeros_like(hat)
             gt_d[0][cb["matches"][0][0], cb["matches"][0][1]] = 1
@@ -110,6 +116,8 @@ def main():
             loss_d.backward()
         res["branch_conf" + tag], res["branch_loss" + tag] = hat.detach().numpy(), np.float64(float(loss_d))
         res["branch_grad_src" + tag], res["branch_grad_tgt" + tag] = fs_d.grad.numpy(), ft_d.grad.numpy()
+        up["branch_up_src" + tag], up["branch_up_tgt" + tag] = s_n.grad.numpy().copy(), t_n.grad.numpy().copy()
+        up["branch_out_src" + tag], up["branch_out_tgt" + tag] = s_n.detach().numpy().copy(), t_n.detach().numpy().copy()
         n_b = 0
         for k, prm in list(pipe.denoising_transformer.named_parameters()) + [("head." + k2, p2) for k2, p2 in pipe.denoising_coarse_matching.named_parameters()]:
             if prm.grad is not None:
@@ -156,6 +164,14 @@ def main():
         keep = dict(res)
     else:
         keep = {k: a for k, a in res.items() if not k.endswith("conf32") and not k.endswith("src32") and not k.endswith("tgt32") and k != "branch_loss32"}
+    if upstream:
+        have = np.load(out_path)
+        assert sorted(have.files) == sorted(keep) and all(np.array_equal(have[k], keep[k]) for k in keep), "this run differs from " + out_path
+        up_path = os.path.join(GOLD, "train_backward_upstream.npz")
+        up = {k: a for k, a in up.items() if not (k.endswith("64") and "_out_" in k)}        # (the float64 outputs are not used by any test)
+        np.savez_compressed(up_path, **up)
+        print("run equals", out_path, "-- wrote", up_path, os.path.getsize(up_path), "bytes;", sorted(up))
+        return
     np.savez_compressed(out_path, **keep)
     print("wrote", out_path, os.path.getsize(out_path), "bytes;", len(keep), "arrays")
 
