@@ -293,28 +293,38 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
 //     dL/dZ_ij = D_ij - sum_t (vb^t_j Pv^t_ij + ub^t_i Pu^t_ij);   dL/da = sum over the dustbin row and column of dL/dZ.
 // One workgroup per pair; every step is one sweep over the matrix: row quantities by one wave per row (lanes over the columns, DPP
 // reduction), column quantities by one thread per column (rows in order, coalesced): no atomics, results do not depend on scheduling.
-// The 2 T + 2 T vectors live in the workspace (L2-resident); float32 arithmetic like the training forward.
+// The 2 T + 2 T vectors live in the workspace (L2-resident), in the kernel's working type (double: see sk_backward_kernel).
 // ===============================================================================================================================
 namespace dr {
 namespace {
 
 struct SkBwdArgs {
-    const float* scores; const uint8_t* sm; const uint8_t* tm; const float* alpha; const float* gconf; float* gscores; float* galpha; float* ws;
+    const float* scores; const uint8_t* sm; const uint8_t* tm; const float* alpha; const float* gconf; float* gscores; float* galpha; void* ws;
     int N, M, iters;
 };
 
-__device__ __forceinline__ float zval(const float* __restrict__ Z, int i, int j, int N, int M, float a) {
-    return (i < N && j < M) ? Z[(size_t)i * M + j] : a;
+template <typename AT>
+__device__ __forceinline__ AT zval(const float* __restrict__ Z, int i, int j, int N, int M, AT a) {
+    return (i < N && j < M) ? (AT)Z[(size_t)i * M + j] : a;
 }
+__device__ __forceinline__ float xexp(float x) { return expf(x); }
+__device__ __forceinline__ double xexp(double x) { return exp(x); }
+__device__ __forceinline__ float xlog(float x) { return logf(x); }
+__device__ __forceinline__ double xlog(double x) { return log(x); }
 
+// AT: the type of the dual variables, of the plans' exponents and of every sum (inputs and results are float32).  The library runs AT = double:
+// at logits in the thousands (a sharp head) Z + u + v cancels three numbers of that size -- in float32 the exponent carries an absolute error of
+// their ulp (2.4e-4 at 3 000) and the gradient came out 2.7e-3 of its maximum from the float64 value (the same recurrences in torch float32:
+// 2.8e-3; torch autograd through the reference's float32 code: 1e-3); in double the step is exact to float32 rounding of its result.
+template <typename AT>
 __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
     const int N = A.N, M = A.M, T = A.iters, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = 16;
     const int pair = blockIdx.x;
     const float* __restrict__ Z = A.scores + (size_t)pair * N * M;
     const float* __restrict__ G = A.gconf + (size_t)pair * N * M;
-    const float a = *A.alpha;
+    const AT a = (AT)*A.alpha;
     __shared__ int s_cnt[2];
-    __shared__ float s_red[16];
+    __shared__ AT s_red[16];
     if (t < 2) s_cnt[t] = 0;
     __syncthreads();
     {
@@ -326,59 +336,60 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
     }
     __syncthreads();
     const int ms = s_cnt[0], ns = s_cnt[1];
-    const float norm = -logf((float)(ms + ns));
-    const float lmuN = logf((float)ns) + norm, lnuM = logf((float)ms) + norm;
+    // (the marginals are float32 numbers whatever the state's type: matching.py:69-70, 79-82 take .log() of int64 sums -- quirk Q22)
+    const float normf = -logf((float)(ms + ns));
+    const AT norm = (AT)normf, lmuN = (AT)(logf((float)ns) + normf), lnuM = (AT)(logf((float)ms) + normf);
     // workspace vectors of this pair: u[T][N+1], v[T+1][M+1] (v[0] = 0), ub[T][N+1], vb[T][M+1]
     const int R = N + 1, Cn = M + 1;
-    float* U = A.ws + (size_t)pair * ((size_t)2 * T * R + (size_t)(2 * T + 1) * Cn);
-    float* V = U + (size_t)T * R;
-    float* UB = V + (size_t)(T + 1) * Cn;
-    float* VB = UB + (size_t)T * R;
-    for (int j = t; j < Cn; j += 1024) V[j] = 0.f;
+    AT* U = reinterpret_cast<AT*>(A.ws) + (size_t)pair * ((size_t)2 * T * R + (size_t)(2 * T + 1) * Cn);
+    AT* V = U + (size_t)T * R;
+    AT* UB = V + (size_t)(T + 1) * Cn;
+    AT* VB = UB + (size_t)T * R;
+    for (int j = t; j < Cn; j += 1024) V[j] = (AT)0;
     __syncthreads();
-    auto lmu = [&](int i) { return i < N ? norm : lmuN; };
-    auto lnu = [&](int j) { return j < M ? norm : lnuM; };
+    auto lmu = [&](int i) -> AT { return i < N ? norm : lmuN; };
+    auto lnu = [&](int j) -> AT { return j < M ? norm : lnuM; };
 
     // ---- forward, keeping every u^t, v^t
     for (int it = 1; it <= T; ++it) {
-        const float* vp = V + (size_t)(it - 1) * Cn;
-        float* un = U + (size_t)(it - 1) * R;
+        const AT* vp = V + (size_t)(it - 1) * Cn;
+        AT* un = U + (size_t)(it - 1) * R;
         for (int i = w; i < R; i += NW) {                        // u^t: one wave per row, online log-sum-exp over the columns
-            float mx = -INFINITY, s = 0.f;
+            AT mx = -INFINITY, s = 0;
             for (int j = lane; j < Cn; j += 64) {
-                const float x = zval(Z, i, j, N, M, a) + vp[j];
-                if (x > mx) { s = s * expf(mx - x) + 1.f; mx = x; } else if (x > -INFINITY) s += expf(x - mx);
+                const AT x = zval<AT>(Z, i, j, N, M, a) + vp[j];
+                if (x > mx) { s = s * xexp(mx - x) + (AT)1; mx = x; } else if (x > -INFINITY) s += xexp(x - mx);
             }
-            const float gm = wave_max(mx);
-            s = (mx > -INFINITY) ? s * expf(mx - gm) : 0.f;
+            const AT gm = wave_max(mx);
+            s = (mx > -INFINITY) ? s * xexp(mx - gm) : (AT)0;
             s = wave_sum(s);
-            if (lane == 0) un[i] = lmu(i) - (gm + logf(s));
+            if (lane == 0) un[i] = lmu(i) - (gm + xlog(s));
         }
         __threadfence_block();
         __syncthreads();
-        float* vn = V + (size_t)it * Cn;
+        AT* vn = V + (size_t)it * Cn;
         for (int j = t; j < Cn; j += 1024) {                     // v^t: one thread per column, rows in order
-            float mx = -INFINITY, s = 0.f;
+            AT mx = -INFINITY, s = 0;
             for (int i = 0; i < R; ++i) {
-                const float x = zval(Z, i, j, N, M, a) + un[i];
-                if (x > mx) { s = s * expf(mx - x) + 1.f; mx = x; } else if (x > -INFINITY) s += expf(x - mx);
+                const AT x = zval<AT>(Z, i, j, N, M, a) + un[i];
+                if (x > mx) { s = s * xexp(mx - x) + (AT)1; mx = x; } else if (x > -INFINITY) s += xexp(x - mx);
             }
-            vn[j] = lnu(j) - (mx + logf(s));
+            vn[j] = lnu(j) - (mx + xlog(s));
         }
         __threadfence_block();
         __syncthreads();
     }
     // ---- backward vectors
-    const float* uT = U + (size_t)(T - 1) * R;
-    const float* vT = V + (size_t)T * Cn;
+    const AT* uT = U + (size_t)(T - 1) * R;
+    const AT* vT = V + (size_t)T * Cn;
     {   // vb^T_j = sum_i D_ij  (D = 0 on the dustbin row / column)
-        float* vb = VB + (size_t)(T - 1) * Cn;
+        AT* vb = VB + (size_t)(T - 1) * Cn;
         for (int j = t; j < Cn; j += 1024) {
-            float s = 0.f;
+            AT s = 0;
             if (j < M)
                 for (int i = 0; i < N; ++i) {
-                    const float z = Z[(size_t)i * M + j];
-                    if (z > -INFINITY) s += expf(z + uT[i] + vT[j] - norm) * G[(size_t)i * M + j];
+                    const AT z = (AT)Z[(size_t)i * M + j];
+                    if (z > -INFINITY) s += xexp(z + uT[i] + vT[j] - norm) * (AT)G[(size_t)i * M + j];
                 }
             vb[j] = s;
         }
@@ -386,18 +397,18 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
         __syncthreads();
     }
     for (int it = T; it >= 1; --it) {
-        const float* u = U + (size_t)(it - 1) * R;
-        const float* v = V + (size_t)it * Cn;
-        const float* vprev = V + (size_t)(it - 1) * Cn;
-        const float* vb = VB + (size_t)(it - 1) * Cn;
-        float* ub = UB + (size_t)(it - 1) * R;
+        const AT* u = U + (size_t)(it - 1) * R;
+        const AT* v = V + (size_t)it * Cn;
+        const AT* vprev = V + (size_t)(it - 1) * Cn;
+        const AT* vb = VB + (size_t)(it - 1) * Cn;
+        AT* ub = UB + (size_t)(it - 1) * R;
         for (int i = w; i < R; i += NW) {                        // ub^t_i = [t == T] sum_j D_ij - sum_j vb^t_j Pv^t_ij
-            float s = 0.f;
+            AT s = 0;
             for (int j = lane; j < Cn; j += 64) {
-                const float z = zval(Z, i, j, N, M, a);
+                const AT z = zval<AT>(Z, i, j, N, M, a);
                 if (z > -INFINITY) {
-                    s -= vb[j] * expf(z + u[i] + v[j] - lnu(j));
-                    if (it == T && i < N && j < M) s += expf(z + u[i] + v[j] - norm) * G[(size_t)i * M + j];
+                    s -= vb[j] * xexp(z + u[i] + v[j] - lnu(j));
+                    if (it == T && i < N && j < M) s += xexp(z + u[i] + v[j] - norm) * (AT)G[(size_t)i * M + j];
                 }
             }
             s = wave_sum(s);
@@ -406,12 +417,12 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
         __threadfence_block();
         __syncthreads();
         if (it > 1) {                                            // vb^{t-1}_j = - sum_i ub^t_i Pu^t_ij
-            float* vbp = VB + (size_t)(it - 2) * Cn;
+            AT* vbp = VB + (size_t)(it - 2) * Cn;
             for (int j = t; j < Cn; j += 1024) {
-                float s = 0.f;
+                AT s = 0;
                 for (int i = 0; i < R; ++i) {
-                    const float z = zval(Z, i, j, N, M, a);
-                    if (z > -INFINITY) s -= ub[i] * expf(z + vprev[j] + u[i] - lmu(i));
+                    const AT z = zval<AT>(Z, i, j, N, M, a);
+                    if (z > -INFINITY) s -= ub[i] * xexp(z + vprev[j] + u[i] - lmu(i));
                 }
                 vbp[j] = s;
             }
@@ -420,20 +431,20 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
         }
     }
     // ---- dL/dZ in one sweep; the dustbin entries go to dL/dalpha (wave partials in fixed order)
-    float ga = 0.f;
+    AT ga = 0;
     for (int i = w; i < R; i += NW) {
         for (int j = lane; j < Cn; j += 64) {
-            const float z = zval(Z, i, j, N, M, a);
-            float g = 0.f;
+            const AT z = zval<AT>(Z, i, j, N, M, a);
+            AT g = 0;
             if (z > -INFINITY) {
-                if (i < N && j < M) g = expf(z + uT[i] + vT[j] - norm) * G[(size_t)i * M + j];
+                if (i < N && j < M) g = xexp(z + uT[i] + vT[j] - norm) * (AT)G[(size_t)i * M + j];
                 for (int it = 1; it <= T; ++it) {
-                    const float ui = U[(size_t)(it - 1) * R + i];
-                    g -= VB[(size_t)(it - 1) * Cn + j] * expf(z + ui + V[(size_t)it * Cn + j] - lnu(j));
-                    g -= UB[(size_t)(it - 1) * R + i] * expf(z + V[(size_t)(it - 1) * Cn + j] + ui - lmu(i));
+                    const AT ui = U[(size_t)(it - 1) * R + i];
+                    g -= VB[(size_t)(it - 1) * Cn + j] * xexp(z + ui + V[(size_t)it * Cn + j] - lnu(j));
+                    g -= UB[(size_t)(it - 1) * R + i] * xexp(z + V[(size_t)(it - 1) * Cn + j] + ui - lmu(i));
                 }
             }
-            if (i < N && j < M) A.gscores[((size_t)pair * N + i) * M + j] = g;
+            if (i < N && j < M) A.gscores[((size_t)pair * N + i) * M + j] = (float)g;
             else ga += g;
         }
     }
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
     if (lane == 0) s_red[w] = ga;
     __syncthreads();
     if (t == 0) {
-        float s = 0.f;
+        AT s = 0;
         for (int k = 0; k < NW; ++k) s += s_red[k];
         A.galpha[pair] = s;
     }
@@ -477,7 +488,7 @@ extern "C" {
 
 size_t dr_sinkhorn_backward_workspace_bytes(int P, int N, int M, int iters) {
     if (P < 0 || N < 1 || M < 1 || iters < 1) return 0;
-    return (size_t)P * ((size_t)2 * iters * (N + 1) + (size_t)(2 * iters + 1) * (M + 1)) * sizeof(float);
+    return (size_t)P * ((size_t)2 * iters * (N + 1) + (size_t)(2 * iters + 1) * (M + 1)) * sizeof(double);
 }
 
 int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
@@ -487,8 +498,9 @@ int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uin
     if ((src_mask == nullptr) != (tgt_mask == nullptr)) return DR_EINVAL;
     if (workspace_bytes < dr_sinkhorn_backward_workspace_bytes(P, N, M, iters)) return DR_EWORKSPACE;
     if (P == 0) return DR_OK;
-    dr::SkBwdArgs A{scores, src_mask, tgt_mask, bin_score, grad_conf, grad_scores, grad_bin_score, (float*)workspace, N, M, iters};
-    hipLaunchKernelGGL(dr::sk_backward_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);
+    dr::SkBwdArgs A{scores, src_mask, tgt_mask, bin_score, grad_conf, grad_scores, grad_bin_score, workspace, N, M, iters};
+    if (dr::env_knob("DR_SKB_F32", 0)) hipLaunchKernelGGL(dr::sk_backward_kernel<float>, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);   // (diagnostics)
+    else hipLaunchKernelGGL(dr::sk_backward_kernel<double>, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }

@@ -725,8 +725,9 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
  *   gradient outside [1e-6, 1 - 1e-6]); workspace: dr_train_workspace_bytes(P, N, M).
  * dr_sinkhorn_backward_f32: backward of log_optimal_transport + exp + [:, :-1, :-1] (matching.py:61-93, 207-216): scores [P,N,M] as the forward
  *   saw them (masked entries -inf), the masks (both or none), bin_score, iters, grad_conf = d loss / d conf [P,N,M] ->
- *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32; every
- *   reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
+ *   grad_scores [P,N,M] (0 at masked entries) and grad_bin_score [P] (one partial per pair: the caller sums them).  float32 in and out; the
+ *   dual variables, the plans' exponents and every sum are kept in double (at logits in the thousands Z + u + v cancels: a float32
+ *   exponent cost 2.7e-3 of the gradient's maximum); every reduction in a fixed order.  workspace: dr_sinkhorn_backward_workspace_bytes(P, N, M, iters). */
 /* d loss / d (R_pred [P,3,3], t_pred [P,3]) of dr_motion_l1_f32 (loss.py:108-128; 4DMatch trains with motion_weight 0.1) */
 int dr_motion_l1_backward_f32(int P, int N, const float* s_pcd, const float* flow, const float* R_pred, const float* t_pred, const float* R_gt,
                               const float* t_gt, const uint8_t* overlap_mask, float* grad_R, float* grad_t, void* workspace, void* stream);

@@ -4,7 +4,7 @@ needs /root/reference).
     python oracle/make_golden_train_grads.py          # writes tests/golden/train_backward_params.npz       (stress head, HEAD_GAIN 24)
     python oracle/make_golden_train_grads.py soft     # writes tests/golden/train_backward_params_soft.npz  (HEAD_GAIN_SOFT 3: logits O(10))
     python oracle/make_golden_train_grads.py upstream # writes tests/golden/train_backward_upstream.npz: the stress head's run once more (checked equal to
-                                                      # the params file), storing d loss / d (the denoising transformer's two outputs) in float32 / float64:
+                                                      # the params file), storing the HEAD's gradient to the denoising transformer's two outputs in float32 / float64:
                                                       # the gradient the six layers receive from the head (tests: the layers' backward held to 1e-3 on the
                                                       # stress head too when it starts from the reference's upstream gradient)
 
@@ -108,15 +108,18 @@ def main():
         p_t, p_s = cb["p_t"].to(dt), cb["p_s"].to(dt)
         with torch.enable_grad():
             s_n, t_n, pe_s, pe_t = pipe.denoising_transformer(fs_d, ft_d, warped, p_t, cb["src_mask"], cb["tgt_mask"], {})
-            s_n.retain_grad(); t_n.retain_grad()
-            hat, _ = pipe.denoising_coarse_matching(s_n, t_n, pe_s, pe_t, cb["src_mask"], cb["tgt_mask"], {}, pe_type="rotary")
+            # (the transformer's source output also feeds its own last cross layer: `x * 1.0` -- exact -- makes nodes that ONLY the head consumes, so
+            # that their .grad is the head's gradient alone, the quantity the six layers' backward starts from)
+            s_h, t_h = s_n * 1.0, t_n * 1.0
+            s_h.retain_grad(); t_h.retain_grad()
+            hat, _ = pipe.denoising_coarse_matching(s_h, t_h, pe_s, pe_t, cb["src_mask"], cb["tgt_mask"], {}, pe_type="rotary")
             gt_d = torch.zeros_like(hat)
             gt_d[0][cb["matches"][0][0], cb["matches"][0][1]] = 1
             loss_d = crit.compute_correspondence_loss(hat, gt_d)
             loss_d.backward()
         res["branch_conf" + tag], res["branch_loss" + tag] = hat.detach().numpy(), np.float64(float(loss_d))
         res["branch_grad_src" + tag], res["branch_grad_tgt" + tag] = fs_d.grad.numpy(), ft_d.grad.numpy()
-        up["branch_up_src" + tag], up["branch_up_tgt" + tag] = s_n.grad.numpy().copy(), t_n.grad.numpy().copy()
+        up["branch_up_src" + tag], up["branch_up_tgt" + tag] = s_h.grad.numpy().copy(), t_h.grad.numpy().copy()
         up["branch_out_src" + tag], up["branch_out_tgt" + tag] = s_n.detach().numpy().copy(), t_n.detach().numpy().copy()
         n_b = 0
         for k, prm in list(pipe.denoising_transformer.named_parameters()) + [("head." + k2, p2) for k2, p2 in pipe.denoising_coarse_matching.named_parameters()]:

@@ -150,13 +150,15 @@ GB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", 
 # train_backward.npz) and for the soft head (HEAD_GAIN_SOFT 3: logits O(10))
 _GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GP = {"main": np.load(os.path.join(_GOLD, "train_backward_params.npz")), "soft": np.load(os.path.join(_GOLD, "train_backward_params_soft.npz"))}
-# The STRESS head (HEAD_GAIN 24: matching logits in the thousands) is held to 4e-2 of the tensor maximum on EVERY entry of all 104 tensors (the
-# old test: 2e-2 on the tensors' NORMS and on two tensors' entries).  Measured (round 5): the device's gradients are up to 2.6e-2 of the tensor
-# maximum from float64 on the denoising branch (layers.4.v_proj.weight: 6.3e-5 against the reference's own 2.2e-6), 4.9e-3 on the coarse branch -- a
-# 1e-4 deviation of a confidence is a percent of the focal loss's gradient at that entry when the matrix is that sharp, and it reaches the early
-# layers amplified.  The SOFT head (logits O(10), same scenes) holds 1e-3 / twice the reference on all 104 tensors: 4.8e-5 of the tensor maximum
-# at worst -- the backward kernels are float32-exact where the problem is conditioned like a trained model's.
-STRESS_REL = 4e-2
+# The STRESS head (HEAD_GAIN 24: matching logits in the thousands) is held to 5e-3 of the tensor maximum on EVERY entry of all 104 tensors.
+# Until round 6 this bound was 4e-2 (measured 2.6e-2 on layers.4.v_proj.weight) and was put down to the head's conditioning.  Taking the chain
+# apart (test_stress_head_gradient_chain_taken_apart, tests/debug_stress_head_steps.py) found ONE
+# step that spent it: the Sinkhorn adjoint recurrences in float32 -- Z + u + v cancels three numbers in the thousands, the plans' exponents
+# carried their ulp (2.4e-4) and d loss / d sim came out 2.7e-3 of its maximum from float64.  dr_sinkhorn_backward_f32 now keeps its dual
+# variables, exponents and sums in double (float32 in and out): that step 8.7e-5, the head on the reference's own layer outputs 1.1e-3 (the
+# reference's float32 autograd: 1.1e-3, its summation-order control 1.4e-3), end to end 1.8e-3 (denoising branch) / 4.7e-4 (coarse branch).
+# The SOFT head (logits O(10), same scenes) holds 1e-3 / twice the reference on all 104 tensors: 3.6e-5 of the tensor maximum at worst.
+STRESS_REL = 5e-3
 
 
 def assert_gradient_entries(dev, ref32, ref64, what, rel=1e-3):
@@ -382,22 +384,25 @@ def test_denoising_branch_backward_end_to_end(family):
             worst = max(worst, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["branch_g64_" + k], "denoising branch d/d " + k, fac))
             if family == "main":
                 ref = float(GB["branch_gradnorm_" + k])
-                assert abs(float(prm.grad.double().norm()) - ref) <= 1e-2 * ref + 1e-9, (k, float(prm.grad.double().norm()), ref)
+                assert abs(float(prm.grad.double().norm()) - ref) <= 3e-3 * ref + 1e-9, (k, float(prm.grad.double().norm()), ref)
             checked += 1
     assert checked == 62
     print("denoising branch (%s head): worst gradient deviation / tensor maximum %.2e" % (family, worst))
 
 
-def test_stress_head_gradient_deviation_is_the_heads_conditioning_not_the_backward_kernels():
-    """Row f3 on the STRESS head, taken apart (tests/golden/train_backward_upstream.npz: d loss / d (the denoising transformer's outputs) of the
-    reference's own run).  The end-to-end test above holds the stress head's gradients to STRESS_REL = 4e-2 of a tensor's maximum; this one shows
+def test_stress_head_gradient_chain_taken_apart():
+    """Row f3 on the STRESS head, taken apart (tests/golden/train_backward_upstream.npz: the gradient the head hands to the denoising
+    transformer's two outputs in the reference's own run -- the head's part alone: the source output also feeds the last cross layer).  The end-to-end test above holds the stress head's gradients to STRESS_REL = 4e-2 of a tensor's maximum; this one shows
     where that slack is spent:
       (i)  the six layers' backward, started from the REFERENCE's upstream gradient: every entry of all 60 layer tensors and of the two feature
            gradients within 1e-3 of the tensor maximum (or as close to float64 as the reference) -- the same bar as the soft head;
       (ii) the matching head alone on the REFERENCE's layer outputs (identical inputs): conf under the loop tests' rule, its input gradients and its
-           two parameter gradients within HEAD_REL of the tensor maximum.
-    What is left for the end-to-end figure is the head's amplification of the layers' FORWARD rounding (the device's layer outputs are ~1e-5
-    from the reference's; at logits in the thousands a 1e-5 change of a feature moves a confidence's gradient by percents)."""
+           gradient to src_proj.weight against the reference's module in float64 on the same float32 inputs: within 1e-3 of the tensor maximum or
+           twice the distance of the reference's own two float32 evaluations (tests/golden/train_backward_head_control.npz: as shipped, and with
+           the feature pairs permuted = another summation order of `sim`; 1.1e-3 / 1.4e-3 of the maximum -- logits in the thousands have an
+           fp32 ulp of 1.2e-4, so any two float32 evaluations differ by that much relatively).  Measured: 1.1e-3.
+    This test is what found the float32 Sinkhorn adjoint (see STRESS_REL above): before, (ii) measured 4.3e-3 on the inputs and 1.7e-2 on
+    src_proj.weight."""
     from diffreg_hip.autograd import _layers_of, matching_head_form
     from models.pipeline import Pipeline
     from tests.test_loop_gpu import assert_matrix_parity
@@ -433,8 +438,9 @@ def test_stress_head_gradient_deviation_is_the_heads_conditioning_not_the_backwa
             worst_l = max(worst_l, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["branch_g64_" + k], "layers from the reference's upstream: " + k))
             n += 1
     assert n == 60
-    # ---- (ii) head on the reference's layer outputs
-    HEAD_REL = 1e-3
+    # ---- (ii) head on the reference's layer outputs, against the reference's module in float64 ON THOSE float32 inputs (h64), with the reference's
+    # two float32 evaluations (as shipped = the end-to-end run's head; feature pairs permuted = another summation order) as the yardstick
+    HC = np.load(os.path.join(_GOLD, "train_backward_head_control.npz"))
     hs = torch.from_numpy(UP["branch_out_src32"]).to(DEV).requires_grad_(True)
     ht = torch.from_numpy(UP["branch_out_tgt32"]).to(DEV).requires_grad_(True)
     head = model.denoising_coarse_matching
@@ -442,18 +448,22 @@ def test_stress_head_gradient_deviation_is_the_heads_conditioning_not_the_backwa
         prm.grad = None
     from diffreg_hip.autograd import focal_loss
     hat = matching_head_form(head, hs, ht, src_pe, tgt_pe, sm, tm, tr.pe_type)
-    assert_matrix_parity(hat.detach().cpu().numpy(), GB["branch_conf"], gp["branch_conf64"], "stress head on the reference's layer outputs")
+    assert_matrix_parity(hat.detach().cpu().numpy(), GB["branch_conf"], HC["h64_conf"].astype(np.float64), "stress head on the reference's layer outputs")
     gt = torch.zeros_like(hat)
     gt[0][c["matches"][0][0].to(DEV), c["matches"][0][1].to(DEV)] = 1
     focal_loss(hat, gt).backward()
-    worst_h = 0.0
-    for got, key in ((hs.grad, "branch_up_src"), (ht.grad, "branch_up_tgt")):
-        worst_h = max(worst_h, assert_gradient_entries(got.cpu().numpy(), UP[key + "32"], UP[key + "64"], "head on identical inputs: " + key, HEAD_REL))
-    for k, prm in head.named_parameters():
-        key = "branch_g32_head." + k
-        worst_h = max(worst_h, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["branch_g64_head." + k], "head on identical inputs: " + k, HEAD_REL))
+    worst_h, yard = 0.0, 0.0
+    for got, key, h32 in ((hs.grad.cpu().numpy(), "up_src", UP["branch_up_src32"]), (ht.grad.cpu().numpy(), "up_tgt", UP["branch_up_tgt32"]),
+                          (param_sub(head.src_proj.weight.grad), "g_src_proj_weight", HC["h32_g_src_proj_weight"])):
+        h64 = HC["h64_" + key]
+        M_ = float(np.abs(h64).max())
+        r = max(float(np.abs(h32 - h64).max()), float(np.abs(HC["h32perm_" + key] - h64).max()))
+        e = float(np.abs(got - h64).max())
+        assert e <= max(1e-3 * M_, 2.0 * r), ("head on identical inputs: " + key, "device %.3e from float64, the reference's float32 evaluations %.3e, max %.3e" % (e, r, M_))
+        worst_h, yard = max(worst_h, e / M_), max(yard, r / M_)
+    assert abs(float(head.bin_score.grad) - float(HC["h64_g_bin_score"])) < 1e-7          # (a stationary point of the bin score: ~1e-19)
     print("stress head taken apart: layer outputs %.1e from the reference's; layers' backward from the reference's upstream gradient %.2e of the tensor "
-          "maximum at worst; head on the reference's layer outputs %.2e" % (d_out, worst_l, worst_h))
+          "maximum at worst; head on the reference's layer outputs %.2e (the reference's two float32 evaluations: %.2e)" % (d_out, worst_l, worst_h, yard))
 
 
 def test_motion_l1_backward_against_torch():
@@ -519,7 +529,7 @@ def test_coarse_branch_backward_with_motion_term(family):
             assert prm.grad is not None, k
             if family == "main":
                 ref = float(GB["coarse_gradnorm_" + k])
-                assert abs(float(prm.grad.double().norm()) - ref) <= 1e-2 * ref + 1e-9, (k, ref)
+                assert abs(float(prm.grad.double().norm()) - ref) <= 3e-3 * ref + 1e-9, (k, ref)
             worst = max(worst, assert_gradient_entries(param_sub(prm.grad), gp[key], gp["coarse_g64_" + k], "coarse branch d/d " + k, fac))
             checked += 1
         else:
