@@ -307,15 +307,17 @@ template <typename AT>
 __device__ __forceinline__ AT zval(const float* __restrict__ Z, int i, int j, int N, int M, AT a) {
     return (i < N && j < M) ? (AT)Z[(size_t)i * M + j] : a;
 }
+// (AT = double: only the SUMS that cancel need the width -- Z + u + v, the running maxima, the adjoint sums.  The transcendentals see O(1)
+// arguments (a difference formed in double, a sum in [1, n]) and are taken in float32: 1e-7 relative, at a tenth of the double routines' cost)
 __device__ __forceinline__ float xexp(float x) { return expf(x); }
-__device__ __forceinline__ double xexp(double x) { return exp(x); }
+__device__ __forceinline__ double xexp(double x) { return (double)expf((float)x); }
 __device__ __forceinline__ float xlog(float x) { return logf(x); }
-__device__ __forceinline__ double xlog(double x) { return log(x); }
+__device__ __forceinline__ double xlog(double x) { return (double)logf((float)x); }
 
 // AT: the type of the dual variables, of the plans' exponents and of every sum (inputs and results are float32).  The library runs AT = double:
 // at logits in the thousands (a sharp head) Z + u + v cancels three numbers of that size -- in float32 the exponent carries an absolute error of
 // their ulp (2.4e-4 at 3 000) and the gradient came out 2.7e-3 of its maximum from the float64 value (the same recurrences in torch float32:
-// 2.8e-3; torch autograd through the reference's float32 code: 1e-3); in double the step is exact to float32 rounding of its result.
+// 2.8e-3; torch autograd through the reference's float32 code: 1e-3); with double sums the step is at the float32 rounding of its inputs.
 template <typename AT>
 __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
     const int N = A.N, M = A.M, T = A.iters, t = threadIdx.x, lane = t & 63, w = t >> 6, NW = 16;
