@@ -645,3 +645,10 @@ def test_k_split_launches_agree_with_unsplit_launches(monkeypatch):
     assert 0.0 < d0 < 2e-5, d0
     assert (on["R_forwd"] - off["R_forwd"]).abs().max().item() < 1e-4 and (on["t_forwd"] - off["t_forwd"]).abs().max().item() < 1e-4
     assert (on["conf_matrix_pred"] - off["conf_matrix_pred"]).abs().max().item() < 1e-4
+    # the split under graph capture and replay (the launch counter of the exchange is baked into the captured arguments; the flags are zeroed
+    # by a memset node of the same graph): eager = capture = two replays, bit for bit
+    on = {k: v.clone() for k, v in on.items()}
+    for _ in range(4):
+        g = eng.run(kw["src_feats"], kw["tgt_feats"], kw["s_pcd"], kw["t_pcd"], kw["x_T"], noise=noise, trace=True, graph=True)
+        g["_status"].check()
+        assert torch.equal(g["conf_matrix_pred"], on["conf_matrix_pred"]) and torch.equal(g["x0"], on["x0"]) and torch.equal(g["R_forwd"], on["R_forwd"])
