@@ -58,7 +58,7 @@ class _Linear(torch.autograd.Function):
         g = g.contiguous().float()
         gx = _mm(g, _tr(W)) if ctx.needs_input_grad[0] else None          # g W
         gW = _weight_grad(g, x) if ctx.needs_input_grad[1] else None         # g^T x
-        gb = g.sum(0) if ctx.has_bias else None
+        gb = g.double().sum(0).float() if ctx.has_bias else None           # (a sum over all points: float64, like the weight gradient's second level)
         return gx, gW, gb
 
 
@@ -100,7 +100,7 @@ class _BiasAct(torch.autograd.Function):
         g = g.contiguous().float()
         if act:
             g = torch.where(out > 0, g, g * 0.1)
-        gs = g.sum(0)
+        gs = g.double().sum(0).float()
         return g, gs, (g if has_b else None), (gs if has_bb else None), None
 
 
