@@ -980,7 +980,7 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 // mlp0, the matching head's projection); the accumulators are in the epilogue's layout as in the 16x16x32 form above.
 // ---------------------------------------------------------------------------------------------------------------------
 struct PgGeomW {
-    static constexpr int NJ = 9, BNW = 144, BN = 288, LBN = 576, BM = 128, NTHR = 256, A_ST = BM * 64, B_ST = BN * 64, STAGE = A_ST + B_ST, NST = 4;
+    static constexpr int NJ = 9, BN = 288, LBN = 576, BM = 128, NTHR = 256, A_ST = BM * 64, B_ST = BN * 64, STAGE = A_ST + B_ST, NST = 4;
     static constexpr int RING = NST * STAGE;
     // + fac[128], rinv[128], red[16], bias[BN], cinv[BN], bound[128]
     static constexpr int SMEM = RING + (128 + 128 + 16 + BN + BN + 128) * 4;
@@ -1343,7 +1343,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (ksplit) {
         // (half of the rounds: the pair this workgroup keeps)
         float4 tb0[NIE], tb1[NIE];
-        const int r0 = 2 * khalf;
         if (khalf == 0) {
             if (rot) { load_tables(0, tb0); load_tables(1, tb1); }
             scale_round(0, v[0]); scale_round(1, v[1]);
@@ -1353,7 +1352,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             scale_round(2, v[2]); scale_round(3, v[3]);
             finish_round(2, tb0); finish_round(3, tb1);
         }
-        (void)r0;
         __builtin_amdgcn_sched_barrier(0);
     } else {
         // every rotary table load precedes the wave's first store (vmcnt retires in order): tables of two rounds in flight at a time
