@@ -100,3 +100,22 @@ def test_deformable_kernels_are_refused():
         overlay_module().KPFCN(cfg)
     with pytest.raises(ValueError):
         overlay_module().KPFCN(dict(cfg, deformable=False, KP_influence="cubic"))
+
+
+@pytest.mark.gpu
+def test_weight_gradient_contraction_is_two_level():
+    """g^T x over thousands of points (the KPConv / unary weight gradients): chunks of 1 024 points on the MFMA, partial products summed in float64
+    -- against the float64 product, and against the one-chain float32 contraction it replaced (which is what a sequential float32 sum gives)"""
+    from diffreg_hip import backbone_autograd as ba
+    gen = torch.Generator().manual_seed(3)
+    R = 9000
+    g = (torch.randn(R, 64, generator=gen) + 0.5).to(DEV)
+    x = (torch.randn(R, 40, generator=gen) + 2.0).to(DEV)            # (a mean: the running sum grows, its rounding with it)
+    ref = g.double().t() @ x.double()
+    two = ba._weight_grad(g, x).double()
+    one = ba._mm(ba._tr(g), ba._tr(x)).double()
+    M_ = float(ref.abs().max())
+    e2, e1 = float((two - ref).abs().max()) / M_, float((one - ref).abs().max()) / M_
+    assert e2 <= 2e-7 and e2 < e1, (e2, e1)
+    small = ba._weight_grad(g[:1500], x[:1500]).double()            # at most two chunks: the single launch
+    assert float((small - g[:1500].double().t() @ x[:1500].double()).abs().max()) <= 1e-5 * M_

@@ -229,3 +229,44 @@ def test_loop_timeouts_are_attributed_to_the_call_that_had_them():
     again = eng_a.run(*args, graph=False)
     again["_status"].check()
     assert torch.equal(again["conf_matrix_pred"], good["conf_matrix_pred"])
+
+
+def test_round_6_entries_refuse_bad_calls():
+    """the entries ABI 0.2.1 added (KPConv influence modes, the dual-softmax backward, the wide weight layout, the per-call status word) and the
+    double-width Sinkhorn backward workspace: bad arguments and short workspaces come back as status codes, nothing is launched"""
+    from diffreg_hip import lib
+    r = lib.raw()
+    lib.ensure_init()
+    q = torch.rand(8, 3, device=DEV); idx = torch.zeros(8, 4, dtype=torch.int64, device=DEV); x = torch.rand(8, 4, device=DEV)
+    kp = torch.rand(15, 3, device=DEV); out = torch.empty(8, 60, device=DEV)
+    st = lib.stream_of(q)
+    args = lambda infl, closest: (8, 8, 4, 4, 15, lib.ptr(q), lib.ptr(q), lib.ptr(idx), lib.ptr(x), lib.ptr(kp), 0.05, infl, closest, lib.ptr(out), 60, st)
+    assert r.dr_kpconv_gather_mode_f32(*args(3, 0)) == EINVAL and r.dr_kpconv_gather_mode_f32(*args(-1, 0)) == EINVAL       # KP_influence outside 0..2
+    assert r.dr_kpconv_gather_mode_f32(*args(lib.KP_INFLUENCE["gaussian"], 1)) == OK
+    # dual-softmax backward: temperature, one mask without the other, a short workspace
+    sim = torch.randn(2, 16, 12, device=DEV); g = torch.randn_like(sim); gs = torch.empty_like(sim)
+    need = r.dr_dual_softmax_backward_workspace_bytes(2, 16, 12)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    m = torch.ones(2, 16, dtype=torch.uint8, device=DEV)
+    call = lambda T, sm, tm, w, nb: r.dr_dual_softmax_backward_f32(2, 16, 12, lib.ptr(sim), T, sm, tm, lib.ptr(g), lib.ptr(gs), w, nb, st)
+    assert call(0.0, None, None, lib.ptr(ws), need) == EINVAL and call(0.1, lib.ptr(m), None, lib.ptr(ws), need) == EINVAL
+    assert call(0.1, None, None, lib.ptr(ws), need - 4) == EWORKSPACE and call(0.1, None, None, None, 0) == EWORKSPACE
+    assert call(0.1, None, None, lib.ptr(ws), need) == OK
+    # the Sinkhorn backward's vectors are doubles since round 6: the reported size is what the call insists on
+    sc = torch.randn(1, 16, 12, device=DEV); one = torch.ones(1, device=DEV); ga = torch.empty(1, device=DEV)
+    need = r.dr_sinkhorn_backward_workspace_bytes(1, 16, 12, 3)
+    assert need == (2 * 3 * 17 + (2 * 3 + 1) * 13) * 8
+    w2 = torch.empty(need, dtype=torch.uint8, device=DEV)
+    skb = lambda nb: r.dr_sinkhorn_backward_f32(1, 16, 12, lib.ptr(sc), None, None, lib.ptr(one), 3, lib.ptr(g[:1].contiguous()), lib.ptr(gs[:1].contiguous()),
+                                                 lib.ptr(ga), lib.ptr(w2), nb, st)
+    assert skb(need // 2) == EWORKSPACE and skb(need) == OK
+    # the wide weight layout: C beyond one logical block of 576 columns, a misaligned destination
+    W = torch.randn(600, 64, device=DEV)
+    assert r.dr_plane_weight_bytes_wide(1, 600, 64, 64, 64) == 0                   # (no size for a shape the layout does not have)
+    buf = torch.empty(int(r.dr_plane_weight_bytes_wide(1, 528, 64, 64, 64)) + 64, dtype=torch.uint8, device=DEV)
+    assert r.dr_pack_weight_planes_wide_f32(1, 600, 64, 64, 64, lib.ptr(W), lib.ptr(buf), st) == EINVAL
+    assert r.dr_pack_weight_planes_wide_f32(1, 528, 64, 64, 64, lib.ptr(W), buf.data_ptr() + 4, st) == EINVAL
+    assert r.dr_pack_weight_planes_wide_f32(0, 528, 64, 64, 64, lib.ptr(W), lib.ptr(buf), st) == EINVAL
+    # the status word of a loop workspace
+    assert r.dr_denoise_loop_status(None, st, 1) == EINVAL
+    torch.cuda.synchronize()
