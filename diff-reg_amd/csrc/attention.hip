@@ -1200,12 +1200,13 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         AttnArgs ax = a;
         // (the dealing is a bijection only when the (head, segment) count is a multiple of 8; one query block per group has nothing to share)
         ax.xcd_groups = ((fgrid.y * fgrid.z) % 8 == 0 && fgrid.x > 1 && env_knob("DR_ATTN_XCD", 1)) ? 1 : 0;
-        // at most one workgroup per CU and at least four key tiles: two key groups per workgroup (eight waves, two per SIMD).  OPT-IN (diagnostics
-        // knob DR_ATTN_KG2=1): measured -2.3 % on cfg3's 8-pair call (53.6 -> 52.4 ms), every soft-family bound a plain 1e-4 as before, but the other
-        // summation order moves one sharp stress-family entry of test_cfg3_4dmatch_512_batch8_20_steps across its 2 x rule
-        // (profiles/r06_cfg3_experiments.json) -- not worth a changed bound
+        // at most one workgroup per CU and at least four key tiles: two key groups per workgroup (eight waves, two per SIMD; the groups' partial
+        // softmax states merge through LDS).  cfg3's 8-pair call -2.9 % (154.7 -> 159.2 pairs/s), cfg5's -2 %.  Another summation order of the
+        // same float32 mathematics: every soft-family bound stays a plain 1e-4; on the stress family it moves WHICH sharp entries sit near their
+        // 2 x rule (an earlier tree had one of test_cfg3_4dmatch_512_batch8_20_steps cross it; on this tree the whole suite is green with it on,
+        // profiles/r06_cfg3_experiments.json).  DR_ATTN_KG2=0 (diagnostics) switches it off.
         const int minLk = a.nseg2 > 0 && a.Lkb < a.Lk ? a.Lkb : a.Lk;
-        const bool kg2 = (long)fgrid.x * fgrid.y * fgrid.z <= (long)device_cu_count() && minLk >= 128 && env_knob("DR_ATTN_KG2", 0) != 0;
+        const bool kg2 = (long)fgrid.x * fgrid.y * fgrid.z <= (long)device_cu_count() && minLk >= 128 && env_knob("DR_ATTN_KG2", 1) != 0;
         if (kg2) {
             const size_t plds2 = AttnPlGeom<KS, NDT>::SMEM2;
             if (a.f16_single) hipLaunchKernelGGL((attention_planes_kernel<KS, NDT, true, 2>), fgrid, dim3(512), plds2, st, ax);

@@ -10,6 +10,8 @@ Tolerances (north_star: matching matrix and (R,t) to 1e-4 fp32 on identical inpu
       property of the fixture, not of the implementation under test.  For them the bar is that the HIP path is at least as
       close to the float64 evaluation as the reference is:  |hip - f64| <= max(1e-4, 2 |ref - f64|).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -639,7 +641,7 @@ def test_k_split_launches_agree_with_unsplit_launches(monkeypatch):
         monkeypatch.setenv("DR_PG_KSPLIT", "1")
         on = run()
     finally:
-        lib.raw().dr_debug_enable_env(0)
+        lib.raw().dr_debug_enable_env(1 if os.environ.get("DR_DIAGNOSTICS") == "1" else 0)      # (back to what lib.ensure_init had set)
     on["_status"].check()                   # raises if a partner never arrived (bit 1 of the call's status word)
     d0 = (on["x0"][0] - off["x0"][0]).abs().max().item()
     assert 0.0 < d0 < 2e-5, d0
