@@ -83,7 +83,7 @@ int dr_debug_launch_chain(int n, int workgroups, int threads, void* stream) {
     return DR_OK;
 }
 
-int dr_version(void) { return DR_ABI_VERSION; /* 0.2.1: the header this library was built from */ }
+int dr_version(void) { return DR_ABI_VERSION; /* 0.2.2: the header this library was built from */ }
 
 const char* dr_strerror(int code) {
     switch (code) {

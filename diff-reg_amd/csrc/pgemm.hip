@@ -1961,7 +1961,27 @@ int dr_linear_planes_f32(const dr_planes_linear* a, void* stream) {
     if (p.mode != PG_F32 && !p.pimg && !p.out) return DR_EINVAL;
     if (p.mode == PG_PLANES && !p.pimg) return DR_EINVAL;
     g.n = 1;
+    if (a->split_workspace) {
+        // [status word, 16 bytes][flags][exchange buffer]; flags zeroed per call, one launch = epoch 1
+        const int bn = a->weight_layout == DR_PL_LAYOUT_WIDE ? 576 : pgemm_bn(a->C);
+        if (a->split_workspace_bytes < dr_plane_split_workspace_bytes(a->C) || ((uintptr_t)a->split_workspace & 15)) return DR_EWORKSPACE;
+        char* w = (char*)a->split_workspace;
+        DR_HIP_CHECK(hipMemsetAsync(w, 0, 16 + pgemm_xk_flag_bytes(), (hipStream_t)stream));
+        p.xk_status = (unsigned*)w; p.xk_flags = (unsigned*)(w + 16); p.xk_buf = (float*)(w + 16 + ((pgemm_xk_flag_bytes() + 255) & ~(size_t)255));
+        p.xk_epoch = 1; p.xk_cap = PG_XK_MAX_RB;
+        (void)bn;
+    }
     return launch_pgemm(g, (hipStream_t)stream);
+}
+
+size_t dr_plane_split_workspace_bytes(int C) {
+    if (C < 16 || C > 576) return 0;
+    return 16 + ((pgemm_xk_flag_bytes() + 255) & ~(size_t)255) + pgemm_xk_buf_bytes(576);     // (sized for the widest geometry: 23.6 MB)
+}
+
+int dr_plane_split_status(void* split_workspace, void* stream, int clear) {
+    if (!split_workspace) return DR_EINVAL;
+    return sinkhorn_call_status((unsigned*)split_workspace, (hipStream_t)stream, clear != 0);
 }
 
 }  // extern "C"

@@ -74,7 +74,8 @@ class PlanesLinear(ctypes.Structure):
                 ("out_image", c_void_p), ("out_image_k", c_int), ("out_k0", c_int), ("out_bound", c_void_p),
                 ("relu", c_int),
                 ("gamma", c_void_p), ("beta", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("bound_resid", c_void_p),
-                ("ln_bound", c_void_p), ("bias", c_void_p), ("bias_max", c_void_p), ("ln_postadd", c_int), ("weight_layout", c_int)]
+                ("ln_bound", c_void_p), ("bias", c_void_p), ("bias_max", c_void_p), ("ln_postadd", c_int), ("weight_layout", c_int),
+                ("split_workspace", c_void_p), ("split_workspace_bytes", c_size_t)]
 
 
 class Loop2D3DConfig(ctypes.Structure):
@@ -108,6 +109,8 @@ SIGNATURES.update({
     "dr_plane_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dr_pack_weight_planes_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_plane_weight_bytes_wide": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dr_plane_split_workspace_bytes": (c_size_t, [c_int]),
+    "dr_plane_split_status": (c_int, [c_void_p, c_void_p, c_int]),
     "dr_pack_weight_planes_wide_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dr_ln_bound_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dr_linear_planes_f32": (c_int, [ctypes.POINTER(PlanesLinear), c_void_p]),
@@ -228,7 +231,7 @@ def _bind(table):
 _bind(SIGNATURES)
 _INIT_DONE = False
 
-ABI_VERSION = 201          # DR_ABI_VERSION of the include/diffreg_hip.h these signatures were written against
+ABI_VERSION = 202          # DR_ABI_VERSION of the include/diffreg_hip.h these signatures were written against
 if _lib.dr_version() // 100 != ABI_VERSION // 100:
     raise ImportError("libdiffreg_hip.so is ABI %d, this binding is written against %d: rebuild (make -C diff-reg_amd/csrc)"
                       % (_lib.dr_version(), ABI_VERSION))
@@ -382,8 +385,9 @@ def ln_bound(gamma, beta):
 
 def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, k1=0, out=None, ldo=0, blk_stride=0, cos_t=None,
                   sin_t=None, rot_mask=0, rot_C=0, scale=1.0, out_image=None, out_image_k=0, out_k0=0, out_bound=None, relu=False,
-                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None, bias=None, ln_postadd=False, wide=False):
-    """dr_linear_planes_f32; bias [nblk * C]: its per-block maxima are computed here (dr_bias_max_f32)"""
+                  gamma=None, beta=None, resid=None, ldr=0, bound_resid=None, lnb=None, bias=None, ln_postadd=False, wide=False, split_ws=None):
+    """dr_linear_planes_f32; bias [nblk * C]: its per-block maxima are computed here (dr_bias_max_f32).  split_ws: a uint8 tensor of
+    plane_split_workspace(C) bytes -- lets a launch that fills at most half the chip split its tiles' k range over two workgroups"""
     a = PlanesLinear()
     a.rows, a.C, a.nblk = rows, C, nblk
     dp = lambda t_: None if t_ is None else t_.data_ptr()
@@ -402,7 +406,18 @@ def linear_planes(rows, C, nblk, a0, b0, k0, packed, mode, *, a1=None, b1=None, 
         check(_lib.dr_bias_max_f32(nblk, C, ptr(bias), ptr(bmax), stream_of(a0)))
     a.bias, a.bias_max, a.ln_postadd = dp(bias), dp(bmax), 1 if ln_postadd else 0
     a.weight_layout = 1 if wide else 0
+    a.split_workspace, a.split_workspace_bytes = dp(split_ws), (split_ws.numel() if split_ws is not None else 0)
     check(_lib.dr_linear_planes_f32(ctypes.byref(a), stream_of(a0)))
+
+
+def plane_split_workspace(C, device):
+    """the exchange workspace of dr_planes_linear.split_workspace (uint8 tensor)"""
+    return torch.empty(_lib.dr_plane_split_workspace_bytes(C), dtype=torch.uint8, device=device)
+
+
+def plane_split_status(split_ws, clear=True):
+    """raises (DR_ETIMEOUT) if a workgroup of the last split launch on this workspace never met its partner"""
+    check(_lib.dr_plane_split_status(ptr(split_ws), stream_of(split_ws), 1 if clear else 0))
 
 
 def scatter_rows(src, src_index, dst_index, dst, validate=True, status=None):

@@ -36,7 +36,7 @@ extern "C" {
  *   0.2.0  dr_loop_trace grew the teacher-forcing fields (a 0.1.0 caller's struct is too short); dr_procrustes_f32 and
  *          dr_top1_union_f32 / _f64 take (workspace, workspace_bytes) in front of `stream` since the last 0.1.0 builds -- a caller
  *          compiled against the header without them passes its stream in the workspace slot. */
-#define DR_ABI_VERSION 201
+#define DR_ABI_VERSION 202
 int dr_version(void);                 /* major*10000 + minor*100 + patch */
 const char* dr_strerror(int code);
 const char* dr_last_hip_error(void);  /* text of the last failing HIP call on this thread */
@@ -203,7 +203,14 @@ typedef struct {
     int ln_postadd;
     /* DR_PL_PLANES: `out` (optional) also receives the block as fp32 rows (ldo, blk_stride as in DR_PL_F32) */
     int weight_layout;             /* DR_PL_LAYOUT_*: how `packed` was packed (ABI 0.2.1)                                */
+    /* ABI 0.2.2, optional (NULL = never): dr_plane_split_workspace_bytes(C) bytes of device memory.  With it, a launch that would fill at most
+     * half the chip (a DR_PL_LN launch of 64-row workgroups; a DR_PL_LAYOUT_WIDE launch of 128 x 288 tiles) splits every tile's k range over
+     * TWO workgroups that swap half of their partial sums (the loops do this with their own workspace).  The first word of the workspace is a
+     * status word: dr_plane_split_status() -> DR_ETIMEOUT if a workgroup's partner never arrived (its rows are NaN then). */
+    void* split_workspace; size_t split_workspace_bytes;
 } dr_planes_linear;
+size_t dr_plane_split_workspace_bytes(int C);
+int dr_plane_split_status(void* split_workspace, void* stream, int clear);
 #define DR_PL_LAYOUT_BLOCK 0   /* dr_pack_weight_planes_f32                                                           */
 #define DR_PL_LAYOUT_WIDE 1    /* dr_pack_weight_planes_wide_f32 (DR_PL_F32 / DR_PL_PLANES only)                      */
 int dr_linear_planes_f32(const dr_planes_linear* args, void* stream);

@@ -384,3 +384,85 @@ def test_wide_wave_kernel_against_float64_and_the_block_layout(rows, C):
         hs[wide] = (back, h_b.clone())
     assert torch.equal(hs[True][1], hs[False][1])               # the same bounds: both kernels scale a row of one image alike
     assert rel(hs[True][0], hs[False][0].double()) < 1e-6
+
+
+@pytest.mark.parametrize("rows", [4096, 4000, 130, 8192])
+@pytest.mark.parametrize("C,K", [(432, 432), (432, 864), (528, 528), (528, 1024), (256, 512)])      # (dr_planes_from_f32 takes K <= 1 024)
+def test_k_split_layernorm_launch_against_float64_and_the_unsplit_launch(rows, C, K):
+    """DR_PL_LN with a split workspace (ABI 0.2.2): a launch of 64-row workgroups that fills at most half the chip gives every row block to TWO
+    workgroups, each half of k; they swap half of their partial sums and each finish half of the LayerNorm rows.  Row counts off the 64- and
+    128-row grid, merge-like (K = C) and mlp2-like (K = 2 C) shapes of all three geometries: float64 accuracy as the unsplit launch, results
+    close to it but not bit-equal where the split ran (another summation order), the status word clean, nothing written outside the outputs."""
+    torch.manual_seed(rows + C + K)
+    h = torch.randn(rows, K, device=DEV) * (torch.rand(rows, 1, device=DEV) * 3 + 0.05)
+    x = torch.randn(rows, C, device=DEV)
+    himg, hb = lib.planes_from_f32(h)
+    _, xb = lib.planes_from_f32(x)
+    W = torch.randn(C, K, device=DEV) / K ** 0.5
+    g1, b1 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+    lnb, pk = lib.ln_bound(g1, b1), lib.pack_weight_planes(W, 1, C)
+    ws = lib.plane_split_workspace(C, DEV)
+    res = {}
+    for tag, w in (("unsplit", None), ("split", ws)):
+        o32, chk_o = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+        o_img, chk_oi = image_like(rows, C)
+        o_b, _ = guarded((rows,), torch.float32, DEV, fill=0)
+        lib.linear_planes(rows, C, 1, himg, hb, K, pk, lib.PL_LN, out=o32, ldo=C, out_image=o_img, out_image_k=C, out_bound=o_b, gamma=g1, beta=b1,
+                          resid=x, ldr=C, bound_resid=xb, lnb=lnb, split_ws=w)
+        chk_o(); chk_oi()
+        res[tag] = (o32.clone(), lib.planes_to_f32(o_img, o_b, rows, C))
+    lib.plane_split_status(ws)
+    ref = x.double() + torch.nn.functional.layer_norm(h.double() @ W.double().t(), (C,), g1.double(), b1.double())
+    for tag in res:
+        assert rel(res[tag][0], ref) < 2e-6 and rel(res[tag][1], ref) < 2e-6, tag
+    split_ran = 2 * ((rows + 63) // 64) <= 256 and K // 16 >= 8
+    same = torch.equal(res["split"][0], res["unsplit"][0])
+    assert same != split_ran or K // 16 < 12, (same, split_ran)          # (the launcher's own minimum of chunks per half decides the short shapes)
+
+
+@pytest.mark.parametrize("rows", [4096, 3900, 200])
+@pytest.mark.parametrize("two_segments", [True, False])
+def test_k_split_wide_wave_launch_against_float64_and_the_unsplit_launch(rows, two_segments):
+    """the wide-wave kernel's split (launches of at most half a chip of 128 x 288 tiles): a two-segment operand [x | msg] split BY SEGMENT with the
+    first half rescaled to the second's row scale, a one-segment operand split at an even chunk; DR_PL_PLANES with ReLU into an image (mlp0) and
+    DR_PL_F32 with rotary (the head / a lone q projection)."""
+    C = 528
+    torch.manual_seed(rows + (7 if two_segments else 0))
+    x = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 4 + 0.02)
+    m = torch.randn(rows, C, device=DEV) * (torch.rand(rows, 1, device=DEV) * 0.3 + 0.01)          # (another scale per row than x's)
+    ximg, xb = lib.planes_from_f32(x)
+    mimg, mb = lib.planes_from_f32(m)
+    ws = lib.plane_split_workspace(C, DEV)
+    if two_segments:
+        W = torch.randn(2 * C, 2 * C, device=DEV) / (2 * C) ** 0.5
+        pk = lib.pack_weight_planes(W, 2, C, wide=True)
+        ref = torch.relu(torch.cat([x, m], 1).double() @ W.double().t())
+        out = {}
+        for tag, w in (("unsplit", None), ("split", ws)):
+            img, chk = image_like(rows, 2 * C)
+            bnd, _ = guarded((rows,), torch.float32, DEV, fill=0)
+            lib.linear_planes(rows, C, 2, ximg, xb, C, pk, lib.PL_PLANES, a1=mimg, b1=mb, k1=C, out_image=img, out_image_k=2 * C, out_bound=bnd, relu=True,
+                              wide=True, split_ws=w)
+            chk()
+            out[tag] = lib.planes_to_f32(img, bnd, rows, 2 * C)
+            assert bool((bnd.double() >= ref.abs().amax(1)).all())
+    else:
+        W = torch.randn(C, C, device=DEV) / C ** 0.5
+        pk = lib.pack_weight_planes(W, 1, C, wide=True)
+        ang = torch.rand(rows, C // 2, device=DEV) * 6.28
+        cos_t, sin_t = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+        y = x.double() @ W.double().t()
+        sw = torch.stack([-y[:, 1::2], y[:, 0::2]], -1).reshape(rows, C)
+        ref = (y * torch.repeat_interleave(cos_t.double(), 2, 1) + sw * torch.repeat_interleave(sin_t.double(), 2, 1)) * 0.25
+        out = {}
+        for tag, w in (("unsplit", None), ("split", ws)):
+            o32, chk = guarded((rows, C), torch.float32, DEV, fill=float("nan"))
+            lib.linear_planes(rows, C, 1, ximg, xb, C, pk, lib.PL_F32, out=o32, ldo=C, cos_t=cos_t, sin_t=sin_t, rot_mask=1, rot_C=C, scale=0.25,
+                              wide=True, split_ws=w)
+            chk()
+            out[tag] = o32.clone()
+    lib.plane_split_status(ws)
+    for tag in out:
+        assert rel(out[tag], ref) < 3e-6, tag
+    assert not torch.equal(out["split"], out["unsplit"])                 # <= 128 tiles: the split ran
+    assert (out["split"].double() - out["unsplit"].double()).abs().max().item() <= 4e-6 * float(ref.abs().max())
