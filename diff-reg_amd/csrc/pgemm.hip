@@ -629,6 +629,15 @@ __global__ __launch_bounds__(128 * WMN) __attribute__((amdgpu_waves_per_eu(WMN /
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[j][8 * khalf + 4 * q2 + e] += y[j][q2][e] + poison;
             __syncthreads();                                     // (s_bad lives in s_sum: read by everybody before the LayerNorm partials overwrite it)
+            if (G.dbg & 64) {                                    // timing builds: main loop + exchange
+                float kp = 0.f;
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) kp += acc[j][r];
+                if (kp == 123.456f && P.out) P.out[0] = kp;
+                return;
+            }
         }
     }
     auto skip = [&](int rr) __attribute__((always_inline)) { return KS_OK && keep >= 0 && rr != keep; };
@@ -1265,17 +1274,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __syncthreads();
         const float poison = *s_bad != 0 ? __uint_as_float(0x7fc00000u) : 0.f;
+        // (all eighteen loads of a lane in flight before the first is waited for: one round trip, not eighteen)
         auto recv = [&](auto KV) __attribute__((always_inline)) {
             constexpr int k0 = 2 * decltype(KV)::value;
             const float* const xr = xrecv;
+            f32x4 y[NJ][2];
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2) {
-                    f32x4 y;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(y) : "v"(xr + (j * 2 + r2) * 256) : "memory");
-                    c16[k0 + r2][j] += y + poison;
-                }
+                for (int r2 = 0; r2 < 2; ++r2)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(y[j][r2]) : "v"(xr + (j * 2 + r2) * 256) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) c16[k0 + r2][j] += y[j][r2] + poison;
         };
         if (khalf == 0) recv(std::integral_constant<int, 0>{}); else recv(std::integral_constant<int, 1>{});
         __syncthreads();
