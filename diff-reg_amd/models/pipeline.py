@@ -12,6 +12,7 @@ denoising branch on the noised ground-truth matrix, for models.loss.MatchMotionL
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -294,21 +295,33 @@ class Pipeline(nn.Module):
         M = tgt_feats.shape[1]
         conf, R, t = dag.coarse_branch(self, src_feats, tgt_feats, s_pcd, t_pcd, src_mask, tgt_mask)
         with torch.no_grad():
-            match_pred, _, _ = self.coarse_matching.get_match(conf.detach(), self.coarse_matching.confidence_threshold)
-            ts = data["ts"] if "ts" in data else torch.randint(0, self.num_timesteps, (1,), device=dev).long()
+            # (host reads are kept OUT of the middle of the forward: the time step is drawn on the host, the schedule read from a host copy, and the
+            # two match lists -- whose lengths are data dependent: one read-back each -- are taken behind the denoising branch, when the device has
+            # the whole forward queued)
+            ts = data["ts"] if "ts" in data else torch.randint(0, self.num_timesteps, (1,)).long()
             rows = [torch.cat([torch.full((1, m.shape[1]), b, dtype=torch.int64, device=m.device), m.to(torch.int64)], 0).t()
                     for b, m in enumerate(data["coarse_matches"])]
             matrix_gt = lib.match_matrix(torch.cat(rows, 0).to(dev), P, N, M)
             random_number = data["randn"] if "randn" in data else torch.randn(P, N, M, device=dev)
-            ac = self.alphas_cumprod[int(ts.reshape(-1)[0])]
+            ac = self._alphas_cumprod_host()[int(ts.reshape(-1)[0])]              # (a CPU tensor of the buffer's dtype: torch's own roots)
             noised = lib.gt_noising(matrix_gt, random_number, float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac)))
             src_w, tgt_w = self.get_warped_from_noising_matching(s_pcd, t_pcd, src_mask, tgt_mask, noised.clone())
         hat = dag.denoising_branch(self, src_feats, tgt_feats, src_w, tgt_w, src_mask, tgt_mask)
         with torch.no_grad():
+            match_pred, _, _ = self.coarse_matching.get_match(conf.detach(), self.coarse_matching.confidence_threshold)
             match_hat, _, _ = self.denoising_coarse_matching.get_match(hat.detach(), self.denoising_coarse_matching.confidence_threshold)
         data.update({"conf_matrix_pred": conf, "coarse_match_pred": match_pred, "R_s2t_pred": R, "t_s2t_pred": t, "matrix_gt_disturbed": noised,
                      "conf_matrix_gt_hat": hat, "coarse_match_gt_hat": match_hat})
         return data
+
+    def _alphas_cumprod_host(self):
+        """the schedule on the host, in the buffer's dtype (the registered buffer lives on the device: indexing it with a Python int and taking
+        float() of the entry is a read-back in the middle of the training forward)"""
+        h = getattr(self, "_ac_host", None)
+        if h is None or h.numel() != self.alphas_cumprod.numel():
+            h = self.alphas_cumprod.detach().cpu()
+            object.__setattr__(self, "_ac_host", h)
+        return h
 
     def get_warped_from_noising_matching(self, s_pcd, t_pcd, src_mask, tgt_mask, matrix_gt_disturbed):
         """pipeline.py:293-309: mask (in place), Sinkhorn in the matrix's dtype, Procrustes on float32(conf), the warped source"""
