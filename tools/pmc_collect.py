@@ -19,8 +19,13 @@ def main():
     for ctrs in PASSES:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
-        r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "--output-format", "csv", "--"] + cmd,
-                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        # (a pass is bounded: PMC_PASS_TIMEOUT seconds, default 600 -- a pass that does not finish is skipped and named, the others still count)
+        try:
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "--output-format", "csv", "--"] + cmd,
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=float(os.environ.get("PMC_PASS_TIMEOUT", "600")))
+        except subprocess.TimeoutExpired:
+            print("pass did not finish:", ctrs, flush=True)
+            continue
         if r.returncode != 0:
             print("pass failed:", ctrs, r.stdout[-2000:])
             continue
