@@ -7,6 +7,8 @@ term, the row scatter of split_feats; the KPFCN backbone's chain lives in backbo
     loss = focal_loss(conf, conf_gt, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0)   # compute_correspondence_loss, sinkhorn form
     loss.backward()                                                                # -> sim_matrix.grad, bin_score.grad
 """
+import weakref
+
 import torch
 
 from . import lib
@@ -212,12 +214,23 @@ class _GeometryAttentionLayer(torch.autograd.Function):
         return (g_x.view(B, L, C), g_s.view(B, S, C), gcx, gsx, gcy, gsy, None, None, None, gWq, gWk, gWv, gWm, gW0, gW2, gg1, gb1, gg2, gb2)
 
 
+_TABLES = {}        # id(position-code tensor) -> (weak reference to it, its version counter, (cos, sin)): dropped when the tensor dies
+
+
 def _tables(pe):
-    """a position code [B,N,C,2] (VolumetricPositionEncoding.forward) or a (cos, sin) pair of half tables [B*N, C/2] -> the pair"""
+    """a position code [B,N,C,2] (VolumetricPositionEncoding.forward) or a (cos, sin) pair of half tables [B*N, C/2] -> the pair.  The pair of a code
+    tensor is built once and kept while that tensor lives unmodified: every layer call and the head of a forward pass ask for the same one (two strided
+    copies per request were 200 small launches of a training step)."""
     if isinstance(pe, (tuple, list)):
         return pe
+    key = id(pe)
+    hit = _TABLES.get(key)
+    if hit is not None and hit[0]() is pe and hit[1] == pe._version:
+        return hit[2]
     from models.position_encoding import half_tables
-    return half_tables(pe)
+    pair = half_tables(pe)
+    _TABLES[key] = (weakref.ref(pe, lambda _r, k=key: _TABLES.pop(k, None)), pe._version, pair)
+    return pair
 
 
 def geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask=None, source_mask=None):
