@@ -133,6 +133,13 @@ _LAYER_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight"
                "norm2.weight", "norm2.bias")
 
 
+def _layer_params(layer):
+    """the ten parameters of a GeometryAttentionLayer in _LAYER_KEYS order, by attribute path (`mlp` is an nn.Sequential: mlp[0], mlp[2]) --
+    dict(layer.named_parameters()) walks the module tree on every call: 0.4 ms of a training step"""
+    return (layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight, layer.merge.weight, layer.mlp[0].weight, layer.mlp[2].weight,
+            layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+
+
 class _GeometryAttentionLayer(torch.autograd.Function):
     """GeometryAttentionLayer.forward (3D/models/transformero.py:43-96, rotary code) and its backward: the attention itself is FUSED both ways
     (forward = the inference kernels, dr_attention_f32; backward = dr_attention_backward_f32, flash-style: per-query log-sum-exp + delta, then dQ by
@@ -238,8 +245,7 @@ def geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask=None, sou
     position codes are constants of the graph, as in the reference: position_encoding.py:83-84 detaches them)"""
     cx, sx = _tables(x_pe)
     cy, sy = _tables(source_pe)
-    p = dict(layer.named_parameters())
-    return _GeometryAttentionLayer.apply(x, source, cx, sx, cy, sy, x_mask, source_mask, layer.nhead, *[p[k] for k in _LAYER_KEYS])
+    return _GeometryAttentionLayer.apply(x, source, cx, sx, cy, sy, x_mask, source_mask, layer.nhead, *_layer_params(layer))
 
 
 class _Procrustes(torch.autograd.Function):
@@ -383,8 +389,7 @@ def geometry_attention_layer_form(layer, x, source, x_pe, source_pe, x_mask=None
     pe_type = getattr(layer, "pe_type", "rotary")
     if pe_type == "rotary" and x_pe is not None:
         return geometry_attention_layer(layer, x, source, x_pe, source_pe, x_mask, source_mask)
-    p = dict(layer.named_parameters())
-    w = [p[k] for k in _LAYER_KEYS]
+    w = _layer_params(layer)
     if x_pe is None:
         return _GeometryAttentionLayerG.apply(x, source, None, None, None, None, None, None, x_mask, source_mask, layer.nhead, *w)
     if pe_type == "sinusoidal":
