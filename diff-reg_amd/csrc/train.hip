@@ -293,7 +293,8 @@ int dr_motion_l1_f32(int P, int N, const float* s_pcd, const float* flow, const 
 //     dL/dZ_ij = D_ij - sum_t (vb^t_j Pv^t_ij + ub^t_i Pu^t_ij);   dL/da = sum over the dustbin row and column of dL/dZ.
 // One workgroup per pair; every step is one sweep over the matrix: row quantities by one wave per row (lanes over the columns, DPP
 // reduction), column quantities by one thread per column (rows in order, coalesced): no atomics, results do not depend on scheduling.
-// The 2 T + 2 T vectors live in the workspace (L2-resident), in the kernel's working type (double: see sk_backward_kernel).
+// The 2 T + 2 T vectors live in the workspace (L2-resident), in double (see sk_backward_kernel).  The library runs the multi-launch form below
+// (skb_*_kernel); the single-workgroup kernel stays as its reference (diagnostics knob DR_SKB_ONE_WG).
 // ===============================================================================================================================
 namespace dr {
 namespace {
@@ -460,6 +461,176 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
     }
 }
 
+// ---- the same recurrences as a SEQUENCE of launches (round 6): the single-workgroup kernel above is one CU working through ~4 T + 2 sweeps of the
+// matrix -- 1.5 ms at 375 x 381 with double sums, the largest kernel of a training step.  Here every sweep is a launch over the whole chip: row
+// quantities by one wave per row, column quantities by 64 columns x 4 row parts per workgroup (partials combined through LDS in a fixed order);
+// 3 T + 4 launches of 5 - 10 us.  Same vectors in the workspace, same double sums, same fixed summation orders (bit-reproducible).
+struct SkbCtx {
+    const float* Z; const float* G; const uint8_t* sm; const uint8_t* tm; const float* alpha;
+    double* ws; size_t ws_stride;                        // per pair: [hdr 8][U T R][V (T+1) Cn][UB T R][VB T Cn][GA R]
+    float* gscores; float* galpha;
+    int N, M, T;
+};
+__device__ __forceinline__ double* skb_pair(const SkbCtx& A, int pair) { return A.ws + (size_t)pair * A.ws_stride; }
+struct SkbVec { double *U, *V, *UB, *VB, *GA; double norm, lmuN, lnuM, a; };
+__device__ __forceinline__ SkbVec skb_vec(const SkbCtx& A, int pair) {
+    double* w = skb_pair(A, pair);
+    const size_t R = A.N + 1, Cn = A.M + 1, T = A.T;
+    SkbVec v;
+    v.norm = w[0]; v.lmuN = w[1]; v.lnuM = w[2]; v.a = w[3];
+    v.U = w + 8; v.V = v.U + T * R; v.UB = v.V + (T + 1) * Cn; v.VB = v.UB + T * R; v.GA = v.VB + T * Cn;
+    return v;
+}
+__device__ __forceinline__ double skb_z(const SkbCtx& A, int pair, int i, int j, double a) {
+    return (i < A.N && j < A.M) ? (double)A.Z[((size_t)pair * A.N + i) * A.M + j] : a;
+}
+
+// header of a pair: the float32 marginals (quirk Q22) and alpha as doubles; v^0 = 0
+__global__ __launch_bounds__(256) void skb_prep_kernel(SkbCtx A) {
+    const int pair = blockIdx.x, t = threadIdx.x, N = A.N, M = A.M;
+    __shared__ int s_cnt[2];
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    int c0 = 0, c1 = 0;
+    for (int i = t; i < N; i += 256) c0 += A.sm ? (A.sm[(size_t)pair * N + i] != 0) : 1;
+    for (int j = t; j < M; j += 256) c1 += A.tm ? (A.tm[(size_t)pair * M + j] != 0) : 1;
+    if (c0) atomicAdd(&s_cnt[0], c0);
+    if (c1) atomicAdd(&s_cnt[1], c1);
+    __syncthreads();
+    double* w = skb_pair(A, pair);
+    if (t == 0) {
+        const int ms = s_cnt[0], ns = s_cnt[1];
+        const float normf = -logf((float)(ms + ns));
+        w[0] = (double)normf; w[1] = (double)(logf((float)ns) + normf); w[2] = (double)(logf((float)ms) + normf); w[3] = (double)*A.alpha;
+    }
+    double* V0 = w + 8 + (size_t)A.T * (N + 1);
+    for (int j = t; j <= M; j += 256) V0[j] = 0.0;
+}
+
+// what a sweep computes
+enum { SKB_U = 0, SKB_UB = 1, SKB_FINAL = 2, SKB_V = 3, SKB_VBT = 4, SKB_VB = 5 };
+
+// row sweeps: one wave per row (4 rows per workgroup), lanes over the columns
+template <int WHAT>
+__global__ __launch_bounds__(256) void skb_rows_kernel(SkbCtx A, int it) {
+    const int pair = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = A.N, M = A.M, T = A.T, R = N + 1, Cn = M + 1;
+    if (i >= R) return;
+    const SkbVec v = skb_vec(A, pair);
+    const double lmu_i = i < N ? v.norm : v.lmuN;
+    const float* __restrict__ G = A.G + (size_t)pair * N * M;
+    if (WHAT == SKB_U) {                                         // u^t_i = log mu_i - LSE_j(Z_ij + v^{t-1}_j)
+        const double* vp = v.V + (size_t)(it - 1) * Cn;
+        double mx = -INFINITY, s = 0;
+        for (int j = lane; j < Cn; j += 64) {
+            const double x = skb_z(A, pair, i, j, v.a) + vp[j];
+            if (x > mx) { s = s * xexp(mx - x) + 1.0; mx = x; } else if (x > -INFINITY) s += xexp(x - mx);
+        }
+        const double gm = wave_max(mx);
+        s = (mx > -INFINITY) ? s * xexp(mx - gm) : 0.0;
+        s = wave_sum(s);
+        if (lane == 0) v.U[(size_t)(it - 1) * R + i] = lmu_i - (gm + xlog(s));
+    } else if (WHAT == SKB_UB) {                                 // ub^t_i = [t == T] sum_j D_ij - sum_j vb^t_j Pv^t_ij
+        const double ui = v.U[(size_t)(it - 1) * R + i];
+        const double* vv = v.V + (size_t)it * Cn;
+        const double* vb = v.VB + (size_t)(it - 1) * Cn;
+        double s = 0;
+        for (int j = lane; j < Cn; j += 64) {
+            const double z = skb_z(A, pair, i, j, v.a);
+            if (z > -INFINITY) {
+                s -= vb[j] * xexp(z + ui + vv[j] - (j < M ? v.norm : v.lnuM));
+                if (it == T && i < N && j < M) s += xexp(z + ui + vv[j] - v.norm) * (double)G[(size_t)i * M + j];
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) v.UB[(size_t)(it - 1) * R + i] = s;
+    } else {                                                     // dL/dZ_ij; the dustbin entries of the row go to GA[i]
+        const double* uT = v.U + (size_t)(T - 1) * R;
+        const double* vT = v.V + (size_t)T * Cn;
+        double ga = 0;
+        for (int j = lane; j < Cn; j += 64) {
+            const double z = skb_z(A, pair, i, j, v.a);
+            double g = 0;
+            if (z > -INFINITY) {
+                if (i < N && j < M) g = xexp(z + uT[i] + vT[j] - v.norm) * (double)G[(size_t)i * M + j];
+                const double lnu_j = j < M ? v.norm : v.lnuM;
+                for (int t2 = 1; t2 <= T; ++t2) {
+                    const double ui = v.U[(size_t)(t2 - 1) * R + i];
+                    g -= v.VB[(size_t)(t2 - 1) * Cn + j] * xexp(z + ui + v.V[(size_t)t2 * Cn + j] - lnu_j);
+                    g -= v.UB[(size_t)(t2 - 1) * R + i] * xexp(z + v.V[(size_t)(t2 - 1) * Cn + j] + ui - lmu_i);
+                }
+            }
+            if (i < N && j < M) A.gscores[((size_t)pair * N + i) * M + j] = (float)g;
+            else ga += g;
+        }
+        ga = wave_sum(ga);
+        if (lane == 0) v.GA[i] = ga;
+    }
+}
+
+// column sweeps: 64 columns x 4 row parts per workgroup (thread (c, p) takes rows p, p + 4, ..: coalesced over c); the four partials of a
+// column are combined through LDS in the order p = 0 .. 3
+template <int WHAT>
+__global__ __launch_bounds__(256) void skb_cols_kernel(SkbCtx A, int it) {
+    const int pair = blockIdx.y, c = threadIdx.x & 63, p = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+    const int N = A.N, M = A.M, T = A.T, R = N + 1, Cn = M + 1;
+    const SkbVec v = skb_vec(A, pair);
+    __shared__ double s_a[4][64], s_b[4][64];
+    const bool live = j < Cn;
+    const float* __restrict__ G = A.G + (size_t)pair * N * M;
+    double mx = -INFINITY, s = 0;
+    if (live) {
+        if (WHAT == SKB_V) {                                     // v^t_j = log nu_j - LSE_i(Z_ij + u^t_i)
+            const double* un = v.U + (size_t)(it - 1) * R;
+            for (int i = p; i < R; i += 4) {
+                const double x = skb_z(A, pair, i, j, v.a) + un[i];
+                if (x > mx) { s = s * xexp(mx - x) + 1.0; mx = x; } else if (x > -INFINITY) s += xexp(x - mx);
+            }
+        } else if (WHAT == SKB_VBT) {                            // vb^T_j = sum_i D_ij
+            const double* uT = v.U + (size_t)(T - 1) * R;
+            const double vTj = v.V[(size_t)T * Cn + j];
+            if (j < M)
+                for (int i = p; i < N; i += 4) {
+                    const double z = (double)A.Z[((size_t)pair * N + i) * M + j];
+                    if (z > -INFINITY) s += xexp(z + uT[i] + vTj - v.norm) * (double)G[(size_t)i * M + j];
+                }
+        } else {                                                 // vb^{t-1}_j = - sum_i ub^t_i Pu^t_ij
+            const double* u = v.U + (size_t)(it - 1) * R;
+            const double* ub = v.UB + (size_t)(it - 1) * R;
+            const double vpj = v.V[(size_t)(it - 1) * Cn + j];
+            for (int i = p; i < R; i += 4) {
+                const double z = skb_z(A, pair, i, j, v.a);
+                if (z > -INFINITY) s -= ub[i] * xexp(z + vpj + u[i] - (i < N ? v.norm : v.lmuN));
+            }
+        }
+    }
+    s_a[p][c] = s; s_b[p][c] = mx;
+    __syncthreads();
+    if (p == 0 && live) {
+        if (WHAT == SKB_V) {
+            double gm = s_b[0][c];
+            for (int k = 1; k < 4; ++k) gm = s_b[k][c] > gm ? s_b[k][c] : gm;
+            double tot = 0;
+            for (int k = 0; k < 4; ++k) tot += s_b[k][c] > -INFINITY ? s_a[k][c] * xexp(s_b[k][c] - gm) : 0.0;
+            v.V[(size_t)it * Cn + j] = (j < M ? v.norm : v.lnuM) - (gm + xlog(tot));
+        } else {
+            const double tot = (s_a[0][c] + s_a[1][c]) + (s_a[2][c] + s_a[3][c]);
+            if (WHAT == SKB_VBT) v.VB[(size_t)(T - 1) * Cn + j] = tot;
+            else v.VB[(size_t)(it - 2) * Cn + j] = tot;
+        }
+    }
+}
+
+// dL/dalpha of a pair: the rows' dustbin partials in row order
+__global__ __launch_bounds__(64) void skb_galpha_kernel(SkbCtx A) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const SkbVec v = skb_vec(A, pair);
+    double s = 0;
+    for (int i = 0; i <= A.N; ++i) s += v.GA[i];
+    A.galpha[pair] = (float)s;
+}
+
 // d loss / d conf of compute_correspondence_loss (sinkhorn form): the clamp passes no gradient outside [1e-6, 1 - 1e-6]
 __global__ __launch_bounds__(256) void focal_backward_kernel(long long n, const float* __restrict__ conf, const float* __restrict__ gt,
                                                              const double* __restrict__ part, float alpha, float gamma, float pos_w, float neg_w,
@@ -490,7 +661,8 @@ extern "C" {
 
 size_t dr_sinkhorn_backward_workspace_bytes(int P, int N, int M, int iters) {
     if (P < 0 || N < 1 || M < 1 || iters < 1) return 0;
-    return (size_t)P * ((size_t)2 * iters * (N + 1) + (size_t)(2 * iters + 1) * (M + 1)) * sizeof(double);
+    // per pair: a header of 8, u [T][N+1], v [T+1][M+1], ub [T][N+1], vb [T][M+1], the rows' dustbin partials [N+1] -- doubles
+    return (size_t)P * (8 + (size_t)2 * iters * (N + 1) + (size_t)(2 * iters + 1) * (M + 1) + (size_t)(N + 1)) * sizeof(double);
 }
 
 int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uint8_t* src_mask, const uint8_t* tgt_mask, const float* bin_score,
@@ -500,9 +672,32 @@ int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uin
     if ((src_mask == nullptr) != (tgt_mask == nullptr)) return DR_EINVAL;
     if (workspace_bytes < dr_sinkhorn_backward_workspace_bytes(P, N, M, iters)) return DR_EWORKSPACE;
     if (P == 0) return DR_OK;
-    dr::SkBwdArgs A{scores, src_mask, tgt_mask, bin_score, grad_conf, grad_scores, grad_bin_score, workspace, N, M, iters};
-    if (dr::env_knob("DR_SKB_F32", 0)) hipLaunchKernelGGL(dr::sk_backward_kernel<float>, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);   // (diagnostics)
-    else hipLaunchKernelGGL(dr::sk_backward_kernel<double>, dim3(P), dim3(1024), 0, (hipStream_t)stream, A);
+    hipStream_t st = (hipStream_t)stream;
+    if (dr::env_knob("DR_SKB_ONE_WG", 0)) {                  // (diagnostics: the single-workgroup form, its vectors at the head of the workspace)
+        dr::SkBwdArgs A1{scores, src_mask, tgt_mask, bin_score, grad_conf, grad_scores, grad_bin_score, workspace, N, M, iters};
+        hipLaunchKernelGGL(dr::sk_backward_kernel<double>, dim3(P), dim3(1024), 0, st, A1);
+        DR_LAUNCH_CHECK();
+        return DR_OK;
+    }
+    const int T = iters, R = N + 1, Cn = M + 1;
+    dr::SkbCtx A{scores, grad_conf, src_mask, tgt_mask, bin_score, (double*)workspace,
+                 8 + (size_t)2 * T * R + (size_t)(2 * T + 1) * Cn + (size_t)R, grad_scores, grad_bin_score, N, M, T};
+    const dim3 grows((R + 3) / 4, P), gcols((Cn + 63) / 64, P);
+    hipLaunchKernelGGL(dr::skb_prep_kernel, dim3(P), dim3(256), 0, st, A);
+    DR_LAUNCH_CHECK();
+    for (int it = 1; it <= T; ++it) {                        // forward, keeping every u^t, v^t
+        hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_U>, grows, dim3(256), 0, st, A, it);
+        hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_V>, gcols, dim3(256), 0, st, A, it);
+    }
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VBT>, gcols, dim3(256), 0, st, A, T);
+    for (int it = T; it >= 1; --it) {                        // the adjoint vectors
+        hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_UB>, grows, dim3(256), 0, st, A, it);
+        if (it > 1) hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VB>, gcols, dim3(256), 0, st, A, it);
+    }
+    DR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_FINAL>, grows, dim3(256), 0, st, A, T);
+    hipLaunchKernelGGL(dr::skb_galpha_kernel, dim3(P), dim3(64), 0, st, A);
     DR_LAUNCH_CHECK();
     return DR_OK;
 }
