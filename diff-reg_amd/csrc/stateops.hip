@@ -387,13 +387,26 @@ __global__ __launch_bounds__(1024) void mutual_match_kernel(const T* __restrict_
     __shared__ int s_cnt[MM_MAX + 1];
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const T* c = conf + (size_t)pair * N * M;
-    for (int j = t; j < M; j += 1024) {
+    // column maxima: 64 columns at a time, the rows dealt to the 16 waves (lane = column: coalesced, independent loads), the waves' partials
+    // combined in wave order.  (One thread per column walking all N rows was a chain of N dependent steps: 190 of this kernel's 207 us at 375 x 381.)
+    __shared__ T s_part[16][64];
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
         T best = -INFINITY;
-        if (mutual)
-            for (int i = 0; i < N; ++i) { const T v = c[(size_t)i * M + j]; best = (v > best || v != v) ? v : best; }   // NaN propagates like torch.max
-        s_col[j] = best;
+        if (mutual && j < M) {
+#pragma unroll 4
+            for (int i = w; i < N; i += 16) { const T v = c[(size_t)i * M + j]; best = (v > best || v != v) ? v : best; }   // NaN propagates like torch.max
+        }
+        s_part[w][lane] = best;
+        __syncthreads();
+        if (w == 0 && j < M) {
+            T b = s_part[0][lane];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { const T o = s_part[k][lane]; b = (o > b || o != o) ? o : b; }
+            s_col[j] = b;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     auto hit = [&](int i, int j, T rowmax) {
         const T v = c[(size_t)i * M + j];
         return v > thr && (!mutual || (v == rowmax && v == s_col[j]));
