@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void sk_backward_kernel(SkBwdArgs A) {
 
 // ---- the same recurrences as a SEQUENCE of launches (round 6): the single-workgroup kernel above is one CU working through ~4 T + 2 sweeps of the
 // matrix -- 1.5 ms at 375 x 381 with double sums, the largest kernel of a training step.  Here every sweep is a launch over the whole chip: row
-// quantities by one wave per row, column quantities by 64 columns x 4 row parts per workgroup (partials combined through LDS in a fixed order);
+// quantities by one wave per row, column quantities by 64 columns x 16 row parts per workgroup (partials combined through LDS in a fixed order);
 // 3 T + 4 launches of 5 - 10 us.  Same vectors in the workspace, same double sums, same fixed summation orders (bit-reproducible).
 struct SkbCtx {
     const float* Z; const float* G; const uint8_t* sm; const uint8_t* tm; const float* alpha;
@@ -568,21 +568,22 @@ __global__ __launch_bounds__(256) void skb_rows_kernel(SkbCtx A, int it) {
     }
 }
 
-// column sweeps: 64 columns x 4 row parts per workgroup (thread (c, p) takes rows p, p + 4, ..: coalesced over c); the four partials of a
-// column are combined through LDS in the order p = 0 .. 3
+// column sweeps: 64 columns x SKB_RP = 16 row parts per workgroup (thread (c, p) takes rows p, p + 16, ..: coalesced over c); the partials of a
+// column are combined through LDS in the order p = 0 .. 15 (four parts: 40 us per sweep at 375 rows, a chain of 94 dependent steps per thread)
+constexpr int SKB_RP = 16;
 template <int WHAT>
-__global__ __launch_bounds__(256) void skb_cols_kernel(SkbCtx A, int it) {
+__global__ __launch_bounds__(64 * SKB_RP) void skb_cols_kernel(SkbCtx A, int it) {
     const int pair = blockIdx.y, c = threadIdx.x & 63, p = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
     const int N = A.N, M = A.M, T = A.T, R = N + 1, Cn = M + 1;
     const SkbVec v = skb_vec(A, pair);
-    __shared__ double s_a[4][64], s_b[4][64];
+    __shared__ double s_a[SKB_RP][64], s_b[SKB_RP][64];
     const bool live = j < Cn;
     const float* __restrict__ G = A.G + (size_t)pair * N * M;
     double mx = -INFINITY, s = 0;
     if (live) {
         if (WHAT == SKB_V) {                                     // v^t_j = log nu_j - LSE_i(Z_ij + u^t_i)
             const double* un = v.U + (size_t)(it - 1) * R;
-            for (int i = p; i < R; i += 4) {
+            for (int i = p; i < R; i += SKB_RP) {
                 const double x = skb_z(A, pair, i, j, v.a) + un[i];
                 if (x > mx) { s = s * xexp(mx - x) + 1.0; mx = x; } else if (x > -INFINITY) s += xexp(x - mx);
             }
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void skb_cols_kernel(SkbCtx A, int it) {
             const double* uT = v.U + (size_t)(T - 1) * R;
             const double vTj = v.V[(size_t)T * Cn + j];
             if (j < M)
-                for (int i = p; i < N; i += 4) {
+                for (int i = p; i < N; i += SKB_RP) {
                     const double z = (double)A.Z[((size_t)pair * N + i) * M + j];
                     if (z > -INFINITY) s += xexp(z + uT[i] + vTj - v.norm) * (double)G[(size_t)i * M + j];
                 }
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void skb_cols_kernel(SkbCtx A, int it) {
             const double* u = v.U + (size_t)(it - 1) * R;
             const double* ub = v.UB + (size_t)(it - 1) * R;
             const double vpj = v.V[(size_t)(it - 1) * Cn + j];
-            for (int i = p; i < R; i += 4) {
+            for (int i = p; i < R; i += SKB_RP) {
                 const double z = skb_z(A, pair, i, j, v.a);
                 if (z > -INFINITY) s -= ub[i] * xexp(z + vpj + u[i] - (i < N ? v.norm : v.lmuN));
             }
@@ -609,12 +610,13 @@ __global__ __launch_bounds__(256) void skb_cols_kernel(SkbCtx A, int it) {
     if (p == 0 && live) {
         if (WHAT == SKB_V) {
             double gm = s_b[0][c];
-            for (int k = 1; k < 4; ++k) gm = s_b[k][c] > gm ? s_b[k][c] : gm;
+            for (int k = 1; k < SKB_RP; ++k) gm = s_b[k][c] > gm ? s_b[k][c] : gm;
             double tot = 0;
-            for (int k = 0; k < 4; ++k) tot += s_b[k][c] > -INFINITY ? s_a[k][c] * xexp(s_b[k][c] - gm) : 0.0;
+            for (int k = 0; k < SKB_RP; ++k) tot += s_b[k][c] > -INFINITY ? s_a[k][c] * xexp(s_b[k][c] - gm) : 0.0;
             v.V[(size_t)it * Cn + j] = (j < M ? v.norm : v.lnuM) - (gm + xlog(tot));
         } else {
-            const double tot = (s_a[0][c] + s_a[1][c]) + (s_a[2][c] + s_a[3][c]);
+            double tot = 0;
+            for (int k = 0; k < SKB_RP; ++k) tot += s_a[k][c];
             if (WHAT == SKB_VBT) v.VB[(size_t)(T - 1) * Cn + j] = tot;
             else v.VB[(size_t)(it - 2) * Cn + j] = tot;
         }
@@ -687,13 +689,13 @@ int dr_sinkhorn_backward_f32(int P, int N, int M, const float* scores, const uin
     DR_LAUNCH_CHECK();
     for (int it = 1; it <= T; ++it) {                        // forward, keeping every u^t, v^t
         hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_U>, grows, dim3(256), 0, st, A, it);
-        hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_V>, gcols, dim3(256), 0, st, A, it);
+        hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_V>, gcols, dim3(64 * dr::SKB_RP), 0, st, A, it);
     }
     DR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VBT>, gcols, dim3(256), 0, st, A, T);
+    hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VBT>, gcols, dim3(64 * dr::SKB_RP), 0, st, A, T);
     for (int it = T; it >= 1; --it) {                        // the adjoint vectors
         hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_UB>, grows, dim3(256), 0, st, A, it);
-        if (it > 1) hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VB>, gcols, dim3(256), 0, st, A, it);
+        if (it > 1) hipLaunchKernelGGL(dr::skb_cols_kernel<dr::SKB_VB>, gcols, dim3(64 * dr::SKB_RP), 0, st, A, it);
     }
     DR_LAUNCH_CHECK();
     hipLaunchKernelGGL(dr::skb_rows_kernel<dr::SKB_FINAL>, grows, dim3(256), 0, st, A, T);
