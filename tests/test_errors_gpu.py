@@ -255,7 +255,7 @@ def test_round_6_entries_refuse_bad_calls():
     # the Sinkhorn backward's vectors are doubles since round 6: the reported size is what the call insists on
     sc = torch.randn(1, 16, 12, device=DEV); one = torch.ones(1, device=DEV); ga = torch.empty(1, device=DEV)
     need = r.dr_sinkhorn_backward_workspace_bytes(1, 16, 12, 3)
-    assert need == (2 * 3 * 17 + (2 * 3 + 1) * 13) * 8
+    assert need == (8 + 2 * 3 * 17 + (2 * 3 + 1) * 13 + 17) * 8          # header, u / ub [T][N+1], v / vb [T+1 | T][M+1], the rows' dustbin partials -- doubles
     w2 = torch.empty(need, dtype=torch.uint8, device=DEV)
     skb = lambda nb: r.dr_sinkhorn_backward_f32(1, 16, 12, lib.ptr(sc), None, None, lib.ptr(one), 3, lib.ptr(g[:1].contiguous()), lib.ptr(gs[:1].contiguous()),
                                                  lib.ptr(ga), lib.ptr(w2), nb, st)
